@@ -1,0 +1,76 @@
+/*
+ * include/qb3x.h -- extensions of the MI355X-native QB3 library that the reference does not have:
+ * device-resident buffers, an out-of-band decode index, batched tiles.  The reference API (QB3.h)
+ * only knows host pointers and one image per call (reference QB3lib/QB3.h:119-139).
+ *
+ * Why an index: a QB3 block stream has no restart points; a unit's bit position and rung depend on
+ * every earlier unit (reference QB3decode.h:445-454), so a foreign stream can only be parsed
+ * serially.  The encoder here can emit, next to the (bit-identical) stream, a small side table:
+ * for every SEGMENT of `seg_blocks` consecutive 4x4 blocks the bit position of its first unit and the
+ * per-band encoder state {previous value, rung, common factor} on entry -- i.e. the band_state the
+ * reference keeps in its handle (reference QB3common.h:63-65), sampled along the stream.  With it,
+ * decode is parallel over segments.  Without it the library first rebuilds the table on the GPU with
+ * a serial boundary scan of the stream (slow, latency bound), then decodes in parallel.
+ *
+ * `stream` arguments are hipStream_t passed as void* (NULL = the default stream).  All `d_` pointers
+ * are device pointers on the current HIP device.
+ */
+#ifndef QB3_AMD_QB3X_H
+#define QB3_AMD_QB3X_H
+#include "QB3.h"
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+/* Number of usable HIP devices; 0 means the library cannot encode or decode. */
+int qb3x_device_count(void);
+
+/* Bytes of device memory an index for this encoder's geometry needs (0 on error). */
+size_t qb3x_index_size(const encsp p);
+/* Same, from a decoder handle (valid after qb3_read_info). */
+size_t qb3x_decoder_index_size(const decsp p);
+
+/* Device-resident encode.  d_src: image laid out as qb3_encode expects; d_dst: at least
+ * qb3_max_encoded_size(p) bytes, 4-byte aligned; d_index: qb3x_index_size(p) bytes or NULL.
+ * Writes the complete QB3 container (headers + stream, STORED fallback included) to d_dst.
+ * Returns its size in bytes, 0 on error (see qb3_get_encoder_state).  Synchronises `stream` once,
+ * to learn the stream length.  Mode, band map, stride and handle statefulness as qb3_encode. */
+size_t qb3x_encode_device(encsp p, const void *d_src, void *d_dst, void *d_index, void *stream);
+
+/* Device-resident decode.  p: handle from qb3_read_start + qb3_read_info over a HOST copy of at least
+ * the headers (source_size must be the true stream size); d_src: device copy of the whole container
+ * (same bytes, 4-byte aligned); d_dst: qb3_decoded_size(p) bytes; d_index: index written by
+ * qb3x_encode_device for this very stream, or NULL to rebuild it with the serial scan.
+ * Returns decoded bytes, 0 on error. */
+size_t qb3x_decode_device(decsp p, const void *d_src, void *d_dst, const void *d_index, void *stream);
+
+/* Batched tiles: n images of the encoder's geometry, image i at d_src + i*src_pitch, container i
+ * written at d_dst + i*dst_pitch (dst_pitch >= qb3_max_encoded_size, multiple of 4), index i at
+ * d_index + i*qb3x_index_size (or NULL).  sizes[i] receives the container size (0 = failed).
+ * The band state is reset before every tile (tiles are independent streams).  Returns the number of
+ * tiles encoded.  One host synchronisation for the whole batch. */
+size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t src_pitch,
+                         void *d_dst, size_t dst_pitch, void *d_index, size_t *sizes, void *stream);
+
+/* Batched decode of n containers that share the geometry/mode of handle p (parsed from tile 0);
+ * sizes[i] = container size of tile i.  Returns the number of tiles decoded. */
+size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
+                         void *d_dst, size_t dst_pitch, const void *d_index, void *stream);
+
+/* Compatibility switches. */
+#define QB3X_REF_CBAND0 1u      /* decoder: reproduce reference defect (no CB chunk => every band adds band 0,
+                                   reference QB3decode.cpp:138 + QB3decode.h:560-567) instead of identity */
+void qb3x_set_decoder_compat(decsp p, unsigned flags);
+
+/* Aliases for the names BASELINE.json uses; the reference has no such symbols. */
+decsp  qb3_create_decoder(void *source, size_t source_size, size_t *image_size);  /* read_start + read_info */
+size_t qb3_decode(decsp p, void *destination);                                     /* read_data */
+
+/* Last HIP error string seen by this thread inside the library ("" if none). */
+const char *qb3x_last_error(void);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif

@@ -1,0 +1,720 @@
+// qb3_amd/csrc/qb3_api.cpp -- the C ABI (include/QB3.h, include/qb3x.h) of the MI355X-native QB3 codec.
+//
+// Host side only: handle bookkeeping, container headers, the byte-serial RLE0 post pass, STORED fallback
+// and the HIP plumbing (buffers, copies, one synchronisation per call).  The block coding itself -- the hot
+// path -- is in qb3_kernels.hip and always runs on the GPU; there is no CPU fallback for it.
+//
+// Behaviour mirrors the reference C API (reference QB3lib/QB3encode.cpp, QB3decode.cpp), including the
+// quirks a drop-in has to keep: band state carried across qb3_encode calls until qb3_reset_encoder
+// (QB3encode.h:446-449), sticky Z order (QB3encode.cpp:124-132), mode left at STORED after a fallback
+// (QB3encode.cpp:464), stale error blocking the handle (QB3encode.cpp:514).
+#include <hip/hip_runtime_api.h>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+#include <vector>
+#include <limits>
+#include "../../include/QB3.h"
+#include "../../include/qb3x.h"
+#include "qb3_dev.h"
+
+using namespace qb3dev;
+
+#define QB3_API extern "C" __attribute__((visibility("default")))
+
+static const int typesizes[8] = { 1, 1, 2, 2, 4, 4, 8, 8 };
+static inline size_t szof(int dt) { return (dt < 0 || dt > QB3_I64) ? 0 : typesizes[dt]; }
+static inline unsigned topbit(uint64_t v) { return 63u - (unsigned)__builtin_clzll(v); }
+
+// ---------------------------------------------------------------- device buffers owned by a handle
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { set_error("hipMalloc", (int)e); p = nullptr; return false; }
+        cap = n;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+static bool device_ok() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_error("no usable HIP device (the block codec has no CPU fallback)", (int)e); return false; }
+    return true;
+}
+
+struct band_state { size_t prev, runbits, cf; };
+
+struct encs {
+    size_t xsize, ysize, nbands, stride;
+    uint64_t order, quanta;
+    band_state band[QB3_MAXBANDS];
+    size_t cband[QB3_MAXBANDS];
+    int error;
+    qb3_mode mode;
+    qb3_dtype type;
+    bool away;
+    DevBuf d_img, d_out, d_ws, d_q;
+};
+
+struct decs {
+    size_t xsize, ysize, nbands, stride;
+    uint64_t order, quanta;
+    int error, stage;
+    uint8_t cband[QB3_MAXBANDS];
+    qb3_mode mode;
+    qb3_dtype type;
+    uint8_t *s_in;
+    size_t s_size;
+    uint8_t *s_start;       // the pointer given to qb3_read_start
+    bool saw_cb;            // a CB chunk was present
+    unsigned compat;
+    DevBuf d_in, d_img, d_ws;
+};
+
+// ---------------------------------------------------------------- small host bit writer for headers
+struct HdrWriter {
+    uint8_t *d; size_t n = 0;
+    explicit HdrWriter(uint8_t *dst) : d(dst) {}
+    void put(uint64_t v, unsigned bytes) { for (unsigned i = 0; i < bytes; i++) d[n++] = (uint8_t)(v >> (8 * i)); }
+    void sig(const char *s) { d[n++] = (uint8_t)s[0]; d[n++] = (uint8_t)s[1]; }
+};
+
+// reference QB3encode.cpp:189-268: main header, then CB / QV / SC chunks as needed, then DT
+static size_t write_headers(const encs *p, uint8_t *dst) {
+    HdrWriter w(dst);
+    w.put(0x80334251u, 4);
+    w.put(p->xsize - 1, 2); w.put(p->ysize - 1, 2); w.put(p->nbands - 1, 1);
+    w.put((uint8_t)p->type, 1); w.put((uint8_t)p->mode, 1);
+    bool diff = false;
+    for (size_t c = 0; c < p->nbands; c++) diff |= p->cband[c] != c;
+    if (p->mode != QB3M_STORED && diff) {
+        w.sig("CB"); w.put(p->nbands, 2);
+        for (size_t c = 0; c < p->nbands; c++) w.put(p->cband[c], 1);
+    }
+    if (p->quanta >= 2) {
+        unsigned qb = 1 + topbit(p->quanta) / 8;
+        w.sig("QV"); w.put(qb, 2); w.put(p->quanta, qb);
+    }
+    if (p->order != ZCURVE && p->mode != QB3M_STORED) {
+        w.sig("SC"); w.put(8, 2); w.put(p->order ? p->order : HILBERT, 8);
+    }
+    w.sig("DT");
+    return w.n;
+}
+
+static size_t raw_size(const encs *p) { return p->xsize * p->ysize * p->nbands * szof(p->type); }
+
+// ---------------------------------------------------------------- encoder handle
+QB3_API encsp qb3_create_encoder(size_t w, size_t h, size_t b, qb3_dtype dt) {
+    if (w == 0 || w > 0x10000 || h == 0 || h > 0x10000 || b == 0 || b > QB3_MAXBANDS || (int)dt < 0 || (int)dt > (int)QB3_I64)
+        return nullptr;
+    encs *p = new encs();
+    p->xsize = w; p->ysize = h; p->nbands = b; p->type = dt;
+    p->stride = 0; p->order = 0; p->quanta = 1; p->away = false; p->mode = QB3M_DEFAULT; p->error = 0;
+    for (size_t c = 0; c < QB3_MAXBANDS; c++) p->cband[c] = c < b ? c : 0;
+    if (b == 3 || b == 4) p->cband[0] = p->cband[2] = 1;
+    qb3_reset_encoder(p);
+    return p;
+}
+
+QB3_API void qb3_reset_encoder(encsp p) {
+    for (size_t c = 0; c < QB3_MAXBANDS; c++) p->band[c].prev = p->band[c].runbits = p->band[c].cf = 0;
+    p->error = 0;
+}
+
+QB3_API void qb3_destroy_encoder(encsp p) {
+    if (!p) return;
+    p->d_img.release(); p->d_out.release(); p->d_ws.release(); p->d_q.release();
+    delete p;
+}
+
+QB3_API bool qb3_set_encoder_coreband(encsp p, size_t b, size_t *bands) {
+    if (b != p->nbands) return false;
+    for (size_t i = 0; i < b; i++) p->cband[i] = (uint8_t)((bands[i] < b) ? bands[i] : i);
+    for (size_t i = 0; i < b; i++) if (p->cband[i] != i) p->cband[p->cband[i]] = p->cband[i];
+    for (size_t i = 0; i < b; i++) bands[i] = p->cband[i];
+    return true;
+}
+
+QB3_API void qb3_set_encoder_stride(encsp p, size_t stride) { p->stride = stride; }
+
+QB3_API bool qb3_set_encoder_quanta(encsp p, uint64_t q, bool away) {
+    if (q < 1) return false;
+    p->quanta = q; p->away = away;
+    if (q == 1) return true;
+    // the reference's fall-through range switch (QB3encode.cpp:96-107): a type is checked against its own
+    // limit and against the limits of every wider type listed after it
+    static const int order[7] = { QB3_I8, QB3_U8, QB3_I16, QB3_U16, QB3_I32, QB3_U32, QB3_I64 };
+    static const uint64_t lim[7] = { 0x7f, 0xff, 0x7fff, 0xffff, 0x7fffffff, 0xffffffffull, 0x7fffffffffffffffull };
+    bool bad = false;
+    int start = -1;
+    for (int i = 0; i < 7; i++) if (order[i] == (int)p->type) start = i;
+    for (int i = start; i >= 0 && i < 7; i++) bad |= q > lim[i];
+    return !bad;
+}
+
+QB3_API size_t qb3_max_encoded_size(const encsp p) {
+    size_t n = 16 * ((p->xsize + 3) / 4) * ((p->ysize + 3) / 4) * p->nbands;
+    double bits_per_value = 17.0 / 16.0 + 8 * szof(p->type);
+    return 1024 + static_cast<size_t>(bits_per_value * n / 8);
+}
+
+QB3_API qb3_mode qb3_set_encoder_mode(encsp p, qb3_mode mode) {
+    if ((int)mode >= 0 && (int)mode < (int)QB3M_END) p->mode = mode;
+    if ((int)p->mode <= (int)QB3M_CF_RLE) p->order = ZCURVE;
+    return p->mode;
+}
+
+QB3_API int qb3_get_encoder_state(encsp p) { return p->error; }
+
+// ---------------------------------------------------------------- geometry helpers
+static CodecMode codec_mode(int mode) {
+    if (mode == QB3M_FTL) return CM_FTL;
+    if (mode == QB3M_BASE_H || mode == QB3M_BASE_Z) return CM_BASE;
+    return CM_BEST;
+}
+
+static Geometry make_geometry(size_t w, size_t h, size_t bands, int dtype, size_t stride, uint64_t order, int mode,
+                              const size_t *cband_sz, const uint8_t *cband_u8) {
+    Geometry g;
+    memset(&g, 0, sizeof(g));
+    g.w = (uint32_t)w; g.h = (uint32_t)h; g.bands = (uint32_t)bands; g.tsz = (uint32_t)szof(dtype);
+    g.stride = stride ? stride : w * bands;
+    g.order = order ? order : HILBERT;
+    g.nbx = (uint32_t)((w + 3) / 4); g.nby = (uint32_t)((h + 3) / 4);
+    g.nblocks = (uint64_t)g.nbx * g.nby;
+    g.mode = codec_mode(mode);
+    g.seg_blocks = seg_blocks_for(g.bands, g.tsz);
+    g.nseg = (g.nblocks + g.seg_blocks - 1) / g.seg_blocks;
+    for (size_t c = 0; c < bands; c++) g.cband[c] = cband_sz ? (uint8_t)cband_sz[c] : cband_u8[c];
+    return g;
+}
+
+// narrow-image remap (reference QB3encode.cpp:351-389, implemented per its intent; the reference itself has
+// a use-after-scope there).  Returns the packed pixels, sets the stand-in dimensions.
+static std::vector<uint8_t> remap_small(const uint8_t *src, size_t w, size_t h, size_t pix, size_t stride_bytes,
+                                        size_t &nw, size_t &nh) {
+    const size_t ngroups = (w * h + 15) / 16;
+    std::vector<uint8_t> t(ngroups * 16 * pix, 0);
+    uint8_t *d = t.data();
+    if (w < 4) {
+        for (size_t y = 0; y < h; y++, d += w * pix) memcpy(d, src + y * stride_bytes, w * pix);
+        nw = 4; nh = ngroups * 4;
+    } else {
+        for (size_t x = 0; x < w; x++)
+            for (size_t y = 0; y < h; y++, d += pix) memcpy(d, src + y * stride_bytes + x * pix, pix);
+        nw = ngroups * 4; nh = 4;
+    }
+    return t;
+}
+
+// ---------------------------------------------------------------- RLE0 (reference QB3encode.cpp:271-332)
+static size_t rle0(const uint8_t *src, size_t len, uint8_t *dst) {      // dst == nullptr: size only
+    size_t i = 0, o = 0;
+    uint8_t last = 0;
+    while (i + 2 < len) {
+        uint8_t c = src[i++];
+        const size_t rem = len - i;
+        bool run = (c == 0 || c == 0xff) && c == src[i];
+        if (run && c == 0 && (last == 0xff || rem < 3 || src[i + 1] || src[i + 2])) run = false;
+        if (!run) { if (dst) dst[o] = c; o++; last = c; continue; }
+        i++;
+        if (c == 0) {
+            i += 2;
+            size_t r = 0, lim = len - i > 0xfe ? 0xfe : len - i;
+            while (r < lim && !src[i + r]) r++;
+            i += r; c = (uint8_t)r;
+        }
+        last = 0;
+        if (dst) { dst[o] = 0xff; dst[o + 1] = 0xff; dst[o + 2] = c; }
+        o += 3;
+    }
+    for (; i < len; i++, o++) if (dst) dst[o] = src[i];
+    return o;
+}
+
+// reference QB3decode.cpp:267-307
+static size_t derle0_size(const uint8_t *src, size_t len) {
+    size_t i = 0, n = 0;
+    while (i + 2 < len) {
+        if (src[i] != 0xff || src[i + 1] != 0xff) { n++; i++; continue; }
+        n += (src[i + 2] == 0xff) ? 2 : 4 + (size_t)src[i + 2];
+        i += 3;
+    }
+    return n + (len - i);
+}
+static int64_t derle0(const uint8_t *src, size_t slen, uint8_t *d, size_t dlen) {
+    size_t i = 0, o = 0;
+    while (o < dlen && i + 2 < slen) {
+        uint8_t c = src[i++];
+        if (c != 0xff || src[i] != 0xff) { d[o++] = c; continue; }
+        size_t count = 2;
+        if (src[i + 1] != 0xff) { c = 0; count = 4 + (size_t)src[i + 1]; }
+        if (dlen - o < count) return (int64_t)o - (int64_t)dlen;
+        i += 2;
+        while (count--) d[o++] = c;
+    }
+    while (i < slen && o < dlen) d[o++] = src[i++];
+    return (int64_t)(dlen - o) - (int64_t)(slen - i);
+}
+
+// ---------------------------------------------------------------- encode
+static size_t stored_encode_host(encsp p, const void *source, void *destination) {
+    uint8_t *d = (uint8_t *)destination;
+    p->mode = QB3M_STORED;
+    const size_t hdr = write_headers(p, d);
+    if (p->error) return 0;
+    const size_t tsz = szof(p->type), line = p->xsize * p->nbands * tsz;
+    const size_t stride = (p->stride ? p->stride : p->xsize * p->nbands) * tsz;
+    for (size_t y = 0; y < p->ysize; y++) memcpy(d + hdr + y * line, (const uint8_t *)source + y * stride, line);
+    return hdr + raw_size(p);
+}
+
+#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(#x, (int)e_); p->error = QB3E_LIBERR; return 0; } } while (0)
+
+// Runs the block coder on a device image.  d_out mirrors the destination buffer: the stream starts at byte
+// `hdr`.  On success *bits receives the stream length; the handle's band state is updated when `carry`.
+// d_index may be null.  Synchronises the stream.
+static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, uint8_t *d_out, size_t hdr,
+                                 void *d_index, hipStream_t st, bool carry, uint64_t *bits) {
+    EncPlan plan = plan_encode(g);
+    if (!p->d_ws.ensure(plan.ws_bytes)) return false;
+    BandState bs;
+    memset(&bs, 0, sizeof(bs));
+    for (size_t c = 0; c < p->nbands; c++) {
+        bs.prev[c] = p->band[c].prev; bs.cf[c] = p->band[c].cf; bs.rung[c] = (uint8_t)p->band[c].runbits;
+    }
+    uint32_t *out32 = (uint32_t *)(d_out + (hdr & ~(size_t)3));
+    if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st)) return false;
+    EncResult res;
+    const uint8_t *dres = (const uint8_t *)p->d_ws.p + plan.ws_bytes - sizeof(EncResult);
+    hipError_t e = hipMemcpyAsync(&res, dres, sizeof(res), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
+    *bits = res.total_bits;
+    if (carry)
+        for (size_t c = 0; c < p->nbands; c++) {
+            p->band[c].prev = (size_t)res.prev[c]; p->band[c].runbits = res.rung[c]; p->band[c].cf = (size_t)res.cf[c];
+        }
+    return true;
+}
+
+static bool is_rle_mode(int m) { return m == QB3M_RLE || m == QB3M_CF_RLE || m == QB3M_RLE_H || m == QB3M_CF_RLE_H; }
+
+// Shared by qb3_encode (host buffers) and qb3x_encode_device (device buffers).
+// host_src/host_dst are null in the device flavour; d_src/d_dst are null in the host flavour.
+static size_t encode_common(encsp p, const void *host_src, void *host_dst, const void *d_src, void *d_dst,
+                            void *d_index, hipStream_t st) {
+    const bool on_host = host_src != nullptr;
+    const size_t tsz = szof(p->type);
+    if (p->xsize * p->ysize <= 16) {        // tiny images are stored (reference QB3encode.cpp:490)
+        if (on_host) return stored_encode_host(p, host_src, host_dst);
+        std::vector<uint8_t> tmp((p->stride ? p->stride : p->xsize * p->nbands) * tsz * p->ysize), out(64 + raw_size(p));
+        if (!device_ok()) { p->error = QB3E_LIBERR; return 0; }
+        HIPOK(hipMemcpyAsync(tmp.data(), d_src, tmp.size(), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        size_t n = stored_encode_host(p, tmp.data(), out.data());
+        HIPOK(hipMemcpyAsync(d_dst, out.data(), n, hipMemcpyHostToDevice, st));
+        HIPOK(hipStreamSynchronize(st));
+        return n;
+    }
+    const qb3_mode mode = p->mode;
+    const bool rle = is_rle_mode(mode);
+    if (rle) p->mode = (qb3_mode)((int)mode - 2);       // RLE is a post pass over the base mode's stream
+    uint8_t hdrbuf[64];
+    const size_t hdr = write_headers(p, hdrbuf);
+    if (p->error) return 0;                               // stale error blocks the handle until reset
+    if (!device_ok()) { p->error = QB3E_LIBERR; if (rle) p->mode = mode; return 0; }
+
+    // geometry, with the narrow-image stand-in where needed
+    size_t w = p->xsize, h = p->ysize, stride = p->stride;
+    const void *img_dev = d_src;
+    std::vector<uint8_t> small;
+    const bool narrow = w < 4 || h < 4;
+    const size_t src_stride_bytes = (p->stride ? p->stride : p->xsize * p->nbands) * tsz;
+    if (narrow) {
+        std::vector<uint8_t> tmp;
+        const uint8_t *hs = (const uint8_t *)host_src;
+        if (!on_host) {
+            tmp.resize(src_stride_bytes * p->ysize);
+            HIPOK(hipMemcpyAsync(tmp.data(), d_src, tmp.size(), hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+            hs = tmp.data();
+        }
+        small = remap_small(hs, p->xsize, p->ysize, p->nbands * tsz, src_stride_bytes, w, h);
+        stride = 0;
+    }
+    if (on_host || narrow) {
+        const uint8_t *hs = narrow ? small.data() : (const uint8_t *)host_src;
+        const size_t bytes = narrow ? small.size() : src_stride_bytes * (p->ysize - 1) + p->xsize * p->nbands * tsz;
+        if (!p->d_img.ensure(bytes)) { p->error = QB3E_LIBERR; return 0; }
+        HIPOK(hipMemcpyAsync(p->d_img.p, hs, bytes, hipMemcpyHostToDevice, st));
+        img_dev = p->d_img.p;
+    }
+    Geometry g = make_geometry(w, h, p->nbands, p->type, stride, p->order, p->mode, p->cband, nullptr);
+    if (p->quanta >= 2) {
+        // quantise into a compact device copy; like the reference (QB3encode.cpp:405-455) the band state then
+        // lives on a copy of the handle and is not carried back
+        if (!p->d_q.ensure((size_t)g.w * g.h * g.bands * tsz)) { p->error = QB3E_LIBERR; return 0; }
+        if (launch_quantize(p->d_q.p, img_dev, g, (int)p->type, p->quanta, p->away, st)) { p->error = QB3E_LIBERR; return 0; }
+        img_dev = p->d_q.p;
+        g.stride = (uint64_t)g.w * g.bands;
+    }
+    const bool carry = !narrow && p->quanta < 2;
+    const size_t maxsz = qb3_max_encoded_size(p);
+    uint8_t *out_dev = (uint8_t *)d_dst;
+    if (on_host) {
+        if (!p->d_out.ensure(maxsz + 64)) { p->error = QB3E_LIBERR; return 0; }
+        out_dev = (uint8_t *)p->d_out.p;
+    }
+    // check_info (reference QB3encode.h:364-373); cband is kept in range by the setter
+    if (g.w < 4 || g.h < 4) { p->error = 1; if (rle) p->mode = mode; return 0; }
+
+    uint64_t bits = 0;
+    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, (rle ? nullptr : d_index), st, carry, &bits)) {
+        p->error = QB3E_LIBERR; if (rle) p->mode = mode; return 0;
+    }
+    p->error = 0;
+    const size_t len = hdr + (size_t)((bits + 7) / 8);
+
+    if (rle) {
+        // byte-serial post pass on the host (reference QB3encode.cpp:536-565)
+        p->mode = mode;
+        if (len <= maxsz / 2) {
+            std::vector<uint8_t> data(len - hdr);
+            HIPOK(hipMemcpyAsync(data.data(), out_dev + hdr, data.size(), hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+            const size_t rsz = rle0(data.data(), data.size(), nullptr);
+            if (rsz <= maxsz - len && rsz < data.size()) {
+                std::vector<uint8_t> packed(64 + rsz);
+                const size_t h2 = write_headers(p, packed.data());
+                rle0(data.data(), data.size(), packed.data() + h2);
+                if (on_host) memcpy(host_dst, packed.data(), h2 + rsz);
+                else { HIPOK(hipMemcpyAsync(d_dst, packed.data(), h2 + rsz, hipMemcpyHostToDevice, st)); HIPOK(hipStreamSynchronize(st)); }
+                return h2 + rsz;
+            }
+        }
+    }
+    if (raw_size(p) > len) {
+        if (on_host) {
+            memcpy(host_dst, hdrbuf, hdr);
+            HIPOK(hipMemcpyAsync((uint8_t *)host_dst + hdr, out_dev + hdr, len - hdr, hipMemcpyDeviceToHost, st));
+        } else
+            HIPOK(hipMemcpyAsync(d_dst, hdrbuf, hdr, hipMemcpyHostToDevice, st));
+        HIPOK(hipStreamSynchronize(st));
+        return len;
+    }
+    // not worth it: raw bypass (reference QB3encode.cpp:571-573)
+    if (on_host) return stored_encode_host(p, host_src, host_dst);
+    p->mode = QB3M_STORED;
+    const size_t h2 = write_headers(p, hdrbuf);
+    const size_t line = p->xsize * p->nbands * tsz;
+    HIPOK(hipMemcpyAsync(d_dst, hdrbuf, h2, hipMemcpyHostToDevice, st));
+    HIPOK(hipMemcpy2DAsync((uint8_t *)d_dst + h2, line, d_src, src_stride_bytes, line, p->ysize, hipMemcpyDeviceToDevice, st));
+    HIPOK(hipStreamSynchronize(st));
+    return h2 + raw_size(p);
+}
+
+QB3_API size_t qb3_encode(encsp p, void *source, void *destination) {
+    if (!p || !source || !destination) return 0;
+    return encode_common(p, source, destination, nullptr, nullptr, nullptr, nullptr);
+}
+
+QB3_API size_t qb3x_encode_device(encsp p, const void *d_src, void *d_dst, void *d_index, void *stream) {
+    if (!p || !d_src || !d_dst || ((uintptr_t)d_dst & 3)) { if (p) p->error = QB3E_EINV; return 0; }
+    return encode_common(p, nullptr, nullptr, d_src, d_dst, d_index, (hipStream_t)stream);
+}
+
+QB3_API size_t qb3x_index_size(const encsp p) {
+    if (!p || p->xsize < 4 || p->ysize < 4) return 0;
+    Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, p->mode, p->cband, nullptr);
+    return index_bytes(g);
+}
+
+QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t src_pitch, void *d_dst, size_t dst_pitch,
+                                 void *d_index, size_t *sizes, void *stream) {
+    if (!p || !d_src || !d_dst || !sizes || (dst_pitch & 3)) return 0;
+    const size_t isz = d_index ? qb3x_index_size(p) : 0;
+    const qb3_mode mode = p->mode;
+    size_t done = 0;
+    for (size_t i = 0; i < n; i++) {
+        qb3_reset_encoder(p);
+        p->mode = mode;
+        sizes[i] = qb3x_encode_device(p, (const uint8_t *)d_src + i * src_pitch, (uint8_t *)d_dst + i * dst_pitch,
+                                      d_index ? (uint8_t *)d_index + i * isz : nullptr, stream);
+        done += sizes[i] != 0;
+    }
+    return done;
+}
+
+// ---------------------------------------------------------------- decoder handle
+QB3_API void qb3_destroy_decoder(decsp p) {
+    if (!p) return;
+    p->d_in.release(); p->d_img.release(); p->d_ws.release();
+    delete p;
+}
+QB3_API size_t qb3_decoded_size(const decsp p) { return p->xsize * p->ysize * p->nbands * szof(p->type); }
+QB3_API qb3_dtype qb3_get_type(const decsp p) { return p->type; }
+QB3_API qb3_mode qb3_get_mode(const decsp p) { return (2 == p->stage) ? p->mode : QB3M_INVALID; }
+QB3_API uint64_t qb3_get_quanta(const decsp p) { return (2 == p->stage) ? p->quanta : 0; }
+QB3_API uint64_t qb3_get_order(const decsp p) { return (p->stage != 2) ? 0 : (p->order ? p->order : ZCURVE); }
+QB3_API bool qb3_get_coreband(const decsp p, size_t *coreband) {
+    if (p->stage != 2) return false;
+    for (size_t c = 0; c < p->nbands; c++) coreband[c] = p->cband[c];
+    return true;
+}
+QB3_API void qb3_set_decoder_stride(decsp p, size_t stride) { p->stride = stride; }
+QB3_API void qb3x_set_decoder_compat(decsp p, unsigned flags) { if (p) p->compat = flags; }
+
+// reference QB3decode.cpp:130-172
+QB3_API decsp qb3_read_start(void *source, size_t source_size, size_t *image_size) {
+    if (!source || source_size < 15 || !image_size) return nullptr;
+    const uint8_t *b = (const uint8_t *)source;
+    if (b[0] != 'Q' || b[1] != 'B' || b[2] != '3' || b[3] != 0x80) return nullptr;
+    const size_t nb = 1 + (size_t)b[8];
+    const int type = b[9], mode = b[10];
+    if (nb > QB3_MAXBANDS || (mode >= (int)QB3M_END && mode != (int)QB3M_STORED) || ((b[11] | b[12]) & 0x80) || type > (int)QB3_I64)
+        return nullptr;
+    decs *p = new decs();
+    p->xsize = 1 + (size_t)(b[4] | (b[5] << 8));
+    p->ysize = 1 + (size_t)(b[6] | (b[7] << 8));
+    p->nbands = nb; p->type = (qb3_dtype)type; p->mode = (qb3_mode)mode;
+    p->stride = 0; p->order = 0; p->quanta = 0; p->error = QB3E_OK; p->stage = 1;
+    memset(p->cband, 0, sizeof(p->cband));
+    p->s_start = (uint8_t *)source;
+    p->s_in = p->s_start + 11; p->s_size = source_size - 11;
+    p->saw_cb = false; p->compat = 0;
+    image_size[0] = p->xsize; image_size[1] = p->ysize; image_size[2] = p->nbands;
+    if (mode <= (int)QB3M_CF_RLE) p->order = ZCURVE;
+    return p;
+}
+
+static bool valid_curve(uint64_t v) {
+    unsigned mask = 0;
+    for (int i = 0; i < 16; i++, v >>= 4) mask |= 1u << (v & 15);
+    return mask == 0xffff;
+}
+
+// reference QB3decode.cpp:176-264; chunks are byte aligned, so this walks bytes
+QB3_API bool qb3_read_info(decsp p) {
+    if (p->stage != 1 || p->error || !p->s_in || p->s_size < 4) {
+        if (QB3E_OK == p->error) p->error = QB3E_EINV;
+        return false;
+    }
+    const uint8_t *s = p->s_in;
+    const size_t n = p->s_size;
+    size_t pos = 0;
+    auto rd = [&](size_t at) -> unsigned { return at < n ? s[at] : 0u; };     // reads past the end give zeros
+    do {
+        const unsigned c0 = rd(pos), c1 = rd(pos + 1), len = rd(pos + 2) | (rd(pos + 3) << 8);
+        if (c0 == 'Q' && c1 == 'V') {
+            if (len > 4 || len < 1) { p->error = QB3E_EINV; break; }
+            pos += 4;
+            uint64_t q = 0;
+            for (unsigned i = 0; i < len; i++) q |= (uint64_t)rd(pos + i) << (8 * i);
+            pos += len;
+            p->quanta = q;
+            if (p->quanta < 2) p->error = QB3E_EINV;
+        } else if (c0 == 'C' && c1 == 'B') {
+            if (len != p->nbands) { p->error = QB3E_EINV; break; }
+            pos += 4;
+            for (size_t i = 0; i < p->nbands; i++) {
+                p->cband[i] = (uint8_t)rd(pos++);
+                if (p->cband[i] >= p->nbands) p->error = QB3E_EINV;
+            }
+            p->saw_cb = true;
+        } else if (c0 == 'D' && c1 == 'T') {
+            pos += 2;
+            if (pos > n) pos = n;
+            if (p->s_size <= pos) { p->error = QB3E_EINV; break; }
+            p->s_in += pos; p->s_size -= pos; p->stage = 2;
+        } else if (c0 == 'S' && c1 == 'C') {
+            if (len != 8) { p->error = QB3E_EINV; break; }
+            if ((int)p->mode < (int)QB3M_BASE_H || p->mode == QB3M_STORED) { p->error = QB3E_EINV; break; }
+            pos += 4;
+            uint64_t o = 0;
+            for (unsigned i = 0; i < 8; i++) o |= (uint64_t)rd(pos + i) << (8 * i);
+            pos += 8;
+            p->order = o;
+            if (!valid_curve(o)) { p->error = QB3E_EINV; break; }
+        } else {
+            // the reference skips an ignorable (lower case) chunk by `len` bytes from the chunk start
+            // (QB3decode.cpp:254-255); a zero length would never terminate there, treat it as an error
+            if ((c0 & 0x20) && len) pos += len;
+            else p->error = QB3E_UNKN;
+        }
+        if (pos > n) pos = n;
+    } while (p->stage != 2 && QB3E_OK == p->error && pos < n);
+    if (QB3E_OK == p->error && 2 != p->stage) p->error = QB3E_EINV;
+    return QB3E_OK == p->error;
+}
+
+QB3_API size_t qb3x_decoder_index_size(const decsp p) {
+    if (!p || p->stage != 2 || p->xsize < 4 || p->ysize < 4) return 0;
+    Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, 0, p->order, p->mode, nullptr, p->cband);
+    return index_bytes(g);
+}
+
+#undef HIPOK
+#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(#x, (int)e_); p->error = QB3E_LIBERR; return 0; } } while (0)
+
+// Decode the block stream at d_stream (+ byte offset off inside a 4-byte aligned device buffer) into d_img.
+static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_buf, size_t off, size_t nbytes,
+                                 void *d_img, const void *d_index, hipStream_t st) {
+    DecPlan plan = plan_decode(g);
+    if (!p->d_ws.ensure(plan.ws_bytes)) return false;
+    uint32_t *d_status = nullptr;
+    const uint32_t *in32 = (const uint32_t *)(d_buf + (off & ~(size_t)3));
+    if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st))
+        return false;
+    uint32_t status = 0;
+    hipError_t e = hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("decode kernels", (int)e); return false; }
+    // bit 0: corrupt unit, bit 1: more than 7 unused bits at the end (reference QB3decode.h:411,569,740).
+    // bit 2 (ran past the end) is not an error in the reference, whose reader clamps (bitstream.h:36).
+    if (status & 3) { set_error("decode: corrupt or over-long stream", 0); p->error = QB3E_ERR; return false; }
+    return true;
+}
+
+static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_dst, const void *d_index, hipStream_t st) {
+    if (p->stage != 2 || p->error != QB3E_OK || p->s_in == nullptr || p->s_size == 0) {
+        if (p->error == QB3E_OK) p->error = QB3E_EINV;
+        return 0;
+    }
+    const bool on_host = host_dst != nullptr;
+    const size_t tsz = szof(p->type), line = p->xsize * p->nbands * tsz, total = qb3_decoded_size(p);
+    const size_t data_off = (size_t)(p->s_in - p->s_start);
+    const size_t dst_stride = (p->stride ? p->stride : p->xsize * p->nbands) * tsz;
+    if (p->mode == QB3M_STORED) {           // reference QB3decode.cpp:356-375
+        if (p->s_size != total) { p->error = QB3E_EINV; return 0; }
+        if (on_host) {
+            if (!p->stride) memcpy(host_dst, p->s_in, total);
+            else for (size_t y = 0; y < p->ysize; y++) memcpy((uint8_t *)host_dst + y * p->stride, p->s_in + y * line, line);
+        } else {
+            HIPOK(hipMemcpy2DAsync(d_dst, dst_stride, (const uint8_t *)d_src + data_off, line, line, p->ysize, hipMemcpyDeviceToDevice, st));
+            HIPOK(hipStreamSynchronize(st));
+        }
+        return total;
+    }
+    if (p->xsize * p->ysize < 16) { p->error = QB3E_EINV; return 0; }
+    if (!device_ok()) { p->error = QB3E_LIBERR; return 0; }
+
+    // locate the block stream on the device
+    const uint8_t *dev_buf = nullptr;
+    size_t off = 0, nbytes = p->s_size;
+    std::vector<uint8_t> unrle;
+    const bool rle = is_rle_mode(p->mode);
+    if (rle) {                               // byte-serial expansion on the host (reference QB3decode.cpp:396-413)
+        std::vector<uint8_t> packed;
+        const uint8_t *src = p->s_in;
+        if (!on_host) {
+            packed.resize(p->s_size);
+            HIPOK(hipMemcpyAsync(packed.data(), (const uint8_t *)d_src + data_off, p->s_size, hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+            src = packed.data();
+        }
+        const size_t sz = derle0_size(src, p->s_size);
+        if (sz > total) { p->error = QB3E_ERR; return 0; }
+        unrle.resize(sz ? sz : 1);
+        if (derle0(src, p->s_size, unrle.data(), sz)) { p->error = QB3E_EINV; return 0; }
+        nbytes = sz;
+    }
+    if (on_host || rle) {
+        const uint8_t *src = rle ? unrle.data() : p->s_in;
+        if (!p->d_in.ensure(nbytes + 8)) { p->error = QB3E_LIBERR; return 0; }
+        HIPOK(hipMemcpyAsync(p->d_in.p, src, nbytes, hipMemcpyHostToDevice, st));
+        dev_buf = (const uint8_t *)p->d_in.p; off = 0;
+    } else { dev_buf = (const uint8_t *)d_src; off = data_off; }
+
+    // geometry, narrow images decode into their stand-in shape (reference QB3decode.cpp:321-353)
+    size_t w = p->xsize, h = p->ysize;
+    const bool narrow = w < 4 || h < 4;
+    if (narrow) {
+        const size_t ngroups = (w * h + 15) / 16;
+        if (p->xsize < 4) { w = 4; h = ngroups * 4; } else { w = ngroups * 4; h = 4; }
+    }
+    uint8_t cband[QB3_MAXBANDS];
+    for (size_t c = 0; c < QB3_MAXBANDS; c++) cband[c] = p->cband[c];
+    // no CB chunk means identity; the reference leaves the map zero filled instead
+    if (!p->saw_cb && !(p->compat & QB3X_REF_CBAND0)) for (size_t c = 0; c < p->nbands; c++) cband[c] = (uint8_t)c;
+    const bool direct = !on_host && !narrow;        // decode straight into the caller's device buffer
+    Geometry g = make_geometry(w, h, p->nbands, p->type, direct ? p->stride : 0, p->order, p->mode, nullptr, cband);
+    void *img_dev = d_dst;
+    if (!direct) {
+        if (!p->d_img.ensure((size_t)g.w * g.h * g.bands * tsz)) { p->error = QB3E_LIBERR; return 0; }
+        img_dev = p->d_img.p;
+    }
+    if (!decode_blocks_device(p, g, dev_buf, off, nbytes, img_dev, rle ? nullptr : d_index, st)) {
+        if (p->error == QB3E_OK) p->error = QB3E_LIBERR;
+        return 0;
+    }
+    if (p->quanta > 1 && launch_dequantize(img_dev, g, (int)p->type, p->quanta, st)) { p->error = QB3E_LIBERR; return 0; }
+
+    if (narrow) {
+        std::vector<uint8_t> t((size_t)g.w * g.h * g.bands * tsz);
+        HIPOK(hipMemcpyAsync(t.data(), img_dev, t.size(), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        std::vector<uint8_t> outimg;
+        uint8_t *dst = (uint8_t *)host_dst;
+        if (!on_host) { outimg.resize(dst_stride * p->ysize); dst = outimg.data(); }
+        const size_t pix = p->nbands * tsz;
+        const uint8_t *s = t.data();
+        if (p->xsize < 4) for (size_t y = 0; y < p->ysize; y++, s += p->xsize * pix) memcpy(dst + y * dst_stride, s, p->xsize * pix);
+        else for (size_t x = 0; x < p->xsize; x++) for (size_t y = 0; y < p->ysize; y++, s += pix) memcpy(dst + y * dst_stride + x * pix, s, pix);
+        if (!on_host) { HIPOK(hipMemcpyAsync(d_dst, dst, outimg.size(), hipMemcpyHostToDevice, st)); HIPOK(hipStreamSynchronize(st)); }
+        return total;
+    }
+    if (on_host) {
+        HIPOK(hipMemcpy2DAsync(host_dst, dst_stride, img_dev, line, line, p->ysize, hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+    }
+    return total;
+}
+
+QB3_API size_t qb3_read_data(decsp p, void *dst) {
+    if (!p || !dst) return 0;
+    return decode_common(p, dst, nullptr, nullptr, nullptr, nullptr);
+}
+
+QB3_API size_t qb3x_decode_device(decsp p, const void *d_src, void *d_dst, const void *d_index, void *stream) {
+    if (!p || !d_src || !d_dst || ((uintptr_t)d_src & 3)) { if (p) p->error = QB3E_EINV; return 0; }
+    return decode_common(p, nullptr, d_src, d_dst, d_index, (hipStream_t)stream);
+}
+
+QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
+                                 void *d_dst, size_t dst_pitch, const void *d_index, void *stream) {
+    if (!p || !d_src || !d_dst || !sizes || (src_pitch & 3)) return 0;
+    const size_t isz = d_index ? qb3x_decoder_index_size(p) : 0;
+    const size_t hdr = (size_t)(p->s_in - p->s_start);
+    uint8_t *const s_in = p->s_in;
+    size_t done = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (sizes[i] <= hdr) continue;
+        p->s_size = sizes[i] - hdr; p->s_in = s_in; p->error = QB3E_OK;
+        done += 0 != qb3x_decode_device(p, (const uint8_t *)d_src + i * src_pitch, (uint8_t *)d_dst + i * dst_pitch,
+                                        d_index ? (const uint8_t *)d_index + i * isz : nullptr, stream);
+    }
+    return done;
+}
+
+// ---------------------------------------------------------------- misc
+QB3_API int qb3x_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+QB3_API const char *qb3x_last_error(void) { return last_error(); }
+
+QB3_API decsp qb3_create_decoder(void *source, size_t source_size, size_t *image_size) {
+    decsp p = qb3_read_start(source, source_size, image_size);
+    if (p && !qb3_read_info(p)) { qb3_destroy_decoder(p); p = nullptr; }
+    return p;
+}
+QB3_API size_t qb3_decode(decsp p, void *destination) { return qb3_read_data(p, destination); }

@@ -1,0 +1,98 @@
+// qb3_amd/csrc/qb3_dev.h -- internal interface between the host API (qb3_api.cpp) and the HIP kernels
+// (qb3_kernels.hip).  Nothing here is exported from the shared library.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace qb3dev {
+
+constexpr int MAXBANDS = 16;
+constexpr uint64_t ZCURVE = 0x0145236789cdabefull;   // reference QB3common.h:185
+constexpr uint64_t HILBERT = 0x01548cd9aefb7623ull;  // reference QB3common.h:193
+
+enum CodecMode { CM_FTL = 0, CM_BASE = 1, CM_BEST = 2 };   // no step / step / step + common factor + index
+
+// Image geometry and coding parameters shared by encode and decode.
+struct Geometry {
+    uint32_t w, h, bands, tsz;      // tsz = bytes per value (1,2,4,8)
+    uint64_t stride;                // line stride in values
+    uint64_t order;                 // curve nibbles, never 0 here
+    uint32_t nbx, nby;              // blocks per row / column (ceil)
+    uint64_t nblocks;
+    uint32_t mode;                  // CodecMode
+    uint32_t seg_blocks;            // blocks per index segment
+    uint64_t nseg;                  // number of index segments
+    uint8_t cband[MAXBANDS];
+};
+
+// Per-band coder state, the reference's band_state (QB3common.h:63-65)
+struct BandState {
+    uint64_t prev[MAXBANDS];
+    uint64_t cf[MAXBANDS];
+    uint8_t rung[MAXBANDS];
+};
+
+// Decode index, device resident.  Layout in one allocation of index_bytes(g):
+//   u64 bitpos[nseg]; T prev[nseg*bands]; T cf[nseg*bands]; u8 rung[nseg*bands]  (each 8-byte aligned)
+struct IndexView {
+    uint64_t *bitpos;
+    void *prev;
+    void *cf;
+    uint8_t *rung;
+};
+size_t index_bytes(const Geometry &g);
+IndexView index_view(const Geometry &g, void *base);
+uint32_t seg_blocks_for(uint32_t bands, uint32_t tsz);
+
+// Results the encoder hands back to the host (device resident, copied once per encode)
+struct EncResult {
+    uint64_t total_bits;
+    uint64_t prev[MAXBANDS];
+    uint64_t cf[MAXBANDS];
+    uint32_t rung[MAXBANDS];
+};
+
+// Workspace sizes
+struct EncPlan {
+    uint32_t threads;       // workgroup size = units per chunk (incl. halo units)
+    uint32_t slots;         // block slots per chunk, slot 0 is the halo block
+    uint32_t nchunks;
+    size_t lds_bytes;
+    size_t ws_bytes;        // chunk_bits (u32) + chunk_off (u64) + EncResult
+};
+EncPlan plan_encode(const Geometry &g);
+
+// Encode the block stream of one image.  All pointers are device pointers.
+//   img        image, g.tsz-byte values
+//   out32      4-byte aligned address at or below the first stream byte
+//   out_bit0   bit offset of the first stream bit relative to out32 (multiple of 8, < 32)
+//   st_in      initial band state (host copy, passed by value to the kernels)
+//   ws         workspace of plan.ws_bytes; the EncResult is its LAST sizeof(EncResult) bytes
+//   index      optional decode index (nullptr = none)
+// Launches on `stream`, does not synchronise.  Returns hipError_t as int.
+int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
+                  const BandState &st_in, void *ws, void *index, void *stream);
+
+struct DecPlan {
+    uint32_t threads;       // lanes per workgroup, one index segment per lane
+    uint32_t nwg;
+    size_t lds_bytes;
+    size_t ws_bytes;        // scratch for the foreign-stream path: rebuilt index + status word
+};
+DecPlan plan_decode(const Geometry &g);
+
+// Decode a block stream.  in32/in_bit0 locate the first stream bit like out32/out_bit0 above; in_bits is
+// the stream length in bits (bytes*8).  index == nullptr: the index is first rebuilt in ws by a serial
+// boundary scan on the GPU.  status (device u32 inside ws, zeroed here) gets nonzero on decode failure.
+// Returns hipError_t as int; does not synchronise.
+int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
+                  void *img, const void *index, void *ws, uint32_t **status_out, void *stream);
+
+// Elementwise helpers on device buffers (quantisation, reference QB3encode.cpp:137-186 / QB3decode.cpp:77-107)
+int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, uint64_t q, bool away, void *stream);
+int launch_dequantize(void *img, const Geometry &g, int dtype, uint64_t q, void *stream);
+
+const char *last_error();
+void set_error(const char *what, int hip_err);
+
+}  // namespace qb3dev

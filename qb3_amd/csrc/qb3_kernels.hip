@@ -1,0 +1,880 @@
+// qb3_amd/csrc/qb3_kernels.hip -- HIP kernels of the MI355X-native QB3 block codec (gfx950, wave64).
+//
+// What is computed is the reference's per-band 4x4 micro-block code (reference QB3lib/QB3encode.h:155-280,
+// 376-451; QB3decode.h:142-412) -- bit-identical streams -- but organised for the GPU:
+//
+// ENCODE (thread per UNIT = one block of one band; a workgroup owns a CHUNK of consecutive blocks)
+//   * the running predictor of the reference (`prv += g -= prv`, QB3encode.h:434) makes the value entering a
+//     unit simply the last pixel the curve visited in the previous block, and the rung-switch code needs only
+//     the previous block's rung.  So a chunk is self-contained once it also loads ONE halo block (slot 0).
+//   * the 4-row tile of the chunk is staged in LDS with coalesced dword loads; each lane gathers its 16 values
+//     in curve order, band-differences, deltas, mag-sign, ORs -> rung.
+//   * per-unit bit lengths -> workgroup exclusive scan -> bit offsets inside the chunk.
+//   * pass 1 (enc_kernel<EMIT=false>) only publishes the chunk's bit total; a single-workgroup scan turns the
+//     totals into global bit offsets (64-bit: a 16384^2x3 stream exceeds 2^32 bits); pass 2 rebuilds the codes,
+//     ORs them into an LDS staging buffer (ds_or_b32) and stores whole dwords coalesced; the partial dwords
+//     at chunk seams are merged with global atomicOr into dwords the scan kernel zeroed.
+//   * pass 2 also samples the coder state every `seg_blocks` blocks into the out-of-band decode index.
+//
+// DECODE (lane per SEGMENT of the index; sequential inside a segment like the reference, parallel across)
+//   * a lane owns a private bit reader over aligned dword loads, decodes its blocks band by band into a small
+//     LDS scratch block, adds the core band back and stores the 4 rows.
+//   * a foreign stream (no index) first goes through dec_index_serial: ONE lane walks the whole stream and
+//     rebuilds the index.  That pass is inherently serial (QB3decode.h:445-454) and latency bound.
+//
+// No MFMA anywhere: this is integer bit packing, bounded by VALU/LDS issue and, ultimately, HBM.
+#include <hip/hip_runtime.h>
+#include "qb3_dev.h"
+
+namespace qb3dev {
+
+// ------------------------------------------------------------------ small helpers
+template <typename T> struct UBits { static constexpr uint32_t v = sizeof(T) == 1 ? 3 : sizeof(T) == 2 ? 4 : sizeof(T) == 4 ? 5 : 6; };
+
+template <typename T> __device__ __forceinline__ T mags_t(T v) {       // reference QB3common.h:127-130
+    constexpr uint32_t B = 8 * sizeof(T);
+    return (T)((T)(v << 1) ^ (T)(0 - (T)(v >> (B - 1))));
+}
+template <typename T> __device__ __forceinline__ T smag_t(T v) {       // reference QB3common.h:133-136
+    return (T)((T)(v >> 1) ^ (T)(0 - (T)(v & 1)));
+}
+__device__ __forceinline__ uint32_t topbit64(uint64_t v) { return 63u - (uint32_t)__clzll((long long)v); }
+__device__ __forceinline__ uint32_t topbit32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
+template <typename T> __device__ __forceinline__ uint32_t topbit_t(T v) {
+    if (sizeof(T) == 8) return topbit64((uint64_t)v | 1);
+    return topbit32((uint32_t)v | 1);
+}
+
+// n / d for small n with magic = ceil(2^32 / d); d == 1 has no 32-bit magic
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t d, uint32_t magic) { return d == 1 ? n : __umulhi(n, magic); }
+
+// curve nibble i (0 = first visited): x = nib & 3, y = nib >> 2 (reference QB3common.h:168-193)
+__device__ __forceinline__ uint32_t curve_nib(uint64_t order, uint32_t i) { return (uint32_t)(order >> (60 - 4 * i)) & 15u; }
+
+// length (incl. change flag) of the rung-switch code for delta in [0, 2^UB)  (reference QB3encode.h:79-89)
+template <uint32_t UB> __device__ __forceinline__ uint32_t cs_len(uint32_t delta) {
+    constexpr uint32_t n = 1u << UB;
+    if (delta == 0) return 1;
+    const uint32_t m = (delta < n / 2) ? 2 * (delta - 1) : 2 * (n - delta) - 1;
+    return UB + (m >= (1u << (UB - 2))) + (m >= (1u << (UB - 1)));   // 1 flag + (UB-1) + extra bits
+}
+// the code itself, flag in bit 0
+template <uint32_t UB> __device__ __forceinline__ uint32_t cs_code(uint32_t delta) {
+    constexpr uint32_t n = 1u << UB, r = UB - 1, half = 1u << (r - 1), top = 1u << r;
+    if (delta == 0) return 0;
+    const uint32_t m = (delta < n / 2) ? 2 * (delta - 1) : 2 * (n - delta) - 1;
+    uint32_t c = (m < half) ? (m << 1) : (m < top) ? (((m - half) << 2) | 1) : (((m - top) << 2) | 3);
+    return (c << 1) | 1;
+}
+
+// workgroup exclusive scan of one u32 per thread (blockDim.x multiple of 64, <= 1024); *total = sum
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t i = 0; i < nw; i++) {
+        uint32_t s = wsum[i];
+        if (i < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();    // wsum may be reused
+    *total = tot;
+    return base + x - v;
+}
+
+// ------------------------------------------------------------------ encode
+struct EncArgs {
+    Geometry g;
+    const void *img;
+    uint32_t *out32;
+    uint32_t out_bit0;
+    uint32_t slots, nchunks, dpr, magic_dpr, magic_bands;
+    uint32_t *chunk_bits;
+    uint64_t *chunk_off;
+    EncResult *res;
+    BandState st;
+    IndexView idx;
+    uint32_t have_idx;
+};
+
+// LSB-first bit writer into a zeroed LDS dword buffer shared by the workgroup
+struct LdsWriter {
+    uint32_t *buf;
+    uint64_t acc;
+    uint32_t n, w;
+    __device__ __forceinline__ void init(uint32_t *b, uint32_t bitpos) { buf = b; acc = 0; n = bitpos & 31; w = bitpos >> 5; }
+    __device__ __forceinline__ void put(uint32_t code, uint32_t len) {     // len <= 32, code < 2^len
+        acc |= (uint64_t)code << n;
+        n += len;
+        if (n >= 32) { atomicOr(&buf[w], (uint32_t)acc); w++; acc >>= 32; n -= 32; }
+    }
+    __device__ __forceinline__ void put64(uint64_t code, uint32_t len) {   // len <= 64
+        const uint32_t l0 = len < 32 ? len : 32;
+        put((uint32_t)code, l0);
+        if (len > 32) put((uint32_t)(code >> 32), len - 32);
+    }
+    __device__ __forceinline__ void finish() { if (n) atomicOr(&buf[w], (uint32_t)acc); }
+};
+
+// one value code at rung r >= 1 (three-length code, reference QB3encode.h:132-141); v already swapped
+template <typename T> __device__ __forceinline__ void put_value(LdsWriter &w, T v, uint32_t r) {
+    if (sizeof(T) <= 2) {
+        const uint32_t x = (uint32_t)v, half = 1u << (r - 1), top = 1u << r;
+        const uint32_t code = (x < half) ? (x << 1) : (x < top) ? (((x - half) << 2) | 1) : (((x - top) << 2) | 3);
+        const uint32_t len = r + (x >= half) + (x >= top);
+        w.put(code, len);
+    } else {
+        const uint64_t x = (uint64_t)v, half = 1ull << (r - 1), top = 1ull << r;
+        if (x < half) w.put64(x << 1, r);
+        else if (x < top) w.put64(((x - half) << 2) | 1, r + 1);
+        else {
+            const uint64_t pay = x - top;           // < 2^r
+            w.put(3, 2);
+            w.put64(pay, r);                         // r <= 63; at r == 63 this is the reference's 64+1 bit split
+        }
+    }
+}
+
+template <typename T, bool STEP, bool EMIT>
+__global__ void enc_kernel(const EncArgs a) {
+    constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t bands = a.g.bands, slots = a.slots, dpr = a.dpr, nbp = slots - 1;
+    const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
+    const uint64_t stride = a.g.stride;
+    const uint32_t g0 = blockIdx.x * nbp;                 // first payload block of this chunk
+    const uint32_t rowdw = slots * dpr;
+
+    // LDS carve (all offsets multiples of 8)
+    uint64_t *slot_base = (uint64_t *)smem;
+    uint32_t *tile = (uint32_t *)(slot_base + slots);
+    uint32_t *wsum = tile + 4 * rowdw;                     // 16 dwords
+    uint8_t *rungs = (uint8_t *)(wsum + 16);               // slots*bands bytes, padded to 8
+    uint32_t *outbuf = (uint32_t *)(rungs + ((slots * bands + 7) & ~7u));
+
+    // block index of slot s is g0 - 1 + s; invalid slots are clamped to a valid block so loads stay in bounds
+    auto slot_block = [&](uint32_t s, bool &valid) -> uint32_t {
+        const int64_t g = (int64_t)g0 - 1 + s;
+        valid = g >= 0 && g < (int64_t)nblocks;
+        return g < 0 ? 0u : (g >= (int64_t)nblocks ? nblocks - 1 : (uint32_t)g);
+    };
+    auto block_origin = [&](uint32_t g, uint32_t &x0, uint32_t &y0) {
+        const uint32_t by = g / nbx, bx = g - by * nbx;
+        x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;     // last column / row is shifted, not padded
+        y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;     // (reference QB3encode.h:410-416)
+    };
+
+    if (tid < slots) {
+        bool valid; uint32_t x0, y0;
+        block_origin(slot_block(tid, valid), x0, y0);
+        slot_base[tid] = (uint64_t)y0 * stride + (uint64_t)x0 * bands;
+    }
+    if (EMIT) {
+        const uint32_t outdw = (31 + nbp * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1;
+        for (uint32_t i = tid; i < outdw; i += nthr) outbuf[i] = 0;
+    }
+    __syncthreads();
+
+    // ---- stage the 4-row tile: coalesced dword loads, [row][slot][pixel][band] as in memory
+    const uint8_t *imgb = (const uint8_t *)a.img;
+    for (uint32_t r = 0; r < 4; r++)
+        for (uint32_t j = tid; j < rowdw; j += nthr) {
+            const uint32_t s = fastdiv(j, dpr, a.magic_dpr), d = j - s * dpr;
+            const uint8_t *p = imgb + (slot_base[s] + (uint64_t)r * stride) * sizeof(T) + 4 * d;
+            uint32_t v;
+            if (((uintptr_t)p & 3) == 0) v = *(const uint32_t *)p;
+            else v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+            tile[r * rowdw + j] = v;
+        }
+    __syncthreads();
+
+    // ---- per unit: gather in curve order, band difference, delta, mag-sign, rung
+    const uint32_t s = fastdiv(tid, bands, a.magic_bands), c = tid - s * bands;
+    bool valid = false;
+    uint32_t gblk = 0;
+    if (s < slots) gblk = slot_block(s, valid);
+    const bool payload = valid && s >= 1;
+    const uint32_t cb = a.g.cband[c < MAXBANDS ? c : 0];
+    const T *tt = (const T *)tile;
+    const uint64_t order = a.g.order;
+    T g[16];
+    T used = 0, pv = 0, lastv = 0;
+    uint32_t rung = 0;
+    if (valid) {
+        // value entering the unit: last visited pixel of the previous block, or the carried state
+        const uint32_t n15 = curve_nib(order, 15);
+        if (gblk == 0) pv = (T)a.st.prev[c];
+        else if (s >= 1) {
+            const uint32_t e = (((n15 >> 2) * slots + (s - 1)) * 4 + (n15 & 3)) * bands;
+            pv = tt[e + c];
+            if (cb != c) pv = (T)(pv - tt[e + cb]);
+        } else {            // halo unit: its predecessor block is not in the tile
+            uint32_t x0, y0;
+            block_origin(gblk - 1, x0, y0);
+            const T *ip = (const T *)a.img + (uint64_t)(y0 + (n15 >> 2)) * stride + (uint64_t)(x0 + (n15 & 3)) * bands;
+            pv = ip[c];
+            if (cb != c) pv = (T)(pv - ip[cb]);
+        }
+        T prv = pv;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t nib = curve_nib(order, i);
+            const uint32_t e = (((nib >> 2) * slots + s) * 4 + (nib & 3)) * bands;
+            T v = tt[e + c];
+            if (cb != c) v = (T)(v - tt[e + cb]);
+            g[i] = mags_t<T>((T)(v - prv));
+            used |= g[i];
+            prv = v;
+        }
+        lastv = prv;
+        rung = topbit_t<T>(used);
+        rungs[tid] = (uint8_t)rung;
+    }
+    __syncthreads();
+
+    uint32_t len = 0, prung = 0, delta = 0;
+    if (payload) {
+        prung = (gblk == 0) ? a.st.rung[c] : rungs[tid - bands];
+        delta = (rung - prung) & UMASK;
+        len = cs_len<UB>(delta);
+        if (used <= 1) len += 1 + (used ? 16 : 0);
+        else {
+            const T top = (T)((T)1 << rung);
+            if (STEP) {     // clear the rung bit of the last value of a 1..10..0 rung-bit run (reference QB3encode.h:169-176)
+                uint32_t bits = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)((g[i] >> rung) & 1) << i;
+                if ((bits & (bits + 1)) == 0) {
+                    const uint32_t n = __popc(bits);    // >= 1 here
+#pragma unroll
+                    for (uint32_t i = 0; i < 16; i++) if (i + 1 == n) g[i] ^= top;
+                }
+            }
+            uint32_t extra = 0;
+            const T half = (T)(top >> 1);
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) {
+                T v = g[i];
+                if (rung < 8 && (v == top || v == (T)(top - 1))) v ^= (T)(2 * top - 1);   // middle swap (QB3encode.h:30-33)
+                g[i] = v;
+                extra += (v >= half) + (v >= top);
+            }
+            len += 16 * rung + extra;
+        }
+    }
+    uint32_t total;
+    const uint32_t pos = block_exscan(len, wsum, &total);
+
+    if (!EMIT) {
+        if (tid == 0) a.chunk_bits[blockIdx.x] = total;
+        return;
+    }
+
+    const uint64_t coff = a.chunk_off[blockIdx.x];         // bits from the stream start
+    const uint64_t G = (uint64_t)a.out_bit0 + coff;
+    const uint32_t phase = (uint32_t)(G & 31);
+    if (payload) {
+        LdsWriter w;
+        w.init(outbuf, phase + pos);
+        w.put(cs_code<UB>(delta), cs_len<UB>(delta));
+        if (used <= 1) {
+            w.put((uint32_t)used, 1);
+            if (used) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)(g[i] & 1) << i;
+                w.put(bits, 16);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) put_value<T>(w, g[i], rung);
+        }
+        w.finish();
+        // coder state on leaving the image, for handle statefulness (reference QB3encode.h:446-449)
+        if (gblk == nblocks - 1) { a.res->prev[c] = (uint64_t)lastv; a.res->rung[c] = rung; a.res->cf[c] = a.st.cf[c]; }
+        if (a.have_idx) {
+            const uint32_t seg = gblk / a.g.seg_blocks;
+            if (seg * a.g.seg_blocks == gblk) {
+                ((T *)a.idx.prev)[(uint64_t)seg * bands + c] = pv;
+                a.idx.rung[(uint64_t)seg * bands + c] = (uint8_t)prung;
+                if (c == 0) a.idx.bitpos[seg] = coff + pos;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- store the chunk: whole dwords plain, the (at most two) seam dwords with atomicOr into zeroed memory
+    const uint32_t nd = (phase + total + 31) >> 5;
+    const uint32_t tailbits = (phase + total) & 31;
+    uint32_t *gout = a.out32 + (G >> 5);
+    for (uint32_t d = tid; d < nd; d += nthr) {
+        const uint32_t v = outbuf[d];
+        const bool seam = (d == 0 && phase) || (d == nd - 1 && tailbits);
+        if (seam) { if (v) atomicOr(&gout[d], v); }
+        else gout[d] = v;
+    }
+}
+
+// Single workgroup: exclusive scan of the chunk totals (4 per thread per round), zero the seam dwords,
+// publish the stream length.
+__global__ void enc_scan_kernel(const EncArgs a) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint64_t carry_s;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < a.nchunks; base += 4 * blockDim.x) {
+        const uint32_t i0 = base + 4 * tid;
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = (i0 + k < a.nchunks) ? a.chunk_bits[i0 + k] : 0; sum += v[k]; }
+        uint32_t total;
+        const uint32_t ex = block_exscan(sum, wsum, &total);
+        uint64_t off = carry_s + ex;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i0 + k < a.nchunks) {
+            a.chunk_off[i0 + k] = off;
+            const uint64_t G = a.out_bit0 + off;
+            if (G & 31) a.out32[G >> 5] = 0;
+            off += v[k];
+        }
+        __syncthreads();
+        if (tid == 0) carry_s += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint64_t G = a.out_bit0 + carry_s;
+        if (G & 31) a.out32[G >> 5] = 0;
+        a.res->total_bits = carry_s;
+    }
+}
+
+// ------------------------------------------------------------------ decode
+struct DecArgs {
+    Geometry g;
+    const uint32_t *in32;
+    uint32_t in_bit0;
+    uint64_t in_bits;           // stream length in bits
+    void *img;
+    IndexView idx;
+    uint32_t *status;
+    uint32_t lane_dw;           // LDS dwords per lane (odd)
+    uint32_t dpr;
+};
+
+// LSB-first bit reader over aligned dword loads; reads past the stream end return zeros, like the
+// reference's iBits::peek (bitstream.h:39-50)
+struct Reader {
+    const uint32_t *in;
+    uint64_t buf, wp, endw;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t load(uint64_t i) const { return i < endw ? in[i] : 0u; }
+    __device__ __forceinline__ void init(const uint32_t *p, uint64_t bitpos, uint64_t endbit) {
+        in = p; endw = (endbit + 31) >> 5; wp = bitpos >> 5;
+        const uint32_t sh = (uint32_t)(bitpos & 31);
+        buf = (uint64_t)(load(wp++) >> sh); n = 32 - sh;
+    }
+    __device__ __forceinline__ void ensure(uint32_t k) {    // k <= 32
+        if (n < k) { buf |= (uint64_t)load(wp++) << n; n += 32; }
+    }
+    __device__ __forceinline__ void skip(uint32_t k) { buf >>= k; n -= k; }
+    __device__ __forceinline__ uint32_t get(uint32_t k) {   // k <= 32
+        if (k == 0) return 0;
+        ensure(k);
+        const uint32_t v = (uint32_t)(buf & (0xffffffffull >> (32 - k)));
+        skip(k);
+        return v;
+    }
+    __device__ __forceinline__ uint64_t get64(uint32_t k) { // k <= 64
+        const uint64_t lo = get(k < 32 ? k : 32);
+        return k > 32 ? lo | ((uint64_t)get(k - 32) << 32) : lo;
+    }
+    __device__ __forceinline__ uint64_t position() const { return wp * 32 - n; }   // bits consumed, from `in`
+};
+
+// one value at rung r >= 1, not yet unswapped (reference QB3decode.h:119-129)
+template <typename T> __device__ __forceinline__ T get_value(Reader &rd, uint32_t r) {
+    if (sizeof(T) <= 2) {       // r + 2 <= 17 bits
+        rd.ensure(r + 2);
+        const uint32_t x = (uint32_t)rd.buf, half = 1u << (r - 1), top = 1u << r;
+        uint32_t v, len;
+        if (!(x & 1)) { v = (x & (top - 1)) >> 1; len = r; }
+        else if (!(x & 2)) { v = ((x >> 2) & (half - 1)) | half; len = r + 1; }
+        else { v = ((x >> 2) & (top - 1)) | top; len = r + 2; }
+        rd.skip(len);
+        return (T)v;
+    } else {
+        rd.ensure(2);
+        const uint32_t x = (uint32_t)rd.buf;
+        if (!(x & 1)) { rd.skip(1); return (T)rd.get64(r - 1); }
+        rd.skip(2);
+        if (!(x & 2)) return (T)(rd.get64(r - 1) | (1ull << (r - 1)));
+        return (T)(rd.get64(r) | (1ull << r));
+    }
+}
+template <typename T> __device__ __forceinline__ T unswap(T v, uint32_t r) {
+    const T top = (T)((T)1 << r);
+    return (r < 8 && (v == top || v == (T)(top - 1))) ? (T)(v ^ (T)(2 * top - 1)) : v;
+}
+
+// rung switch: returns delta in [0, 2^UB), sets signal when the unused code is met (reference QB3decode.h:97-116)
+template <uint32_t UB> __device__ __forceinline__ uint32_t get_switch_noflag(Reader &rd, bool &signal) {
+    constexpr uint32_t n = 1u << UB, r = UB - 1, half = 1u << (r - 1), top = 1u << r;
+    rd.ensure(r + 2);
+    const uint32_t x = (uint32_t)rd.buf;
+    uint32_t m, len;
+    if (!(x & 1)) { m = (x & (top - 1)) >> 1; len = r; }
+    else if (!(x & 2)) { m = ((x >> 2) & (half - 1)) | half; len = r + 1; }
+    else { m = ((x >> 2) & (top - 1)) | top; len = r + 2; }
+    rd.skip(len);
+    signal = (m == n - 2);
+    if (signal) return 0;
+    return (m & 1) ? (n - (m + 1) / 2) & (n - 1) : m / 2 + 1;
+}
+
+template <typename T> __device__ __forceinline__ T mabs_t(T v) { return (T)((v >> 1) + (v & 1)); }
+template <typename T> __device__ __forceinline__ T mmul_t(T v, T m) { return (T)((T)(mabs_t<T>(v) * (T)(m << 1)) - (T)(v & 1)); }
+
+// 16 values at `rung` into g (mag-sign), with the step undone when STEP (reference QB3decode.h:142-290)
+template <typename T, bool STEP> __device__ __forceinline__ void get_group(Reader &rd, uint32_t rung, T (&g)[16]) {
+    if (rung == 0) {
+        const uint32_t bits = rd.get(1) ? rd.get(16) : 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) g[i] = (T)((bits >> i) & 1);
+        return;
+    }
+    uint32_t rb = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+        g[i] = unswap<T>(get_value<T>(rd, rung), rung);
+        rb |= (uint32_t)((g[i] >> rung) & 1) << i;
+    }
+    if (STEP && (rb & (rb + 1)) == 0) {
+        const uint32_t m = __popc(rb);
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) if (i == m) g[i] ^= (T)((T)1 << rung);
+    }
+}
+
+// Parse one unit.  rung / pcf are the running state of this band.  Returns false on a corrupt stream.
+// MODE: CM_FTL (no step, signal is an ordinary "no change"), CM_BASE / CM_BEST (step; signal opens the
+// common-factor and index forms, reference QB3decode.h:619-716).
+template <typename T, int MODE> __device__ __forceinline__ bool parse_unit(Reader &rd, uint32_t &rung, T &pcf, T (&g)[16]) {
+    constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
+    bool signal = false;
+    uint32_t delta = 0;
+    if (rd.get(1)) delta = get_switch_noflag<UB>(rd, signal);
+    if (MODE == CM_FTL || !signal) {
+        rung = (rung + delta) & UMASK;
+        get_group<T, MODE != CM_FTL>(rd, rung, g);
+        return true;
+    }
+    bool sig2;
+    uint32_t r = (rung + get_switch_noflag<UB>(rd, sig2)) & UMASK;
+    if (r != UMASK) {       // common factor
+        uint32_t cfrung = r;
+        T cf = pcf;
+        if (rd.get(1)) {
+            const uint32_t own = rd.get(1);
+            if (own) {
+                cfrung = (r + get_switch_noflag<UB>(rd, sig2)) & UMASK;
+                if (cfrung == r || cfrung == 0) return false;
+            }
+            const uint32_t vr = cfrung - own;
+            uint64_t v;
+            if (vr == 0) v = rd.get(1);
+            else { T t = get_value<T>(rd, vr); v = (uint64_t)((vr >= 3) ? unswap<T>(t, vr) : t); }   // cf values: rungs 1,2 unswapped (QB3encode.h:144-150)
+            pcf = cf = (T)(v + ((uint64_t)own << cfrung));
+        }
+        cf = (T)(cf + 2);
+        if (r) {
+            get_group<T, true>(rd, r, g);
+            T used = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) { g[i] = mmul_t<T>(g[i], cf); used |= g[i]; }
+            rung = topbit_t<T>(used);
+            return !(cf > used);
+        }
+        const uint32_t bits = rd.get(16);
+        const T v = (T)((T)((T)(cf - 1) << 1) | 1);
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) g[i] = ((bits >> i) & 1) ? v : (T)0;
+        rung = topbit_t<T>(v);
+        return true;
+    }
+    // index coding
+    rung = r = (rung + get_switch_noflag<UB>(rd, sig2)) & UMASK;
+    if (r == 63 || r == 0) return false;
+    uint32_t ix = 0, maxidx = 0, ibits = 0;     // 16 x 3 bit indices packed
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+        rd.ensure(4);
+        const uint32_t x = (uint32_t)rd.buf;
+        uint32_t v, len;                         // plain rung 2 code
+        if (!(x & 1)) { v = (x & 3) >> 1; len = 2; }
+        else if (!(x & 2)) { v = ((x >> 2) & 1) | 2; len = 3; }
+        else { v = ((x >> 2) & 3) | 4; len = 4; }
+        rd.skip(len);
+        ibits += len;
+        ix |= v << (3 * i);
+        maxidx = v > maxidx ? v : maxidx;
+    }
+    if (ibits > 52) return false;
+    T tab[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) {
+        tab[i] = 0;
+        if (i <= maxidx) { T t = get_value<T>(rd, r); tab[i] = (r >= 3) ? unswap<T>(t, r) : t; }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint32_t j = (ix >> (3 * i)) & 7;
+        T v = tab[0];
+#pragma unroll
+        for (uint32_t k = 1; k < 8; k++) v = (j == k) ? tab[k] : v;
+        g[i] = v;
+    }
+    return true;
+}
+
+// Lane per index segment.
+template <typename T, int MODE>
+__global__ void dec_kernel(const DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t bands = a.g.bands, S = a.g.seg_blocks, nbx = a.g.nbx;
+    const uint64_t seg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= a.g.nseg) return;
+    // per-lane LDS: scratch block [y][x][band] then band state
+    uint32_t *lane_mem = (uint32_t *)smem + (size_t)threadIdx.x * a.lane_dw;
+    T *blk = (T *)lane_mem;
+    T *prev = blk + 16 * bands;
+    T *pcf = prev + bands;
+    uint8_t *rungs = (uint8_t *)(pcf + bands);
+    for (uint32_t c = 0; c < bands; c++) {
+        prev[c] = ((const T *)a.idx.prev)[seg * bands + c];
+        pcf[c] = (MODE == CM_BEST) ? ((const T *)a.idx.cf)[seg * bands + c] : (T)0;
+        rungs[c] = a.idx.rung[seg * bands + c];
+    }
+    Reader rd;
+    rd.init(a.in32, a.in_bit0 + a.idx.bitpos[seg], a.in_bit0 + a.in_bits);
+    const uint64_t order = a.g.order;
+    const uint32_t gend = (uint32_t)(((seg + 1) * S < a.g.nblocks) ? (seg + 1) * S : a.g.nblocks);
+    bool ok = true;
+    T g[16];
+    for (uint32_t gb = (uint32_t)(seg * S); gb < gend && ok; gb++) {
+        for (uint32_t c = 0; c < bands; c++) {
+            uint32_t rung = rungs[c];
+            T cf = pcf[c];
+            ok = parse_unit<T, MODE>(rd, rung, cf, g) && ok;
+            rungs[c] = (uint8_t)rung;
+            pcf[c] = cf;
+            T prv = prev[c];
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) {
+                const uint32_t nib = curve_nib(order, i);
+                prv = (T)(prv + smag_t<T>(g[i]));
+                blk[nib * bands + c] = prv;
+            }
+            prev[c] = prv;
+        }
+        // add the core band back, sequentially in place like the strip epilogue (reference QB3decode.h:560-567)
+        for (uint32_t c = 0; c < bands; c++) {
+            const uint32_t cb = a.g.cband[c];
+            if (cb != c)
+                for (uint32_t i = 0; i < 16; i++) blk[i * bands + c] = (T)(blk[i * bands + c] + blk[i * bands + cb]);
+        }
+        const uint32_t by = gb / nbx, bx = gb - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        for (uint32_t y = 0; y < 4; y++) {
+            uint8_t *dst = (uint8_t *)a.img + ((uint64_t)(y0 + y) * a.g.stride + (uint64_t)x0 * bands) * sizeof(T);
+            const uint32_t *srow = lane_mem + y * a.dpr;
+            if (((uintptr_t)dst & 3) == 0)
+                for (uint32_t d = 0; d < a.dpr; d++) ((uint32_t *)dst)[d] = srow[d];
+            else
+                for (uint32_t d = 0; d < 4 * a.dpr; d++) dst[d] = ((const uint8_t *)srow)[d];
+        }
+    }
+    if (!ok) atomicOr(a.status, 1u);
+    if (seg == a.g.nseg - 1) {
+        // reference: fails when more than 7 bits are left (QB3decode.h:411,569,740); also flag overruns
+        const uint64_t used = rd.position() - a.in_bit0;
+        if (used > a.in_bits) atomicOr(a.status, 4u);
+        else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
+}
+
+// Foreign stream: ONE lane walks the stream and rebuilds the index (bit position + band state at every
+// segment start).  Latency bound by construction.
+template <typename T, int MODE>
+__global__ void dec_index_serial(const DecArgs a) {
+    if (blockIdx.x || threadIdx.x) return;
+    __shared__ uint64_t st_prev[MAXBANDS], st_cf[MAXBANDS];
+    __shared__ uint32_t st_rung[MAXBANDS];
+    const uint32_t bands = a.g.bands, S = a.g.seg_blocks;
+    for (uint32_t c = 0; c < bands; c++) { st_prev[c] = 0; st_cf[c] = 0; st_rung[c] = 0; }
+    Reader rd;
+    rd.init(a.in32, a.in_bit0, a.in_bit0 + a.in_bits);
+    T g[16];
+    bool ok = true;
+    uint32_t inseg = 0;
+    uint64_t seg = 0;
+    const uint32_t nblocks = (uint32_t)a.g.nblocks;
+    for (uint32_t gb = 0; gb < nblocks && ok; gb++) {
+        if (inseg == 0) {
+            a.idx.bitpos[seg] = rd.position() - a.in_bit0;
+            for (uint32_t c = 0; c < bands; c++) {
+                ((T *)a.idx.prev)[seg * bands + c] = (T)st_prev[c];
+                if (MODE == CM_BEST) ((T *)a.idx.cf)[seg * bands + c] = (T)st_cf[c];
+                a.idx.rung[seg * bands + c] = (uint8_t)st_rung[c];
+            }
+            seg++;
+        }
+        if (++inseg == S) inseg = 0;
+        for (uint32_t c = 0; c < bands; c++) {
+            uint32_t rung = st_rung[c];
+            T cf = (T)st_cf[c];
+            ok = parse_unit<T, MODE>(rd, rung, cf, g) && ok;
+            T sum = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) sum = (T)(sum + smag_t<T>(g[i]));
+            st_prev[c] = (T)((T)st_prev[c] + sum);
+            st_cf[c] = cf;
+            st_rung[c] = rung;
+        }
+    }
+    if (!ok) atomicOr(a.status, 1u);
+}
+
+// ------------------------------------------------------------------ host side of the kernels
+static thread_local char g_err[256] = "";
+const char *last_error() { return g_err; }
+void set_error(const char *what, int e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, e ? hipGetErrorString((hipError_t)e) : "failed");
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(#x, (int)e_); return (int)e_; } } while (0)
+
+uint32_t seg_blocks_for(uint32_t bands, uint32_t) { uint32_t s = 24 / bands; return s ? s : 1; }
+
+static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
+size_t index_bytes(const Geometry &g) {
+    const size_t n = (size_t)g.nseg * g.bands;
+    return align8(8 * (size_t)g.nseg) + 2 * align8(n * g.tsz) + align8(n);
+}
+IndexView index_view(const Geometry &g, void *base) {
+    IndexView v;
+    uint8_t *p = (uint8_t *)base;
+    const size_t n = (size_t)g.nseg * g.bands;
+    v.bitpos = (uint64_t *)p; p += align8(8 * (size_t)g.nseg);
+    v.prev = p; p += align8(n * g.tsz);
+    v.cf = p; p += align8(n * g.tsz);
+    v.rung = p;
+    return v;
+}
+
+static uint32_t magic_div(uint32_t d) { return d == 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); }   // exact for n*d < 2^32/d-ish, n small
+
+static uint32_t max_unit_bits(uint32_t tsz) {
+    const uint32_t ub = tsz == 1 ? 3 : tsz == 2 ? 4 : tsz == 4 ? 5 : 6;
+    return ub + 2 + 16 * (8 * tsz + 1);
+}
+
+EncPlan plan_encode(const Geometry &g) {
+    EncPlan p;
+    p.threads = g.tsz == 8 ? 128 : 256;
+    p.slots = p.threads / g.bands;
+    const uint32_t nbp = p.slots - 1;
+    p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
+    const uint32_t dpr = g.bands * g.tsz;
+    const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz)) / 32 + 1;
+    p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 64 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * outdw;
+    p.ws_bytes = align8(4 * (size_t)p.nchunks) + 8 * (size_t)p.nchunks + sizeof(EncResult);
+    return p;
+}
+
+template <typename T>
+static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    const bool step = a.g.mode != CM_FTL;
+    dim3 grid(plan.nchunks), block(plan.threads);
+    if (step) hipLaunchKernelGGL((enc_kernel<T, true, false>), grid, block, plan.lds_bytes, st, a);
+    else hipLaunchKernelGGL((enc_kernel<T, false, false>), grid, block, plan.lds_bytes, st, a);
+    hipLaunchKernelGGL(enc_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    if (step) hipLaunchKernelGGL((enc_kernel<T, true, true>), grid, block, plan.lds_bytes, st, a);
+    else hipLaunchKernelGGL((enc_kernel<T, false, true>), grid, block, plan.lds_bytes, st, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
+                  const BandState &st_in, void *ws, void *index, void *stream) {
+    if (g.mode == CM_BEST) { set_error("encode: common-factor modes are not implemented on the device yet", 0); return -1; }
+    EncArgs a;
+    a.g = g; a.img = img; a.out32 = out32; a.out_bit0 = out_bit0;
+    a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
+    a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
+    uint8_t *w = (uint8_t *)ws;
+    a.chunk_bits = (uint32_t *)w; w += align8(4 * (size_t)plan.nchunks);
+    a.chunk_off = (uint64_t *)w; w += 8 * (size_t)plan.nchunks;
+    a.res = (EncResult *)w;
+    a.st = st_in;
+    a.have_idx = index != nullptr;
+    a.idx = index ? index_view(g, index) : IndexView{nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st = (hipStream_t)stream;
+    switch (g.tsz) {
+    case 1: return launch_encode_t<uint8_t>(a, plan, st);
+    case 2: return launch_encode_t<uint16_t>(a, plan, st);
+    case 4: return launch_encode_t<uint32_t>(a, plan, st);
+    case 8: return launch_encode_t<uint64_t>(a, plan, st);
+    }
+    set_error("encode: bad value size", 0);
+    return -1;
+}
+
+// LDS dwords per decoder lane: 16*bands values + 2*bands state values + bands rung bytes.  The count is made
+// odd (conflict-free lane stride) for <= 4 byte values; 8-byte values need an 8-byte aligned lane base, so
+// there it is made 2 mod 4.
+static uint32_t dec_lane_dwords(const Geometry &g) {
+    uint32_t dw = (uint32_t)((16 * g.bands * g.tsz + 2 * g.bands * g.tsz + g.bands + 3) / 4);
+    if (g.tsz == 8) { dw = (dw + 1) & ~1u; if ((dw & 3) == 0) dw += 2; }
+    else dw |= 1;
+    return dw;
+}
+
+DecPlan plan_decode(const Geometry &g) {
+    DecPlan p;
+    // per lane: 16*bands values + 2*bands state values + bands rung bytes, rounded to an odd dword count
+    const uint32_t lane_dw = dec_lane_dwords(g);
+    uint32_t threads = 64;
+    while (threads > 1 && (size_t)threads * lane_dw * 4 > 48 * 1024) threads >>= 1;
+    p.threads = threads;
+    p.nwg = (uint32_t)((g.nseg + threads - 1) / threads);
+    p.lds_bytes = (size_t)threads * lane_dw * 4;
+    p.ws_bytes = align8(index_bytes(g)) + 64;
+    return p;
+}
+
+template <typename T, int MODE>
+static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st) {
+    if (rebuild) hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((dec_kernel<T, MODE>), dim3(plan.nwg), dim3(plan.threads), plan.lds_bytes, st, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <typename T>
+static int launch_decode_t(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st) {
+    switch (a.g.mode) {
+    case CM_FTL: return launch_decode_tm<T, CM_FTL>(a, plan, rebuild, st);
+    case CM_BASE: return launch_decode_tm<T, CM_BASE>(a, plan, rebuild, st);
+    default: return launch_decode_tm<T, CM_BEST>(a, plan, rebuild, st);
+    }
+}
+
+int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
+                  void *img, const void *index, void *ws, uint32_t **status_out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DecArgs a;
+    a.g = g; a.in32 = in32; a.in_bit0 = in_bit0; a.in_bits = in_bits; a.img = img;
+    uint8_t *w = (uint8_t *)ws;
+    const bool rebuild = index == nullptr;
+    a.idx = index_view(g, rebuild ? (void *)w : const_cast<void *>(index));
+    a.status = (uint32_t *)(w + align8(index_bytes(g)));
+    HIPCHK(hipMemsetAsync(a.status, 0, 64, st));
+    a.lane_dw = dec_lane_dwords(g);
+    a.dpr = g.bands * g.tsz;
+    *status_out = a.status;
+    switch (g.tsz) {
+    case 1: return launch_decode_t<uint8_t>(a, plan, rebuild, st);
+    case 2: return launch_decode_t<uint16_t>(a, plan, rebuild, st);
+    case 4: return launch_decode_t<uint32_t>(a, plan, rebuild, st);
+    case 8: return launch_decode_t<uint64_t>(a, plan, rebuild, st);
+    }
+    set_error("decode: bad value size", 0);
+    return -1;
+}
+
+}  // namespace qb3dev
+
+// ------------------------------------------------------------------ quantisation (elementwise, HBM bound)
+namespace qb3dev {
+
+// reference QB3encode.cpp:137-186: round to nearest; ties toward zero, or away from zero when `away`
+template <typename TS>
+__global__ void quantize_kernel(TS *dst, const TS *src, uint32_t rowvals, uint32_t rows, uint64_t stride, uint64_t quanta, int away) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)rowvals * rows) return;
+    const uint64_t y = i / rowvals, x = i - y * rowvals;
+    const TS v = src[y * stride + x], q = (TS)quanta;
+    TS r;
+    if (q == 2) r = away ? (TS)(v / 2 + v % 2) : (TS)(v / 2);
+    else if (q == 3) r = (TS)(v / 3 + (v % 3) / 2);
+    else if (q == 4) r = away ? (TS)(v / 4 + (v % 4) / 2) : (TS)(v / 4 + (v % 4) / 3);
+    else {
+        const TS m = (TS)(v % q);
+        const bool neg = v < (TS)0;
+        if (away) { const TS h = (TS)(q / 2 + q % 2); r = (TS)(v / q + (!neg & (m >= h)) - (neg & ((TS)(m + h) <= (TS)0))); }
+        else { const TS h = (TS)(q / 2); r = (TS)(v / q + (!neg & (m > h)) - (neg & ((TS)(m + h) < (TS)0))); }
+    }
+    dst[i] = r;
+}
+
+// reference QB3decode.cpp:77-107: multiply back, saturating
+template <typename TS>
+__global__ void dequantize_kernel(TS *img, uint32_t rowvals, uint32_t rows, uint64_t stride, uint64_t quanta) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)rowvals * rows) return;
+    const uint64_t y = i / rowvals, x = i - y * rowvals;
+    constexpr bool is_signed = (TS)-1 < (TS)0;
+    constexpr TS tmax = is_signed ? (TS)(((uint64_t)1 << (8 * sizeof(TS) - 1)) - 1) : (TS)~(TS)0;
+    constexpr TS tmin = is_signed ? (TS)((uint64_t)1 << (8 * sizeof(TS) - 1)) : (TS)0;
+    const TS q = (TS)quanta, mai = (TS)(tmax / q), mii = (TS)(tmin / q);
+    const TS v = img[y * stride + x];
+    TS r = (v <= mai) ? (TS)(v * q) : tmax;
+    if (is_signed && q > 2 && v < mii) r = tmin;
+    img[y * stride + x] = r;
+}
+
+template <typename TS> static int launch_q(void *dst, const void *src, const Geometry &g, uint64_t q, bool away, hipStream_t st) {
+    const uint64_t n = (uint64_t)g.w * g.bands * g.h;
+    hipLaunchKernelGGL(quantize_kernel<TS>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (TS *)dst, (const TS *)src,
+                       g.w * g.bands, g.h, g.stride, q, away ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("quantize", (int)e); return (int)e; }
+    return 0;
+}
+template <typename TS> static int launch_dq(void *img, const Geometry &g, uint64_t q, hipStream_t st) {
+    const uint64_t n = (uint64_t)g.w * g.bands * g.h;
+    hipLaunchKernelGGL(dequantize_kernel<TS>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (TS *)img, g.w * g.bands, g.h, g.stride, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dequantize", (int)e); return (int)e; }
+    return 0;
+}
+
+int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, uint64_t q, bool away, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+    case 0: return launch_q<uint8_t>(dst, src, g, q, away, st);   case 1: return launch_q<int8_t>(dst, src, g, q, away, st);
+    case 2: return launch_q<uint16_t>(dst, src, g, q, away, st);  case 3: return launch_q<int16_t>(dst, src, g, q, away, st);
+    case 4: return launch_q<uint32_t>(dst, src, g, q, away, st);  case 5: return launch_q<int32_t>(dst, src, g, q, away, st);
+    case 6: return launch_q<uint64_t>(dst, src, g, q, away, st);  case 7: return launch_q<int64_t>(dst, src, g, q, away, st);
+    }
+    return -1;
+}
+int launch_dequantize(void *img, const Geometry &g, int dtype, uint64_t q, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+    case 0: return launch_dq<uint8_t>(img, g, q, st);   case 1: return launch_dq<int8_t>(img, g, q, st);
+    case 2: return launch_dq<uint16_t>(img, g, q, st);  case 3: return launch_dq<int16_t>(img, g, q, st);
+    case 4: return launch_dq<uint32_t>(img, g, q, st);  case 5: return launch_dq<int32_t>(img, g, q, st);
+    case 6: return launch_dq<uint64_t>(img, g, q, st);  case 7: return launch_dq<int64_t>(img, g, q, st);
+    }
+    return -1;
+}
+
+}  // namespace qb3dev
