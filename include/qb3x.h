@@ -67,6 +67,14 @@ void qb3x_set_decoder_compat(decsp p, unsigned flags);
 decsp  qb3_create_decoder(void *source, size_t source_size, size_t *image_size);  /* read_start + read_info */
 size_t qb3_decode(decsp p, void *destination);                                     /* read_data */
 
+/* Per-kernel timing for benchmarks: when enabled, every kernel the library launches is bracketed by HIP
+ * events on the launch stream; totals are resolved at the library's own synchronisation points.
+ * Kernel names: enc_lengths, enc_scan, enc_emit, dec_index_serial, dec_segments. */
+void qb3x_profile_enable(int on);
+void qb3x_profile_reset(void);
+int  qb3x_profile_get(const char *kernel, double *total_ms, uint64_t *count);   /* 1 if the kernel was seen */
+int  qb3x_profile_names(char *buf, size_t bufsize);                             /* comma separated, returns count */
+
 /* Last HIP error string seen by this thread inside the library ("" if none). */
 const char *qb3x_last_error(void);
 

@@ -7,6 +7,12 @@
 #include <stdlib.h>
 #include <limits.h>
 
+#include <stdio.h>
+/* debugging aid for the tests: when set, the encoder writes one character per unit (0 zero/one-bit unit,
+ * N normal, C common factor, I index) */
+FILE *qb3o_trace = NULL;
+void qb3o_set_trace(const char *path) { if (qb3o_trace) fclose(qb3o_trace); qb3o_trace = path ? fopen(path, "w") : NULL; }
+
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 

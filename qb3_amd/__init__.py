@@ -16,6 +16,14 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "or `make -C qb3_amd/csrc` (there is no CPU fallback)")
 
+# One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and libQB3.so is linked against the
+# system one (same soname).  Whichever is loaded first serves both, and torch does not see the GPU when the
+# system copy wins -- so when torch is installed, load it first.  The library itself does not need torch.
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:         # pure C/ctypes use
+    _torch = None
+
 lib = C.CDLL(LIB_PATH)
 
 # enum values as in include/QB3.h
@@ -61,6 +69,10 @@ _PROTOS = {
     "qb3_create_decoder": (_vp, [_vp, _sz, C.POINTER(_sz)]),
     "qb3_decode": (_sz, [_vp, _vp]),
     "qb3x_last_error": (C.c_char_p, []),
+    "qb3x_profile_enable": (None, [C.c_int]),
+    "qb3x_profile_reset": (None, []),
+    "qb3x_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "qb3x_profile_names": (C.c_int, [C.c_char_p, _sz]),
 }
 for _name, (_res, _args) in _PROTOS.items():
     _f = getattr(lib, _name)        # AttributeError here = the library does not export a declared symbol

@@ -298,6 +298,7 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     hipError_t e = hipMemcpyAsync(&res, dres, sizeof(res), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
+    prof_collect();
     *bits = res.total_bits;
     if (carry)
         for (size_t c = 0; c < p->nbands; c++) {
@@ -378,7 +379,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     if (g.w < 4 || g.h < 4) { p->error = 1; if (rle) p->mode = mode; return 0; }
 
     uint64_t bits = 0;
-    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, (rle ? nullptr : d_index), st, carry, &bits)) {
+    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits)) {   // the index describes the block stream, RLE0 wrapped or not
         p->error = QB3E_LIBERR; if (rle) p->mode = mode; return 0;
     }
     p->error = 0;
@@ -578,6 +579,7 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
     hipError_t e = hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("decode kernels", (int)e); return false; }
+    prof_collect();
     // bit 0: corrupt unit, bit 1: more than 7 unused bits at the end (reference QB3decode.h:411,569,740).
     // bit 2 (ran past the end) is not an error in the reference, whose reader clamps (bitstream.h:36).
     if (status & 3) { set_error("decode: corrupt or over-long stream", 0); p->error = QB3E_ERR; return false; }
@@ -652,7 +654,7 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
         if (!p->d_img.ensure((size_t)g.w * g.h * g.bands * tsz)) { p->error = QB3E_LIBERR; return 0; }
         img_dev = p->d_img.p;
     }
-    if (!decode_blocks_device(p, g, dev_buf, off, nbytes, img_dev, rle ? nullptr : d_index, st)) {
+    if (!decode_blocks_device(p, g, dev_buf, off, nbytes, img_dev, d_index, st)) {
         if (p->error == QB3E_OK) p->error = QB3E_LIBERR;
         return 0;
     }
@@ -711,6 +713,10 @@ QB3_API int qb3x_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 QB3_API const char *qb3x_last_error(void) { return last_error(); }
+QB3_API void qb3x_profile_enable(int on) { prof_enable(on != 0); }
+QB3_API void qb3x_profile_reset(void) { prof_reset(); }
+QB3_API int qb3x_profile_get(const char *kernel, double *total_ms, uint64_t *count) { return prof_get(kernel, total_ms, count) ? 1 : 0; }
+QB3_API int qb3x_profile_names(char *buf, size_t bufsize) { return prof_names(buf, bufsize); }
 
 QB3_API decsp qb3_create_decoder(void *source, size_t source_size, size_t *image_size) {
     decsp p = qb3_read_start(source, source_size, image_size);

@@ -92,6 +92,13 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
 int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, uint64_t q, bool away, void *stream);
 int launch_dequantize(void *img, const Geometry &g, int dtype, uint64_t q, void *stream);
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (off by default).
+void prof_enable(bool on);
+void prof_reset();
+void prof_collect();                                    // call after the stream was synchronised
+bool prof_get(const char *name, double *total_ms, uint64_t *count);
+int  prof_names(char *buf, size_t bufsize);             // comma separated kernel names seen so far
+
 const char *last_error();
 void set_error(const char *what, int hip_err);
 

@@ -512,7 +512,8 @@ template <typename T, int MODE> __device__ __forceinline__ bool parse_unit(Reade
     // index coding
     rung = r = (rung + get_switch_noflag<UB>(rd, sig2)) & UMASK;
     if (r == 63 || r == 0) return false;
-    uint32_t ix = 0, maxidx = 0, ibits = 0;     // 16 x 3 bit indices packed
+    uint64_t ix = 0;                            // 16 x 3 bit indices packed
+    uint32_t maxidx = 0, ibits = 0;
 #pragma unroll
     for (uint32_t i = 0; i < 16; i++) {
         rd.ensure(4);
@@ -523,7 +524,7 @@ template <typename T, int MODE> __device__ __forceinline__ bool parse_unit(Reade
         else { v = ((x >> 2) & 3) | 4; len = 4; }
         rd.skip(len);
         ibits += len;
-        ix |= v << (3 * i);
+        ix |= (uint64_t)v << (3 * i);
         maxidx = v > maxidx ? v : maxidx;
     }
     if (ibits > 52) return false;
@@ -535,7 +536,7 @@ template <typename T, int MODE> __device__ __forceinline__ bool parse_unit(Reade
     }
 #pragma unroll
     for (uint32_t i = 0; i < 16; i++) {
-        const uint32_t j = (ix >> (3 * i)) & 7;
+        const uint32_t j = (uint32_t)(ix >> (3 * i)) & 7;
         T v = tab[0];
 #pragma unroll
         for (uint32_t k = 1; k < 8; k++) v = (j == k) ? tab[k] : v;
@@ -659,6 +660,65 @@ const char *last_error() { return g_err; }
 void set_error(const char *what, int e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, e ? hipGetErrorString((hipError_t)e) : "failed");
 }
+// ---- per-kernel timing: hipEvents recorded on the launch stream, resolved after the caller's sync
+}  // namespace qb3dev
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+namespace qb3dev {
+struct ProfPending { const char *name; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfPending> g_prof_pending;
+static std::vector<hipEvent_t> g_prof_pool;
+static std::map<std::string, std::pair<double, uint64_t>> g_prof_acc;
+void prof_enable(bool on) { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_on = on; }
+void prof_reset() { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_acc.clear(); }
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {      // records an event before and after the launches made in its lifetime
+    hipStream_t st; hipEvent_t a = nullptr, b = nullptr; const char *name; bool on;
+    ProfScope(const char *n, hipStream_t s) : st(s), name(n) {
+        std::lock_guard<std::mutex> l(g_prof_mu);
+        on = g_prof_on;
+        if (on) { a = prof_event(); b = prof_event(); (void)hipEventRecord(a, st); }
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> l(g_prof_mu);
+        g_prof_pending.push_back({name, a, b});
+    }
+};
+void prof_collect() {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    for (auto &p : g_prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { auto &acc = g_prof_acc[p.name]; acc.first += ms; acc.second++; }
+        g_prof_pool.push_back(p.a); g_prof_pool.push_back(p.b);
+    }
+    g_prof_pending.clear();
+}
+bool prof_get(const char *name, double *total_ms, uint64_t *count) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    auto it = g_prof_acc.find(name);
+    if (it == g_prof_acc.end()) return false;
+    *total_ms = it->second.first; *count = it->second.second;
+    return true;
+}
+int prof_names(char *buf, size_t n) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    std::string s;
+    for (auto &kv : g_prof_acc) { if (!s.empty()) s += ","; s += kv.first; }
+    snprintf(buf, n, "%s", s.c_str());
+    return (int)g_prof_acc.size();
+}
+
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(#x, (int)e_); return (int)e_; } } while (0)
 
 uint32_t seg_blocks_for(uint32_t bands, uint32_t) { uint32_t s = 24 / bands; return s ? s : 1; }
@@ -703,11 +763,20 @@ template <typename T>
 static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL;
     dim3 grid(plan.nchunks), block(plan.threads);
-    if (step) hipLaunchKernelGGL((enc_kernel<T, true, false>), grid, block, plan.lds_bytes, st, a);
-    else hipLaunchKernelGGL((enc_kernel<T, false, false>), grid, block, plan.lds_bytes, st, a);
-    hipLaunchKernelGGL(enc_scan_kernel, dim3(1), dim3(1024), 0, st, a);
-    if (step) hipLaunchKernelGGL((enc_kernel<T, true, true>), grid, block, plan.lds_bytes, st, a);
-    else hipLaunchKernelGGL((enc_kernel<T, false, true>), grid, block, plan.lds_bytes, st, a);
+    {
+        ProfScope ps("enc_lengths", st);
+        if (step) hipLaunchKernelGGL((enc_kernel<T, true, false>), grid, block, plan.lds_bytes, st, a);
+        else hipLaunchKernelGGL((enc_kernel<T, false, false>), grid, block, plan.lds_bytes, st, a);
+    }
+    {
+        ProfScope ps("enc_scan", st);
+        hipLaunchKernelGGL(enc_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    }
+    {
+        ProfScope ps("enc_emit", st);
+        if (step) hipLaunchKernelGGL((enc_kernel<T, true, true>), grid, block, plan.lds_bytes, st, a);
+        else hipLaunchKernelGGL((enc_kernel<T, false, true>), grid, block, plan.lds_bytes, st, a);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -762,8 +831,14 @@ DecPlan plan_decode(const Geometry &g) {
 
 template <typename T, int MODE>
 static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st) {
-    if (rebuild) hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(1), dim3(64), 0, st, a);
-    hipLaunchKernelGGL((dec_kernel<T, MODE>), dim3(plan.nwg), dim3(plan.threads), plan.lds_bytes, st, a);
+    if (rebuild) {
+        ProfScope ps("dec_index_serial", st);
+        hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(1), dim3(64), 0, st, a);
+    }
+    {
+        ProfScope ps("dec_segments", st);
+        hipLaunchKernelGGL((dec_kernel<T, MODE>), dim3(plan.nwg), dim3(plan.threads), plan.lds_bytes, st, a);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,118 @@
+"""qb3_amd/device.py -- device-resident encode/decode through the qb3x_ C entry points, on torch tensors.
+
+torch only supplies device memory and the stream handle; every byte of work happens inside libQB3.so.
+The handles follow the reference's usage pattern (cqb3.cpp:405-493 for encode, :276-323 for decode):
+create, set mode / band map, encode; read_start, read_info, read_data.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib, last_error, TYPESIZE, QB3M_FTL, _sz
+
+_vp = C.c_void_p
+
+
+def _stream_ptr():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceEncoder:
+    """One encoder handle bound to the current device; output and index buffers are reused across calls."""
+
+    def __init__(self, w, h, bands, dtype, mode=QB3M_FTL, cband=None, want_index=True):
+        self.w, self.h, self.bands, self.dtype = w, h, bands, dtype
+        self.p = lib.qb3_create_encoder(w, h, bands, dtype)
+        if not self.p:
+            raise ValueError("qb3_create_encoder refused the parameters")
+        self.mode = lib.qb3_set_encoder_mode(self.p, mode)
+        if cband is not None:
+            arr = (_sz * bands)(*cband)
+            lib.qb3_set_encoder_coreband(self.p, bands, arr)
+        self.max_size = lib.qb3_max_encoded_size(self.p)
+        self.raw_bytes = w * h * bands * TYPESIZE[dtype]
+        self.index_bytes = lib.qb3x_index_size(self.p) if want_index else 0
+        self.dst = None
+        self.index = None
+
+    def close(self):
+        if self.p:
+            lib.qb3_destroy_encoder(self.p)
+            self.p = None
+
+    __del__ = close
+
+    def encode(self, src, dst=None, index=None):
+        """src: device tensor holding the image bytes.  Returns (dst uint8 tensor, container size, index tensor)."""
+        assert src.is_cuda and src.is_contiguous() and src.numel() * src.element_size() >= self.raw_bytes
+        if dst is None:
+            if self.dst is None:
+                self.dst = torch.empty((self.max_size + 3) // 4 * 4, dtype=torch.uint8, device=src.device)
+            dst = self.dst
+        if index is None and self.index_bytes:
+            if self.index is None:
+                self.index = torch.empty(self.index_bytes, dtype=torch.uint8, device=src.device)
+            index = self.index
+        lib.qb3_reset_encoder(self.p)               # independent images: do not carry the band state
+        lib.qb3_set_encoder_mode(self.p, self.mode)  # a STORED fallback leaves the handle's mode at 255
+        n = lib.qb3x_encode_device(self.p, _vp(src.data_ptr()), _vp(dst.data_ptr()),
+                                   _vp(index.data_ptr()) if index is not None else None, _stream_ptr())
+        if n == 0:
+            raise RuntimeError(f"qb3x_encode_device failed (state {lib.qb3_get_encoder_state(self.p)}): {last_error()}")
+        return dst, n, index
+
+
+class DeviceDecoder:
+    """Decoder for one device-resident container.  `header` is a host copy of (at least) its first 64 bytes."""
+
+    def __init__(self, header, nbytes):
+        self.hdr = np.ascontiguousarray(header, dtype=np.uint8)
+        dims = (_sz * 3)()
+        self.p = lib.qb3_read_start(self.hdr.ctypes.data_as(_vp), nbytes, dims)
+        if not self.p:
+            raise ValueError("qb3_read_start rejected the stream")
+        if not lib.qb3_read_info(self.p):
+            lib.qb3_destroy_decoder(self.p)
+            self.p = None
+            raise ValueError("qb3_read_info failed")
+        self.w, self.h, self.bands = dims[0], dims[1], dims[2]
+        self.out_bytes = lib.qb3_decoded_size(self.p)
+        self.nbytes = nbytes
+
+    def close(self):
+        if self.p:
+            lib.qb3_destroy_decoder(self.p)
+            self.p = None
+
+    __del__ = close
+
+    def decode(self, d_stream, out=None, index=None):
+        assert d_stream.is_cuda
+        if out is None:
+            out = torch.empty(self.out_bytes, dtype=torch.uint8, device=d_stream.device)
+        n = lib.qb3x_decode_device(self.p, _vp(d_stream.data_ptr()), _vp(out.data_ptr()),
+                                   _vp(index.data_ptr()) if index is not None else None, _stream_ptr())
+        if n == 0:
+            raise RuntimeError(f"qb3x_decode_device failed: {last_error()}")
+        return out
+
+
+def profile_enable(on=True):
+    lib.qb3x_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib.qb3x_profile_reset()
+
+
+def profile_report():
+    """{kernel name: (total ms, launches)} measured with HIP events on the launch stream."""
+    buf = C.create_string_buffer(1024)
+    lib.qb3x_profile_names(buf, 1024)
+    out = {}
+    for name in filter(None, buf.value.decode().split(",")):
+        ms, cnt = C.c_double(), C.c_uint64()
+        if lib.qb3x_profile_get(name.encode(), C.byref(ms), C.byref(cnt)):
+            out[name] = (ms.value, cnt.value)
+    return out

@@ -1,0 +1,57 @@
+"""qb3_amd/tiles.py -- independent tiles across the GPUs of one node.
+
+The path shards by image tile (every tile is its own QB3 stream): no collective while
+coding.  The only exchange is the variable-size gather of the finished containers to one rank, done with
+point-to-point sends (RCCL send/recv on the `nccl` backend; `gloo` on CPU in the tests), one message per
+peer sized to the bytes actually produced -- over xGMI each peer owns its own link to the root, so the
+gather is bound by the per-link rate, not by a ring.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced split of n_items; returns (first, count) for `rank`."""
+    base, extra = divmod(n_items, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def gather_streams(payload, sizes, root=0, group=None):
+    """Gather variable-size byte payloads on `root`.
+
+    payload: 1-D uint8 tensor holding this rank's containers back to back (only the first sum(sizes) bytes count)
+    sizes:   list[int], container sizes of this rank's tiles, in tile order
+    Returns on root: (list of per-rank uint8 tensors, list of per-rank size lists); elsewhere (None, None).
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    device = payload.device
+    counts = torch.tensor([len(sizes)], dtype=torch.int64, device=device)
+    all_counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    maxn = int(max(int(c.item()) for c in all_counts))
+    mine = torch.zeros(maxn, dtype=torch.int64, device=device)
+    if sizes:
+        mine[:len(sizes)] = torch.tensor(sizes, dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros(maxn, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_sizes, mine, group=group)
+    size_lists = [[int(v) for v in s[:int(c.item())].tolist()] for s, c in zip(all_sizes, all_counts)]
+    total = sum(sizes)
+    if rank == root:
+        bufs, reqs = [], []
+        for r in range(world):
+            nbytes = sum(size_lists[r])
+            if r == root:
+                bufs.append(payload[:total])
+                continue
+            b = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            bufs.append(b)
+            if nbytes:
+                reqs.append(dist.irecv(b, src=r, group=group))
+        for q in reqs:
+            q.wait()
+        return bufs, size_lists
+    if total:
+        dist.send(payload[:total].contiguous(), dst=root, group=group)
+    return None, None

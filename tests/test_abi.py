@@ -1,0 +1,152 @@
+"""C-ABI drop-in boundary, CPU side: the shared library loads, exports every symbol include/*.h declares,
+and its host logic (handles, setters, header writer/parser, STORED path, error conventions) behaves like the
+reference's (QB3encode.cpp:26-134, QB3decode.cpp:36-264), checked against the oracle's restatement.
+No block coding happens here -- that needs the GPU and has no CPU fallback, which is also asserted."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = []
+    for hdr in ("QB3.h", "qb3x.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(qb3x?_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_every_declared_symbol_is_exported(qb3):
+    names = declared_functions()
+    assert len(names) >= 21 + 8
+    for n in names:
+        assert hasattr(qb3.lib, n), f"{n} is declared in include/ but not exported by libQB3.so"
+    # the reference's 21 entry points (QB3.h:85-162)
+    for n in ("qb3_create_encoder qb3_destroy_encoder qb3_reset_encoder qb3_set_encoder_coreband qb3_set_encoder_quanta "
+              "qb3_max_encoded_size qb3_set_encoder_mode qb3_set_encoder_stride qb3_encode qb3_get_encoder_state "
+              "qb3_read_start qb3_read_info qb3_read_data qb3_destroy_decoder qb3_decoded_size qb3_get_type "
+              "qb3_set_decoder_stride qb3_get_mode qb3_get_quanta qb3_get_order qb3_get_coreband").split():
+        assert n in names
+
+
+def test_binding_covers_all_declarations(qb3):
+    assert set(declared_functions()) <= set(qb3.EXPORTED)
+
+
+def test_create_encoder_validation(qb3):
+    L = qb3.lib
+    for bad in ((0, 4, 1, 0), (4, 0, 1, 0), (65537, 4, 1, 0), (4, 4, 0, 0), (4, 4, 17, 0), (4, 4, 1, 8)):
+        assert not L.qb3_create_encoder(*bad)
+    p = L.qb3_create_encoder(65536, 65536, 16, 7)
+    assert p
+    L.qb3_destroy_encoder(p)
+
+
+@pytest.mark.parametrize("w,h,b,dt", [(512, 512, 3, 0), (509, 515, 3, 0), (8192, 8192, 8, 2), (4096, 4096, 1, 7), (16384, 16384, 3, 0), (5, 7, 16, 5)])
+def test_max_encoded_size_matches(qb3, oracle, w, h, b, dt):
+    p = qb3.lib.qb3_create_encoder(w, h, b, dt)
+    e = oracle.Encoder(w, h, b, dt)
+    assert qb3.lib.qb3_max_encoded_size(p) == e.max_size()
+    qb3.lib.qb3_destroy_encoder(p)
+    if (w, h, b, dt) == (16384, 16384, 3, 0):
+        assert e.max_size() == 912262144
+
+
+def test_setters_match_oracle(qb3, oracle):
+    L = qb3.lib
+    p = L.qb3_create_encoder(16, 16, 5, 2)
+    e = oracle.Encoder(16, 16, 5, 2)
+    for m in (8, 9, -1, 300, 4, 7, 2, 0, 8):
+        assert L.qb3_set_encoder_mode(p, m) == e.set_mode(m)
+    for cb in ([1, 1, 1, 3, 4], [4, 4, 4, 4, 4], [9, 0, 1, 2, 3], [1, 2, 3, 4, 0]):
+        arr = (C.c_size_t * 5)(*cb)
+        assert L.qb3_set_encoder_coreband(p, 5, arr)
+        assert list(arr) == e.set_coreband(cb)
+    assert not L.qb3_set_encoder_coreband(p, 4, (C.c_size_t * 4)(0, 0, 0, 0))
+    for dt in range(8):
+        q = L.qb3_create_encoder(8, 8, 1, dt)
+        o = oracle.Encoder(8, 8, 1, dt)
+        for v in (0, 1, 2, 127, 128, 255, 256, 32767, 32768, 65535, 65536, 2**31 - 1, 2**31, 2**32, 2**63 - 1, 2**63):
+            assert L.qb3_set_encoder_quanta(q, v, False) == o.set_quanta(v), (dt, v)
+        L.qb3_destroy_encoder(q)
+    L.qb3_destroy_encoder(p)
+
+
+def test_tiny_images_are_stored_without_gpu(qb3, oracle):
+    """w*h <= 16 never reaches the block coder (reference QB3encode.cpp:490): host only, must equal the oracle"""
+    for (w, h, b, dt) in ((4, 4, 3, 0), (1, 1, 1, 7), (16, 1, 2, 3), (2, 8, 4, 5)):
+        img = oracle.generate(w, h, b, dt, "RANDOM", 3)
+        ref = oracle.encode(img, dt, 8)
+        got = qb3.encode(img, dt, 8)
+        assert np.array_equal(got, ref) and got[10] == 255
+        out, dims, t, mode = qb3.decode(got)
+        assert dims == (w, h, b) and t == dt and mode == 255
+        assert np.array_equal(out, img.view(np.uint8).ravel())
+
+
+@pytest.mark.parametrize("mode", range(9))
+def test_header_parse_matches_oracle(qb3, oracle, mode):
+    L = qb3.lib
+    for (w, h, b, dt, q) in ((33, 21, 3, 0, 1), (16, 16, 8, 2, 1), (20, 20, 1, 5, 7), (16, 16, 4, 1, 300 if False else 3)):
+        img = oracle.generate(w, h, b, dt, "NOISY3", 4)
+        s = oracle.encode(img, dt, mode, quanta=q)
+        dims = (C.c_size_t * 3)()
+        p = L.qb3_read_start(s.ctypes.data, s.size, dims)
+        assert p and tuple(dims) == (w, h, b)
+        assert L.qb3_get_mode(p) == -1 and L.qb3_get_quanta(p) == 0 and L.qb3_get_order(p) == 0   # before read_info
+        cb = (C.c_size_t * 16)()
+        assert not L.qb3_get_coreband(p, cb)
+        assert L.qb3_read_info(p)
+        od = oracle.lib.qb3o_decoder_new(s.ctypes.data, s.size, (C.c_size_t * 3)())
+        assert oracle.lib.qb3o_read_info(od)
+        assert L.qb3_get_mode(p) == oracle.lib.qb3o_decoder_mode(od) == s[10]
+        assert L.qb3_get_type(p) == dt
+        assert L.qb3_get_quanta(p) == oracle.lib.qb3o_decoder_quanta(od)
+        assert L.qb3_get_order(p) == oracle.lib.qb3o_decoder_order(od)
+        assert L.qb3_decoded_size(p) == img.nbytes
+        ocb = (C.c_size_t * 16)()
+        assert L.qb3_get_coreband(p, cb) and oracle.lib.qb3o_decoder_coreband(od, ocb)
+        assert list(cb)[:b] == list(ocb)[:b]
+        assert not L.qb3_read_info(p)               # wrong stage the second time (QB3decode.cpp:178)
+        oracle.lib.qb3o_free(od)
+        L.qb3_destroy_decoder(p)
+
+
+def test_read_start_rejections(qb3, oracle):
+    L = qb3.lib
+    img = oracle.generate(16, 16, 3, 0, "NOISY3", 1)
+    s = oracle.encode(img, 0, 8)
+    dims = (C.c_size_t * 3)()
+    assert not L.qb3_read_start(s.ctypes.data, 14, dims)            # shorter than 15 bytes
+    assert not L.qb3_read_start(s.ctypes.data, s.size, None)
+    for off, val in ((0, 0x51 ^ 1), (3, 0x81), (8, 16), (9, 8), (10, 9), (11, 0x80 | ord("C"))):
+        t = s.copy()
+        t[off] = val
+        assert not L.qb3_read_start(t.ctypes.data, t.size, dims), (off, val)
+    t = s.copy()
+    t[11:13] = np.frombuffer(b"XY", np.uint8)                        # unknown upper-case chunk -> QB3E_UNKN
+    p = L.qb3_read_start(t.ctypes.data, t.size, dims)
+    assert p and not L.qb3_read_info(p)
+    assert L.qb3_read_data(p, t.ctypes.data) == 0
+    L.qb3_destroy_decoder(p)
+
+
+def test_block_coding_fails_loudly_without_gpu(qb3, oracle):
+    """No CPU fallback: on a box without a HIP device qb3_encode / qb3_read_data return 0 and say why."""
+    if qb3.lib.qb3x_device_count() > 0:
+        pytest.skip("a GPU is present")
+    img = oracle.generate(32, 32, 3, 0, "NOISY3", 1)
+    p = qb3.lib.qb3_create_encoder(32, 32, 3, 0)
+    dst = np.zeros(qb3.lib.qb3_max_encoded_size(p), np.uint8)
+    assert qb3.lib.qb3_encode(p, img.ctypes.data, dst.ctypes.data) == 0
+    assert qb3.lib.qb3_get_encoder_state(p) == 255                   # QB3E_LIBERR
+    assert "no usable HIP device" in qb3.last_error()
+    qb3.lib.qb3_destroy_encoder(p)
+    s = oracle.encode(img, 0, 8)
+    with pytest.raises(RuntimeError):
+        qb3.decode(s)
