@@ -114,7 +114,7 @@ def main():
         avg = ms / max(cnt, 1)
         kernels[name] = {"avg_ms": round(avg, 4), "launches": int(cnt), "GBps_algorithmic": round(algo_bytes / avg / 1e6, 1) if avg > 0 else None}
     enc_ms = sum(kernels[k]["avg_ms"] for k in ("enc_lengths", "enc_scan", "enc_emit") if k in kernels)
-    dec_ms = sum(kernels[k]["avg_ms"] for k in ("dec_index_serial", "dec_segments") if k in kernels)
+    dec_ms = sum(kernels[k]["avg_ms"] for k in ("dec_index_serial", "dec_segments", "dec_units") if k in kernels)
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
     traffic = None
     try:

@@ -177,7 +177,7 @@ QB3_API int qb3_get_encoder_state(encsp p) { return p->error; }
 // ---------------------------------------------------------------- geometry helpers
 static CodecMode codec_mode(int mode) {
     if (mode == QB3M_FTL) return CM_FTL;
-    if (mode == QB3M_BASE_H || mode == QB3M_BASE_Z) return CM_BASE;
+    if (mode == QB3M_BASE_H || mode == QB3M_BASE_Z || mode == QB3M_RLE || mode == QB3M_RLE_H) return CM_BASE;   // RLE0 only wraps the BASE stream
     return CM_BEST;
 }
 
@@ -191,7 +191,8 @@ static Geometry make_geometry(size_t w, size_t h, size_t bands, int dtype, size_
     g.nbx = (uint32_t)((w + 3) / 4); g.nby = (uint32_t)((h + 3) / 4);
     g.nblocks = (uint64_t)g.nbx * g.nby;
     g.mode = codec_mode(mode);
-    g.seg_blocks = seg_blocks_for(g.bands, g.tsz);
+    g.seg_blocks = seg_blocks_for(g.bands, g.tsz, g.mode);
+    g.ulen_sz = ulen_size_for(g.tsz, g.mode);
     g.nseg = (g.nblocks + g.seg_blocks - 1) / g.seg_blocks;
     for (size_t c = 0; c < bands; c++) g.cband[c] = cband_sz ? (uint8_t)cband_sz[c] : cband_u8[c];
     return g;

@@ -22,6 +22,7 @@ struct Geometry {
     uint32_t mode;                  // CodecMode
     uint32_t seg_blocks;            // blocks per index segment
     uint64_t nseg;                  // number of index segments
+    uint32_t ulen_sz;               // bytes per entry of the per-unit bit-length table (1, 2; 0 = none)
     uint8_t cband[MAXBANDS];
 };
 
@@ -33,16 +34,22 @@ struct BandState {
 };
 
 // Decode index, device resident.  Layout in one allocation of index_bytes(g):
-//   u64 bitpos[nseg]; T prev[nseg*bands]; T cf[nseg*bands]; u8 rung[nseg*bands]  (each 8-byte aligned)
+//   u64 bitpos[nseg]; T prev[nseg*bands]; T cf[nseg*bands]; u8 rung[nseg*bands]; ulen[nblocks*bands]
+// (each 8-byte aligned).  A segment entry is the coder state on entering a run of seg_blocks blocks.  For
+// FTL/BASE streams segments are as large as a decoder workgroup and `ulen` holds the bit length of every unit
+// (u8 for 8-bit data, u16 otherwise), which is what lets the decoder place every unit with a scan; for the
+// common-factor modes segments are short, there is no ulen, and a lane walks each segment serially.
 struct IndexView {
     uint64_t *bitpos;
     void *prev;
     void *cf;
     uint8_t *rung;
+    void *ulen;
 };
 size_t index_bytes(const Geometry &g);
 IndexView index_view(const Geometry &g, void *base);
-uint32_t seg_blocks_for(uint32_t bands, uint32_t tsz);
+uint32_t seg_blocks_for(uint32_t bands, uint32_t tsz, uint32_t mode);
+uint32_t ulen_size_for(uint32_t tsz, uint32_t mode);
 
 // Results the encoder hands back to the host (device resident, copied once per encode)
 struct EncResult {
@@ -78,6 +85,10 @@ struct DecPlan {
     uint32_t nwg;
     size_t lds_bytes;
     size_t ws_bytes;        // scratch for the foreign-stream path: rebuilt index + status word
+    // unit-parallel kernel (FTL/BASE with ordinary band maps): one workgroup per index segment
+    bool fast;
+    uint32_t threads2, bpp, passes, in_cap_dw;
+    size_t lds2_bytes;
 };
 DecPlan plan_decode(const Geometry &g);
 

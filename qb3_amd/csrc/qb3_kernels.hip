@@ -301,6 +301,8 @@ __global__ void enc_kernel(const EncArgs a) {
         // coder state on leaving the image, for handle statefulness (reference QB3encode.h:446-449)
         if (gblk == nblocks - 1) { a.res->prev[c] = (uint64_t)lastv; a.res->rung[c] = rung; a.res->cf[c] = a.st.cf[c]; }
         if (a.have_idx) {
+            if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gblk * bands + c] = (uint8_t)len;
+            else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gblk * bands + c] = (uint16_t)len;
             const uint32_t seg = gblk / a.g.seg_blocks;
             if (seg * a.g.seg_blocks == gblk) {
                 ((T *)a.idx.prev)[(uint64_t)seg * bands + c] = pv;
@@ -367,16 +369,20 @@ struct DecArgs {
     uint32_t *status;
     uint32_t lane_dw;           // LDS dwords per lane (odd)
     uint32_t dpr;
+    // unit-parallel kernel (dec3_kernel)
+    uint32_t bpp, passes, in_cap_dw, magic_bpp, magic_dpr;
 };
 
 // LSB-first bit reader over aligned dword loads; reads past the stream end return zeros, like the
 // reference's iBits::peek (bitstream.h:39-50)
-struct Reader {
-    const uint32_t *in;
+typedef const __attribute__((address_space(3))) uint32_t *LdsWords;   // explicit LDS pointer: loads become ds_read
+template <typename PTR>
+struct ReaderT {
+    PTR in;
     uint64_t buf, wp, endw;
     uint32_t n;
     __device__ __forceinline__ uint32_t load(uint64_t i) const { return i < endw ? in[i] : 0u; }
-    __device__ __forceinline__ void init(const uint32_t *p, uint64_t bitpos, uint64_t endbit) {
+    __device__ __forceinline__ void init(PTR p, uint64_t bitpos, uint64_t endbit) {
         in = p; endw = (endbit + 31) >> 5; wp = bitpos >> 5;
         const uint32_t sh = (uint32_t)(bitpos & 31);
         buf = (uint64_t)(load(wp++) >> sh); n = 32 - sh;
@@ -398,9 +404,10 @@ struct Reader {
     }
     __device__ __forceinline__ uint64_t position() const { return wp * 32 - n; }   // bits consumed, from `in`
 };
+typedef ReaderT<const uint32_t *> Reader;
 
 // one value at rung r >= 1, not yet unswapped (reference QB3decode.h:119-129)
-template <typename T> __device__ __forceinline__ T get_value(Reader &rd, uint32_t r) {
+template <typename T, typename RD> __device__ __forceinline__ T get_value(RD &rd, uint32_t r) {
     if (sizeof(T) <= 2) {       // r + 2 <= 17 bits
         rd.ensure(r + 2);
         const uint32_t x = (uint32_t)rd.buf, half = 1u << (r - 1), top = 1u << r;
@@ -425,7 +432,7 @@ template <typename T> __device__ __forceinline__ T unswap(T v, uint32_t r) {
 }
 
 // rung switch: returns delta in [0, 2^UB), sets signal when the unused code is met (reference QB3decode.h:97-116)
-template <uint32_t UB> __device__ __forceinline__ uint32_t get_switch_noflag(Reader &rd, bool &signal) {
+template <uint32_t UB, typename RD> __device__ __forceinline__ uint32_t get_switch_noflag(RD &rd, bool &signal) {
     constexpr uint32_t n = 1u << UB, r = UB - 1, half = 1u << (r - 1), top = 1u << r;
     rd.ensure(r + 2);
     const uint32_t x = (uint32_t)rd.buf;
@@ -443,7 +450,7 @@ template <typename T> __device__ __forceinline__ T mabs_t(T v) { return (T)((v >
 template <typename T> __device__ __forceinline__ T mmul_t(T v, T m) { return (T)((T)(mabs_t<T>(v) * (T)(m << 1)) - (T)(v & 1)); }
 
 // 16 values at `rung` into g (mag-sign), with the step undone when STEP (reference QB3decode.h:142-290)
-template <typename T, bool STEP> __device__ __forceinline__ void get_group(Reader &rd, uint32_t rung, T (&g)[16]) {
+template <typename T, bool STEP, typename RD> __device__ __forceinline__ void get_group(RD &rd, uint32_t rung, T (&g)[16]) {
     if (rung == 0) {
         const uint32_t bits = rd.get(1) ? rd.get(16) : 0;
 #pragma unroll
@@ -453,7 +460,7 @@ template <typename T, bool STEP> __device__ __forceinline__ void get_group(Reade
     uint32_t rb = 0;
 #pragma unroll
     for (uint32_t i = 0; i < 16; i++) {
-        g[i] = unswap<T>(get_value<T>(rd, rung), rung);
+        g[i] = unswap<T>(get_value<T, RD>(rd, rung), rung);
         rb |= (uint32_t)((g[i] >> rung) & 1) << i;
     }
     if (STEP && (rb & (rb + 1)) == 0) {
@@ -466,36 +473,36 @@ template <typename T, bool STEP> __device__ __forceinline__ void get_group(Reade
 // Parse one unit.  rung / pcf are the running state of this band.  Returns false on a corrupt stream.
 // MODE: CM_FTL (no step, signal is an ordinary "no change"), CM_BASE / CM_BEST (step; signal opens the
 // common-factor and index forms, reference QB3decode.h:619-716).
-template <typename T, int MODE> __device__ __forceinline__ bool parse_unit(Reader &rd, uint32_t &rung, T &pcf, T (&g)[16]) {
+template <typename T, int MODE, typename RD> __device__ __forceinline__ bool parse_unit(RD &rd, uint32_t &rung, T &pcf, T (&g)[16]) {
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     bool signal = false;
     uint32_t delta = 0;
-    if (rd.get(1)) delta = get_switch_noflag<UB>(rd, signal);
+    if (rd.get(1)) delta = get_switch_noflag<UB, RD>(rd, signal);
     if (MODE == CM_FTL || !signal) {
         rung = (rung + delta) & UMASK;
-        get_group<T, MODE != CM_FTL>(rd, rung, g);
+        get_group<T, MODE != CM_FTL, RD>(rd, rung, g);
         return true;
     }
     bool sig2;
-    uint32_t r = (rung + get_switch_noflag<UB>(rd, sig2)) & UMASK;
+    uint32_t r = (rung + get_switch_noflag<UB, RD>(rd, sig2)) & UMASK;
     if (r != UMASK) {       // common factor
         uint32_t cfrung = r;
         T cf = pcf;
         if (rd.get(1)) {
             const uint32_t own = rd.get(1);
             if (own) {
-                cfrung = (r + get_switch_noflag<UB>(rd, sig2)) & UMASK;
+                cfrung = (r + get_switch_noflag<UB, RD>(rd, sig2)) & UMASK;
                 if (cfrung == r || cfrung == 0) return false;
             }
             const uint32_t vr = cfrung - own;
             uint64_t v;
             if (vr == 0) v = rd.get(1);
-            else { T t = get_value<T>(rd, vr); v = (uint64_t)((vr >= 3) ? unswap<T>(t, vr) : t); }   // cf values: rungs 1,2 unswapped (QB3encode.h:144-150)
+            else { T t = get_value<T, RD>(rd, vr); v = (uint64_t)((vr >= 3) ? unswap<T>(t, vr) : t); }   // cf values: rungs 1,2 unswapped (QB3encode.h:144-150)
             pcf = cf = (T)(v + ((uint64_t)own << cfrung));
         }
         cf = (T)(cf + 2);
         if (r) {
-            get_group<T, true>(rd, r, g);
+            get_group<T, true, RD>(rd, r, g);
             T used = 0;
 #pragma unroll
             for (uint32_t i = 0; i < 16; i++) { g[i] = mmul_t<T>(g[i], cf); used |= g[i]; }
@@ -510,7 +517,7 @@ template <typename T, int MODE> __device__ __forceinline__ bool parse_unit(Reade
         return true;
     }
     // index coding
-    rung = r = (rung + get_switch_noflag<UB>(rd, sig2)) & UMASK;
+    rung = r = (rung + get_switch_noflag<UB, RD>(rd, sig2)) & UMASK;
     if (r == 63 || r == 0) return false;
     uint64_t ix = 0;                            // 16 x 3 bit indices packed
     uint32_t maxidx = 0, ibits = 0;
@@ -532,7 +539,7 @@ template <typename T, int MODE> __device__ __forceinline__ bool parse_unit(Reade
 #pragma unroll
     for (uint32_t i = 0; i < 8; i++) {
         tab[i] = 0;
-        if (i <= maxidx) { T t = get_value<T>(rd, r); tab[i] = (r >= 3) ? unswap<T>(t, r) : t; }
+        if (i <= maxidx) { T t = get_value<T, RD>(rd, r); tab[i] = (r >= 3) ? unswap<T>(t, r) : t; }
     }
 #pragma unroll
     for (uint32_t i = 0; i < 16; i++) {
@@ -573,7 +580,7 @@ __global__ void dec_kernel(const DecArgs a) {
         for (uint32_t c = 0; c < bands; c++) {
             uint32_t rung = rungs[c];
             T cf = pcf[c];
-            ok = parse_unit<T, MODE>(rd, rung, cf, g) && ok;
+            ok = parse_unit<T, MODE, Reader>(rd, rung, cf, g) && ok;
             rungs[c] = (uint8_t)rung;
             pcf[c] = cf;
             T prv = prev[c];
@@ -612,6 +619,203 @@ __global__ void dec_kernel(const DecArgs a) {
     }
 }
 
+// ---- unit-parallel decode (FTL / BASE, band maps whose core bands are themselves core) ------------------
+// One workgroup per index segment (= NB blocks).  Nothing in it is serial: the index carries the bit length of
+// every unit, so
+//   positions   exclusive scan of block lengths, plus the unit lengths inside the block
+//   rungs       each lane reads its own rung-switch code; the rung is the entry rung of the band plus the
+//               per-band scan of the switch deltas (mod 2^UB)
+//   values      lane per unit decodes its 16 codes, undoes step and mag-sign; the value entering the unit is
+//               the band's entry value plus the per-band scan of the unit totals
+// Lanes are ordered band-major inside a pass (lane = band*BPP + block) so that a per-band scan is a plain
+// workgroup scan minus its value at the band's first lane.  The compressed range is staged in LDS with
+// coalesced loads, pixels are assembled in an LDS tile laid out like the image and stored as coalesced dwords.
+template <typename V>
+__device__ __forceinline__ V block_exscan_v(V v, V *wsum) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    V x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        V y = __shfl_up(x, d, 64);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    V base = 0;
+    for (uint32_t i = 0; i < nw; i++) if (i < wave) base += wsum[i];
+    __syncthreads();
+    return (V)(base + x - v);
+}
+
+// reads the rung-switch code at bit `pos`: returns the delta (mod 2^UB), sets *gpos to the first value code
+template <typename T, typename PTR>
+__device__ __forceinline__ uint32_t dec3_switch(PTR src, uint32_t endw, uint32_t pos, uint32_t *gpos, bool *signal) {
+    constexpr uint32_t UB = UBits<T>::v;
+    ReaderT<PTR> rd;
+    rd.in = src; rd.endw = endw; rd.wp = pos >> 5;
+    const uint32_t sh = pos & 31;
+    rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
+    uint32_t delta = 0;
+    *signal = false;
+    if (rd.get(1)) delta = get_switch_noflag<UB, ReaderT<PTR>>(rd, *signal);
+    *gpos = (uint32_t)rd.position();
+    return delta;
+}
+
+// decodes the 16 values at bit `gpos`; run[i] = sum of the first i+1 deltas in curve order
+template <typename T, bool STEP, typename PTR>
+__device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos, uint32_t rung, T (&run)[16]) {
+    ReaderT<PTR> rd;
+    rd.in = src; rd.endw = endw; rd.wp = gpos >> 5;
+    const uint32_t sh = gpos & 31;
+    rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
+    get_group<T, STEP, ReaderT<PTR>>(rd, rung, run);
+    T acc = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) { acc = (T)(acc + smag_t<T>(run[i])); run[i] = acc; }
+}
+
+template <typename T, bool STEP>
+__global__ void dec3_kernel(const DecArgs a) {
+    constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t bands = a.g.bands, NB = a.g.seg_blocks, dpr = a.dpr, nbx = a.g.nbx, BPP = a.bpp;
+    const uint64_t seg = blockIdx.x;
+    const uint32_t g0 = (uint32_t)(seg * NB);
+    const uint32_t nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
+    const uint64_t stride = a.g.stride;
+
+    // LDS carve (8-byte aligned pieces)
+    uint64_t *slot_base = (uint64_t *)smem;
+    uint64_t *wsum = slot_base + NB;                   // 16: scan scratch
+    uint64_t *cprev = wsum + 16;                       // MAXBANDS: value entering the pass, per band
+    uint64_t *ebaseT = cprev + MAXBANDS;               // MAXBANDS: scan value at the band's first lane (totals)
+    uint32_t *crung = (uint32_t *)(ebaseT + MAXBANDS); // MAXBANDS
+    uint32_t *ebase = crung + MAXBANDS;                // MAXBANDS (deltas)
+    uint32_t *bpos = ebase + MAXBANDS;                 // BPP (+pad)
+    uint32_t *stage = bpos + ((BPP + 1) & ~1u);
+    uint32_t *tile = stage + a.in_cap_dw;
+    uint16_t *ulen_s = (uint16_t *)(tile + 4 * NB * dpr);   // BPP*bands
+
+    // the compressed range of this segment, in bits from a.in32
+    const uint64_t P0 = a.idx.bitpos[seg];
+    const uint64_t P1 = (seg + 1 < a.g.nseg) ? a.idx.bitpos[seg + 1] : a.in_bits;
+    const uint64_t w0 = (a.in_bit0 + P0) >> 5;
+    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
+    const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0 + 2;
+    const bool staged = ndw64 <= a.in_cap_dw;          // workgroup uniform
+    const uint32_t ndw = (uint32_t)ndw64;
+    if (staged)
+        for (uint32_t i = tid; i < ndw; i += nthr) stage[i] = (w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+    const uint32_t endw_g = (uint32_t)((endw_abs - w0 < 0xffffffffull) ? endw_abs - w0 : 0xffffffffull);
+    for (uint32_t sl = tid; sl < nb_here; sl += nthr) {
+        const uint32_t g = g0 + sl, by = g / nbx, bx = g - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        slot_base[sl] = (uint64_t)y0 * stride + (uint64_t)x0 * bands;
+    }
+    if (tid < bands) {
+        cprev[tid] = (uint64_t)((const T *)a.idx.prev)[seg * bands + tid];
+        crung[tid] = a.idx.rung[seg * bands + tid];
+    }
+    uint32_t cpos = (uint32_t)(a.in_bit0 + P0 - 32 * w0);     // bit position of the pass, relative to word w0
+    const uint32_t c = fastdiv(tid, BPP, a.magic_bpp), b = tid - c * BPP;
+    const uint32_t cb = a.g.cband[c < MAXBANDS ? c : 0];
+    const uint64_t order = a.g.order;
+    T *tt = (T *)tile;
+    bool bad = false;
+    __syncthreads();
+
+    for (uint32_t p = 0; p < a.passes; p++) {
+        const uint32_t pb0 = p * BPP;
+        const uint32_t nbp = pb0 >= nb_here ? 0 : ((nb_here - pb0 < BPP) ? nb_here - pb0 : BPP);
+        // unit lengths of this pass (contiguous in the table)
+        const uint64_t ubase = ((uint64_t)g0 + pb0) * bands;
+        if (a.g.ulen_sz == 1) for (uint32_t i = tid; i < nbp * bands; i += nthr) ulen_s[i] = ((const uint8_t *)a.idx.ulen)[ubase + i];
+        else for (uint32_t i = tid; i < nbp * bands; i += nthr) ulen_s[i] = ((const uint16_t *)a.idx.ulen)[ubase + i];
+        __syncthreads();
+        uint32_t blen = 0;
+        if (tid < nbp) for (uint32_t k = 0; k < bands; k++) blen += ulen_s[tid * bands + k];
+        const uint32_t bex = (uint32_t)block_exscan_v<uint64_t>(blen, wsum);
+        if (tid < nbp) bpos[tid] = cpos + bex;
+        if (tid == nthr - 1) wsum[15] = bex + blen;        // pass total (lane nthr-1 holds the inclusive sum)
+        __syncthreads();
+        const uint32_t ptotal = (uint32_t)wsum[15];
+        const bool act = c < bands && b < nbp;
+        const uint32_t sl = pb0 + b;
+        uint32_t pos = 0, gpos = 0, delta = 0;
+        if (act) {
+            pos = bpos[b];
+            for (uint32_t k = 0; k < c; k++) pos += ulen_s[b * bands + k];
+            bool sig;
+            delta = staged ? dec3_switch<T, LdsWords>((LdsWords)stage, ndw, pos, &gpos, &sig)
+                           : dec3_switch<T, const uint32_t *>(a.in32 + w0, endw_g, pos, &gpos, &sig);
+            if (sig && STEP) bad = true;       // common-factor / index unit in a BASE stream: not handled here
+        }
+        // per-band scan of the rung deltas
+        const uint32_t dex = (uint32_t)block_exscan_v<uint64_t>(act ? delta : 0u, wsum);
+        if (act && b == 0) ebase[c] = dex;
+        __syncthreads();
+        T run[16];
+        T usum = 0;
+        uint32_t rung = 0;
+        if (act) {
+            rung = (crung[c] + dex + delta - ebase[c]) & UMASK;
+            if (staged) dec3_group<T, STEP, LdsWords>((LdsWords)stage, ndw, gpos, rung, run);
+            else dec3_group<T, STEP, const uint32_t *>(a.in32 + w0, endw_g, gpos, rung, run);
+            usum = run[15];
+        }
+        // per-band scan of the unit totals -> value entering each unit
+        const uint64_t sex = block_exscan_v<uint64_t>(act ? (uint64_t)usum : 0ull, wsum);
+        if (act && b == 0) ebaseT[c] = sex;
+        __syncthreads();
+        T pv = 0;
+        if (act) {
+            pv = (T)(cprev[c] + sex - ebaseT[c]);
+            if (cb == c) {
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t nib = curve_nib(order, i);
+                    tt[(((nib >> 2) * NB + sl) * 4 + (nib & 3)) * bands + c] = (T)(run[i] + pv);
+                }
+            }
+        }
+        __syncthreads();            // core bands are in the tile; every read of crung/cprev is done
+        if (act) {
+            if (cb != c) {
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t nib = curve_nib(order, i);
+                    const uint32_t e = (((nib >> 2) * NB + sl) * 4 + (nib & 3)) * bands;
+                    tt[e + c] = (T)(run[i] + pv + tt[e + cb]);
+                }
+            }
+            if (b == nbp - 1) { crung[c] = rung; cprev[c] = (uint64_t)(T)(pv + usum); }
+        }
+        cpos += ptotal;
+        __syncthreads();
+    }
+    if (bad) atomicOr(a.status, 1u);
+    if (tid == 0 && seg == a.g.nseg - 1) {      // reference: more than 7 unused bits at the end is a failure
+        const uint64_t used = (uint64_t)cpos + 32 * w0 - a.in_bit0;
+        if (used > a.in_bits) atomicOr(a.status, 4u);
+        else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
+
+    // ---- store the tile rows, coalesced dwords
+    const uint32_t rowdw = nb_here * dpr;
+    for (uint32_t r = 0; r < 4; r++)
+        for (uint32_t j = tid; j < rowdw; j += nthr) {
+            const uint32_t sl = fastdiv(j, dpr, a.magic_dpr), d = j - sl * dpr;
+            uint8_t *dst = (uint8_t *)a.img + (slot_base[sl] + (uint64_t)r * stride) * sizeof(T) + 4 * d;
+            const uint32_t v = tile[r * NB * dpr + j];
+            if (((uintptr_t)dst & 3) == 0) *(uint32_t *)dst = v;
+            else { dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); dst[3] = (uint8_t)(v >> 24); }
+        }
+}
+
 // Foreign stream: ONE lane walks the stream and rebuilds the index (bit position + band state at every
 // segment start).  Latency bound by construction.
 template <typename T, int MODE>
@@ -642,7 +846,10 @@ __global__ void dec_index_serial(const DecArgs a) {
         for (uint32_t c = 0; c < bands; c++) {
             uint32_t rung = st_rung[c];
             T cf = (T)st_cf[c];
-            ok = parse_unit<T, MODE>(rd, rung, cf, g) && ok;
+            const uint64_t ustart = rd.position();
+            ok = parse_unit<T, MODE, Reader>(rd, rung, cf, g) && ok;
+            if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint8_t)(rd.position() - ustart);
+            else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint16_t)(rd.position() - ustart);
             T sum = 0;
 #pragma unroll
             for (uint32_t i = 0; i < 16; i++) sum = (T)(sum + smag_t<T>(g[i]));
@@ -721,12 +928,30 @@ int prof_names(char *buf, size_t n) {
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(#x, (int)e_); return (int)e_; } } while (0)
 
-uint32_t seg_blocks_for(uint32_t bands, uint32_t) { uint32_t s = 24 / bands; return s ? s : 1; }
+// Decoder workgroup geometry of the unit-parallel kernel: threads, blocks per pass, passes
+static void fast_geometry(uint32_t bands, uint32_t tsz, uint32_t *threads, uint32_t *bpp, uint32_t *passes) {
+    *threads = tsz == 8 ? 128 : 256;
+    *bpp = *threads / bands;
+    uint32_t k = (uint32_t)(16384 / ((size_t)*bpp * bands * tsz * 16));    // keep the pixel tile near 16 KB
+    *passes = k < 1 ? 1 : (k > 3 ? 3 : k);
+}
+uint32_t seg_blocks_for(uint32_t bands, uint32_t tsz, uint32_t mode) {
+    if (mode != CM_BEST) {      // one segment = the blocks of one unit-parallel workgroup
+        uint32_t threads, bpp, passes;
+        fast_geometry(bands, tsz, &threads, &bpp, &passes);
+        return bpp * passes;
+    }
+    // common-factor modes: a lane walks the segment serially, keep it short (QB3_SEG_UNITS: tuning knob)
+    static const uint32_t units = [] { const char *e = getenv("QB3_SEG_UNITS"); int v = e ? atoi(e) : 12; return (uint32_t)(v < 1 ? 1 : v); }();
+    uint32_t s = units / bands;
+    return s ? s : 1;
+}
+uint32_t ulen_size_for(uint32_t tsz, uint32_t mode) { return mode == CM_BEST ? 0 : (tsz == 1 ? 1 : 2); }
 
 static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 size_t index_bytes(const Geometry &g) {
     const size_t n = (size_t)g.nseg * g.bands;
-    return align8(8 * (size_t)g.nseg) + 2 * align8(n * g.tsz) + align8(n);
+    return align8(8 * (size_t)g.nseg) + 2 * align8(n * g.tsz) + align8(n) + align8((size_t)g.nblocks * g.bands * g.ulen_sz);
 }
 IndexView index_view(const Geometry &g, void *base) {
     IndexView v;
@@ -735,7 +960,8 @@ IndexView index_view(const Geometry &g, void *base) {
     v.bitpos = (uint64_t *)p; p += align8(8 * (size_t)g.nseg);
     v.prev = p; p += align8(n * g.tsz);
     v.cf = p; p += align8(n * g.tsz);
-    v.rung = p;
+    v.rung = p; p += align8(n);
+    v.ulen = g.ulen_sz ? p : nullptr;
     return v;
 }
 
@@ -794,7 +1020,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.res = (EncResult *)w;
     a.st = st_in;
     a.have_idx = index != nullptr;
-    a.idx = index ? index_view(g, index) : IndexView{nullptr, nullptr, nullptr, nullptr};
+    a.idx = index ? index_view(g, index) : IndexView{nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     switch (g.tsz) {
     case 1: return launch_encode_t<uint8_t>(a, plan, st);
@@ -826,6 +1052,18 @@ DecPlan plan_decode(const Geometry &g) {
     p.nwg = (uint32_t)((g.nseg + threads - 1) / threads);
     p.lds_bytes = (size_t)threads * lane_dw * 4;
     p.ws_bytes = align8(index_bytes(g)) + 64;
+    // unit-parallel kernel: FTL/BASE with a per-unit length table, and every core band must itself be core
+    // (true for every map the encoder's setter can produce, reference QB3encode.cpp:70-72); anything else keeps
+    // the lane-per-segment kernel
+    bool simple = g.mode != CM_BEST && g.ulen_sz != 0;
+    for (uint32_t c = 0; c < g.bands; c++) simple = simple && g.cband[g.cband[c]] == g.cband[c];
+    fast_geometry(g.bands, g.tsz, &p.threads2, &p.bpp, &p.passes);
+    const uint32_t dpr = g.bands * g.tsz, NB = g.seg_blocks;
+    simple = simple && NB == p.bpp * p.passes;
+    p.in_cap_dw = (NB * dpr * 4 + 8 + 1) & ~1u;         // room for a stream as large as the raw blocks
+    p.lds2_bytes = 8 * (size_t)NB + 8 * 16 + 8 * 2 * MAXBANDS + 4 * 2 * MAXBANDS + 4 * (size_t)((p.bpp + 1) & ~1u)
+                 + 4 * (size_t)p.in_cap_dw + 16 * (size_t)NB * dpr + align8(2 * (size_t)p.bpp * g.bands);
+    p.fast = simple && p.lds2_bytes <= 64 * 1024;
     return p;
 }
 
@@ -835,7 +1073,10 @@ static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild,
         ProfScope ps("dec_index_serial", st);
         hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(1), dim3(64), 0, st, a);
     }
-    {
+    if (plan.fast && MODE != CM_BEST) {
+        ProfScope ps("dec_units", st);
+        hipLaunchKernelGGL((dec3_kernel<T, MODE == CM_BASE>), dim3((uint32_t)a.g.nseg), dim3(plan.threads2), plan.lds2_bytes, st, a);
+    } else {
         ProfScope ps("dec_segments", st);
         hipLaunchKernelGGL((dec_kernel<T, MODE>), dim3(plan.nwg), dim3(plan.threads), plan.lds_bytes, st, a);
     }
@@ -863,6 +1104,8 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
     HIPCHK(hipMemsetAsync(a.status, 0, 64, st));
     a.lane_dw = dec_lane_dwords(g);
     a.dpr = g.bands * g.tsz;
+    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = plan.in_cap_dw;
+    a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;
     switch (g.tsz) {
     case 1: return launch_decode_t<uint8_t>(a, plan, rebuild, st);
