@@ -113,7 +113,7 @@ def main():
     for name, (ms, cnt) in prof.items():
         avg = ms / max(cnt, 1)
         kernels[name] = {"avg_ms": round(avg, 4), "launches": int(cnt), "GBps_algorithmic": round(algo_bytes / avg / 1e6, 1) if avg > 0 else None}
-    enc_ms = sum(kernels[k]["avg_ms"] for k in ("enc_lengths", "enc_scan", "enc_emit") if k in kernels)
+    enc_ms = sum(kernels[k]["avg_ms"] for k in ("enc_units", "enc_scan", "enc_concat", "enc_seams") if k in kernels)
     dec_ms = sum(kernels[k]["avg_ms"] for k in ("dec_index_serial", "dec_segments", "dec_units") if k in kernels)
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
     traffic = None

@@ -69,7 +69,7 @@ size_t qb3_decode(decsp p, void *destination);                                  
 
 /* Per-kernel timing for benchmarks: when enabled, every kernel the library launches is bracketed by HIP
  * events on the launch stream; totals are resolved at the library's own synchronisation points.
- * Kernel names: enc_lengths, enc_scan, enc_emit, dec_index_serial, dec_units, dec_segments. */
+ * Kernel names: enc_units, enc_scan, enc_concat, enc_seams, dec_index_serial, dec_units, dec_segments. */
 void qb3x_profile_enable(int on);
 void qb3x_profile_reset(void);
 int  qb3x_profile_get(const char *kernel, double *total_ms, uint64_t *count);   /* 1 if the kernel was seen */

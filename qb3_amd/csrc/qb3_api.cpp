@@ -293,9 +293,9 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
         bs.prev[c] = p->band[c].prev; bs.cf[c] = p->band[c].cf; bs.rung[c] = (uint8_t)p->band[c].runbits;
     }
     uint32_t *out32 = (uint32_t *)(d_out + (hdr & ~(size_t)3));
-    if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st)) return false;
     EncResult res;
     const uint8_t *dres = (const uint8_t *)p->d_ws.p + plan.ws_bytes - sizeof(EncResult);
+    if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st)) return false;
     hipError_t e = hipMemcpyAsync(&res, dres, sizeof(res), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }

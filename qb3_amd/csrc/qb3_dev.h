@@ -57,6 +57,8 @@ struct EncResult {
     uint64_t prev[MAXBANDS];
     uint64_t cf[MAXBANDS];
     uint32_t rung[MAXBANDS];
+    uint32_t error;             // reserved
+    uint32_t pad;
 };
 
 // Workspace sizes
@@ -65,7 +67,7 @@ struct EncPlan {
     uint32_t slots;         // block slots per chunk, slot 0 is the halo block
     uint32_t nchunks;
     size_t lds_bytes;
-    size_t ws_bytes;        // chunk_bits (u32) + chunk_off (u64) + EncResult
+    size_t ws_bytes;        // chunk counts/offsets, seam table, per-chunk scratch slots, EncResult (last)
 };
 EncPlan plan_encode(const Geometry &g);
 

@@ -96,8 +96,12 @@ struct EncArgs {
     uint32_t *out32;
     uint32_t out_bit0;
     uint32_t slots, nchunks, dpr, magic_dpr, magic_bands;
-    uint32_t *chunk_bits;
-    uint64_t *chunk_off;
+    uint32_t *chunk_bits;   // per chunk: bits produced
+    uint64_t *chunk_off;    // per chunk: exclusive bit offset inside its scan group (SCAN_GROUP chunks)
+    uint64_t *group_sum;    // per scan group: bits produced
+    uint32_t *scratch;      // per chunk: slot_dw dwords, the chunk's bits starting at bit 0
+    uint32_t slot_dw;
+    uint32_t *seams;        // per chunk: first and last dword after shifting, for the dwords two chunks share
     EncResult *res;
     BandState st;
     IndexView idx;
@@ -142,7 +146,9 @@ template <typename T> __device__ __forceinline__ void put_value(LdsWriter &w, T 
     }
 }
 
-template <typename T, bool STEP, bool EMIT>
+constexpr uint32_t SCAN_GROUP = 4096;      // chunks per workgroup of enc_scan_kernel
+
+template <typename T, bool STEP>
 __global__ void enc_kernel(const EncArgs a) {
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -150,15 +156,17 @@ __global__ void enc_kernel(const EncArgs a) {
     const uint32_t bands = a.g.bands, slots = a.slots, dpr = a.dpr, nbp = slots - 1;
     const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
     const uint64_t stride = a.g.stride;
-    const uint32_t g0 = blockIdx.x * nbp;                 // first payload block of this chunk
     const uint32_t rowdw = slots * dpr;
 
     // LDS carve (all offsets multiples of 8)
     uint64_t *slot_base = (uint64_t *)smem;
     uint32_t *tile = (uint32_t *)(slot_base + slots);
-    uint32_t *wsum = tile + 4 * rowdw;                     // 16 dwords
-    uint8_t *rungs = (uint8_t *)(wsum + 16);               // slots*bands bytes, padded to 8
+    uint32_t *wsum = tile + 4 * rowdw;                     // 64 dwords: scan partials, ticket, look-back scratch
+    uint8_t *rungs = (uint8_t *)(wsum + 64);               // slots*bands bytes, padded to 8
     uint32_t *outbuf = (uint32_t *)(rungs + ((slots * bands + 7) & ~7u));
+
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t g0 = chunk * nbp;                      // first payload block of this chunk
 
     // block index of slot s is g0 - 1 + s; invalid slots are clamped to a valid block so loads stay in bounds
     auto slot_block = [&](uint32_t s, bool &valid) -> uint32_t {
@@ -177,7 +185,7 @@ __global__ void enc_kernel(const EncArgs a) {
         block_origin(slot_block(tid, valid), x0, y0);
         slot_base[tid] = (uint64_t)y0 * stride + (uint64_t)x0 * bands;
     }
-    if (EMIT) {
+    {
         const uint32_t outdw = (31 + nbp * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1;
         for (uint32_t i = tid; i < outdw; i += nthr) outbuf[i] = 0;
     }
@@ -273,17 +281,13 @@ __global__ void enc_kernel(const EncArgs a) {
     uint32_t total;
     const uint32_t pos = block_exscan(len, wsum, &total);
 
-    if (!EMIT) {
-        if (tid == 0) a.chunk_bits[blockIdx.x] = total;
-        return;
-    }
-
-    const uint64_t coff = a.chunk_off[blockIdx.x];         // bits from the stream start
-    const uint64_t G = (uint64_t)a.out_bit0 + coff;
-    const uint32_t phase = (uint32_t)(G & 31);
+    // ---- emit: the chunk's bits are assembled in LDS starting at bit 0 and go to the chunk's private slot.
+    // Where they land in the stream is only known after all chunks are counted; enc_concat_kernel moves them.
+    // (A single pass with a decoupled look-back was measured slower here: at ~160 chunks/us the prefix frontier
+    // cannot keep up with L2 polling latency, and a ticket counter alone caps the kernel at ~88 chunks/us.)
     if (payload) {
         LdsWriter w;
-        w.init(outbuf, phase + pos);
+        w.init(outbuf, pos);
         w.put(cs_code<UB>(delta), cs_len<UB>(delta));
         if (used <= 1) {
             w.put((uint32_t)used, 1);
@@ -307,55 +311,86 @@ __global__ void enc_kernel(const EncArgs a) {
             if (seg * a.g.seg_blocks == gblk) {
                 ((T *)a.idx.prev)[(uint64_t)seg * bands + c] = pv;
                 a.idx.rung[(uint64_t)seg * bands + c] = (uint8_t)prung;
-                if (c == 0) a.idx.bitpos[seg] = coff + pos;
+                if (c == 0) a.idx.bitpos[seg] = ((uint64_t)chunk << 32) | pos;     // chunk-relative; fixed up by enc_seam_kernel
             }
         }
     }
     __syncthreads();
-    // ---- store the chunk: whole dwords plain, the (at most two) seam dwords with atomicOr into zeroed memory
-    const uint32_t nd = (phase + total + 31) >> 5;
-    const uint32_t tailbits = (phase + total) & 31;
+    const uint32_t nd = (total + 31) >> 5;
+    uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;
+    for (uint32_t d = tid; d < nd; d += nthr) slot[d] = outbuf[d];
+    if (tid == 0) a.chunk_bits[chunk] = total;
+}
+
+// Exclusive scan of the chunk bit counts, one workgroup per SCAN_GROUP chunks (4 per thread); the per-group sums
+// are folded in by the consumers.  64-bit offsets: a 16384^2 x 3 stream exceeds 2^32 bits.
+__global__ void enc_scan_kernel(const EncArgs a) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, i0 = blockIdx.x * SCAN_GROUP + 4 * tid;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = (i0 + k < a.nchunks) ? a.chunk_bits[i0 + k] : 0; sum += v[k]; }
+    uint32_t total;
+    uint64_t off = block_exscan(sum, wsum, &total);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i0 + k < a.nchunks) { a.chunk_off[i0 + k] = off; off += v[k]; }
+    if (tid == 0) a.group_sum[blockIdx.x] = total;
+}
+
+// start of chunk k in the stream, in bits (k == nchunks: the stream length)
+__device__ __forceinline__ uint64_t chunk_start(const EncArgs &a, uint32_t k) {
+    const uint32_t grp = (k < a.nchunks ? k : a.nchunks - 1) / SCAN_GROUP;
+    uint64_t base = 0;
+    for (uint32_t i = 0; i < grp; i++) base += a.group_sum[i];
+    return k < a.nchunks ? base + a.chunk_off[k] : base + a.chunk_off[a.nchunks - 1] + a.chunk_bits[a.nchunks - 1];
+}
+
+// Concatenate: workgroup per chunk reads the chunk's slot, funnel-shifts it to its bit position and stores the
+// dwords that lie wholly inside the chunk; the first and last shifted dword go to the seam table.
+__global__ void enc_concat_kernel(const EncArgs a) {
+    __shared__ uint64_t start_s;
+    const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) start_s = chunk_start(a, chunk);
+    __syncthreads();
+    const uint64_t G = (uint64_t)a.out_bit0 + start_s;
+    const uint32_t total = a.chunk_bits[chunk];
+    const uint32_t phase = (uint32_t)(G & 31), nsrc = (total + 31) >> 5;
+    const uint32_t nd = (phase + total + 31) >> 5, tailbits = (phase + total) & 31;
+    const uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;
     uint32_t *gout = a.out32 + (G >> 5);
-    for (uint32_t d = tid; d < nd; d += nthr) {
-        const uint32_t v = outbuf[d];
-        const bool seam = (d == 0 && phase) || (d == nd - 1 && tailbits);
-        if (seam) { if (v) atomicOr(&gout[d], v); }
-        else gout[d] = v;
+    for (uint32_t d = tid; d < nd; d += blockDim.x) {
+        const uint32_t lo = d < nsrc ? slot[d] : 0u, prv = (d > 0 && d - 1 < nsrc) ? slot[d - 1] : 0u;
+        const uint32_t v = phase ? (uint32_t)((((uint64_t)lo << 32) | prv) >> (32 - phase)) : lo;
+        const bool shared = (d == 0 && phase) || (d == nd - 1 && tailbits);
+        if (!shared) gout[d] = v;
+        if (d == 0) a.seams[2 * chunk] = v;
+        if (d == nd - 1) a.seams[2 * chunk + 1] = v;
     }
 }
 
-// Single workgroup: exclusive scan of the chunk totals (4 per thread per round), zero the seam dwords,
-// publish the stream length.
-__global__ void enc_scan_kernel(const EncArgs a) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint64_t carry_s;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < a.nchunks; base += 4 * blockDim.x) {
-        const uint32_t i0 = base + 4 * tid;
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { v[k] = (i0 + k < a.nchunks) ? a.chunk_bits[i0 + k] : 0; sum += v[k]; }
-        uint32_t total;
-        const uint32_t ex = block_exscan(sum, wsum, &total);
-        uint64_t off = carry_s + ex;
-#pragma unroll
-        for (int k = 0; k < 4; k++) if (i0 + k < a.nchunks) {
-            a.chunk_off[i0 + k] = off;
-            const uint64_t G = a.out_bit0 + off;
-            if (G & 31) a.out32[G >> 5] = 0;
-            off += v[k];
+// One thread per chunk boundary: a dword that holds the end of one chunk and the start of the next is the OR of
+// their edge dwords; the thread of the FIRST boundary inside a dword assembles it.  The same launch turns the
+// chunk-relative index positions into stream positions and publishes the stream length.
+__global__ void enc_seam_kernel(const EncArgs a) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    if (a.have_idx)
+        for (uint64_t sgi = k; sgi < a.g.nseg; sgi += nthreads) {
+            const uint64_t v = a.idx.bitpos[sgi];
+            a.idx.bitpos[sgi] = chunk_start(a, (uint32_t)(v >> 32)) + (v & 0xffffffffu);
         }
-        __syncthreads();
-        if (tid == 0) carry_s += total;
-        __syncthreads();
+    if (k > a.nchunks) return;
+    const uint64_t Ek = (uint64_t)a.out_bit0 + chunk_start(a, k);
+    if (k == a.nchunks) a.res->total_bits = Ek - a.out_bit0;
+    if ((Ek & 31) == 0) return;
+    const uint64_t d = Ek >> 5;
+    if (k > 0) { const uint64_t Ep = (uint64_t)a.out_bit0 + chunk_start(a, k - 1); if ((Ep >> 5) == d && (Ep & 31)) return; }
+    uint32_t v = k > 0 ? a.seams[2 * (k - 1) + 1] : 0u;
+    for (uint32_t j = k; j < a.nchunks; j++) {
+        v |= a.seams[2 * j];
+        const uint64_t En = (uint64_t)a.out_bit0 + chunk_start(a, j + 1);
+        if ((En >> 5) != d || (En & 31) == 0) break;       // chunk j reaches the end of the dword
     }
-    if (tid == 0) {
-        const uint64_t G = a.out_bit0 + carry_s;
-        if (G & 31) a.out32[G >> 5] = 0;
-        a.res->total_bits = carry_s;
-    }
+    a.out32[d] = v;
 }
 
 // ------------------------------------------------------------------ decode
@@ -972,16 +1007,34 @@ static uint32_t max_unit_bits(uint32_t tsz) {
     return ub + 2 + 16 * (8 * tsz + 1);
 }
 
+// encoder workspace layout (all 8-byte aligned), EncResult last
+struct EncWs { size_t bits, off, gsum, seams, scratch, res, total; uint32_t slot_dw, ngroups; };
+static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
+    EncWs w;
+    w.slot_dw = (uint32_t)((31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz)) / 32 + 1);
+    w.ngroups = (nchunks + SCAN_GROUP - 1) / SCAN_GROUP;
+    size_t o = 0;
+    w.bits = o; o += align8(4 * (size_t)nchunks);
+    w.off = o; o += 8 * (size_t)nchunks;
+    w.gsum = o; o += 8 * (size_t)w.ngroups;
+    w.seams = o; o += 8 * (size_t)nchunks;
+    w.scratch = o; o += align8(4 * (size_t)nchunks * w.slot_dw);
+    w.res = o; o += sizeof(EncResult);
+    w.total = o;
+    return w;
+}
+
 EncPlan plan_encode(const Geometry &g) {
     EncPlan p;
     p.threads = g.tsz == 8 ? 128 : 256;
+    if (const char *e = getenv("QB3_ENC_THREADS")) p.threads = (uint32_t)atoi(e);      // tuning knob
     p.slots = p.threads / g.bands;
     const uint32_t nbp = p.slots - 1;
     p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
     const uint32_t dpr = g.bands * g.tsz;
     const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz)) / 32 + 1;
-    p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 64 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * outdw;
-    p.ws_bytes = align8(4 * (size_t)p.nchunks) + 8 * (size_t)p.nchunks + sizeof(EncResult);
+    p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * outdw;
+    p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp).total;
     return p;
 }
 
@@ -990,18 +1043,21 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
     const bool step = a.g.mode != CM_FTL;
     dim3 grid(plan.nchunks), block(plan.threads);
     {
-        ProfScope ps("enc_lengths", st);
-        if (step) hipLaunchKernelGGL((enc_kernel<T, true, false>), grid, block, plan.lds_bytes, st, a);
-        else hipLaunchKernelGGL((enc_kernel<T, false, false>), grid, block, plan.lds_bytes, st, a);
+        ProfScope ps("enc_units", st);
+        if (step) hipLaunchKernelGGL((enc_kernel<T, true>), grid, block, plan.lds_bytes, st, a);
+        else hipLaunchKernelGGL((enc_kernel<T, false>), grid, block, plan.lds_bytes, st, a);
     }
     {
         ProfScope ps("enc_scan", st);
-        hipLaunchKernelGGL(enc_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(enc_scan_kernel, dim3((plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP), dim3(SCAN_GROUP / 4), 0, st, a);
     }
     {
-        ProfScope ps("enc_emit", st);
-        if (step) hipLaunchKernelGGL((enc_kernel<T, true, true>), grid, block, plan.lds_bytes, st, a);
-        else hipLaunchKernelGGL((enc_kernel<T, false, true>), grid, block, plan.lds_bytes, st, a);
+        ProfScope ps("enc_concat", st);
+        hipLaunchKernelGGL(enc_concat_kernel, grid, dim3(256), 0, st, a);
+    }
+    {
+        ProfScope ps("enc_seams", st);
+        hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1015,9 +1071,14 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
     a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
     uint8_t *w = (uint8_t *)ws;
-    a.chunk_bits = (uint32_t *)w; w += align8(4 * (size_t)plan.nchunks);
-    a.chunk_off = (uint64_t *)w; w += 8 * (size_t)plan.nchunks;
-    a.res = (EncResult *)w;
+    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.slots - 1);
+    a.chunk_bits = (uint32_t *)(w + L.bits);
+    a.chunk_off = (uint64_t *)(w + L.off);
+    a.group_sum = (uint64_t *)(w + L.gsum);
+    a.seams = (uint32_t *)(w + L.seams);
+    a.scratch = (uint32_t *)(w + L.scratch);
+    a.slot_dw = L.slot_dw;
+    a.res = (EncResult *)(w + L.res);
     a.st = st_in;
     a.have_idx = index != nullptr;
     a.idx = index ? index_view(g, index) : IndexView{nullptr, nullptr, nullptr, nullptr, nullptr};

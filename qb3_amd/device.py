@@ -37,7 +37,7 @@ class DeviceEncoder:
         self.index = None
 
     def close(self):
-        if self.p:
+        if self.p and lib is not None:      # `lib` may already be gone at interpreter shutdown
             lib.qb3_destroy_encoder(self.p)
             self.p = None
 
@@ -81,7 +81,7 @@ class DeviceDecoder:
         self.nbytes = nbytes
 
     def close(self):
-        if self.p:
+        if self.p and lib is not None:
             lib.qb3_destroy_decoder(self.p)
             self.p = None
 
