@@ -67,6 +67,36 @@ template <uint32_t UB> __device__ __forceinline__ uint32_t cs_code(uint32_t delt
     return (c << 1) | 1;
 }
 
+
+// ---- code tables in LDS, generated from the code rules (never transcribed) ---------------------------------
+// Encode: ENC_TAB_SIZE entries; rung r in 1..7 occupies [2^(r+1)-4, 2^(r+2)-4), indexed by the mag-sign value,
+// entry = len<<12 | code with the middle swap applied (reference QB3encode.h:30-33, 132-141).
+// Decode: DEC_TAB_SIZE entries; rung r in 1..7 occupies [2^(r+2)-8, 2^(r+3)-8), indexed by the next r+2 stream
+// bits, entry = len<<12 | value with the swap undone (reference QB3decode.h:119-129).
+constexpr uint32_t ENC_TAB_SIZE = 508, DEC_TAB_SIZE = 1016;
+__device__ __forceinline__ uint32_t enc_tab_off(uint32_t r) { return (2u << r) - 4; }
+__device__ __forceinline__ uint32_t dec_tab_off(uint32_t r) { return (4u << r) - 8; }
+__device__ __forceinline__ void fill_enc_tab(uint16_t *tab) {
+    for (uint32_t idx = threadIdx.x; idx < ENC_TAB_SIZE; idx += blockDim.x) {
+        const uint32_t r = topbit32(idx + 4) - 1, top = 1u << r, half = top >> 1;
+        uint32_t v = idx - enc_tab_off(r);
+        if (v == top || v == top - 1) v ^= 2 * top - 1;
+        const uint32_t code = (v < half) ? (v << 1) : (v < top) ? (((v - half) << 2) | 1) : (((v - top) << 2) | 3);
+        tab[idx] = (uint16_t)(((r + (v >= half) + (v >= top)) << 12) | code);
+    }
+}
+__device__ __forceinline__ void fill_dec_tab(uint16_t *tab) {
+    for (uint32_t idx = threadIdx.x; idx < DEC_TAB_SIZE; idx += blockDim.x) {
+        const uint32_t r = topbit32(idx + 8) - 2, top = 1u << r, half = top >> 1, x = idx - dec_tab_off(r);
+        uint32_t v, len;
+        if (!(x & 1)) { v = (x & (top - 1)) >> 1; len = r; }
+        else if (!(x & 2)) { v = ((x >> 2) & (half - 1)) | half; len = r + 1; }
+        else { v = ((x >> 2) & (top - 1)) | top; len = r + 2; }
+        if (v == top || v == top - 1) v ^= 2 * top - 1;
+        tab[idx] = (uint16_t)((len << 12) | v);
+    }
+}
+
 // workgroup exclusive scan of one u32 per thread (blockDim.x multiple of 64, <= 1024); *total = sum
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum, uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -89,6 +119,23 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *wsum, uin
     return base + x - v;
 }
 
+template <typename V>
+__device__ __forceinline__ V block_exscan_v(V v, V *wsum) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    V x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        V y = __shfl_up(x, d, 64);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    V base = 0;
+    for (uint32_t i = 0; i < nw; i++) if (i < wave) base += wsum[i];
+    __syncthreads();
+    return (V)(base + x - v);
+}
+
 // ------------------------------------------------------------------ encode
 struct EncArgs {
     Geometry g;
@@ -102,6 +149,7 @@ struct EncArgs {
     uint32_t *scratch;      // per chunk: slot_dw dwords, the chunk's bits starting at bit 0
     uint32_t slot_dw;
     uint32_t *seams;        // per chunk: first and last dword after shifting, for the dwords two chunks share
+    uint32_t flags;         // tuning switches (QB3_ENC_FLAGS): bit 0 = codes from the LDS table instead of the rule
     EncResult *res;
     BandState st;
     IndexView idx;
@@ -163,7 +211,9 @@ __global__ void enc_kernel(const EncArgs a) {
     uint32_t *tile = (uint32_t *)(slot_base + slots);
     uint32_t *wsum = tile + 4 * rowdw;                     // 64 dwords: scan partials, ticket, look-back scratch
     uint8_t *rungs = (uint8_t *)(wsum + 64);               // slots*bands bytes, padded to 8
-    uint32_t *outbuf = (uint32_t *)(rungs + ((slots * bands + 7) & ~7u));
+    uint16_t *etab = (uint16_t *)(rungs + ((slots * bands + 7) & ~7u));     // ENC_TAB_SIZE + pad
+    uint32_t *outbuf = (uint32_t *)(etab + 512);
+    fill_enc_tab(etab);
 
     const uint32_t chunk = blockIdx.x;
     const uint32_t g0 = chunk * nbp;                      // first payload block of this chunk
@@ -232,10 +282,12 @@ __global__ void enc_kernel(const EncArgs a) {
             if (cb != c) pv = (T)(pv - ip[cb]);
         }
         T prv = pv;
+        // element index = lane part (slot, band) + a wave-uniform part per curve position (scalar arithmetic)
+        const uint32_t ebase = s * 4 * bands, rowel = slots * 4 * bands;
 #pragma unroll
         for (uint32_t i = 0; i < 16; i++) {
             const uint32_t nib = curve_nib(order, i);
-            const uint32_t e = (((nib >> 2) * slots + s) * 4 + (nib & 3)) * bands;
+            const uint32_t e = ebase + ((nib >> 2) * rowel + (nib & 3) * bands);
             T v = tt[e + c];
             if (cb != c) v = (T)(v - tt[e + cb]);
             g[i] = mags_t<T>((T)(v - prv));
@@ -248,13 +300,28 @@ __global__ void enc_kernel(const EncArgs a) {
     }
     __syncthreads();
 
+    // ---- unit bit string.  Short units (rung < 8, always the case for 8-bit data) are assembled BEFORE the scan
+    // into six pieces of at most 27 bits -- [switch, c0, c1] [c2..c4] [c5..c7] [c8..c10] [c11..c13] [c14, c15] --
+    // so that only six words and their packed lengths stay live across the scan (the 16 values die here).
+    // Wider units keep their values and are coded from the rule after the scan.
     uint32_t len = 0, prung = 0, delta = 0;
+    uint32_t pc[6] = {0, 0, 0, 0, 0, 0}, plens = 0;        // pieces and their lengths (5 bits each)
+    bool pieces = false;
     if (payload) {
         prung = (gblk == 0) ? a.st.rung[c] : rungs[tid - bands];
         delta = (rung - prung) & UMASK;
-        len = cs_len<UB>(delta);
-        if (used <= 1) len += 1 + (used ? 16 : 0);
-        else {
+        const uint32_t csl = cs_len<UB>(delta), csc = cs_code<UB>(delta);
+        len = csl;
+        if (used <= 1) {            // flag, then the sixteen one-bit values if any is set (reference QB3encode.h:159-166)
+            uint32_t bits = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)(g[i] & 1) << i;
+            const uint32_t l = 1 + (used ? 16 : 0);
+            pc[0] = csc | ((uint32_t)used << csl) | (bits << (csl + 1));
+            plens = csl + l;        // <= 8 + 17
+            len += l;
+            pieces = true;
+        } else {
             const T top = (T)((T)1 << rung);
             if (STEP) {     // clear the rung bit of the last value of a 1..10..0 rung-bit run (reference QB3encode.h:169-176)
                 uint32_t bits = 0;
@@ -266,16 +333,36 @@ __global__ void enc_kernel(const EncArgs a) {
                     for (uint32_t i = 0; i < 16; i++) if (i + 1 == n) g[i] ^= top;
                 }
             }
-            uint32_t extra = 0;
-            const T half = (T)(top >> 1);
+            if (sizeof(T) == 1 || rung < 8) {
+                // code and length per value from the rule, middle swap included (QB3encode.h:30-33,132-141),
+                // or from the LDS table (flag bit 0)
+                const uint32_t tp = 1u << rung, hf = tp >> 1;
+                const uint16_t *tab = etab + enc_tab_off(rung);
+                uint32_t acc = csc, al = csl, k = 0, lsum = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < 16; i++) {
-                T v = g[i];
-                if (rung < 8 && (v == top || v == (T)(top - 1))) v ^= (T)(2 * top - 1);   // middle swap (QB3encode.h:30-33)
-                g[i] = v;
-                extra += (v >= half) + (v >= top);
+                for (uint32_t i = 0; i < 16; i++) {
+                    uint32_t code, l;
+                    if (a.flags & 1) { const uint32_t e = tab[(uint32_t)g[i]]; code = e & 0xfff; l = e >> 12; }
+                    else {
+                        uint32_t v = (uint32_t)g[i];
+                        if (v == tp || v == tp - 1) v ^= 2 * tp - 1;
+                        code = (v < hf) ? (v << 1) : (v < tp) ? (((v - hf) << 2) | 1) : (((v - tp) << 2) | 3);
+                        l = rung + (v >= hf) + (v >= tp);
+                    }
+                    acc |= code << al; al += l; lsum += l;
+                    if (i == 1 || i == 4 || i == 7 || i == 10 || i == 13 || i == 15) {   // piece boundary (static)
+                        pc[k] = acc; plens |= al << (5 * k); k++; acc = 0; al = 0;
+                    }
+                }
+                len += lsum;
+                pieces = true;
+            } else {                                 // computed three-length code, no swap above rung 7
+                uint32_t extra = 0;
+                const T half = (T)(top >> 1);
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) extra += (g[i] >= half) + (g[i] >= top);
+                len += 16 * rung + extra;
             }
-            len += 16 * rung + extra;
         }
     }
     uint32_t total;
@@ -288,16 +375,11 @@ __global__ void enc_kernel(const EncArgs a) {
     if (payload) {
         LdsWriter w;
         w.init(outbuf, pos);
-        w.put(cs_code<UB>(delta), cs_len<UB>(delta));
-        if (used <= 1) {
-            w.put((uint32_t)used, 1);
-            if (used) {
-                uint32_t bits = 0;
+        if (pieces) {
 #pragma unroll
-                for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)(g[i] & 1) << i;
-                w.put(bits, 16);
-            }
+            for (uint32_t k = 0; k < 6; k++) w.put(pc[k], (plens >> (5 * k)) & 31);
         } else {
+            w.put(cs_code<UB>(delta), cs_len<UB>(delta));
 #pragma unroll
             for (uint32_t i = 0; i < 16; i++) put_value<T>(w, g[i], rung);
         }
@@ -337,28 +419,44 @@ __global__ void enc_scan_kernel(const EncArgs a) {
     if (tid == 0) a.group_sum[blockIdx.x] = total;
 }
 
-// start of chunk k in the stream, in bits (k == nchunks: the stream length)
-__device__ __forceinline__ uint64_t chunk_start(const EncArgs &a, uint32_t k) {
-    const uint32_t grp = (k < a.nchunks ? k : a.nchunks - 1) / SCAN_GROUP;
-    uint64_t base = 0;
-    for (uint32_t i = 0; i < grp; i++) base += a.group_sum[i];
-    return k < a.nchunks ? base + a.chunk_off[k] : base + a.chunk_off[a.nchunks - 1] + a.chunk_bits[a.nchunks - 1];
+// Second level: exclusive scan of the group sums in place (one workgroup); entry [ngroups] gets the total.
+__global__ void enc_scan2_kernel(const EncArgs a) {
+    __shared__ uint64_t wsum64[16];
+    __shared__ uint64_t carry;
+    const uint32_t ngroups = (a.nchunks + SCAN_GROUP - 1) / SCAN_GROUP;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ngroups; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < ngroups ? a.group_sum[i] : 0ull;
+        const uint64_t ex = block_exscan_v<uint64_t>(v, wsum64);
+        const uint64_t c0 = carry;
+        if (i < ngroups) a.group_sum[i] = c0 + ex;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry = c0 + ex + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.group_sum[ngroups] = carry;
 }
 
-// Concatenate: workgroup per chunk reads the chunk's slot, funnel-shifts it to its bit position and stores the
+// start of chunk k in the stream, in bits (k == nchunks: the stream length)
+__device__ __forceinline__ uint64_t chunk_start(const EncArgs &a, uint32_t k) {
+    if (k >= a.nchunks) return a.group_sum[(a.nchunks + SCAN_GROUP - 1) / SCAN_GROUP];
+    return a.group_sum[k / SCAN_GROUP] + a.chunk_off[k];
+}
+
+// Concatenate: one WAVE per chunk reads the chunk's slot, funnel-shifts it to its bit position and stores the
 // dwords that lie wholly inside the chunk; the first and last shifted dword go to the seam table.
 __global__ void enc_concat_kernel(const EncArgs a) {
-    __shared__ uint64_t start_s;
-    const uint32_t chunk = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) start_s = chunk_start(a, chunk);
-    __syncthreads();
-    const uint64_t G = (uint64_t)a.out_bit0 + start_s;
+    const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (chunk >= a.nchunks) return;
+    const uint64_t G = (uint64_t)a.out_bit0 + chunk_start(a, chunk);
     const uint32_t total = a.chunk_bits[chunk];
     const uint32_t phase = (uint32_t)(G & 31), nsrc = (total + 31) >> 5;
     const uint32_t nd = (phase + total + 31) >> 5, tailbits = (phase + total) & 31;
     const uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;
     uint32_t *gout = a.out32 + (G >> 5);
-    for (uint32_t d = tid; d < nd; d += blockDim.x) {
+    for (uint32_t d = lane; d < nd; d += 64) {
         const uint32_t lo = d < nsrc ? slot[d] : 0u, prv = (d > 0 && d - 1 < nsrc) ? slot[d - 1] : 0u;
         const uint32_t v = phase ? (uint32_t)((((uint64_t)lo << 32) | prv) >> (32 - phase)) : lo;
         const bool shared = (d == 0 && phase) || (d == nd - 1 && tailbits);
@@ -665,23 +763,6 @@ __global__ void dec_kernel(const DecArgs a) {
 // Lanes are ordered band-major inside a pass (lane = band*BPP + block) so that a per-band scan is a plain
 // workgroup scan minus its value at the band's first lane.  The compressed range is staged in LDS with
 // coalesced loads, pixels are assembled in an LDS tile laid out like the image and stored as coalesced dwords.
-template <typename V>
-__device__ __forceinline__ V block_exscan_v(V v, V *wsum) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    V x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        V y = __shfl_up(x, d, 64);
-        if (lane >= (uint32_t)d) x += y;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    V base = 0;
-    for (uint32_t i = 0; i < nw; i++) if (i < wave) base += wsum[i];
-    __syncthreads();
-    return (V)(base + x - v);
-}
-
 // reads the rung-switch code at bit `pos`: returns the delta (mod 2^UB), sets *gpos to the first value code
 template <typename T, typename PTR>
 __device__ __forceinline__ uint32_t dec3_switch(PTR src, uint32_t endw, uint32_t pos, uint32_t *gpos, bool *signal) {
@@ -697,14 +778,33 @@ __device__ __forceinline__ uint32_t dec3_switch(PTR src, uint32_t endw, uint32_t
     return delta;
 }
 
-// decodes the 16 values at bit `gpos`; run[i] = sum of the first i+1 deltas in curve order
+// decodes the 16 values at bit `gpos`; run[i] = sum of the first i+1 deltas in curve order.
+// Rungs 1..7 go through the LDS table (one read per value, three values per refill of the bit buffer).
 template <typename T, bool STEP, typename PTR>
-__device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos, uint32_t rung, T (&run)[16]) {
+__device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos, uint32_t rung, const uint16_t *dtab, T (&run)[16]) {
     ReaderT<PTR> rd;
     rd.in = src; rd.endw = endw; rd.wp = gpos >> 5;
     const uint32_t sh = gpos & 31;
     rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
-    get_group<T, STEP, ReaderT<PTR>>(rd, rung, run);
+    if (rung >= 1 && rung < 8) {
+        const uint16_t *tab = dtab + dec_tab_off(rung);
+        const uint32_t mask = (4u << rung) - 1;
+        uint32_t rb = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            if (i % 3 == 0) rd.ensure(32);          // three codes are at most 27 bits
+            const uint32_t e = tab[(uint32_t)rd.buf & mask];
+            rd.skip(e >> 12);
+            run[i] = (T)(e & 0xfff);
+            rb |= ((e >> rung) & 1) << i;
+        }
+        if (STEP && (rb & (rb + 1)) == 0) {         // undo the step (reference QB3decode.h:285-289)
+            const uint32_t m = __popc(rb);
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) if (i == m) run[i] ^= (T)((T)1 << rung);
+        }
+    } else
+        get_group<T, STEP, ReaderT<PTR>>(rd, rung, run);
     T acc = 0;
 #pragma unroll
     for (uint32_t i = 0; i < 16; i++) { acc = (T)(acc + smag_t<T>(run[i])); run[i] = acc; }
@@ -732,7 +832,9 @@ __global__ void dec3_kernel(const DecArgs a) {
     uint32_t *bpos = ebase + MAXBANDS;                 // BPP (+pad)
     uint32_t *stage = bpos + ((BPP + 1) & ~1u);
     uint32_t *tile = stage + a.in_cap_dw;
-    uint16_t *ulen_s = (uint16_t *)(tile + 4 * NB * dpr);   // BPP*bands
+    uint16_t *ulen_s = (uint16_t *)(tile + 4 * NB * dpr);   // BPP*bands (padded to 8 bytes)
+    uint16_t *dtab = ulen_s + ((BPP * bands + 3) & ~3u);    // DEC_TAB_SIZE + pad
+    fill_dec_tab(dtab);
 
     // the compressed range of this segment, in bits from a.in32
     const uint64_t P0 = a.idx.bitpos[seg];
@@ -760,6 +862,7 @@ __global__ void dec3_kernel(const DecArgs a) {
     const uint32_t cb = a.g.cband[c < MAXBANDS ? c : 0];
     const uint64_t order = a.g.order;
     T *tt = (T *)tile;
+    const uint32_t rowel = NB * 4 * bands;       // tile elements per pixel row
     bool bad = false;
     __syncthreads();
 
@@ -798,8 +901,8 @@ __global__ void dec3_kernel(const DecArgs a) {
         uint32_t rung = 0;
         if (act) {
             rung = (crung[c] + dex + delta - ebase[c]) & UMASK;
-            if (staged) dec3_group<T, STEP, LdsWords>((LdsWords)stage, ndw, gpos, rung, run);
-            else dec3_group<T, STEP, const uint32_t *>(a.in32 + w0, endw_g, gpos, rung, run);
+            if (staged) dec3_group<T, STEP, LdsWords>((LdsWords)stage, ndw, gpos, rung, dtab, run);
+            else dec3_group<T, STEP, const uint32_t *>(a.in32 + w0, endw_g, gpos, rung, dtab, run);
             usum = run[15];
         }
         // per-band scan of the unit totals -> value entering each unit
@@ -813,7 +916,7 @@ __global__ void dec3_kernel(const DecArgs a) {
 #pragma unroll
                 for (uint32_t i = 0; i < 16; i++) {
                     const uint32_t nib = curve_nib(order, i);
-                    tt[(((nib >> 2) * NB + sl) * 4 + (nib & 3)) * bands + c] = (T)(run[i] + pv);
+                    tt[sl * 4 * bands + c + ((nib >> 2) * rowel + (nib & 3) * bands)] = (T)(run[i] + pv);
                 }
             }
         }
@@ -823,7 +926,7 @@ __global__ void dec3_kernel(const DecArgs a) {
 #pragma unroll
                 for (uint32_t i = 0; i < 16; i++) {
                     const uint32_t nib = curve_nib(order, i);
-                    const uint32_t e = (((nib >> 2) * NB + sl) * 4 + (nib & 3)) * bands;
+                    const uint32_t e = sl * 4 * bands + ((nib >> 2) * rowel + (nib & 3) * bands);
                     tt[e + c] = (T)(run[i] + pv + tt[e + cb]);
                 }
             }
@@ -1016,7 +1119,7 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
     size_t o = 0;
     w.bits = o; o += align8(4 * (size_t)nchunks);
     w.off = o; o += 8 * (size_t)nchunks;
-    w.gsum = o; o += 8 * (size_t)w.ngroups;
+    w.gsum = o; o += 8 * ((size_t)w.ngroups + 1);
     w.seams = o; o += 8 * (size_t)nchunks;
     w.scratch = o; o += align8(4 * (size_t)nchunks * w.slot_dw);
     w.res = o; o += sizeof(EncResult);
@@ -1033,7 +1136,7 @@ EncPlan plan_encode(const Geometry &g) {
     p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
     const uint32_t dpr = g.bands * g.tsz;
     const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz)) / 32 + 1;
-    p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * outdw;
+    p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * outdw;
     p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp).total;
     return p;
 }
@@ -1052,8 +1155,12 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
         hipLaunchKernelGGL(enc_scan_kernel, dim3((plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP), dim3(SCAN_GROUP / 4), 0, st, a);
     }
     {
+        ProfScope ps("enc_scan", st);
+        hipLaunchKernelGGL(enc_scan2_kernel, dim3(1), dim3(1024), 0, st, a);
+    }
+    {
         ProfScope ps("enc_concat", st);
-        hipLaunchKernelGGL(enc_concat_kernel, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(enc_concat_kernel, dim3((plan.nchunks + 3) / 4), dim3(256), 0, st, a);
     }
     {
         ProfScope ps("enc_seams", st);
@@ -1081,6 +1188,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.res = (EncResult *)(w + L.res);
     a.st = st_in;
     a.have_idx = index != nullptr;
+    { const char *e = getenv("QB3_ENC_FLAGS"); a.flags = e ? (uint32_t)atoi(e) : 1; }
     a.idx = index ? index_view(g, index) : IndexView{nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     switch (g.tsz) {
@@ -1123,7 +1231,7 @@ DecPlan plan_decode(const Geometry &g) {
     simple = simple && NB == p.bpp * p.passes;
     p.in_cap_dw = (NB * dpr * 4 + 8 + 1) & ~1u;         // room for a stream as large as the raw blocks
     p.lds2_bytes = 8 * (size_t)NB + 8 * 16 + 8 * 2 * MAXBANDS + 4 * 2 * MAXBANDS + 4 * (size_t)((p.bpp + 1) & ~1u)
-                 + 4 * (size_t)p.in_cap_dw + 16 * (size_t)NB * dpr + align8(2 * (size_t)p.bpp * g.bands);
+                 + 4 * (size_t)p.in_cap_dw + 16 * (size_t)NB * dpr + align8(2 * (size_t)p.bpp * g.bands) + 2048;
     p.fast = simple && p.lds2_bytes <= 64 * 1024;
     return p;
 }
