@@ -131,10 +131,12 @@ class Encoder:
         return dst[:n].copy()
 
 
-def encode(img, dtype, mode=8, cband=None, stride=0, quanta=1, away=False):
+def encode(img, dtype, mode=8, cband=None, stride=0, quanta=1, away=False, fix_b2=False):
     h, w, b = img.shape
     e = Encoder(w, h, b, dtype)
     e.set_mode(mode)
+    if fix_b2:
+        lib.qb3o_set_fix_b2(e.p, 1)
     if cband is not None:
         e.set_coreband(cband)
     if stride:

@@ -38,6 +38,8 @@ template <typename T> __device__ __forceinline__ T mags_t(T v) {       // refere
 template <typename T> __device__ __forceinline__ T smag_t(T v) {       // reference QB3common.h:133-136
     return (T)((T)(v >> 1) ^ (T)(0 - (T)(v & 1)));
 }
+template <typename T> __device__ __forceinline__ T mabs_t(T v) { return (T)((v >> 1) + (v & 1)); }
+template <typename T> __device__ __forceinline__ T mmul_t(T v, T m) { return (T)((T)(mabs_t<T>(v) * (T)(m << 1)) - (T)(v & 1)); }
 __device__ __forceinline__ uint32_t topbit64(uint64_t v) { return 63u - (uint32_t)__clzll((long long)v); }
 __device__ __forceinline__ uint32_t topbit32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
 template <typename T> __device__ __forceinline__ uint32_t topbit_t(T v) {
@@ -149,6 +151,9 @@ struct EncArgs {
     uint32_t *scratch;      // per chunk: slot_dw dwords, the chunk's bits starting at bit 0
     uint32_t slot_dw;
     uint32_t *seams;        // per chunk: first and last dword after shifting, for the dwords two chunks share
+    uint8_t *cw_has;        // common-factor modes: per chunk and band, does the chunk overwrite the band's factor
+    uint64_t *cw_val;       //   ... and with what (cf - 2)
+    uint64_t *centry;       //   ... factor state on entering the chunk (after best_scan_kernel)
     uint32_t flags;         // tuning switches (QB3_ENC_FLAGS): bit 0 = codes from the LDS table instead of the rule
     EncResult *res;
     BandState st;
@@ -196,10 +201,16 @@ template <typename T> __device__ __forceinline__ void put_value(LdsWriter &w, T 
 
 constexpr uint32_t SCAN_GROUP = 4096;      // chunks per workgroup of enc_scan_kernel
 
-template <typename T, bool STEP>
-__global__ void enc_kernel(const EncArgs a) {
-    constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// Everything a unit-per-lane encoder kernel needs before coding: LDS carve, tile staging, gather, deltas.
+template <typename T> struct EncFront {
+    uint64_t *slot_base; uint32_t *tile, *wsum; uint8_t *rungs; uint16_t *etab; uint32_t *outbuf;
+    uint32_t s, c, cb, gblk, rung, nbp, chunk;
+    bool valid, payload;
+    T used, pv, lastv;
+};
+
+template <typename T>
+__device__ __forceinline__ void enc_front(const EncArgs &a, uint8_t *smem, uint32_t outdw, EncFront<T> &f, T (&g)[16]) {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t bands = a.g.bands, slots = a.slots, dpr = a.dpr, nbp = slots - 1;
     const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
@@ -207,16 +218,18 @@ __global__ void enc_kernel(const EncArgs a) {
     const uint32_t rowdw = slots * dpr;
 
     // LDS carve (all offsets multiples of 8)
-    uint64_t *slot_base = (uint64_t *)smem;
-    uint32_t *tile = (uint32_t *)(slot_base + slots);
-    uint32_t *wsum = tile + 4 * rowdw;                     // 64 dwords: scan partials, ticket, look-back scratch
-    uint8_t *rungs = (uint8_t *)(wsum + 64);               // slots*bands bytes, padded to 8
-    uint16_t *etab = (uint16_t *)(rungs + ((slots * bands + 7) & ~7u));     // ENC_TAB_SIZE + pad
-    uint32_t *outbuf = (uint32_t *)(etab + 512);
-    fill_enc_tab(etab);
+    f.slot_base = (uint64_t *)smem;
+    f.tile = (uint32_t *)(f.slot_base + slots);
+    f.wsum = f.tile + 4 * rowdw;                          // 64 dwords of scan scratch
+    f.rungs = (uint8_t *)(f.wsum + 64);                   // slots*bands bytes, padded to 8
+    f.etab = (uint16_t *)(f.rungs + ((slots * bands + 7) & ~7u));     // ENC_TAB_SIZE + pad
+    f.outbuf = (uint32_t *)(f.etab + 512);
+    fill_enc_tab(f.etab);
+    uint64_t *slot_base = f.slot_base; uint32_t *tile = f.tile;
 
     const uint32_t chunk = blockIdx.x;
     const uint32_t g0 = chunk * nbp;                      // first payload block of this chunk
+    f.nbp = nbp; f.chunk = chunk;
 
     // block index of slot s is g0 - 1 + s; invalid slots are clamped to a valid block so loads stay in bounds
     auto slot_block = [&](uint32_t s, bool &valid) -> uint32_t {
@@ -235,10 +248,7 @@ __global__ void enc_kernel(const EncArgs a) {
         block_origin(slot_block(tid, valid), x0, y0);
         slot_base[tid] = (uint64_t)y0 * stride + (uint64_t)x0 * bands;
     }
-    {
-        const uint32_t outdw = (31 + nbp * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1;
-        for (uint32_t i = tid; i < outdw; i += nthr) outbuf[i] = 0;
-    }
+    for (uint32_t i = tid; i < outdw; i += nthr) f.outbuf[i] = 0;
     __syncthreads();
 
     // ---- stage the 4-row tile: coalesced dword loads, [row][slot][pixel][band] as in memory
@@ -259,11 +269,9 @@ __global__ void enc_kernel(const EncArgs a) {
     bool valid = false;
     uint32_t gblk = 0;
     if (s < slots) gblk = slot_block(s, valid);
-    const bool payload = valid && s >= 1;
     const uint32_t cb = a.g.cband[c < MAXBANDS ? c : 0];
     const T *tt = (const T *)tile;
     const uint64_t order = a.g.order;
-    T g[16];
     T used = 0, pv = 0, lastv = 0;
     uint32_t rung = 0;
     if (valid) {
@@ -296,9 +304,27 @@ __global__ void enc_kernel(const EncArgs a) {
         }
         lastv = prv;
         rung = topbit_t<T>(used);
-        rungs[tid] = (uint8_t)rung;
+        f.rungs[tid] = (uint8_t)rung;
     }
     __syncthreads();
+    f.s = s; f.c = c; f.cb = cb; f.gblk = gblk; f.rung = rung;
+    f.valid = valid; f.payload = valid && s >= 1;
+    f.used = used; f.pv = pv; f.lastv = lastv;
+}
+
+template <typename T, bool STEP>
+__global__ void enc_kernel(const EncArgs a) {
+    constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t bands = a.g.bands, nblocks = (uint32_t)a.g.nblocks;
+    T g[16];
+    EncFront<T> f;
+    enc_front<T>(a, smem, (31 + (a.slots - 1) * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1, f, g);
+    const uint32_t c = f.c, gblk = f.gblk, rung = f.rung, chunk = f.chunk;
+    const bool payload = f.payload;
+    const T used = f.used, pv = f.pv, lastv = f.lastv;
+    uint8_t *rungs = f.rungs; uint16_t *etab = f.etab; uint32_t *outbuf = f.outbuf, *wsum = f.wsum;
 
     // ---- unit bit string.  Short units (rung < 8, always the case for 8-bit data) are assembled BEFORE the scan
     // into six pieces of at most 27 bits -- [switch, c0, c1] [c2..c4] [c5..c7] [c8..c10] [c11..c13] [c14, c15] --
@@ -402,6 +428,343 @@ __global__ void enc_kernel(const EncArgs a) {
     uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;
     for (uint32_t d = tid; d < nd; d += nthr) slot[d] = outbuf[d];
     if (tid == 0) a.chunk_bits[chunk] = total;
+}
+
+// ------------------------------------------------------------------ common-factor + index coding (BEST)
+// Reference: encode_best (QB3encode.h:617-724), cfgenc (:283-361), ienc (:557-613).  A unit can be coded
+// plainly, as common factor times a smaller group, or as up to eight distinct values plus indices.  The only
+// state besides the rung is pcf, the previous factor of the band.  A unit overwrites pcf with cf-2 exactly when
+// cf >= 2 and index coding does not beat the "factor differs" size -- a condition that does not involve pcf
+// itself -- so pcf is a LAST-WRITER scan over units: pass 0 records each chunk's last writer per band,
+// best_scan_kernel carries it across chunks, pass 1 codes with the right pcf.
+template <typename T> __device__ __forceinline__ T mdiv_t(T v, T cf) { return (T)((T)((T)(mabs_t<T>(v) / cf) << 1) - (T)(v & 1)); }
+
+template <typename T> __device__ __forceinline__ T gcf_t(const T (&g)[16]) {      // gcd of the non-zero magnitudes (QB3encode.h:98-126)
+    T x = 0;
+#pragma unroll 1
+    for (uint32_t i = 0; i < 16 && x != 1; i++) {
+        T y = mabs_t<T>(g[i]);
+        while (y) { const T t = (T)(x % y); x = y; y = t; }
+    }
+    return x;
+}
+// bit length of one value coded on its own at rung r (reference qb3csztbl, QB3encode.h:144-150): rung 0 is one raw
+// bit, rungs 1-2 plain, rungs 3-7 with the middle swap, above that plain
+template <typename T> __device__ __forceinline__ uint32_t vlen_t(T v, uint32_t r) {
+    if (r == 0) return 1;
+    const T top = (T)((T)1 << r), half = (T)(top >> 1);
+    if (r >= 3 && r < 8 && (v == top || v == (T)(top - 1))) v ^= (T)(2 * top - 1);
+    return r + (v >= half) + (v >= top);
+}
+template <typename T> __device__ __forceinline__ void put_single(LdsWriter &w, T v, uint32_t r) {
+    if (r == 0) { w.put((uint32_t)v & 1, 1); return; }
+    const T top = (T)((T)1 << r);
+    if (r >= 3 && r < 8 && (v == top || v == (T)(top - 1))) v ^= (T)(2 * top - 1);
+    put_value<T>(w, v, r);
+}
+// step transform in place (QB3encode.h:169-176)
+template <typename T> __device__ __forceinline__ void apply_step(T (&v)[16], uint32_t rung) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)((v[i] >> rung) & 1) << i;
+    if (bits && (bits & (bits + 1)) == 0) {
+        const uint32_t n = __popc(bits);
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) if (i + 1 == n) v[i] ^= (T)((T)1 << rung);
+    }
+}
+// 16 group codes at rung >= 1, values already stepped: total length / emission
+template <typename T> __device__ __forceinline__ uint32_t group_len(const T (&v)[16], uint32_t rung) {
+    const T top = (T)((T)1 << rung), half = (T)(top >> 1);
+    uint32_t n = 16 * rung;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+        T x = v[i];
+        if (rung < 8 && (x == top || x == (T)(top - 1))) x ^= (T)(2 * top - 1);
+        n += (x >= half) + (x >= top);
+    }
+    return n;
+}
+template <typename T> __device__ __forceinline__ void put_group(LdsWriter &w, const T (&v)[16], uint32_t rung) {
+    const T top = (T)((T)1 << rung);
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+        T x = v[i];
+        if (rung < 8 && (x == top || x == (T)(top - 1))) x ^= (T)(2 * top - 1);
+        put_value<T>(w, x, rung);
+    }
+}
+template <uint32_t UB> __device__ __forceinline__ uint32_t sw_noflag_len(uint32_t delta) {       // switch without flag, signal for "no change"
+    const uint32_t l = cs_len<UB>(delta & ((1u << UB) - 1));
+    return (l == 1 ? UB + 2 : l) - 1;
+}
+template <uint32_t UB> __device__ __forceinline__ void put_sw_noflag(LdsWriter &w, uint32_t delta) {
+    delta &= (1u << UB) - 1;
+    constexpr uint32_t r = UB - 1, sig = ((((1u << UB) - 2 - (1u << r)) << 2) | 3);    // code of 2^UB-2 at rung UB-1 (long form)
+    if (delta == 0) w.put(sig, UB + 1);
+    else w.put(cs_code<UB>(delta) >> 1, cs_len<UB>(delta) - 1);
+}
+template <uint32_t UB> __device__ __forceinline__ void put_signal(LdsWriter &w) {
+    constexpr uint32_t r = UB - 1, sig = ((((1u << UB) - 2 - (1u << r)) << 2) | 3);
+    w.put((sig << 1) | 1, UB + 2);
+}
+
+// Everything pass 0 and pass 1 agree on for one unit (used > 1)
+template <typename T> struct BestUnit {
+    T cf;                   // common factor (>= 1)
+    uint32_t szN;           // plain coding size
+    uint32_t szBase;        // cf coding: signal + switch + same/diff flag + divided group
+    uint32_t szCf;          // cf coding: extra bits when the factor has to be written
+    uint32_t idx;           // index coding size, 0xffffffff if more than 8 distinct values
+    uint32_t trung;
+    bool writer;            // overwrites pcf with cf-2
+};
+
+template <typename T>
+__device__ __forceinline__ void best_analyse(const T (&g)[16], uint32_t rung, uint32_t oldrung, BestUnit<T> &u) {
+    constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
+    u.cf = gcf_t<T>(g);
+    u.szN = u.szBase = u.szCf = 0; u.trung = 0;
+    if (u.cf >= 2) {
+        T d[16], usedd = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) { d[i] = mdiv_t<T>(g[i], u.cf); usedd |= d[i]; }
+        const T cfm = (T)(u.cf - 2);
+        const uint32_t trung = topbit_t<T>(usedd), cfrung = topbit_t<T>(cfm);
+        u.trung = trung;
+        uint32_t grp = 16;
+        if (trung) { apply_step<T>(d, trung); grp = group_len<T>(d, trung); }
+        u.szBase = (UB + 2) + sw_noflag_len<UB>(trung - oldrung) + 1 + grp;
+        if (trung >= cfrung && (trung < cfrung + UB || cfrung == 0)) u.szCf = 1 + vlen_t<T>(cfm, trung);
+        else u.szCf = cs_len<UB>((cfrung - trung) & UMASK) + vlen_t<T>((T)(cfm ^ (T)((T)1 << cfrung)), cfrung - 1);
+    } else {
+        T v[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) v[i] = g[i];
+        apply_step<T>(v, rung);
+        u.szN = cs_len<UB>((rung - oldrung) & UMASK) + group_len<T>(v, rung);
+    }
+    // index coding (QB3encode.h:557-613)
+    u.idx = 0xffffffffu;
+    if (rung > 3 && rung < 63) {
+        T val[8]; uint32_t cnt[8], n = 0;
+        bool fits = true;
+#pragma unroll 1
+        for (uint32_t i = 0; i < 16 && fits; i++) {
+            uint32_t j = 0;
+            while (j < n && val[j] != g[i]) j++;
+            if (j == n) { if (n == 8) fits = false; else { val[n] = g[i]; cnt[n++] = 1; } }
+            else cnt[j]++;
+        }
+        if (fits) {
+            // stable sort by descending count (QB3encode.h:546-554)
+#pragma unroll 1
+            for (uint32_t i = 1; i < n; i++)
+                for (uint32_t j = i; j > 0 && cnt[j] > cnt[j - 1]; j--) {
+                    const T tv = val[j]; val[j] = val[j - 1]; val[j - 1] = tv;
+                    const uint32_t tc = cnt[j]; cnt[j] = cnt[j - 1]; cnt[j - 1] = tc;
+                }
+            uint32_t bits = (UB + 2) + sw_noflag_len<UB>(UMASK - oldrung) + sw_noflag_len<UB>(rung - oldrung);
+#pragma unroll 1
+            for (uint32_t j = 0; j < n; j++) bits += cnt[j] * (2 + (j >= 2) + (j >= 4)) + vlen_t<T>(val[j], rung);   // plain rung-2 index codes
+            u.idx = bits;
+        }
+    }
+    const uint32_t thr = 36 + 3 * UB + 2 * rung;
+    const uint32_t szDiff = u.szBase + u.szCf;
+    u.writer = u.cf >= 2 && !(szDiff >= thr && u.idx < szDiff);
+}
+
+// per-band "last writer" inclusive scan over the lanes of the workgroup (lanes are slot-major, band-minor, so the
+// band's units are `bands` lanes apart): key = 0 for "no writer", else anything non-zero; doubling in LDS
+__device__ __forceinline__ void last_writer_scan(uint32_t *key, uint64_t *val, uint32_t n, uint32_t bands, uint32_t mykey, uint64_t myval) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < n) { key[tid] = mykey; val[tid] = myval; }
+    __syncthreads();
+    for (uint32_t d = bands; d < n; d <<= 1) {
+        uint32_t k = 0; uint64_t v = 0;
+        const bool take = tid < n && tid >= d && key[tid] == 0;
+        if (take) { k = key[tid - d]; v = val[tid - d]; }
+        __syncthreads();
+        if (take && k) { key[tid] = k; val[tid] = v; }
+        __syncthreads();
+    }
+}
+
+template <typename T, int PASS>
+__global__ void enc_best_kernel(const EncArgs a) {
+    constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t bands = a.g.bands, nblocks = (uint32_t)a.g.nblocks, slots = a.slots, nunits = slots * bands;
+    T g[16];
+    EncFront<T> f;
+    const uint32_t outdw = a.slot_dw;
+    enc_front<T>(a, smem, PASS ? outdw : 0, f, g);
+    const uint32_t c = f.c, gblk = f.gblk, rung = f.rung, chunk = f.chunk;
+    const bool payload = f.payload;
+    const T used = f.used;
+    uint64_t *wval = (uint64_t *)(f.outbuf + ((outdw + 1) & ~1u));
+    uint32_t *wkey = (uint32_t *)(wval + nunits);
+
+    uint32_t oldrung = 0;
+    BestUnit<T> u;
+    u.writer = false; u.cf = 1; u.szN = u.szBase = u.szCf = 0; u.idx = 0xffffffffu; u.trung = 0;
+    if (payload) {
+        oldrung = (gblk == 0) ? a.st.rung[c] : f.rungs[tid - bands];
+        if (used > 1) best_analyse<T>(g, rung, oldrung, u);
+    }
+    // who wrote the band's factor last, up to and including each unit
+    last_writer_scan(wkey, wval, nunits, bands, (payload && u.writer) ? 1u : 0u, (uint64_t)(T)(u.cf - 2));
+    if (PASS == 0) {
+        // chunk summary: the entry of the last payload slot of each band
+        const uint32_t last = (slots - 1) * bands + tid;
+        if (tid < bands) { a.cw_has[(uint64_t)chunk * bands + tid] = (uint8_t)(wkey[last] != 0); a.cw_val[(uint64_t)chunk * bands + tid] = wval[last]; }
+        return;
+    }
+    // factor state entering this unit: previous unit of the band in the chunk, else the chunk's entry state
+    T pcf = (T)a.centry[(uint64_t)chunk * bands + c];
+    if (payload && tid >= bands && wkey[tid - bands]) pcf = (T)wval[tid - bands];
+    __syncthreads();
+
+    // ---- choose the coding and its length (QB3encode.h:679-713)
+    uint32_t len = 0, kind = 0;     // kind: 0 low (used <= 1), 1 plain, 2 common factor, 3 index
+    bool same = false;
+    if (payload) {
+        if (used <= 1) len = cs_len<UB>((rung - oldrung) & UMASK) + 1 + (used ? 16 : 0);
+        else {
+            const uint32_t thr = 36 + 3 * UB + 2 * rung;
+            uint32_t size;
+            if (u.cf >= 2) { same = (T)(u.cf - 2) == pcf; size = u.szBase + (same ? 0 : u.szCf); kind = 2; }
+            else { size = u.szN; kind = 1; }
+            if (size >= thr && u.idx < size) { size = u.idx; kind = 3; }
+            len = size;
+        }
+    }
+    uint32_t total;
+    const uint32_t pos = block_exscan(len, f.wsum, &total);
+
+    if (payload) {
+        LdsWriter w;
+        w.init(f.outbuf, pos);
+        if (kind == 0) {
+            w.put(cs_code<UB>((rung - oldrung) & UMASK), cs_len<UB>((rung - oldrung) & UMASK));
+            w.put((uint32_t)used, 1);
+            if (used) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)(g[i] & 1) << i;
+                w.put(bits, 16);
+            }
+        } else if (kind == 1) {
+            w.put(cs_code<UB>((rung - oldrung) & UMASK), cs_len<UB>((rung - oldrung) & UMASK));
+            apply_step<T>(g, rung);
+            put_group<T>(w, g, rung);
+        } else if (kind == 2) {     // cfgenc, QB3encode.h:283-361
+            T d[16];
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) d[i] = mdiv_t<T>(g[i], u.cf);
+            const T cfm = (T)(u.cf - 2);
+            const uint32_t trung = u.trung, cfrung = topbit_t<T>(cfm);
+            put_signal<UB>(w);
+            put_sw_noflag<UB>(w, trung - oldrung);
+            if (!same) {
+                w.put(1, 1);
+                if (trung >= cfrung && (trung < cfrung + UB || cfrung == 0)) { w.put(0, 1); put_single<T>(w, cfm, trung); }
+                else {
+                    const uint32_t dl = (cfrung - trung) & UMASK;
+                    w.put(cs_code<UB>(dl), cs_len<UB>(dl));         // its change flag doubles as the "own rung" marker
+                    put_single<T>(w, (T)(cfm ^ (T)((T)1 << cfrung)), cfrung - 1);
+                }
+            } else w.put(0, 1);
+            if (trung == 0) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)(d[i] & 1) << i;
+                w.put(bits, 16);
+            } else { apply_step<T>(d, trung); put_group<T>(w, d, trung); }
+        } else {                    // ienc, QB3encode.h:557-613
+            T val[8]; uint32_t cnt[8], n = 0;
+#pragma unroll 1
+            for (uint32_t i = 0; i < 16; i++) {
+                uint32_t j = 0;
+                while (j < n && val[j] != g[i]) j++;
+                if (j == n) { val[n] = g[i]; cnt[n++] = 1; } else cnt[j]++;
+            }
+#pragma unroll 1
+            for (uint32_t i = 1; i < n; i++)
+                for (uint32_t j = i; j > 0 && cnt[j] > cnt[j - 1]; j--) {
+                    const T tv = val[j]; val[j] = val[j - 1]; val[j - 1] = tv;
+                    const uint32_t tc = cnt[j]; cnt[j] = cnt[j - 1]; cnt[j - 1] = tc;
+                }
+            put_signal<UB>(w);
+            put_sw_noflag<UB>(w, UMASK - oldrung);
+            put_sw_noflag<UB>(w, rung - oldrung);
+#pragma unroll 1
+            for (uint32_t i = 0; i < 16; i++) {
+                uint32_t j = 0;
+                while (val[j] != g[i]) j++;
+                // plain rung-2 code of j (0..7): {0,2,1,5,3,7,11,15} with lengths {2,2,3,3,4,4,4,4}
+                const uint32_t code = j < 2 ? (j << 1) : j < 4 ? (((j - 2) << 2) | 1) : (((j - 4) << 2) | 3);
+                w.put(code, 2 + (j >= 2) + (j >= 4));
+            }
+#pragma unroll 1
+            for (uint32_t j = 0; j < n; j++) put_single<T>(w, val[j], rung);
+        }
+        w.finish();
+        // coder state on leaving the image (reference QB3encode.h:718-722)
+        if (gblk == nblocks - 1) {
+            a.res->prev[c] = (uint64_t)f.lastv; a.res->rung[c] = rung;
+            a.res->cf[c] = (uint64_t)(kind == 2 ? (T)(u.cf - 2) : pcf);     // only a kept common-factor coding moves pcf
+        }
+        if (a.have_idx) {
+            const uint32_t seg = gblk / a.g.seg_blocks;
+            if (seg * a.g.seg_blocks == gblk) {
+                ((T *)a.idx.prev)[(uint64_t)seg * bands + c] = f.pv;
+                ((T *)a.idx.cf)[(uint64_t)seg * bands + c] = pcf;
+                a.idx.rung[(uint64_t)seg * bands + c] = (uint8_t)oldrung;
+                if (c == 0) a.idx.bitpos[seg] = ((uint64_t)chunk << 32) | pos;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nd = (total + 31) >> 5;
+    uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;
+    for (uint32_t d = tid; d < nd; d += nthr) slot[d] = f.outbuf[d];
+    if (tid == 0) a.chunk_bits[chunk] = total;
+}
+
+// Carries the last factor writer across chunks: centry[k][c] = factor state on entering chunk k.  One workgroup;
+// "last non-empty" is a max-scan over (chunk index + 1).
+__global__ void best_scan_kernel(const EncArgs a) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const uint32_t bands = a.g.bands, tid = threadIdx.x;
+    for (uint32_t c = 0; c < bands; c++) {
+        if (tid == 0) carry = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < a.nchunks; base += blockDim.x) {
+            const uint32_t k = base + tid;
+            uint32_t x = (k < a.nchunks && a.cw_has[(uint64_t)k * bands + c]) ? k + 1 : 0;
+            // inclusive max-scan within the workgroup
+            const uint32_t lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+            uint32_t m = x;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(m, d, 64); if (lane >= (uint32_t)d) m = max(m, y); }
+            if (lane == 63) wsum[wave] = m;
+            __syncthreads();
+            uint32_t before = carry;
+            for (uint32_t i = 0; i < wave && i < nw; i++) before = max(before, wsum[i]);
+            const uint32_t incl = max(before, m);
+            // exclusive: the last writer strictly before chunk k
+            const uint32_t up = __shfl_up(m, 1, 64);
+            const uint32_t excl = max(before, lane ? up : 0u);
+            if (k < a.nchunks) a.centry[(uint64_t)k * bands + c] = excl ? a.cw_val[(uint64_t)(excl - 1) * bands + c] : a.st.cf[c];
+            __syncthreads();
+            if (tid == blockDim.x - 1) carry = incl;
+            __syncthreads();
+        }
+    }
 }
 
 // Exclusive scan of the chunk bit counts, one workgroup per SCAN_GROUP chunks (4 per thread); the per-group sums
@@ -579,8 +942,6 @@ template <uint32_t UB, typename RD> __device__ __forceinline__ uint32_t get_swit
     return (m & 1) ? (n - (m + 1) / 2) & (n - 1) : m / 2 + 1;
 }
 
-template <typename T> __device__ __forceinline__ T mabs_t(T v) { return (T)((v >> 1) + (v & 1)); }
-template <typename T> __device__ __forceinline__ T mmul_t(T v, T m) { return (T)((T)(mabs_t<T>(v) * (T)(m << 1)) - (T)(v & 1)); }
 
 // 16 values at `rung` into g (mag-sign), with the step undone when STEP (reference QB3decode.h:142-290)
 template <typename T, bool STEP, typename RD> __device__ __forceinline__ void get_group(RD &rd, uint32_t rung, T (&g)[16]) {
@@ -793,8 +1154,9 @@ __device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos
 #pragma unroll
         for (uint32_t i = 0; i < 16; i++) {
             if (i % 3 == 0) rd.ensure(32);          // three codes are at most 27 bits
-            const uint32_t e = tab[(uint32_t)rd.buf & mask];
-            rd.skip(e >> 12);
+            const uint32_t x = (uint32_t)rd.buf & mask;
+            const uint32_t e = tab[x];              // value: off the critical path, the reads pipeline
+            rd.skip(rung + (x & 1) + ((x & 3) == 3));   // length from the two flag bits alone (QB3decode.h:119-129)
             run[i] = (T)(e & 0xfff);
             rb |= ((e >> rung) & 1) << i;
         }
@@ -1072,6 +1434,8 @@ static void fast_geometry(uint32_t bands, uint32_t tsz, uint32_t *threads, uint3
     *bpp = *threads / bands;
     uint32_t k = (uint32_t)(16384 / ((size_t)*bpp * bands * tsz * 16));    // keep the pixel tile near 16 KB
     *passes = k < 1 ? 1 : (k > 3 ? 3 : k);
+    static const int knob = [] { const char *e = getenv("QB3_DEC_PASSES"); return e ? atoi(e) : 0; }();   // tuning knob
+    if (knob > 0 && (uint32_t)knob < *passes) *passes = (uint32_t)knob;
 }
 uint32_t seg_blocks_for(uint32_t bands, uint32_t tsz, uint32_t mode) {
     if (mode != CM_BEST) {      // one segment = the blocks of one unit-parallel workgroup
@@ -1105,16 +1469,18 @@ IndexView index_view(const Geometry &g, void *base) {
 
 static uint32_t magic_div(uint32_t d) { return d == 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); }   // exact for n*d < 2^32/d-ish, n small
 
-static uint32_t max_unit_bits(uint32_t tsz) {
+static uint32_t max_unit_bits(uint32_t tsz, uint32_t mode = CM_FTL) {
     const uint32_t ub = tsz == 1 ? 3 : tsz == 2 ? 4 : tsz == 4 ? 5 : 6;
-    return ub + 2 + 16 * (8 * tsz + 1);
+    const uint32_t plain = ub + 2 + 16 * (8 * tsz + 1);
+    // common factor: signal + switch + 2 flags + own-rung switch + factor code + group
+    return mode == CM_BEST ? plain + 3 * ub + 8 + 8 * tsz + 2 : plain;
 }
 
 // encoder workspace layout (all 8-byte aligned), EncResult last
-struct EncWs { size_t bits, off, gsum, seams, scratch, res, total; uint32_t slot_dw, ngroups; };
+struct EncWs { size_t bits, off, gsum, seams, scratch, cwhas, cwval, centry, res, total; uint32_t slot_dw, ngroups; };
 static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
     EncWs w;
-    w.slot_dw = (uint32_t)((31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz)) / 32 + 1);
+    w.slot_dw = (uint32_t)((31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1);
     w.ngroups = (nchunks + SCAN_GROUP - 1) / SCAN_GROUP;
     size_t o = 0;
     w.bits = o; o += align8(4 * (size_t)nchunks);
@@ -1122,6 +1488,10 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
     w.gsum = o; o += 8 * ((size_t)w.ngroups + 1);
     w.seams = o; o += 8 * (size_t)nchunks;
     w.scratch = o; o += align8(4 * (size_t)nchunks * w.slot_dw);
+    const size_t nb = g.mode == CM_BEST ? (size_t)nchunks * g.bands : 0;
+    w.cwhas = o; o += align8(nb);
+    w.cwval = o; o += 8 * nb;
+    w.centry = o; o += 8 * nb;
     w.res = o; o += sizeof(EncResult);
     w.total = o;
     return w;
@@ -1135,8 +1505,9 @@ EncPlan plan_encode(const Geometry &g) {
     const uint32_t nbp = p.slots - 1;
     p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
     const uint32_t dpr = g.bands * g.tsz;
-    const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz)) / 32 + 1;
-    p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * outdw;
+    const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1;
+    p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * ((outdw + 1) & ~(size_t)1);
+    if (g.mode == CM_BEST) p.lds_bytes += 12 * (size_t)p.slots * g.bands + 8;
     p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp).total;
     return p;
 }
@@ -1145,7 +1516,20 @@ template <typename T>
 static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL;
     dim3 grid(plan.nchunks), block(plan.threads);
-    {
+    if (a.g.mode == CM_BEST) {
+        {
+            ProfScope ps("enc_best_pass0", st);
+            hipLaunchKernelGGL((enc_best_kernel<T, 0>), grid, block, plan.lds_bytes, st, a);
+        }
+        {
+            ProfScope ps("enc_best_scan", st);
+            hipLaunchKernelGGL(best_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+        }
+        {
+            ProfScope ps("enc_best_units", st);
+            hipLaunchKernelGGL((enc_best_kernel<T, 1>), grid, block, plan.lds_bytes, st, a);
+        }
+    } else {
         ProfScope ps("enc_units", st);
         if (step) hipLaunchKernelGGL((enc_kernel<T, true>), grid, block, plan.lds_bytes, st, a);
         else hipLaunchKernelGGL((enc_kernel<T, false>), grid, block, plan.lds_bytes, st, a);
@@ -1172,7 +1556,6 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
 
 int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
                   const BandState &st_in, void *ws, void *index, void *stream) {
-    if (g.mode == CM_BEST) { set_error("encode: common-factor modes are not implemented on the device yet", 0); return -1; }
     EncArgs a;
     a.g = g; a.img = img; a.out32 = out32; a.out_bit0 = out_bit0;
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
@@ -1184,6 +1567,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.group_sum = (uint64_t *)(w + L.gsum);
     a.seams = (uint32_t *)(w + L.seams);
     a.scratch = (uint32_t *)(w + L.scratch);
+    a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry);
     a.slot_dw = L.slot_dw;
     a.res = (EncResult *)(w + L.res);
     a.st = st_in;

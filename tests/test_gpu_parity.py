@@ -127,7 +127,7 @@ GEN_NAMES = ["GRAD", "NOISY3", "LANDSAT16", "DEM", "TERRACE", "FEW", "PALETTE", 
 def test_full_size_anchor_on_device(qb3, oracle, a):
     """BASELINE.json's full-size configurations: the container made on the GPU must have the size and FNV-1a64
     the reference produced, and decode back to the input.  Modes the device encoder
-    does not implement yet (common factor: 1, 3, 5, 7) are decode-only here: the oracle's stream is decoded."""
+    All nine modes are encoded on the device, common factor + index coding included."""
     import torch
     from qb3_amd import synth, device as qdev
     gen = GEN_NAMES[a["gen"]]
@@ -139,7 +139,7 @@ def test_full_size_anchor_on_device(qb3, oracle, a):
         host = None
     raw = img.reshape(-1).view(torch.uint8)
     cb = [1, 1, 1] + list(range(3, a["bands"])) if a["explicit_cb"] else None
-    device_can_encode = a["mode"] in (0, 2, 4, 6, 8)
+    device_can_encode = True
     if device_can_encode:
         enc = qdev.DeviceEncoder(a["w"], a["h"], a["bands"], a["dtype"], mode=a["mode"], cband=cb)
         dst, n, index = enc.encode(img)
@@ -178,6 +178,24 @@ def test_decode_common_factor_and_rle_streams(qb3, oracle, case, mode):
     out, dims, dtype, m = qb3.decode(stream)
     assert dims == (w, h, b) and dtype == dt and m == stream[10]
     assert np.array_equal(out, img.view(np.uint8).ravel())
+
+
+@pytest.mark.parametrize("mode", [1, 3, 5, 7])
+@pytest.mark.parametrize("case", CASES + [(64, 48, 3, 0, "PALETTE", 3), (96, 64, 1, 5, "TERRACE", 4), (64, 64, 1, 5, "FEW", 4), (64, 64, 1, 2, "PALETTE", 7),
+                                          (64, 64, 3, 3, "TERRACE", 2), (48, 48, 1, 7, "TERRACE", 4), (48, 48, 1, 6, "PALETTE", 5), (33, 47, 2, 4, "FEW", 9)],
+                         ids=lambda c: "%dx%dx%d-t%d-%s" % c[:5])
+def test_encode_common_factor_modes(qb3, oracle, case, mode):
+    """common factor + index coding on the device (reference encode_best, QB3encode.h:617-724).  64-bit data is
+    compared with the oracle's corrected index sentinel (reference defect B-2 drops units over 800 bits)."""
+    w, h, b, dt, gen, seed = case
+    img = oracle.generate(w, h, b, dt, gen, seed)
+    ref = oracle.encode(img, dt, mode, fix_b2=True)
+    got = qb3.encode(img, dt, mode)
+    assert len(got) == len(ref) and np.array_equal(got, ref), \
+        f"stream differs: len {len(got)} vs {len(ref)}, first diff at byte {first_diff(got, ref)}"
+    out, dims, _, _ = qb3.decode(got, compat=0)
+    if b in (1, 3, 4):
+        assert np.array_equal(out, img.view(np.uint8).ravel())
 
 
 @pytest.mark.parametrize("mode", [2, 6])
@@ -257,11 +275,10 @@ def test_stored_fallback_and_sticky_mode(qb3, oracle):
     p = L.qb3_create_encoder(64, 64, 1, 5)
     e = oracle.Encoder(64, 64, 1, 5)
     dst = np.zeros(L.qb3_max_encoded_size(p), np.uint8)
-    # (a second call on the same handle would run the common-factor encoder under a STORED header in the
-    #  reference -- defect B-5; the device encoder has no common-factor mode yet, so that call is not made here)
-    n = L.qb3_encode(p, img.ctypes.data, dst.ctypes.data)
-    ref = e.encode(img)
-    assert n == len(ref) and np.array_equal(dst[:n], ref) and dst[10] == 255
+    for _ in range(2):      # the second call runs the common-factor coder under the sticky STORED mode (defect B-5)
+        n = L.qb3_encode(p, img.ctypes.data, dst.ctypes.data)
+        ref = e.encode(img)
+        assert n == len(ref) and np.array_equal(dst[:n], ref) and dst[10] == 255
     assert L.qb3_set_encoder_mode(p, 99) == 255          # the handle's mode stays at STORED
     L.qb3_destroy_encoder(p)
     out, _, _, mode = qb3.decode(dst[:n])
