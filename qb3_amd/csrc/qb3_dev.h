@@ -68,6 +68,7 @@ struct EncPlan {
     uint32_t nchunks;
     size_t lds_bytes;
     size_t ws_bytes;        // chunk counts/offsets, seam table, per-chunk scratch slots, EncResult (last)
+    uint32_t nbp;           // payload blocks per chunk
 };
 EncPlan plan_encode(const Geometry &g);
 

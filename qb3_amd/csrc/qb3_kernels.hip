@@ -290,14 +290,14 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, uint8_t *smem, uint3
             if (cb != c) pv = (T)(pv - ip[cb]);
         }
         T prv = pv;
+        const T cbmask = (cb != c) ? (T)~(T)0 : (T)0;
         // element index = lane part (slot, band) + a wave-uniform part per curve position (scalar arithmetic)
         const uint32_t ebase = s * 4 * bands, rowel = slots * 4 * bands;
 #pragma unroll
         for (uint32_t i = 0; i < 16; i++) {
             const uint32_t nib = curve_nib(order, i);
             const uint32_t e = ebase + ((nib >> 2) * rowel + (nib & 3) * bands);
-            T v = tt[e + c];
-            if (cb != c) v = (T)(v - tt[e + cb]);
+            const T v = (T)(tt[e + c] - (tt[e + cb] & cbmask));    // core band read always: no branch, same-address LDS reads broadcast
             g[i] = mags_t<T>((T)(v - prv));
             used |= g[i];
             prv = v;
@@ -430,6 +430,17 @@ __global__ void enc_kernel(const EncArgs a) {
     if (tid == 0) a.chunk_bits[chunk] = total;
 }
 
+// step transform in place (QB3encode.h:169-176)
+template <typename T> __device__ __forceinline__ void apply_step(T (&v)[16], uint32_t rung) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)((v[i] >> rung) & 1) << i;
+    if (bits && (bits & (bits + 1)) == 0) {
+        const uint32_t n = __popc(bits);
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) if (i + 1 == n) v[i] ^= (T)((T)1 << rung);
+    }
+}
 // ------------------------------------------------------------------ common-factor + index coding (BEST)
 // Reference: encode_best (QB3encode.h:617-724), cfgenc (:283-361), ienc (:557-613).  A unit can be coded
 // plainly, as common factor times a smaller group, or as up to eight distinct values plus indices.  The only
@@ -461,17 +472,6 @@ template <typename T> __device__ __forceinline__ void put_single(LdsWriter &w, T
     const T top = (T)((T)1 << r);
     if (r >= 3 && r < 8 && (v == top || v == (T)(top - 1))) v ^= (T)(2 * top - 1);
     put_value<T>(w, v, r);
-}
-// step transform in place (QB3encode.h:169-176)
-template <typename T> __device__ __forceinline__ void apply_step(T (&v)[16], uint32_t rung) {
-    uint32_t bits = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)((v[i] >> rung) & 1) << i;
-    if (bits && (bits & (bits + 1)) == 0) {
-        const uint32_t n = __popc(bits);
-#pragma unroll
-        for (uint32_t i = 0; i < 16; i++) if (i + 1 == n) v[i] ^= (T)((T)1 << rung);
-    }
 }
 // 16 group codes at rung >= 1, values already stepped: total length / emission
 template <typename T> __device__ __forceinline__ uint32_t group_len(const T (&v)[16], uint32_t rung) {
@@ -1499,12 +1499,13 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
 
 EncPlan plan_encode(const Geometry &g) {
     EncPlan p;
+    const uint32_t dpr = g.bands * g.tsz;
     p.threads = g.tsz == 8 ? 128 : 256;
     if (const char *e = getenv("QB3_ENC_THREADS")) p.threads = (uint32_t)atoi(e);      // tuning knob
     p.slots = p.threads / g.bands;
     const uint32_t nbp = p.slots - 1;
+    p.nbp = nbp;
     p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
-    const uint32_t dpr = g.bands * g.tsz;
     const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1;
     p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * ((outdw + 1) & ~(size_t)1);
     if (g.mode == CM_BEST) p.lds_bytes += 12 * (size_t)p.slots * g.bands + 8;
@@ -1561,7 +1562,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
     a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
     uint8_t *w = (uint8_t *)ws;
-    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.slots - 1);
+    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp);
     a.chunk_bits = (uint32_t *)(w + L.bits);
     a.chunk_off = (uint64_t *)(w + L.off);
     a.group_sum = (uint64_t *)(w + L.gsum);

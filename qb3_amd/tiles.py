@@ -38,8 +38,10 @@ def gather_streams(payload, sizes, root=0, group=None):
     dist.all_gather(all_sizes, mine, group=group)
     size_lists = [[int(v) for v in s[:int(c.item())].tolist()] for s, c in zip(all_sizes, all_counts)]
     total = sum(sizes)
+    # one batched group of point-to-point operations: every peer sends exactly the bytes it produced
+    ops, bufs = [], None
     if rank == root:
-        bufs, reqs = [], []
+        bufs = []
         for r in range(world):
             nbytes = sum(size_lists[r])
             if r == root:
@@ -48,10 +50,10 @@ def gather_streams(payload, sizes, root=0, group=None):
             b = torch.empty(nbytes, dtype=torch.uint8, device=device)
             bufs.append(b)
             if nbytes:
-                reqs.append(dist.irecv(b, src=r, group=group))
-        for q in reqs:
+                ops.append(dist.P2POp(dist.irecv, b, r, group))
+    elif total:
+        ops.append(dist.P2POp(dist.isend, payload[:total].contiguous(), root, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
-        return bufs, size_lists
-    if total:
-        dist.send(payload[:total].contiguous(), dst=root, group=group)
-    return None, None
+    return (bufs, size_lists) if rank == root else (None, None)
