@@ -69,6 +69,8 @@ struct EncPlan {
     size_t lds_bytes;
     size_t ws_bytes;        // chunk counts/offsets, seam table, per-chunk scratch slots, EncResult (last)
     uint32_t nbp;           // payload blocks per chunk
+    bool px;                // 8-bit 1/3/4-band register-resident kernel applies (lane per block)
+    bool px_rgb;            //   ... with the default R-G,G,B-G map (else identity)
 };
 EncPlan plan_encode(const Geometry &g);
 

@@ -441,6 +441,197 @@ template <typename T> __device__ __forceinline__ void apply_step(T (&v)[16], uin
         for (uint32_t i = 0; i < 16; i++) if (i + 1 == n) v[i] ^= (T)((T)1 << rung);
     }
 }
+// ------------------------------------------------------------------ 8-bit, 1/3/4 bands: lane per BLOCK, in registers
+// Specialisation of enc_kernel for the common rasters (uint8, grey / RGB / RGBA, width a multiple of 4, identity
+// or default R-G,G,B-G band map, Hilbert or Z curve).  Same bit stream, different organisation:
+//   * a lane owns a whole block: it loads the four rows of the block straight from HBM (B dwords per row: 64
+//     lanes x 4*B bytes are one contiguous run, so the loads are coalesced without an LDS tile) plus the one
+//     dword that holds the previous block's last visited pixel;
+//   * every byte position is a compile-time constant (band count and curve are template parameters), so the
+//     gather is shifts and masks on registers; the 16 mag-sign deltas of a band are kept packed, 4 per register;
+//   * rungs of the neighbouring block come from the neighbouring lane (__shfl_up, LDS only across waves); lane 0
+//     of the workgroup is the halo block (computes rungs only), so a chunk is 255 blocks;
+//   * one workgroup scan per chunk (block bit lengths), one LDS bit writer per lane running through all bands.
+constexpr uint32_t order_nib(uint64_t order, int i) { return (uint32_t)(order >> (60 - 4 * i)) & 15u; }
+
+template <int B> __device__ __forceinline__ uint32_t px_byte(const uint32_t (&w)[4][B], int x, int y, int c) {
+    const int bi = x * B + c;
+    return (w[y][bi >> 2] >> ((bi & 3) * 8)) & 0xffu;
+}
+// core band of band c under the default map: R-G, G, B-G (, A)   (reference QB3encode.cpp:41-45)
+template <int B, bool RGB> constexpr int core_of(int c) { return (RGB && (c == 0 || c == 2)) ? 1 : c; }
+
+template <int B, bool RGB, uint64_t ORDER, bool STEP>
+__global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a) {
+    constexpr uint32_t UB = 3, UMASK = 7;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
+    const uint64_t stride = a.g.stride;
+
+    uint16_t *etab = (uint16_t *)smem;                      // 512 entries
+    uint32_t *wsum = (uint32_t *)(etab + 512);              // 64 dwords: scan scratch, [32..35] rungs of each wave's last lane
+    uint32_t *outbuf = wsum + 64;
+    fill_enc_tab(etab);
+    for (uint32_t i = tid; i < a.slot_dw; i += 256) outbuf[i] = 0;
+
+    const uint32_t chunk = blockIdx.x;
+    const int64_t gs = (int64_t)chunk * 255 - 1 + tid;     // lane 0 is the halo block
+    const bool valid = gs >= 0 && gs < (int64_t)nblocks, payload = valid && tid >= 1;
+    const uint32_t gblk = valid ? (uint32_t)gs : 0u;
+
+    // ---- load the block (4 rows x B dwords) and the dword holding the previous block's last visited pixel
+    uint32_t w[4][B];
+    uint32_t pd = 0;
+    constexpr uint32_t n15 = order_nib(ORDER, 15);
+    if (valid) {
+        const uint32_t by = gblk / nbx, bx = gblk - by * nbx;
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        const uint8_t *p0 = (const uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t *rp = (const uint32_t *)(p0 + (uint64_t)r * stride);
+#pragma unroll
+            for (int k = 0; k < B; k++) w[r][k] = rp[k];
+        }
+        if (gblk) {
+            const uint32_t pb = gblk - 1, pby = pb / nbx, pbx = pb - pby * nbx;
+            const uint32_t py0 = (4 * pby + 4 > a.g.h) ? a.g.h - 4 : 4 * pby;
+            pd = *(const uint32_t *)((const uint8_t *)a.img + (uint64_t)(py0 + (n15 >> 2)) * stride + (uint64_t)pbx * 4 * B + 4 * (B - 1));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int k = 0; k < B; k++) w[r][k] = 0;
+    }
+
+    // ---- per band: deltas in curve order, mag-sign, packed four to a register
+    uint32_t gp[B][4], usedv[B], lastv[B], pvv[B];
+    uint32_t rp_packed = 0;
+#pragma unroll
+    for (int c = 0; c < B; c++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int cb = core_of<B, RGB>(c);
+        uint32_t prv;
+        if (gblk == 0) prv = (uint32_t)a.st.prev[c] & 0xffu;
+        else {      // pixel x = 3 of the previous block sits in the last dword of its row: byte c + 4 - B
+            prv = (pd >> (8 * (c + 4 - B))) & 0xffu;
+            if (cb != c) prv = (prv - ((pd >> (8 * (cb + 4 - B))) & 0xffu)) & 0xffu;
+        }
+        pvv[c] = prv;
+        uint32_t used = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) gp[c][q] = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            constexpr uint32_t dummy2 = 0; (void)dummy2;
+            const uint32_t nib = order_nib(ORDER, i);
+            uint32_t v = px_byte<B>(w, nib & 3, nib >> 2, c);
+            if (cb != c) v = (v - px_byte<B>(w, nib & 3, nib >> 2, cb)) & 0xffu;
+            const uint32_t d = (v - prv) & 0xffu;
+            const uint32_t m = ((d << 1) ^ (0u - (d >> 7))) & 0xffu;       // mag-sign (reference QB3common.h:127-130)
+            used |= m;
+            gp[c][i >> 2] |= m << (8 * (i & 3));
+            prv = v;
+        }
+        usedv[c] = used; lastv[c] = prv;
+        rp_packed |= topbit32(used | 1) << (4 * c);
+    }
+    // rungs of the previous block: neighbouring lane, or the last lane of the previous wave through LDS
+    uint32_t prp = __shfl_up(rp_packed, 1, 64);
+    if (lane == 63) wsum[32 + wave] = rp_packed;
+    __syncthreads();
+    if (lane == 0 && wave) prp = wsum[32 + wave - 1];
+    if (gblk == 0) { prp = 0;
+#pragma unroll
+        for (int c = 0; c < B; c++) prp |= ((uint32_t)a.st.rung[c] & 15u) << (4 * c); }
+
+    // ---- per band: the unit's bit string as six pieces of at most 27 bits (see enc_kernel)
+    uint32_t pc[B][6], plens[B], lens[B], blen = 0;
+#pragma unroll
+    for (int c = 0; c < B; c++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) pc[c][k] = 0;
+        plens[c] = 0; lens[c] = 0;
+        if (payload) {
+            const uint32_t rung = (rp_packed >> (4 * c)) & 15u, prung = (prp >> (4 * c)) & 15u, used = usedv[c];
+            const uint32_t delta = (rung - prung) & UMASK;
+            const uint32_t csl = cs_len<UB>(delta), csc = cs_code<UB>(delta);
+            uint32_t len = csl;
+            if (used <= 1) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) bits |= ((gp[c][i >> 2] >> (8 * (i & 3))) & 1u) << i;
+                const uint32_t l = 1 + (used ? 16 : 0);
+                pc[c][0] = csc | (used << csl) | (bits << (csl + 1));
+                plens[c] = csl + l;
+                len += l;
+            } else {
+                uint32_t g4[4] = {gp[c][0], gp[c][1], gp[c][2], gp[c][3]};
+                if (STEP) {     // clear the rung bit of the last value of a 1..10..0 rung-bit run (reference QB3encode.h:169-176)
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) bits |= ((g4[i >> 2] >> (8 * (i & 3) + rung)) & 1u) << i;
+                    if ((bits & (bits + 1)) == 0) {
+                        const uint32_t n = __popc(bits) - 1;        // index of the value to change
+#pragma unroll
+                        for (int q = 0; q < 4; q++) if ((n >> 2) == (uint32_t)q) g4[q] ^= (1u << rung) << (8 * (n & 3));
+                    }
+                }
+                const uint16_t *tab = etab + enc_tab_off(rung);
+                uint32_t acc = csc, al = csl, k = 0, lsum = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t e = tab[(g4[i >> 2] >> (8 * (i & 3))) & 0xffu];
+                    const uint32_t l = e >> 12;
+                    acc |= (e & 0xfff) << al; al += l; lsum += l;
+                    if (i == 1 || i == 4 || i == 7 || i == 10 || i == 13 || i == 15) {
+                        pc[c][k] = acc; plens[c] |= al << (5 * k); k++; acc = 0; al = 0;
+                    }
+                }
+                len += lsum;
+            }
+            lens[c] = len; blen += len;
+        }
+    }
+    uint32_t total;
+    const uint32_t pos = block_exscan(blen, wsum, &total);
+
+    if (payload) {
+        LdsWriter wr;
+        wr.init(outbuf, pos);
+#pragma unroll
+        for (int c = 0; c < B; c++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) wr.put(pc[c][k], (plens[c] >> (5 * k)) & 31);
+        wr.finish();
+        if (gblk == nblocks - 1) {
+#pragma unroll
+            for (int c = 0; c < B; c++) { a.res->prev[c] = lastv[c]; a.res->rung[c] = (rp_packed >> (4 * c)) & 15u; a.res->cf[c] = a.st.cf[c]; }
+        }
+        if (a.have_idx) {
+            uint8_t *ul = (uint8_t *)a.idx.ulen + (uint64_t)gblk * B;
+#pragma unroll
+            for (int c = 0; c < B; c++) ul[c] = (uint8_t)lens[c];
+            const uint32_t seg = gblk / a.g.seg_blocks;
+            if (seg * a.g.seg_blocks == gblk) {
+#pragma unroll
+                for (int c = 0; c < B; c++) {
+                    ((uint8_t *)a.idx.prev)[(uint64_t)seg * B + c] = (uint8_t)pvv[c];
+                    a.idx.rung[(uint64_t)seg * B + c] = (uint8_t)((prp >> (4 * c)) & 15u);
+                }
+                a.idx.bitpos[seg] = ((uint64_t)chunk << 32) | pos;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nd = (total + 31) >> 5;
+    uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;
+    for (uint32_t d = tid; d < nd; d += 256) slot[d] = outbuf[d];
+    if (tid == 0) a.chunk_bits[chunk] = total;
+}
+
 // ------------------------------------------------------------------ common-factor + index coding (BEST)
 // Reference: encode_best (QB3encode.h:617-724), cfgenc (:283-361), ienc (:557-613).  A unit can be coded
 // plainly, as common factor times a smaller group, or as up to eight distinct values plus indices.  The only
@@ -1497,9 +1688,33 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
     return w;
 }
 
+// the 8-bit lane-per-block kernels need: uint8, 1/3/4 bands, rows of whole blocks at dword-aligned addresses,
+// Hilbert or Z curve, identity or default RGB(A) band map
+static bool px_eligible(const Geometry &g, bool *rgb) {
+    if (g.tsz != 1 || !(g.bands == 1 || g.bands == 3 || g.bands == 4) || g.mode == CM_BEST) return false;
+    if ((g.w & 3) || (g.stride & 3) || g.h < 4) return false;
+    if (g.order != HILBERT && g.order != ZCURVE) return false;
+    bool ident = true, def = g.bands >= 3;
+    for (uint32_t c = 0; c < g.bands; c++) {
+        ident = ident && g.cband[c] == c;
+        def = def && g.cband[c] == ((c == 0 || c == 2) ? 1u : c);
+    }
+    *rgb = def && !ident;
+    return (ident || def) && !getenv("QB3_NO_PX");
+}
+
 EncPlan plan_encode(const Geometry &g) {
     EncPlan p;
     const uint32_t dpr = g.bands * g.tsz;
+    p.px = px_eligible(g, &p.px_rgb);
+    if (p.px) {
+        p.threads = 256; p.slots = 256; p.nbp = 255;
+        p.nchunks = (uint32_t)((g.nblocks + 254) / 255);
+        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp);
+        p.lds_bytes = 1024 + 256 + 4 * (size_t)L.slot_dw;
+        p.ws_bytes = L.total;
+        return p;
+    }
     p.threads = g.tsz == 8 ? 128 : 256;
     if (const char *e = getenv("QB3_ENC_THREADS")) p.threads = (uint32_t)atoi(e);      // tuning knob
     p.slots = p.threads / g.bands;
@@ -1511,6 +1726,22 @@ EncPlan plan_encode(const Geometry &g) {
     if (g.mode == CM_BEST) p.lds_bytes += 12 * (size_t)p.slots * g.bands + 8;
     p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp).total;
     return p;
+}
+
+// dispatch of the 8-bit lane-per-block encoder over its compile-time parameters
+template <int B, bool RGB>
+static void launch_enc_px_b(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
+    dim3 grid(plan.nchunks), block(256);
+    if (!z && !step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, HILBERT, false>), grid, block, plan.lds_bytes, st, a);
+    else if (!z && step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_bytes, st, a);
+    else if (z && !step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, ZCURVE, false>), grid, block, plan.lds_bytes, st, a);
+    else hipLaunchKernelGGL((enc_px_kernel<B, RGB, ZCURVE, true>), grid, block, plan.lds_bytes, st, a);
+}
+static void launch_enc_px(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    if (a.g.bands == 1) launch_enc_px_b<1, false>(a, plan, st);
+    else if (a.g.bands == 3) { if (plan.px_rgb) launch_enc_px_b<3, true>(a, plan, st); else launch_enc_px_b<3, false>(a, plan, st); }
+    else { if (plan.px_rgb) launch_enc_px_b<4, true>(a, plan, st); else launch_enc_px_b<4, false>(a, plan, st); }
 }
 
 template <typename T>
@@ -1530,6 +1761,9 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
             ProfScope ps("enc_best_units", st);
             hipLaunchKernelGGL((enc_best_kernel<T, 1>), grid, block, plan.lds_bytes, st, a);
         }
+    } else if (plan.px && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0) {
+        ProfScope ps("enc_units", st);
+        launch_enc_px(a, plan, st);
     } else {
         ProfScope ps("enc_units", st);
         if (step) hipLaunchKernelGGL((enc_kernel<T, true>), grid, block, plan.lds_bytes, st, a);
