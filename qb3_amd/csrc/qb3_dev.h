@@ -94,6 +94,9 @@ struct DecPlan {
     bool fast;
     uint32_t threads2, bpp, passes, in_cap_dw;
     size_t lds2_bytes;
+    // 8-bit 1/3/4-band lane-per-block kernel
+    bool px, px_rgb;
+    size_t lds_px;
 };
 DecPlan plan_decode(const Geometry &g);
 

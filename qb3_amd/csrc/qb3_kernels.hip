@@ -1507,6 +1507,165 @@ __global__ void dec3_kernel(const DecArgs a) {
         }
 }
 
+// ---- 8-bit, 1/3/4 bands: lane per BLOCK decode, in registers (counterpart of enc_px_kernel) -------------
+// Workgroup per index segment, lane per block (passes of 256 blocks).  Per pass: block bit positions from a scan
+// of the per-unit lengths; each lane reads the rung switches of its B units, rungs come from ONE packed 64-bit scan
+// (16 bits per band); the lane decodes its B units (LDS table), keeps the running sums packed four to a register;
+// the values entering the units come from ONE more packed scan of the unit totals; SWAR byte adds apply them and
+// the core band; bytes are permuted to pixel order and the four rows go straight to HBM (B dwords per lane and
+// row: 64 lanes write one contiguous run).  No pixel tile in LDS.
+__device__ __forceinline__ uint32_t swar_add8(uint32_t x, uint32_t y) {       // four independent byte adds
+    return ((x & 0x7f7f7f7fu) + (y & 0x7f7f7f7fu)) ^ ((x ^ y) & 0x80808080u);
+}
+constexpr int curve_pos_of(uint64_t order, int x, int y) {      // inverse of the curve: visit index of pixel (x, y)
+    for (int i = 0; i < 16; i++) if ((int)order_nib(order, i) == ((y << 2) | x)) return i;
+    return 0;
+}
+
+template <int B, bool RGB, uint64_t ORDER, bool STEP, typename PTR>
+__device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t endw, uint32_t cpos0, uint32_t g0, uint32_t nb_here,
+                                            uint64_t seg, uint64_t w0, uint64_t *wsum, uint64_t *carry, const uint8_t *ulen_s, const uint16_t *dtab) {
+    constexpr uint32_t UMASK = 7;
+    const uint32_t tid = threadIdx.x, nbx = a.g.nbx;
+    const uint64_t stride = a.g.stride;
+    uint32_t cpos = cpos0;
+    bool bad = false;
+    const uint32_t npass = (nb_here + 255) / 256;
+    for (uint32_t p = 0; p < npass; p++) {
+        const uint32_t sl = p * 256 + tid;
+        const bool act = sl < nb_here;
+        uint32_t ul[B], blen = 0;
+#pragma unroll
+        for (int c = 0; c < B; c++) { ul[c] = act ? ulen_s[sl * B + c] : 0u; blen += ul[c]; }
+        const uint64_t bex = block_exscan_v<uint64_t>(blen, wsum);
+        if (tid == 255) carry[0] = bex + blen;                          // bits of this pass
+        // rung switches of the lane's units
+        uint32_t gpos[B], pos = cpos + (uint32_t)bex;
+        uint64_t dpk = 0;
+#pragma unroll
+        for (int c = 0; c < B; c++) {
+            gpos[c] = 0;
+            if (act) {
+                bool sig;
+                const uint32_t d = dec3_switch<uint8_t, PTR>(src, endw, pos, &gpos[c], &sig);
+                if (sig && STEP) bad = true;                            // common-factor / index unit: not handled here
+                dpk |= (uint64_t)d << (16 * c);
+                pos += ul[c];
+            }
+        }
+        const uint64_t dex = block_exscan_v<uint64_t>(dpk, wsum) + dpk;  // inclusive, per band in 16-bit fields
+        // decode the units; running sums packed 4 per register, in curve order
+        uint32_t rp[B][4], rungs = 0;
+        uint64_t spk = 0;
+#pragma unroll
+        for (int c = 0; c < B; c++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) rp[c][q] = 0;
+            if (act) {
+                const uint32_t rung = ((uint32_t)carry[1 + c] + (uint32_t)((dex >> (16 * c)) & 0xffffu)) & UMASK;
+                rungs |= rung << (4 * c);
+                uint8_t run[16];
+                dec3_group<uint8_t, STEP, PTR>(src, endw, gpos[c], rung, dtab, run);
+#pragma unroll
+                for (int i = 0; i < 16; i++) rp[c][i >> 2] |= (uint32_t)run[i] << (8 * (i & 3));
+                spk |= (uint64_t)run[15] << (16 * c);
+            }
+        }
+        const uint64_t sex = block_exscan_v<uint64_t>(spk, wsum);        // exclusive
+        uint32_t pv[B];
+#pragma unroll
+        for (int c = 0; c < B; c++) pv[c] = ((uint32_t)carry[1 + B + c] + (uint32_t)((sex >> (16 * c)) & 0xffffu)) & 0xffu;
+        __syncthreads();                                                 // everyone has read the carries
+        if (act && (sl == nb_here - 1 || tid == 255)) {                  // state leaving the pass
+#pragma unroll
+            for (int c = 0; c < B; c++) {
+                carry[1 + c] = (rungs >> (4 * c)) & 15u;
+                carry[1 + B + c] = (pv[c] + (uint32_t)((spk >> (16 * c)) & 0xffu)) & 0xffu;
+            }
+        }
+        if (act) {
+            // entering value, then the core band (reference QB3decode.h:560-567)
+#pragma unroll
+            for (int c = 0; c < B; c++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) rp[c][q] = swar_add8(rp[c][q], pv[c] * 0x01010101u);
+#pragma unroll
+            for (int c = 0; c < B; c++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int cb = core_of<B, RGB>(c);
+                if (cb != c)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) rp[c][q] = swar_add8(rp[c][q], rp[cb][q]);
+            }
+            // curve order, band planar -> pixel order, band interleaved; store the four rows
+            const uint32_t g = g0 + sl, by = g / nbx, bx = g - by * nbx;
+            const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+            uint8_t *p0 = (uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B;
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                uint32_t ow[B];
+#pragma unroll
+                for (int k = 0; k < B; k++) ow[k] = 0;
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+#pragma unroll
+                    for (int c = 0; c < B; c++) {
+                        const int i = curve_pos_of(ORDER, x, y), bi = x * B + c;
+                        ow[bi >> 2] |= ((rp[c][i >> 2] >> (8 * (i & 3))) & 0xffu) << (8 * (bi & 3));
+                    }
+                uint32_t *dst = (uint32_t *)(p0 + (uint64_t)y * stride);
+#pragma unroll
+                for (int k = 0; k < B; k++) dst[k] = ow[k];
+            }
+        }
+        __syncthreads();
+        cpos += (uint32_t)carry[0];
+    }
+    if (bad) atomicOr(a.status, 1u);
+    if (tid == 0 && seg == a.g.nseg - 1) {      // reference: more than 7 unused bits at the end is a failure
+        const uint64_t used = (uint64_t)cpos + 32 * w0 - a.in_bit0;
+        if (used > a.in_bits) atomicOr(a.status, 4u);
+        else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
+}
+
+template <int B, bool RGB, uint64_t ORDER, bool STEP>
+__global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, NB = a.g.seg_blocks;
+    const uint64_t seg = blockIdx.x;
+    const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
+
+    uint64_t *wsum = (uint64_t *)smem;                  // 16
+    uint64_t *carry = wsum + 16;                        // [0] pass bits, [1..B] rung, [1+B..2B] entering value
+    uint16_t *dtab = (uint16_t *)(carry + 16);          // 1024 entries
+    uint8_t *ulen_s = (uint8_t *)(dtab + 1024);         // NB*B bytes, padded to 8
+    uint32_t *stage = (uint32_t *)(ulen_s + ((NB * B + 7) & ~7u));
+    fill_dec_tab(dtab);
+
+    const uint64_t P0 = a.idx.bitpos[seg];
+    const uint64_t P1 = (seg + 1 < a.g.nseg) ? a.idx.bitpos[seg + 1] : a.in_bits;
+    const uint64_t w0 = (a.in_bit0 + P0) >> 5;
+    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
+    const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0 + 2;
+    const bool staged = ndw64 <= a.in_cap_dw;           // workgroup uniform
+    const uint32_t ndw = (uint32_t)ndw64;
+    if (staged)
+        for (uint32_t i = tid; i < ndw; i += 256) stage[i] = (w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+    const uint32_t endw_g = (uint32_t)((endw_abs - w0 < 0xffffffffull) ? endw_abs - w0 : 0xffffffffull);
+    const uint8_t *ul = (const uint8_t *)a.idx.ulen + (uint64_t)g0 * B;
+    for (uint32_t i = tid; i < nb_here * B; i += 256) ulen_s[i] = ul[i];
+    if (tid < B) {
+        carry[1 + tid] = a.idx.rung[seg * B + tid];
+        carry[1 + B + tid] = ((const uint8_t *)a.idx.prev)[seg * B + tid];
+    }
+    __syncthreads();
+    const uint32_t cpos0 = (uint32_t)(a.in_bit0 + P0 - 32 * w0);
+    if (staged) dec_px_body<B, RGB, ORDER, STEP, LdsWords>(a, (LdsWords)stage, ndw, cpos0, g0, nb_here, seg, w0, wsum, carry, ulen_s, dtab);
+    else dec_px_body<B, RGB, ORDER, STEP, const uint32_t *>(a, a.in32 + w0, endw_g, cpos0, g0, nb_here, seg, w0, wsum, carry, ulen_s, dtab);
+}
+
 // Foreign stream: ONE lane walks the stream and rebuilds the index (bit position + band state at every
 // segment start).  Latency bound by construction.
 template <typename T, int MODE>
@@ -1852,7 +2011,27 @@ DecPlan plan_decode(const Geometry &g) {
     p.lds2_bytes = 8 * (size_t)NB + 8 * 16 + 8 * 2 * MAXBANDS + 4 * 2 * MAXBANDS + 4 * (size_t)((p.bpp + 1) & ~1u)
                  + 4 * (size_t)p.in_cap_dw + 16 * (size_t)NB * dpr + align8(2 * (size_t)p.bpp * g.bands) + 2048;
     p.fast = simple && p.lds2_bytes <= 64 * 1024;
+    // 8-bit lane-per-block kernel
+    bool rgb = false;
+    p.px = p.fast && px_eligible(g, &rgb);
+    p.px_rgb = rgb;
+    p.lds_px = 8 * 32 + 2048 + (((size_t)NB * g.bands + 7) & ~(size_t)7) + 4 * (size_t)p.in_cap_dw;
     return p;
+}
+
+template <int B, bool RGB>
+static void launch_dec_px_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
+    const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
+    dim3 grid((uint32_t)a.g.nseg), block(256);
+    if (!z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, false>), grid, block, plan.lds_px, st, a);
+    else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);
+    else if (z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, false>), grid, block, plan.lds_px, st, a);
+    else hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, true>), grid, block, plan.lds_px, st, a);
+}
+static void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
+    if (a.g.bands == 1) launch_dec_px_b<1, false>(a, plan, st);
+    else if (a.g.bands == 3) { if (plan.px_rgb) launch_dec_px_b<3, true>(a, plan, st); else launch_dec_px_b<3, false>(a, plan, st); }
+    else { if (plan.px_rgb) launch_dec_px_b<4, true>(a, plan, st); else launch_dec_px_b<4, false>(a, plan, st); }
 }
 
 template <typename T, int MODE>
@@ -1861,7 +2040,10 @@ static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild,
         ProfScope ps("dec_index_serial", st);
         hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(1), dim3(64), 0, st, a);
     }
-    if (plan.fast && MODE != CM_BEST) {
+    if (plan.px && MODE != CM_BEST && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0) {
+        ProfScope ps("dec_units", st);
+        launch_dec_px(a, plan, st);
+    } else if (plan.fast && MODE != CM_BEST) {
         ProfScope ps("dec_units", st);
         hipLaunchKernelGGL((dec3_kernel<T, MODE == CM_BASE>), dim3((uint32_t)a.g.nseg), dim3(plan.threads2), plan.lds2_bytes, st, a);
     } else {

@@ -46,6 +46,14 @@ CASES = [
     (64, 64, 16, 0, "NOISY3", 11),
     (32, 32, 16, 6, "RANDOM", 12),
     (256, 256, 3, 0, "CONST", 0),
+    # 8-bit 1/3/4 bands with width % 4 == 0 take the lane-per-block kernels; heights that need a shifted last row,
+    # more than one 255-block chunk, all three band counts
+    (64, 37, 3, 0, "NOISY3", 3),
+    (128, 50, 4, 0, "NOISY3", 4),
+    (256, 19, 1, 0, "NOISY3", 5),
+    (1024, 64, 3, 0, "NOISY3", 6),
+    (2048, 8, 4, 0, "RANDOM", 7),
+    (4096, 12, 1, 0, "GRAD", 0),
 ]
 
 
@@ -100,6 +108,18 @@ def test_device_api_with_index(qb3, oracle, case, mode):
     img, stream = dev_roundtrip(qb3, oracle, torch, w, h, b, dt, gen, seed, mode, cb)
     host = img.cpu().numpy().view(oracle.NPTYPE[dt])
     ref = oracle.encode(host, dt, mode, cband=cb)
+    assert np.array_equal(stream, ref)
+
+
+@pytest.mark.parametrize("mode", [FTL, BASE, BASE_Z])
+@pytest.mark.parametrize("shape", [(320, 44, 3), (320, 44, 4), (512, 20, 3)])
+def test_identity_band_map_on_rgb(qb3, oracle, shape, mode):
+    """explicit identity map on 3/4 bands (the other variant of the lane-per-block kernels)"""
+    import torch
+    w, h, b = shape
+    cb = list(range(b))
+    img, stream = dev_roundtrip(qb3, oracle, torch, w, h, b, 0, "NOISY3", 21, mode, cb)
+    ref = oracle.encode(img.cpu().numpy(), 0, mode, cband=cb)
     assert np.array_equal(stream, ref)
 
 
