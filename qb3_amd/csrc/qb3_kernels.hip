@@ -1315,6 +1315,23 @@ __global__ void dec_kernel(const DecArgs a) {
 // Lanes are ordered band-major inside a pass (lane = band*BPP + block) so that a per-band scan is a plain
 // workgroup scan minus its value at the band's first lane.  The compressed range is staged in LDS with
 // coalesced loads, pixels are assembled in an LDS tile laid out like the image and stored as coalesced dwords.
+// same, with ONE barrier: the scratch must not be rewritten before the caller's next barrier (use distinct areas)
+template <typename V>
+__device__ __forceinline__ V block_exscan_1b(V v, V *wsum) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    V x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        V y = __shfl_up(x, d, 64);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    V base = 0;
+    for (uint32_t i = 0; i < wave; i++) base += wsum[i];
+    return (V)(base + x - v);
+}
+
 // reads the rung-switch code at bit `pos`: returns the delta (mod 2^UB), sets *gpos to the first value code
 template <typename T, typename PTR>
 __device__ __forceinline__ uint32_t dec3_switch(PTR src, uint32_t endw, uint32_t pos, uint32_t *gpos, bool *signal) {
@@ -1522,6 +1539,84 @@ constexpr int curve_pos_of(uint64_t order, int x, int y) {      // inverse of th
     return 0;
 }
 
+// Bit reader for one 8-bit unit: the unit's bits (at most 8 + 16*9 = 152, plus up to 31 of misalignment) are
+// fetched as six dwords with independent loads and then consumed from registers -- no dependent memory round
+// trips on the decode path.
+template <typename PTR>
+struct QReader {
+    uint64_t buf; uint32_t n, q0, q1, q2, q3, q4;
+    __device__ __forceinline__ void init(PTR src, uint32_t endw, uint32_t pos) {
+        const uint32_t w = pos >> 5, sh = pos & 31;
+        const uint32_t d0 = w < endw ? src[w] : 0u;
+        q0 = w + 1 < endw ? src[w + 1] : 0u; q1 = w + 2 < endw ? src[w + 2] : 0u; q2 = w + 3 < endw ? src[w + 3] : 0u;
+        q3 = w + 4 < endw ? src[w + 4] : 0u; q4 = w + 5 < endw ? src[w + 5] : 0u;
+        buf = (uint64_t)(d0 >> sh); n = 32 - sh;
+    }
+    __device__ __forceinline__ void ensure32() {        // after this at least 32 bits are valid
+        if (n < 32) { buf |= (uint64_t)q0 << n; n += 32; q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = 0; }
+    }
+    __device__ __forceinline__ void skip(uint32_t k) { buf >>= k; n -= k; }
+};
+
+// rung switch of an 8-bit unit at bit `pos`: delta (mod 8); *cslen = bits consumed
+template <typename PTR>
+__device__ __forceinline__ uint32_t px_switch(PTR src, uint32_t endw, uint32_t pos, uint32_t *cslen, bool *signal) {
+    const uint32_t w = pos >> 5, sh = pos & 31;
+    const uint32_t d0 = w < endw ? src[w] : 0u, d1 = w + 1 < endw ? src[w + 1] : 0u;
+    uint32_t x = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+    *signal = false;
+    if (!(x & 1)) { *cslen = 1; return 0; }
+    x >>= 1;                                            // code at rung 2 (reference QB3decode.h:97-116)
+    uint32_t m, len;
+    if (!(x & 1)) { m = (x & 3) >> 1; len = 2; }
+    else if (!(x & 2)) { m = ((x >> 2) & 1) | 2; len = 3; }
+    else { m = ((x >> 2) & 3) | 4; len = 4; }
+    *cslen = 1 + len;
+    if (m == 6) { *signal = true; return 0; }
+    return (m & 1) ? (8 - (m + 1) / 2) & 7 : m / 2 + 1;
+}
+
+// the 16 values of an 8-bit unit whose codes start at bit `gpos`; run[i] = running sum, packed 4 per register
+template <bool STEP, typename PTR>
+__device__ __forceinline__ void px_group(PTR src, uint32_t endw, uint32_t gpos, uint32_t rung, const uint16_t *dtab, uint32_t (&rp)[4]) {
+    QReader<PTR> rd;
+    rd.init(src, endw, gpos);
+    uint32_t g[16];
+    if (rung == 0) {
+        rd.ensure32();
+        const uint32_t x = (uint32_t)rd.buf;
+        const uint32_t bits = (x & 1) ? (x >> 1) & 0xffffu : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) g[i] = (bits >> i) & 1u;
+    } else {
+        const uint16_t *tab = dtab + dec_tab_off(rung);
+        const uint32_t mask = (4u << rung) - 1;
+        uint32_t rb = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i % 3 == 0) rd.ensure32();              // three codes are at most 27 bits
+            const uint32_t x = (uint32_t)rd.buf & mask;
+            const uint32_t e = tab[x];
+            rd.skip(rung + (x & 1) + ((x & 3) == 3));
+            g[i] = e & 0xfffu;
+            rb |= ((e >> rung) & 1u) << i;
+        }
+        if (STEP && (rb & (rb + 1)) == 0) {             // undo the step (reference QB3decode.h:285-289)
+            const uint32_t m = __popc(rb);
+#pragma unroll
+            for (int i = 0; i < 16; i++) if ((uint32_t)i == m) g[i] ^= 1u << rung;
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) rp[q] = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        acc = (acc + ((g[i] >> 1) ^ (0u - (g[i] & 1u)))) & 0xffu;      // undo mag-sign, accumulate (mod 256)
+        rp[i >> 2] |= acc << (8 * (i & 3));
+    }
+}
+
 template <int B, bool RGB, uint64_t ORDER, bool STEP, typename PTR>
 __device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t endw, uint32_t cpos0, uint32_t g0, uint32_t nb_here,
                                             uint64_t seg, uint64_t w0, uint64_t *wsum, uint64_t *carry, const uint8_t *ulen_s, const uint16_t *dtab) {
@@ -1537,7 +1632,7 @@ __device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t 
         uint32_t ul[B], blen = 0;
 #pragma unroll
         for (int c = 0; c < B; c++) { ul[c] = act ? ulen_s[sl * B + c] : 0u; blen += ul[c]; }
-        const uint64_t bex = block_exscan_v<uint64_t>(blen, wsum);
+        const uint64_t bex = block_exscan_1b<uint64_t>(blen, wsum);
         if (tid == 255) carry[0] = bex + blen;                          // bits of this pass
         // rung switches of the lane's units
         uint32_t gpos[B], pos = cpos + (uint32_t)bex;
@@ -1546,14 +1641,15 @@ __device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t 
         for (int c = 0; c < B; c++) {
             gpos[c] = 0;
             if (act) {
-                bool sig;
-                const uint32_t d = dec3_switch<uint8_t, PTR>(src, endw, pos, &gpos[c], &sig);
+                bool sig; uint32_t csl;
+                const uint32_t d = px_switch<PTR>(src, endw, pos, &csl, &sig);
+                gpos[c] = pos + csl;
                 if (sig && STEP) bad = true;                            // common-factor / index unit: not handled here
                 dpk |= (uint64_t)d << (16 * c);
                 pos += ul[c];
             }
         }
-        const uint64_t dex = block_exscan_v<uint64_t>(dpk, wsum) + dpk;  // inclusive, per band in 16-bit fields
+        const uint64_t dex = block_exscan_1b<uint64_t>(dpk, wsum + 4) + dpk;  // inclusive, per band in 16-bit fields
         // decode the units; running sums packed 4 per register, in curve order
         uint32_t rp[B][4], rungs = 0;
         uint64_t spk = 0;
@@ -1564,14 +1660,11 @@ __device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t 
             if (act) {
                 const uint32_t rung = ((uint32_t)carry[1 + c] + (uint32_t)((dex >> (16 * c)) & 0xffffu)) & UMASK;
                 rungs |= rung << (4 * c);
-                uint8_t run[16];
-                dec3_group<uint8_t, STEP, PTR>(src, endw, gpos[c], rung, dtab, run);
-#pragma unroll
-                for (int i = 0; i < 16; i++) rp[c][i >> 2] |= (uint32_t)run[i] << (8 * (i & 3));
-                spk |= (uint64_t)run[15] << (16 * c);
+                px_group<STEP, PTR>(src, endw, gpos[c], rung, dtab, rp[c]);
+                spk |= (uint64_t)(rp[c][3] >> 24) << (16 * c);
             }
         }
-        const uint64_t sex = block_exscan_v<uint64_t>(spk, wsum);        // exclusive
+        const uint64_t sex = block_exscan_1b<uint64_t>(spk, wsum + 8);    // exclusive
         uint32_t pv[B];
 #pragma unroll
         for (int c = 0; c < B; c++) pv[c] = ((uint32_t)carry[1 + B + c] + (uint32_t)((sex >> (16 * c)) & 0xffffu)) & 0xffu;
