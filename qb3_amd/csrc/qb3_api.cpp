@@ -191,10 +191,10 @@ static Geometry make_geometry(size_t w, size_t h, size_t bands, int dtype, size_
     g.nbx = (uint32_t)((w + 3) / 4); g.nby = (uint32_t)((h + 3) / 4);
     g.nblocks = (uint64_t)g.nbx * g.nby;
     g.mode = codec_mode(mode);
-    g.seg_blocks = seg_blocks_for(g.bands, g.tsz, g.mode);
     g.ulen_sz = ulen_size_for(g.tsz, g.mode);
-    g.nseg = (g.nblocks + g.seg_blocks - 1) / g.seg_blocks;
     for (size_t c = 0; c < bands; c++) g.cband[c] = cband_sz ? (uint8_t)cband_sz[c] : cband_u8[c];
+    g.seg_blocks = seg_blocks_for(g);
+    g.nseg = (g.nblocks + g.seg_blocks - 1) / g.seg_blocks;
     return g;
 }
 

@@ -48,7 +48,7 @@ struct IndexView {
 };
 size_t index_bytes(const Geometry &g);
 IndexView index_view(const Geometry &g, void *base);
-uint32_t seg_blocks_for(uint32_t bands, uint32_t tsz, uint32_t mode);
+uint32_t seg_blocks_for(const Geometry &g);      // needs w, h, bands, tsz, stride, order, mode, cband
 uint32_t ulen_size_for(uint32_t tsz, uint32_t mode);
 
 // Results the encoder hands back to the host (device resident, copied once per encode)

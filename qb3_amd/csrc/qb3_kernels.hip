@@ -1621,19 +1621,19 @@ template <int B, bool RGB, uint64_t ORDER, bool STEP, typename PTR>
 __device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t endw, uint32_t cpos0, uint32_t g0, uint32_t nb_here,
                                             uint64_t seg, uint64_t w0, uint64_t *wsum, uint64_t *carry, const uint8_t *ulen_s, const uint16_t *dtab) {
     constexpr uint32_t UMASK = 7;
-    const uint32_t tid = threadIdx.x, nbx = a.g.nbx;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, nbx = a.g.nbx;
     const uint64_t stride = a.g.stride;
     uint32_t cpos = cpos0;
     bool bad = false;
-    const uint32_t npass = (nb_here + 255) / 256;
+    const uint32_t npass = (nb_here + nthr - 1) / nthr;
     for (uint32_t p = 0; p < npass; p++) {
-        const uint32_t sl = p * 256 + tid;
+        const uint32_t sl = p * nthr + tid;
         const bool act = sl < nb_here;
         uint32_t ul[B], blen = 0;
 #pragma unroll
         for (int c = 0; c < B; c++) { ul[c] = act ? ulen_s[sl * B + c] : 0u; blen += ul[c]; }
         const uint64_t bex = block_exscan_1b<uint64_t>(blen, wsum);
-        if (tid == 255) carry[0] = bex + blen;                          // bits of this pass
+        if (tid == nthr - 1) carry[0] = bex + blen;                          // bits of this pass
         // rung switches of the lane's units
         uint32_t gpos[B], pos = cpos + (uint32_t)bex;
         uint64_t dpk = 0;
@@ -1669,7 +1669,7 @@ __device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t 
 #pragma unroll
         for (int c = 0; c < B; c++) pv[c] = ((uint32_t)carry[1 + B + c] + (uint32_t)((sex >> (16 * c)) & 0xffffu)) & 0xffu;
         __syncthreads();                                                 // everyone has read the carries
-        if (act && (sl == nb_here - 1 || tid == 255)) {                  // state leaving the pass
+        if (act && (sl == nb_here - 1 || tid == nthr - 1)) {                  // state leaving the pass
 #pragma unroll
             for (int c = 0; c < B; c++) {
                 carry[1 + c] = (rungs >> (4 * c)) & 15u;
@@ -1724,6 +1724,7 @@ __device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t 
 
 template <int B, bool RGB, uint64_t ORDER, bool STEP>
 __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a) {
+    const uint32_t nthr = blockDim.x;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, NB = a.g.seg_blocks;
     const uint64_t seg = blockIdx.x;
@@ -1745,10 +1746,10 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a) {
     const bool staged = ndw64 <= a.in_cap_dw;           // workgroup uniform
     const uint32_t ndw = (uint32_t)ndw64;
     if (staged)
-        for (uint32_t i = tid; i < ndw; i += 256) stage[i] = (w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+        for (uint32_t i = tid; i < ndw; i += nthr) stage[i] = (w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
     const uint32_t endw_g = (uint32_t)((endw_abs - w0 < 0xffffffffull) ? endw_abs - w0 : 0xffffffffull);
     const uint8_t *ul = (const uint8_t *)a.idx.ulen + (uint64_t)g0 * B;
-    for (uint32_t i = tid; i < nb_here * B; i += 256) ulen_s[i] = ul[i];
+    for (uint32_t i = tid; i < nb_here * B; i += nthr) ulen_s[i] = ul[i];
     if (tid < B) {
         carry[1 + tid] = a.idx.rung[seg * B + tid];
         carry[1 + B + tid] = ((const uint8_t *)a.idx.prev)[seg * B + tid];
@@ -1880,15 +1881,20 @@ static void fast_geometry(uint32_t bands, uint32_t tsz, uint32_t *threads, uint3
     static const int knob = [] { const char *e = getenv("QB3_DEC_PASSES"); return e ? atoi(e) : 0; }();   // tuning knob
     if (knob > 0 && (uint32_t)knob < *passes) *passes = (uint32_t)knob;
 }
-uint32_t seg_blocks_for(uint32_t bands, uint32_t tsz, uint32_t mode) {
-    if (mode != CM_BEST) {      // one segment = the blocks of one unit-parallel workgroup
+// Blocks per index segment.  A function of stream-intrinsic properties only (bands, value size, mode): encoder
+// and decoder must agree on it whatever their strides, band maps or buffer alignments are.
+uint32_t seg_blocks_for(const Geometry &g) {
+    if (g.mode != CM_BEST) {      // one segment = the blocks of one decoder workgroup, at most 256
+        static const uint32_t knob = [] { const char *e = getenv("QB3_SEG_BLOCKS"); int k = e ? atoi(e) : 0; return (uint32_t)(k < 0 ? 0 : k); }();
+        if (knob) return knob;                                                  // tuning knob, process wide
         uint32_t threads, bpp, passes;
-        fast_geometry(bands, tsz, &threads, &bpp, &passes);
+        fast_geometry(g.bands, g.tsz, &threads, &bpp, &passes);
+        while (passes > 1 && bpp * passes > 256) passes--;
         return bpp * passes;
     }
     // common-factor modes: a lane walks the segment serially, keep it short (QB3_SEG_UNITS: tuning knob)
     static const uint32_t units = [] { const char *e = getenv("QB3_SEG_UNITS"); int v = e ? atoi(e) : 12; return (uint32_t)(v < 1 ? 1 : v); }();
-    uint32_t s = units / bands;
+    uint32_t s = units / g.bands;
     return s ? s : 1;
 }
 uint32_t ulen_size_for(uint32_t tsz, uint32_t mode) { return mode == CM_BEST ? 0 : (tsz == 1 ? 1 : 2); }
@@ -2099,7 +2105,7 @@ DecPlan plan_decode(const Geometry &g) {
     for (uint32_t c = 0; c < g.bands; c++) simple = simple && g.cband[g.cband[c]] == g.cband[c];
     fast_geometry(g.bands, g.tsz, &p.threads2, &p.bpp, &p.passes);
     const uint32_t dpr = g.bands * g.tsz, NB = g.seg_blocks;
-    simple = simple && NB == p.bpp * p.passes;
+    p.passes = (NB + p.bpp - 1) / p.bpp;
     p.in_cap_dw = (NB * dpr * 4 + 8 + 1) & ~1u;         // room for a stream as large as the raw blocks
     p.lds2_bytes = 8 * (size_t)NB + 8 * 16 + 8 * 2 * MAXBANDS + 4 * 2 * MAXBANDS + 4 * (size_t)((p.bpp + 1) & ~1u)
                  + 4 * (size_t)p.in_cap_dw + 16 * (size_t)NB * dpr + align8(2 * (size_t)p.bpp * g.bands) + 2048;
@@ -2115,7 +2121,8 @@ DecPlan plan_decode(const Geometry &g) {
 template <int B, bool RGB>
 static void launch_dec_px_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    dim3 grid((uint32_t)a.g.nseg), block(256);
+    const uint32_t nt = a.g.seg_blocks >= 256 ? 256u : ((a.g.seg_blocks + 63) / 64) * 64;
+    dim3 grid((uint32_t)a.g.nseg), block(nt);
     if (!z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, false>), grid, block, plan.lds_px, st, a);
     else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);
     else if (z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, false>), grid, block, plan.lds_px, st, a);
