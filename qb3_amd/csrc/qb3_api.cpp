@@ -284,7 +284,7 @@ static size_t stored_encode_host(encsp p, const void *source, void *destination)
 // `hdr`.  On success *bits receives the stream length; the handle's band state is updated when `carry`.
 // d_index may be null.  Synchronises the stream.
 static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, uint8_t *d_out, size_t hdr,
-                                 void *d_index, hipStream_t st, bool carry, uint64_t *bits) {
+                                 void *d_index, hipStream_t st, bool carry, uint64_t *bits, const uint8_t *hdrbytes) {
     EncPlan plan = plan_encode(g);
     if (!p->d_ws.ensure(plan.ws_bytes)) return false;
     BandState bs;
@@ -295,7 +295,7 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     uint32_t *out32 = (uint32_t *)(d_out + (hdr & ~(size_t)3));
     EncResult res;
     const uint8_t *dres = (const uint8_t *)p->d_ws.p + plan.ws_bytes - sizeof(EncResult);
-    if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st)) return false;
+    if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st, TileBatch(), hdrbytes, (uint32_t)hdr)) return false;
     hipError_t e = hipMemcpyAsync(&res, dres, sizeof(res), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
@@ -380,7 +380,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     if (g.w < 4 || g.h < 4) { p->error = 1; if (rle) p->mode = mode; return 0; }
 
     uint64_t bits = 0;
-    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits)) {   // the index describes the block stream, RLE0 wrapped or not
+    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits, hdrbuf)) {   // the index describes the block stream, RLE0 wrapped or not
         p->error = QB3E_LIBERR; if (rle) p->mode = mode; return 0;
     }
     p->error = 0;
@@ -408,9 +408,8 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
         if (on_host) {
             memcpy(host_dst, hdrbuf, hdr);
             HIPOK(hipMemcpyAsync((uint8_t *)host_dst + hdr, out_dev + hdr, len - hdr, hipMemcpyDeviceToHost, st));
-        } else
-            HIPOK(hipMemcpyAsync(d_dst, hdrbuf, hdr, hipMemcpyHostToDevice, st));
-        HIPOK(hipStreamSynchronize(st));
+            HIPOK(hipStreamSynchronize(st));
+        }       // device flavour: the header was stamped by write_header_kernel, in stream order
         return len;
     }
     // not worth it: raw bypass (reference QB3encode.cpp:571-573)
@@ -440,19 +439,70 @@ QB3_API size_t qb3x_index_size(const encsp p) {
     return index_bytes(g);
 }
 
-QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t src_pitch, void *d_dst, size_t dst_pitch,
-                                 void *d_index, size_t *sizes, void *stream) {
-    if (!p || !d_src || !d_dst || !sizes || (dst_pitch & 3)) return 0;
-    const size_t isz = d_index ? qb3x_index_size(p) : 0;
-    const qb3_mode mode = p->mode;
+// One tile at a time (general path: RLE modes, quantisation, narrow or tiny tiles, STORED fallbacks)
+static size_t encode_tiles_loop(encsp p, const void *d_src, size_t first, size_t n, size_t src_pitch, void *d_dst, size_t dst_pitch,
+                                void *d_index, size_t isz, size_t *sizes, void *stream, qb3_mode mode) {
     size_t done = 0;
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = first; i < first + n; i++) {
         qb3_reset_encoder(p);
         p->mode = mode;
         sizes[i] = qb3x_encode_device(p, (const uint8_t *)d_src + i * src_pitch, (uint8_t *)d_dst + i * dst_pitch,
                                       d_index ? (uint8_t *)d_index + i * isz : nullptr, stream);
         done += sizes[i] != 0;
     }
+    return done;
+}
+
+QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t src_pitch, void *d_dst, size_t dst_pitch,
+                                 void *d_index, size_t *sizes, void *stream) {
+    if (!p || !d_src || !d_dst || !sizes || (dst_pitch & 3) || ((uintptr_t)d_dst & 3)) return 0;
+    const size_t isz = d_index ? qb3x_index_size(p) : 0;
+    const qb3_mode mode = p->mode;
+    const size_t tsz = szof(p->type);
+    hipStream_t st = (hipStream_t)stream;
+    // batched path: every tile of the call goes through ONE set of kernel launches (blockIdx.y = tile) and one
+    // host synchronisation.  Anything unusual takes the one-by-one path.
+    const bool batchable = !is_rle_mode(mode) && mode != QB3M_STORED && p->quanta < 2 && p->xsize >= 4 && p->ysize >= 4 &&
+                           p->xsize * p->ysize > 16 && !p->error && device_ok();
+    if (!batchable) return encode_tiles_loop(p, d_src, 0, n, src_pitch, d_dst, dst_pitch, d_index, isz, sizes, stream, mode);
+
+    uint8_t hdrbuf[64];
+    const size_t hdr = write_headers(p, hdrbuf);
+    Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, p->mode, p->cband, nullptr);
+    const EncPlan plan = plan_encode(g);
+    const size_t wsp = (plan.ws_bytes + 255) & ~(size_t)255;
+    size_t batch = (size_t)8 << 30 >= wsp ? ((size_t)8 << 30) / wsp : 1;     // keep the workspace under 8 GiB
+    if (batch > n) batch = n;
+    if (batch > 65535) batch = 65535;
+    if (!p->d_ws.ensure(batch * wsp)) { p->error = QB3E_LIBERR; return 0; }
+    BandState bs;
+    memset(&bs, 0, sizeof(bs));             // tiles are independent streams: every tile starts from the reset state
+    std::vector<EncResult> res(batch);
+    size_t done = 0;
+    for (size_t first = 0; first < n; first += batch) {
+        const size_t cnt = (n - first < batch) ? n - first : batch;
+        TileBatch tb;
+        tb.n = (uint32_t)cnt; tb.src_pitch = src_pitch; tb.dst_pitch = dst_pitch; tb.ws_pitch = wsp; tb.idx_pitch = isz;
+        uint8_t *out0 = (uint8_t *)d_dst + first * dst_pitch;
+        if (launch_encode(g, plan, (const uint8_t *)d_src + first * src_pitch, (uint32_t *)(out0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), bs,
+                          p->d_ws.p, d_index ? (uint8_t *)d_index + first * isz : nullptr, st, tb, hdrbuf, (uint32_t)hdr)) { p->error = QB3E_LIBERR; return done; }
+        const uint8_t *dres = (const uint8_t *)p->d_ws.p + plan.ws_bytes - sizeof(EncResult);
+        hipError_t e = hipMemcpy2DAsync(res.data(), sizeof(EncResult), dres, wsp, sizeof(EncResult), cnt, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("encode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
+        prof_collect();
+        const size_t raw = p->xsize * p->ysize * p->nbands * tsz;
+        for (size_t i = 0; i < cnt; i++) {
+            const size_t len = hdr + (size_t)((res[i].total_bits + 7) / 8);
+            if (raw > len) { sizes[first + i] = len; done++; }
+            else done += encode_tiles_loop(p, d_src, first + i, 1, src_pitch, d_dst, dst_pitch, d_index, isz, sizes, stream, mode);   // STORED fallback
+        }
+        // handle state as after a loop over the tiles: the state left by the last one
+        for (size_t c = 0; c < p->nbands; c++) {
+            p->band[c].prev = (size_t)res[cnt - 1].prev[c]; p->band[c].runbits = res[cnt - 1].rung[c]; p->band[c].cf = (size_t)res[cnt - 1].cf[c];
+        }
+    }
+    p->error = 0;
     return done;
 }
 
@@ -692,19 +742,63 @@ QB3_API size_t qb3x_decode_device(decsp p, const void *d_src, void *d_dst, const
     return decode_common(p, nullptr, d_src, d_dst, d_index, (hipStream_t)stream);
 }
 
-QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
-                                 void *d_dst, size_t dst_pitch, const void *d_index, void *stream) {
-    if (!p || !d_src || !d_dst || !sizes || (src_pitch & 3)) return 0;
-    const size_t isz = d_index ? qb3x_decoder_index_size(p) : 0;
+static size_t decode_tiles_loop(decsp p, const void *d_src, size_t first, size_t n, size_t src_pitch, const size_t *sizes,
+                                void *d_dst, size_t dst_pitch, const void *d_index, size_t isz, void *stream) {
     const size_t hdr = (size_t)(p->s_in - p->s_start);
-    uint8_t *const s_in = p->s_in;
     size_t done = 0;
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = first; i < first + n; i++) {
         if (sizes[i] <= hdr) continue;
-        p->s_size = sizes[i] - hdr; p->s_in = s_in; p->error = QB3E_OK;
+        p->s_size = sizes[i] - hdr; p->error = QB3E_OK;
         done += 0 != qb3x_decode_device(p, (const uint8_t *)d_src + i * src_pitch, (uint8_t *)d_dst + i * dst_pitch,
                                         d_index ? (const uint8_t *)d_index + i * isz : nullptr, stream);
     }
+    return done;
+}
+
+QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
+                                 void *d_dst, size_t dst_pitch, const void *d_index, void *stream) {
+    if (!p || !d_src || !d_dst || !sizes || (src_pitch & 3) || ((uintptr_t)d_src & 3)) return 0;
+    if (p->stage != 2 || p->error != QB3E_OK) return 0;
+    const size_t isz = d_index ? qb3x_decoder_index_size(p) : 0;
+    const size_t hdr = (size_t)(p->s_in - p->s_start), s_size0 = p->s_size;
+    hipStream_t st = (hipStream_t)stream;
+    // batched path (all tiles share the geometry, mode and header layout of tile 0); else one by one
+    const bool batchable = !is_rle_mode(p->mode) && p->mode != QB3M_STORED && p->quanta <= 1 && p->xsize >= 4 && p->ysize >= 4 &&
+                           p->xsize * p->ysize >= 16 && device_ok();
+    size_t done = 0;
+    if (!batchable) done = decode_tiles_loop(p, d_src, 0, n, src_pitch, sizes, d_dst, dst_pitch, d_index, isz, stream);
+    else {
+        uint8_t cband[QB3_MAXBANDS];
+        for (size_t c = 0; c < QB3_MAXBANDS; c++) cband[c] = p->cband[c];
+        if (!p->saw_cb && !(p->compat & QB3X_REF_CBAND0)) for (size_t c = 0; c < p->nbands; c++) cband[c] = (uint8_t)c;
+        Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, p->mode, nullptr, cband);
+        const DecPlan plan = plan_decode(g);
+        const size_t wsp = (plan.ws_bytes + 255) & ~(size_t)255;
+        size_t batch = d_index ? n : (((size_t)8 << 30) / wsp ? ((size_t)8 << 30) / wsp : 1);
+        if (batch > n) batch = n;
+        if (batch > 65535) batch = 65535;
+        if (!p->d_ws.ensure(256 * ((batch + 63) / 64) + (d_index ? 0 : batch * wsp)) || !p->d_in.ensure(8 * batch)) { p->error = QB3E_LIBERR; return 0; }
+        std::vector<uint64_t> bits(batch);
+        std::vector<uint32_t> status(batch);
+        for (size_t first = 0; first < n; first += batch) {
+            const size_t cnt = (n - first < batch) ? n - first : batch;
+            for (size_t i = 0; i < cnt; i++) bits[i] = sizes[first + i] > hdr ? (uint64_t)(sizes[first + i] - hdr) * 8 : 0;
+            hipError_t e = hipMemcpyAsync(p->d_in.p, bits.data(), 8 * cnt, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) { set_error("decode tiles: upload of stream lengths", (int)e); p->error = QB3E_LIBERR; return done; }
+            TileBatch tb;
+            tb.n = (uint32_t)cnt; tb.src_pitch = src_pitch; tb.dst_pitch = dst_pitch; tb.idx_pitch = isz;
+            const uint8_t *src0 = (const uint8_t *)d_src + first * src_pitch;
+            uint32_t *d_status = nullptr;
+            if (launch_decode(g, plan, (const uint32_t *)(src0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), 0, (uint8_t *)d_dst + first * dst_pitch,
+                              d_index ? (const uint8_t *)d_index + first * isz : nullptr, p->d_ws.p, &d_status, st, tb, (const uint64_t *)p->d_in.p)) { p->error = QB3E_LIBERR; return done; }
+            e = hipMemcpyAsync(status.data(), d_status, 4 * cnt, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
+            prof_collect();
+            for (size_t i = 0; i < cnt; i++) done += bits[i] && !(status[i] & 3);
+        }
+    }
+    p->s_size = s_size0;
     return done;
 }
 

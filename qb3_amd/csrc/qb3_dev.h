@@ -74,6 +74,10 @@ struct EncPlan {
 };
 EncPlan plan_encode(const Geometry &g);
 
+// Batched tiles: n images/streams laid out at fixed byte pitches, processed by one set of launches (blockIdx.y).
+// n == 0 means a single image.  ws_pitch = plan.ws_bytes of one tile; idx_pitch = index_bytes of one tile.
+struct TileBatch { uint32_t n = 0; uint64_t src_pitch = 0, dst_pitch = 0, ws_pitch = 0, idx_pitch = 0; };
+
 // Encode the block stream of one image.  All pointers are device pointers.
 //   img        image, g.tsz-byte values
 //   out32      4-byte aligned address at or below the first stream byte
@@ -83,7 +87,8 @@ EncPlan plan_encode(const Geometry &g);
 //   index      optional decode index (nullptr = none)
 // Launches on `stream`, does not synchronise.  Returns hipError_t as int.
 int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
-                  const BandState &st_in, void *ws, void *index, void *stream);
+                  const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb = TileBatch(),
+                  const uint8_t *hdr = nullptr, uint32_t hdr_len = 0);     // hdr: container header stamped before each stream
 
 struct DecPlan {
     uint32_t threads;       // lanes per workgroup, one index segment per lane
@@ -105,7 +110,8 @@ DecPlan plan_decode(const Geometry &g);
 // boundary scan on the GPU.  status (device u32 inside ws, zeroed here) gets nonzero on decode failure.
 // Returns hipError_t as int; does not synchronise.
 int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
-                  void *img, const void *index, void *ws, uint32_t **status_out, void *stream);
+                  void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb = TileBatch(),
+                  const uint64_t *tile_bits = nullptr);    // tile_bits: device array, stream length of each tile in bits
 
 // Elementwise helpers on device buffers (quantisation, reference QB3encode.cpp:137-186 / QB3decode.cpp:77-107)
 int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, uint64_t q, bool away, void *stream);

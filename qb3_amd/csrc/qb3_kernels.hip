@@ -154,12 +154,33 @@ struct EncArgs {
     uint8_t *cw_has;        // common-factor modes: per chunk and band, does the chunk overwrite the band's factor
     uint64_t *cw_val;       //   ... and with what (cf - 2)
     uint64_t *centry;       //   ... factor state on entering the chunk (after best_scan_kernel)
+    uint32_t ntiles;
+    uint64_t ts_img, ts_out, ts_ws, ts_idx;     // batched tiles: byte strides from tile to tile (blockIdx.y = tile)
+    uint32_t hdr_len;       // container header bytes to stamp in front of the stream (write_header_kernel)
+    uint8_t hdr[64];
     uint32_t flags;         // tuning switches (QB3_ENC_FLAGS): bit 0 = codes from the LDS table instead of the rule
     EncResult *res;
     BandState st;
     IndexView idx;
     uint32_t have_idx;
 };
+
+
+// Batched tiles: every kernel of the encoder takes the tile from blockIdx.y and shifts its per-tile pointers.
+template <typename P> __device__ __forceinline__ P *shift_ptr(P *p, uint64_t bytes) { return p ? (P *)((uint8_t *)p + bytes) : p; }
+__device__ __forceinline__ EncArgs enc_for_tile(EncArgs a, uint32_t t) {
+    if (t) {
+        a.img = (const uint8_t *)a.img + t * a.ts_img;
+        a.out32 = shift_ptr(a.out32, t * a.ts_out);
+        const uint64_t w = t * a.ts_ws, x = t * a.ts_idx;
+        a.chunk_bits = shift_ptr(a.chunk_bits, w); a.chunk_off = shift_ptr(a.chunk_off, w); a.group_sum = shift_ptr(a.group_sum, w);
+        a.scratch = shift_ptr(a.scratch, w); a.seams = shift_ptr(a.seams, w); a.res = shift_ptr(a.res, w);
+        a.cw_has = shift_ptr(a.cw_has, w); a.cw_val = shift_ptr(a.cw_val, w); a.centry = shift_ptr(a.centry, w);
+        a.idx.bitpos = shift_ptr(a.idx.bitpos, x); a.idx.prev = shift_ptr(a.idx.prev, x); a.idx.cf = shift_ptr(a.idx.cf, x);
+        a.idx.rung = shift_ptr(a.idx.rung, x); a.idx.ulen = shift_ptr(a.idx.ulen, x);
+    }
+    return a;
+}
 
 // LSB-first bit writer into a zeroed LDS dword buffer shared by the workgroup
 struct LdsWriter {
@@ -210,7 +231,7 @@ template <typename T> struct EncFront {
 };
 
 template <typename T>
-__device__ __forceinline__ void enc_front(const EncArgs &a, uint8_t *smem, uint32_t outdw, EncFront<T> &f, T (&g)[16]) {
+__device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, uint8_t *smem, uint32_t outdw, EncFront<T> &f, T (&g)[16]) {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t bands = a.g.bands, slots = a.slots, dpr = a.dpr, nbp = slots - 1;
     const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
@@ -269,7 +290,7 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, uint8_t *smem, uint3
     bool valid = false;
     uint32_t gblk = 0;
     if (s < slots) gblk = slot_block(s, valid);
-    const uint32_t cb = a.g.cband[c < MAXBANDS ? c : 0];
+    const uint32_t cb = a0.g.cband[c < MAXBANDS ? c : 0];
     const T *tt = (const T *)tile;
     const uint64_t order = a.g.order;
     T used = 0, pv = 0, lastv = 0;
@@ -277,7 +298,7 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, uint8_t *smem, uint3
     if (valid) {
         // value entering the unit: last visited pixel of the previous block, or the carried state
         const uint32_t n15 = curve_nib(order, 15);
-        if (gblk == 0) pv = (T)a.st.prev[c];
+        if (gblk == 0) pv = (T)a0.st.prev[c];
         else if (s >= 1) {
             const uint32_t e = (((n15 >> 2) * slots + (s - 1)) * 4 + (n15 & 3)) * bands;
             pv = tt[e + c];
@@ -313,14 +334,15 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, uint8_t *smem, uint3
 }
 
 template <typename T, bool STEP>
-__global__ void enc_kernel(const EncArgs a) {
+__global__ void enc_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t bands = a.g.bands, nblocks = (uint32_t)a.g.nblocks;
     T g[16];
     EncFront<T> f;
-    enc_front<T>(a, smem, (31 + (a.slots - 1) * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1, f, g);
+    enc_front<T>(a, a0, smem, (31 + (a.slots - 1) * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1, f, g);
     const uint32_t c = f.c, gblk = f.gblk, rung = f.rung, chunk = f.chunk;
     const bool payload = f.payload;
     const T used = f.used, pv = f.pv, lastv = f.lastv;
@@ -334,7 +356,7 @@ __global__ void enc_kernel(const EncArgs a) {
     uint32_t pc[6] = {0, 0, 0, 0, 0, 0}, plens = 0;        // pieces and their lengths (5 bits each)
     bool pieces = false;
     if (payload) {
-        prung = (gblk == 0) ? a.st.rung[c] : rungs[tid - bands];
+        prung = (gblk == 0) ? a0.st.rung[c] : rungs[tid - bands];
         delta = (rung - prung) & UMASK;
         const uint32_t csl = cs_len<UB>(delta), csc = cs_code<UB>(delta);
         len = csl;
@@ -411,7 +433,7 @@ __global__ void enc_kernel(const EncArgs a) {
         }
         w.finish();
         // coder state on leaving the image, for handle statefulness (reference QB3encode.h:446-449)
-        if (gblk == nblocks - 1) { a.res->prev[c] = (uint64_t)lastv; a.res->rung[c] = rung; a.res->cf[c] = a.st.cf[c]; }
+        if (gblk == nblocks - 1) { a.res->prev[c] = (uint64_t)lastv; a.res->rung[c] = rung; a.res->cf[c] = a0.st.cf[c]; }
         if (a.have_idx) {
             if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gblk * bands + c] = (uint8_t)len;
             else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gblk * bands + c] = (uint16_t)len;
@@ -462,7 +484,8 @@ template <int B> __device__ __forceinline__ uint32_t px_byte(const uint32_t (&w)
 template <int B, bool RGB> constexpr int core_of(int c) { return (RGB && (c == 0 || c == 2)) ? 1 : c; }
 
 template <int B, bool RGB, uint64_t ORDER, bool STEP>
-__global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a) {
+__global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
     constexpr uint32_t UB = 3, UMASK = 7;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -514,7 +537,7 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a) {
         constexpr int dummy = 0; (void)dummy;
         const int cb = core_of<B, RGB>(c);
         uint32_t prv;
-        if (gblk == 0) prv = (uint32_t)a.st.prev[c] & 0xffu;
+        if (gblk == 0) prv = (uint32_t)a0.st.prev[c] & 0xffu;
         else {      // pixel x = 3 of the previous block sits in the last dword of its row: byte c + 4 - B
             prv = (pd >> (8 * (c + 4 - B))) & 0xffu;
             if (cb != c) prv = (prv - ((pd >> (8 * (cb + 4 - B))) & 0xffu)) & 0xffu;
@@ -545,7 +568,7 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a) {
     if (lane == 0 && wave) prp = wsum[32 + wave - 1];
     if (gblk == 0) { prp = 0;
 #pragma unroll
-        for (int c = 0; c < B; c++) prp |= ((uint32_t)a.st.rung[c] & 15u) << (4 * c); }
+        for (int c = 0; c < B; c++) prp |= ((uint32_t)a0.st.rung[c] & 15u) << (4 * c); }
 
     // ---- per band: the unit's bit string as six pieces of at most 27 bits (see enc_kernel)
     uint32_t pc[B][6], plens[B], lens[B], blen = 0;
@@ -608,7 +631,7 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a) {
         wr.finish();
         if (gblk == nblocks - 1) {
 #pragma unroll
-            for (int c = 0; c < B; c++) { a.res->prev[c] = lastv[c]; a.res->rung[c] = (rp_packed >> (4 * c)) & 15u; a.res->cf[c] = a.st.cf[c]; }
+            for (int c = 0; c < B; c++) { a.res->prev[c] = lastv[c]; a.res->rung[c] = (rp_packed >> (4 * c)) & 15u; a.res->cf[c] = a0.st.cf[c]; }
         }
         if (a.have_idx) {
             uint8_t *ul = (uint8_t *)a.idx.ulen + (uint64_t)gblk * B;
@@ -783,7 +806,8 @@ __device__ __forceinline__ void last_writer_scan(uint32_t *key, uint64_t *val, u
 }
 
 template <typename T, int PASS>
-__global__ void enc_best_kernel(const EncArgs a) {
+__global__ void enc_best_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
@@ -791,7 +815,7 @@ __global__ void enc_best_kernel(const EncArgs a) {
     T g[16];
     EncFront<T> f;
     const uint32_t outdw = a.slot_dw;
-    enc_front<T>(a, smem, PASS ? outdw : 0, f, g);
+    enc_front<T>(a, a0, smem, PASS ? outdw : 0, f, g);
     const uint32_t c = f.c, gblk = f.gblk, rung = f.rung, chunk = f.chunk;
     const bool payload = f.payload;
     const T used = f.used;
@@ -802,7 +826,7 @@ __global__ void enc_best_kernel(const EncArgs a) {
     BestUnit<T> u;
     u.writer = false; u.cf = 1; u.szN = u.szBase = u.szCf = 0; u.idx = 0xffffffffu; u.trung = 0;
     if (payload) {
-        oldrung = (gblk == 0) ? a.st.rung[c] : f.rungs[tid - bands];
+        oldrung = (gblk == 0) ? a0.st.rung[c] : f.rungs[tid - bands];
         if (used > 1) best_analyse<T>(g, rung, oldrung, u);
     }
     // who wrote the band's factor last, up to and including each unit
@@ -927,7 +951,8 @@ __global__ void enc_best_kernel(const EncArgs a) {
 
 // Carries the last factor writer across chunks: centry[k][c] = factor state on entering chunk k.  One workgroup;
 // "last non-empty" is a max-scan over (chunk index + 1).
-__global__ void best_scan_kernel(const EncArgs a) {
+__global__ void best_scan_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
     const uint32_t bands = a.g.bands, tid = threadIdx.x;
@@ -950,7 +975,7 @@ __global__ void best_scan_kernel(const EncArgs a) {
             // exclusive: the last writer strictly before chunk k
             const uint32_t up = __shfl_up(m, 1, 64);
             const uint32_t excl = max(before, lane ? up : 0u);
-            if (k < a.nchunks) a.centry[(uint64_t)k * bands + c] = excl ? a.cw_val[(uint64_t)(excl - 1) * bands + c] : a.st.cf[c];
+            if (k < a.nchunks) a.centry[(uint64_t)k * bands + c] = excl ? a.cw_val[(uint64_t)(excl - 1) * bands + c] : a0.st.cf[c];
             __syncthreads();
             if (tid == blockDim.x - 1) carry = incl;
             __syncthreads();
@@ -960,7 +985,8 @@ __global__ void best_scan_kernel(const EncArgs a) {
 
 // Exclusive scan of the chunk bit counts, one workgroup per SCAN_GROUP chunks (4 per thread); the per-group sums
 // are folded in by the consumers.  64-bit offsets: a 16384^2 x 3 stream exceeds 2^32 bits.
-__global__ void enc_scan_kernel(const EncArgs a) {
+__global__ void enc_scan_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
     __shared__ uint32_t wsum[16];
     const uint32_t tid = threadIdx.x, i0 = blockIdx.x * SCAN_GROUP + 4 * tid;
     uint32_t v[4], sum = 0;
@@ -974,7 +1000,8 @@ __global__ void enc_scan_kernel(const EncArgs a) {
 }
 
 // Second level: exclusive scan of the group sums in place (one workgroup); entry [ngroups] gets the total.
-__global__ void enc_scan2_kernel(const EncArgs a) {
+__global__ void enc_scan2_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
     __shared__ uint64_t wsum64[16];
     __shared__ uint64_t carry;
     const uint32_t ngroups = (a.nchunks + SCAN_GROUP - 1) / SCAN_GROUP;
@@ -1001,7 +1028,8 @@ __device__ __forceinline__ uint64_t chunk_start(const EncArgs &a, uint32_t k) {
 
 // Concatenate: one WAVE per chunk reads the chunk's slot, funnel-shifts it to its bit position and stores the
 // dwords that lie wholly inside the chunk; the first and last shifted dword go to the seam table.
-__global__ void enc_concat_kernel(const EncArgs a) {
+__global__ void enc_concat_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (chunk >= a.nchunks) return;
     const uint64_t G = (uint64_t)a.out_bit0 + chunk_start(a, chunk);
@@ -1023,7 +1051,8 @@ __global__ void enc_concat_kernel(const EncArgs a) {
 // One thread per chunk boundary: a dword that holds the end of one chunk and the start of the next is the OR of
 // their edge dwords; the thread of the FIRST boundary inside a dword assembles it.  The same launch turns the
 // chunk-relative index positions into stream positions and publishes the stream length.
-__global__ void enc_seam_kernel(const EncArgs a) {
+__global__ void enc_seam_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     if (a.have_idx)
         for (uint64_t sgi = k; sgi < a.g.nseg; sgi += nthreads) {
@@ -1045,6 +1074,14 @@ __global__ void enc_seam_kernel(const EncArgs a) {
     a.out32[d] = v;
 }
 
+// Writes the container header in front of every tile's stream (after enc_seam_kernel, which owns the first dword).
+__global__ void write_header_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    // the stream starts at out32 + out_bit0/8; the header ends there
+    uint8_t *end = (uint8_t *)a.out32 + (a.out_bit0 >> 3);
+    if (threadIdx.x < a.hdr_len) end[(int)threadIdx.x - (int)a.hdr_len] = a0.hdr[threadIdx.x];
+}
+
 // ------------------------------------------------------------------ decode
 struct DecArgs {
     Geometry g;
@@ -1058,7 +1095,25 @@ struct DecArgs {
     uint32_t dpr;
     // unit-parallel kernel (dec3_kernel)
     uint32_t bpp, passes, in_cap_dw, magic_bpp, magic_dpr;
+    // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
+    uint32_t ntiles;
+    uint64_t ts_in, ts_img, ts_idx;
+    const uint64_t *tile_bits;
 };
+
+
+__device__ __forceinline__ DecArgs dec_for_tile(DecArgs a, uint32_t t) {
+    if (a.tile_bits) a.in_bits = a.tile_bits[t];
+    if (t) {
+        a.in32 = shift_ptr(a.in32, t * a.ts_in);
+        a.img = shift_ptr((uint8_t *)a.img, t * a.ts_img);
+        const uint64_t x = t * a.ts_idx;
+        a.idx.bitpos = shift_ptr(a.idx.bitpos, x); a.idx.prev = shift_ptr(a.idx.prev, x); a.idx.cf = shift_ptr(a.idx.cf, x);
+        a.idx.rung = shift_ptr(a.idx.rung, x); a.idx.ulen = shift_ptr(a.idx.ulen, x);
+        a.status += t;
+    }
+    return a;
+}
 
 // LSB-first bit reader over aligned dword loads; reads past the stream end return zeros, like the
 // reference's iBits::peek (bitstream.h:39-50)
@@ -1239,7 +1294,8 @@ template <typename T, int MODE, typename RD> __device__ __forceinline__ bool par
 
 // Lane per index segment.
 template <typename T, int MODE>
-__global__ void dec_kernel(const DecArgs a) {
+__global__ void dec_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t bands = a.g.bands, S = a.g.seg_blocks, nbx = a.g.nbx;
     const uint64_t seg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1279,7 +1335,7 @@ __global__ void dec_kernel(const DecArgs a) {
         }
         // add the core band back, sequentially in place like the strip epilogue (reference QB3decode.h:560-567)
         for (uint32_t c = 0; c < bands; c++) {
-            const uint32_t cb = a.g.cband[c];
+            const uint32_t cb = a0.g.cband[c];
             if (cb != c)
                 for (uint32_t i = 0; i < 16; i++) blk[i * bands + c] = (T)(blk[i * bands + c] + blk[i * bands + cb]);
         }
@@ -1381,7 +1437,8 @@ __device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos
 }
 
 template <typename T, bool STEP>
-__global__ void dec3_kernel(const DecArgs a) {
+__global__ void dec3_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
@@ -1429,7 +1486,7 @@ __global__ void dec3_kernel(const DecArgs a) {
     }
     uint32_t cpos = (uint32_t)(a.in_bit0 + P0 - 32 * w0);     // bit position of the pass, relative to word w0
     const uint32_t c = fastdiv(tid, BPP, a.magic_bpp), b = tid - c * BPP;
-    const uint32_t cb = a.g.cband[c < MAXBANDS ? c : 0];
+    const uint32_t cb = a0.g.cband[c < MAXBANDS ? c : 0];
     const uint64_t order = a.g.order;
     T *tt = (T *)tile;
     const uint32_t rowel = NB * 4 * bands;       // tile elements per pixel row
@@ -1723,7 +1780,8 @@ __device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t 
 }
 
 template <int B, bool RGB, uint64_t ORDER, bool STEP>
-__global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a) {
+__global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
     const uint32_t nthr = blockDim.x;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, NB = a.g.seg_blocks;
@@ -1763,8 +1821,9 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a) {
 // Foreign stream: ONE lane walks the stream and rebuilds the index (bit position + band state at every
 // segment start).  Latency bound by construction.
 template <typename T, int MODE>
-__global__ void dec_index_serial(const DecArgs a) {
-    if (blockIdx.x || threadIdx.x) return;
+__global__ void dec_index_serial(const DecArgs a0) {
+    if (threadIdx.x) return;
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);       // one lane per tile
     __shared__ uint64_t st_prev[MAXBANDS], st_cf[MAXBANDS];
     __shared__ uint32_t st_rung[MAXBANDS];
     const uint32_t bands = a.g.bands, S = a.g.seg_blocks;
@@ -1990,7 +2049,7 @@ EncPlan plan_encode(const Geometry &g) {
 template <int B, bool RGB>
 static void launch_enc_px_b(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    dim3 grid(plan.nchunks), block(256);
+    dim3 grid(plan.nchunks, a.ntiles), block(256);
     if (!z && !step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, HILBERT, false>), grid, block, plan.lds_bytes, st, a);
     else if (!z && step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_bytes, st, a);
     else if (z && !step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, ZCURVE, false>), grid, block, plan.lds_bytes, st, a);
@@ -2005,7 +2064,8 @@ static void launch_enc_px(const EncArgs &a, const EncPlan &plan, hipStream_t st)
 template <typename T>
 static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL;
-    dim3 grid(plan.nchunks), block(plan.threads);
+    const uint32_t nt = a.ntiles;
+    dim3 grid(plan.nchunks, nt), block(plan.threads);
     if (a.g.mode == CM_BEST) {
         {
             ProfScope ps("enc_best_pass0", st);
@@ -2013,7 +2073,7 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
         }
         {
             ProfScope ps("enc_best_scan", st);
-            hipLaunchKernelGGL(best_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+            hipLaunchKernelGGL(best_scan_kernel, dim3(1, nt), dim3(1024), 0, st, a);
         }
         {
             ProfScope ps("enc_best_units", st);
@@ -2029,27 +2089,32 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
     }
     {
         ProfScope ps("enc_scan", st);
-        hipLaunchKernelGGL(enc_scan_kernel, dim3((plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP), dim3(SCAN_GROUP / 4), 0, st, a);
+        hipLaunchKernelGGL(enc_scan_kernel, dim3((plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP, nt), dim3(SCAN_GROUP / 4), 0, st, a);
     }
     {
         ProfScope ps("enc_scan", st);
-        hipLaunchKernelGGL(enc_scan2_kernel, dim3(1), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(enc_scan2_kernel, dim3(1, nt), dim3(1024), 0, st, a);
     }
     {
         ProfScope ps("enc_concat", st);
-        hipLaunchKernelGGL(enc_concat_kernel, dim3((plan.nchunks + 3) / 4), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(enc_concat_kernel, dim3((plan.nchunks + 3) / 4, nt), dim3(256), 0, st, a);
     }
     {
         ProfScope ps("enc_seams", st);
-        hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256, nt), dim3(256), 0, st, a);
+        if (a.hdr_len) hipLaunchKernelGGL(write_header_kernel, dim3(1, nt), dim3(64), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
-                  const BandState &st_in, void *ws, void *index, void *stream) {
+                  const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb,
+                  const uint8_t *hdr, uint32_t hdr_len) {
     EncArgs a;
+    a.ntiles = tb.n ? tb.n : 1; a.ts_img = tb.src_pitch; a.ts_out = tb.dst_pitch; a.ts_ws = tb.ws_pitch; a.ts_idx = tb.idx_pitch;
+    a.hdr_len = hdr_len <= 64 ? hdr_len : 0;
+    for (uint32_t i = 0; i < a.hdr_len; i++) a.hdr[i] = hdr[i];
     a.g = g; a.img = img; a.out32 = out32; a.out_bit0 = out_bit0;
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
     a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
@@ -2097,7 +2162,7 @@ DecPlan plan_decode(const Geometry &g) {
     p.threads = threads;
     p.nwg = (uint32_t)((g.nseg + threads - 1) / threads);
     p.lds_bytes = (size_t)threads * lane_dw * 4;
-    p.ws_bytes = align8(index_bytes(g)) + 64;
+    p.ws_bytes = align8(index_bytes(g)) + 64;          // per tile: rebuilt index + its share of the status words
     // unit-parallel kernel: FTL/BASE with a per-unit length table, and every core band must itself be core
     // (true for every map the encoder's setter can produce, reference QB3encode.cpp:70-72); anything else keeps
     // the lane-per-segment kernel
@@ -2122,7 +2187,7 @@ template <int B, bool RGB>
 static void launch_dec_px_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
     const uint32_t nt = a.g.seg_blocks >= 256 ? 256u : ((a.g.seg_blocks + 63) / 64) * 64;
-    dim3 grid((uint32_t)a.g.nseg), block(nt);
+    dim3 grid((uint32_t)a.g.nseg, a.ntiles), block(nt);
     if (!z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, false>), grid, block, plan.lds_px, st, a);
     else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);
     else if (z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, false>), grid, block, plan.lds_px, st, a);
@@ -2138,17 +2203,17 @@ template <typename T, int MODE>
 static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st) {
     if (rebuild) {
         ProfScope ps("dec_index_serial", st);
-        hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(1), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(a.ntiles), dim3(64), 0, st, a);
     }
     if (plan.px && MODE != CM_BEST && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0) {
         ProfScope ps("dec_units", st);
         launch_dec_px(a, plan, st);
     } else if (plan.fast && MODE != CM_BEST) {
         ProfScope ps("dec_units", st);
-        hipLaunchKernelGGL((dec3_kernel<T, MODE == CM_BASE>), dim3((uint32_t)a.g.nseg), dim3(plan.threads2), plan.lds2_bytes, st, a);
+        hipLaunchKernelGGL((dec3_kernel<T, MODE == CM_BASE>), dim3((uint32_t)a.g.nseg, a.ntiles), dim3(plan.threads2), plan.lds2_bytes, st, a);
     } else {
         ProfScope ps("dec_segments", st);
-        hipLaunchKernelGGL((dec_kernel<T, MODE>), dim3(plan.nwg), dim3(plan.threads), plan.lds_bytes, st, a);
+        hipLaunchKernelGGL((dec_kernel<T, MODE>), dim3(plan.nwg, a.ntiles), dim3(plan.threads), plan.lds_bytes, st, a);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -2163,15 +2228,20 @@ static int launch_decode_t(const DecArgs &a, const DecPlan &plan, bool rebuild, 
 }
 
 int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
-                  void *img, const void *index, void *ws, uint32_t **status_out, void *stream) {
+                  void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb,
+                  const uint64_t *tile_bits) {
     hipStream_t st = (hipStream_t)stream;
     DecArgs a;
     a.g = g; a.in32 = in32; a.in_bit0 = in_bit0; a.in_bits = in_bits; a.img = img;
+    a.ntiles = tb.n ? tb.n : 1; a.ts_in = tb.src_pitch; a.ts_img = tb.dst_pitch; a.tile_bits = tile_bits;
     uint8_t *w = (uint8_t *)ws;
     const bool rebuild = index == nullptr;
-    a.idx = index_view(g, rebuild ? (void *)w : const_cast<void *>(index));
-    a.status = (uint32_t *)(w + align8(index_bytes(g)));
-    HIPCHK(hipMemsetAsync(a.status, 0, 64, st));
+    // workspace: [status words, 64 bytes per 16 tiles][rebuilt indices, one per tile]
+    const size_t status_bytes = ((4 * (size_t)a.ntiles + 63) / 64) * 64;
+    a.status = (uint32_t *)w;
+    a.idx = index_view(g, rebuild ? (void *)(w + status_bytes) : const_cast<void *>(index));
+    a.ts_idx = rebuild ? align8(index_bytes(g)) : tb.idx_pitch;
+    HIPCHK(hipMemsetAsync(a.status, 0, status_bytes, st));
     a.lane_dw = dec_lane_dwords(g);
     a.dpr = g.bands * g.tsz;
     a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = plan.in_cap_dw;

@@ -26,6 +26,8 @@ def gather_streams(payload, sizes, root=0, group=None):
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if payload.is_cuda and dist.get_backend(group) != "nccl":
+        payload = payload.cpu()         # gloo moves host memory (CPU tests, single-GPU rehearsals); RCCL moves HBM to HBM
     device = payload.device
     counts = torch.tensor([len(sizes)], dtype=torch.int64, device=device)
     all_counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
