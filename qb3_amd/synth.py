@@ -6,6 +6,7 @@ published stream size / FNV of the reference without going through the host:
     r = splitmix64(seed + idx),  idx = (y*W + x)*bands + c
     GRAD = x + y + 17c            NOISY3 = GRAD + (r & 7)       LANDSAT16 = 7000 + 3x + 2y + 301c + (r & 63)
     DEM = 37(x+y) - 50000 + (r&63)   TERRACE = 1000*(x//16 + y//16 - 100)   RANDOM = r
+    FEW = ((r mod 6) << (bits-6)) - (1 << (bits-4))      PALETTE = (splitmix64(77 + r mod 5) >> (66-bits)) | 1
 
 torch is used for device memory and arithmetic only (int64 wraps like uint64; logical shifts are masked).
 """
@@ -32,6 +33,11 @@ def splitmix64(x):
     return z ^ _lsr(z, 31)
 
 
+def _umod(r, m):
+    """r mod m for uint64 bit patterns held in int64 (m small)."""
+    return ((_lsr(r, 1) % m) * 2 + (r & 1)) % m
+
+
 def generate(w, h, bands, dtype, gen, seed, device="cuda", rows_per_chunk=None):
     """Returns a contiguous tensor of shape (h, w, bands) whose BYTES equal the generator's output truncated to
     the value width (the torch dtype is the same-width signed type where torch lacks the unsigned one)."""
@@ -56,6 +62,12 @@ def generate(w, h, bands, dtype, gen, seed, device="cuda", rows_per_chunk=None):
             v = 37 * (xs + ys) - 50000 + (r & 63) + 0 * cs
         elif gen == "TERRACE":
             v = 1000 * (xs // 16 + ys // 16 - 100) + 0 * cs
+        elif gen == "FEW":
+            bits = 8 * tsz
+            v = (_umod(r, 6) << (bits - 6)) - (1 << (bits - 4))
+        elif gen == "PALETTE":
+            bits = 8 * tsz
+            v = _lsr(splitmix64(77 + _umod(r, 5)), 66 - bits) | 1
         elif gen == "RANDOM":
             v = r
         elif gen == "CONST":
