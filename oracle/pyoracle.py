@@ -39,6 +39,7 @@ for name, res, args in [
     ("qb3o_set_mode", C.c_int, [_vp, C.c_int]),
     ("qb3o_set_stride", None, [_vp, _sz]),
     ("qb3o_set_fix_b2", None, [_vp, C.c_int]),
+    ("qb3o_set_order", None, [_vp, _u64]),
     ("qb3o_get_error", C.c_int, [_vp]),
     ("qb3o_get_encoder_mode", C.c_int, [_vp]),
     ("qb3o_get_band_state", None, [_vp, C.POINTER(_u64)]),
@@ -131,10 +132,12 @@ class Encoder:
         return dst[:n].copy()
 
 
-def encode(img, dtype, mode=8, cband=None, stride=0, quanta=1, away=False, fix_b2=False):
+def encode(img, dtype, mode=8, cband=None, stride=0, quanta=1, away=False, fix_b2=False, order=0):
     h, w, b = img.shape
     e = Encoder(w, h, b, dtype)
     e.set_mode(mode)
+    if order:
+        lib.qb3o_set_order(e.p, order)
     if fix_b2:
         lib.qb3o_set_fix_b2(e.p, 1)
     if cband is not None:

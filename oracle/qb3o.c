@@ -516,6 +516,8 @@ qb3o_decoder *qb3o_decoder_new(const void *src, size_t n, size_t *dims) {
 void qb3o_free(void *p) { free(p); }
 void qb3o_set_stride(qb3o_encoder *p, size_t stride) { p->stride = stride; }
 void qb3o_set_fix_b2(qb3o_encoder *p, int on) { p->fix_b2 = on; }
+/* the reference's API cannot set a custom curve, but its format carries one (SC chunk) and its decoder honours it */
+void qb3o_set_order(qb3o_encoder *p, uint64_t order) { p->order = order; }
 int  qb3o_get_error(const qb3o_encoder *p) { return p->error; }
 int  qb3o_get_encoder_mode(const qb3o_encoder *p) { return p->mode; }
 void qb3o_get_band_state(const qb3o_encoder *p, uint64_t *out3n) {

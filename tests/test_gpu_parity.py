@@ -3,6 +3,7 @@
 Bit-exact is the bar: the encoded container must equal the oracle's byte for byte, and decoding the
 oracle's (foreign, index-less) stream must reproduce the input exactly.
 """
+import os
 import numpy as np
 import pytest
 
@@ -364,3 +365,100 @@ def test_encode_is_repeatable(qb3, oracle, case):
         dst, n, _ = enc.encode(img)
         got = dst[:n].cpu().numpy()
         assert n == len(ref) and np.array_equal(got, ref), f"run {rep}: first diff at byte {first_diff(got, ref)}"
+
+
+@pytest.mark.parametrize("order", [0x0123456789abcdef, 0xfedcba9876543210, 0x048c159d26ae37bf, 0x05af16b827c93de4])
+@pytest.mark.parametrize("case", [(64, 48, 3, 0, "NOISY3", 1, 8), (96, 64, 1, 5, "DEM", 4, 4), (40, 44, 4, 0, "NOISY3", 8, 5), (64, 64, 1, 7, "TERRACE", 4, 7)],
+                         ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % (c[0], c[1], c[2], c[3], c[4], c[6]))
+def test_decode_custom_scan_curve(qb3, oracle, case, order):
+    """streams carrying their own scan curve in an SC chunk (reference QB3decode.cpp:231-250): the reference's
+    encoder API cannot make them, its decoder reads them -- so must this one (generic kernels, run-time curve)"""
+    import ctypes as C
+    w, h, b, dt, gen, seed, mode = case
+    img = oracle.generate(w, h, b, dt, gen, seed)
+    stream = oracle.encode(img, dt, mode, order=order)
+    assert bytes(stream[11:13]) in (b"CB", b"SC")
+    out, dims, dtype, m = qb3.decode(stream)
+    assert dims == (w, h, b) and np.array_equal(out, img.view(np.uint8).ravel())
+    dimsv = (C.c_size_t * 3)()
+    p = qb3.lib.qb3_read_start(stream.ctypes.data, stream.size, dimsv)
+    assert qb3.lib.qb3_read_info(p) and qb3.lib.qb3_get_order(p) == order
+    qb3.lib.qb3_destroy_decoder(p)
+
+
+def _cli(*args):
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qb3_amd", "cqb3x")
+    return subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+
+
+@pytest.mark.parametrize("case", [
+    # (w, h, bands, dtype, gen, flags, reference mode, quanta, trim)
+    (203, 131, 3, 0, "NOISY3", [], 8, 1, False),            # cqb3 default: QB3M_BASE
+    (203, 131, 3, 0, "NOISY3", ["-f"], 7, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-b"], 5, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-l"], 0, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-b", "-l"], 1, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-r"], 6, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-l", "-r"], 2, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-b", "-r"], 4, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-b", "-l", "-r"], 3, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-m"], 8, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-m", "2,2,2"], 8, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-q", "5"], 8, 5, False),
+    (203, 131, 3, 0, "NOISY3", ["-q", "+4"], 8, 4, False),
+    (203, 131, 3, 0, "NOISY3", ["-t"], 8, 1, True),
+    (130, 67, 1, 2, "LANDSAT16", ["-b"], 5, 1, False),
+    (130, 67, 1, 2, "LANDSAT16", ["-t", "-f"], 7, 1, True),
+], ids=lambda c: "%dx%dx%d-t%d%s" % (c[0], c[1], c[2], c[3], "".join(c[5])))
+def test_cli_pnm_roundtrip(qb3, oracle, tmp_path, case):
+    """tools/cqb3x.cpp, the cqb3 counterpart (reference cqb3.cpp:405-493 encode, :276-323 decode): PNM in, the same
+    .qb3 bytes the reference library writes for those options, PNM back out"""
+    w, h, b, dt, gen, flags, mode, quanta, trim = case
+    img = oracle.generate(w, h, b, dt, gen, 3)
+    pnm = tmp_path / "in.pnm"
+    body = img.astype(">u2").tobytes() if dt == 2 else img.tobytes()
+    pnm.write_bytes(b"P%c\n# made by the test\n%d %d\n%d\n" % (b"56"[b == 3], w, h, 255 if dt == 0 else 65535) + body)
+    r = _cli("-v", *flags, pnm, tmp_path / "out.qb3")
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "out.qb3", dtype=np.uint8)
+    src, stride = img, 0
+    if trim:        # cqb3.cpp:393-402
+        x0, y0 = int(w % 4 > 1), int(h % 4 > 1)
+        src = np.ascontiguousarray(img[y0:y0 + h - h % 4, x0:x0 + w - w % 4])
+    cband = None
+    if "-m" in flags:
+        cband = [2, 2, 2] if "2,2,2" in flags else list(range(b))
+    away = any(f.startswith("+") for f in flags)
+    want = oracle.encode(src, dt, mode, cband=cband, quanta=quanta, away=away)
+    assert np.array_equal(got, want)
+    r = _cli("-d", "-v", tmp_path / "out.qb3", tmp_path / "back.pnm")
+    assert r.returncode == 0, r.stderr
+    back = (tmp_path / "back.pnm").read_bytes()
+    hh, ww = src.shape[:2]
+    hdr = b"P%c\n%d %d\n%d\n" % (b"56"[b == 3], ww, hh, 255 if dt == 0 else 65535)
+    assert back.startswith(hdr)
+    ref, _, _, _ = oracle.decode(want)
+    px = np.frombuffer(back[len(hdr):], dtype=np.uint8)
+    if dt == 2:
+        px = px.view(">u2").astype("<u2").view(np.uint8)
+    assert np.array_equal(px, ref)
+    if quanta == 1:
+        assert np.array_equal(px, src.view(np.uint8).ravel())
+
+
+def test_cli_raw_and_errors(qb3, oracle, tmp_path):
+    img = oracle.generate(64, 40, 5, 5, "DEM", 2)       # 5 bands of int32: no PNM form
+    (tmp_path / "a.raw").write_bytes(img.tobytes())
+    r = _cli("-s", "64,40,5,5", "-m", tmp_path / "a.raw")
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "a.qb3", dtype=np.uint8)
+    assert np.array_equal(got, oracle.encode(img, 5, 8, cband=list(range(5))))
+    r = _cli("-d", "-s", tmp_path / "a.qb3")
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "a.raw").read_bytes() == img.tobytes()
+    assert _cli("-d", tmp_path / "a.raw").returncode == 1           # not a QB3 stream
+    assert _cli("-x", tmp_path / "a.raw").returncode == 2
+    assert _cli().returncode == 2
+    (tmp_path / "t.qb3").write_bytes(got[:200].tobytes())           # truncated stream: fails, does not crash
+    assert _cli("-d", "-s", tmp_path / "t.qb3").returncode == 1
