@@ -633,7 +633,8 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
     prof_collect();
     // bit 0: corrupt unit, bit 1: more than 7 unused bits at the end (reference QB3decode.h:411,569,740).
     // bit 2 (ran past the end) is not an error in the reference, whose reader clamps (bitstream.h:36).
-    if (status & 3) { set_error("decode: corrupt or over-long stream", 0); p->error = QB3E_ERR; return false; }
+    // bit 3: the index handed in does not describe this stream (a segment longer than any valid one).
+    if (status & 11) { set_error("decode: corrupt or over-long stream", 0); p->error = QB3E_ERR; return false; }
     return true;
 }
 
@@ -795,7 +796,7 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
             prof_collect();
-            for (size_t i = 0; i < cnt; i++) done += bits[i] && !(status[i] & 3);
+            for (size_t i = 0; i < cnt; i++) done += bits[i] && !(status[i] & 11);
         }
     }
     p->s_size = s_size0;

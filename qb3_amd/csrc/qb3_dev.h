@@ -102,6 +102,7 @@ struct DecPlan {
     // 8-bit 1/3/4-band lane-per-block kernel
     bool px, px_rgb;
     size_t lds_px;
+    uint32_t px_cap_dw;     // staging capacity (dwords) of the 8-bit lane-per-block kernel
 };
 DecPlan plan_decode(const Geometry &g);
 

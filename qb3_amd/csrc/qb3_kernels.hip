@@ -1582,45 +1582,91 @@ __global__ void dec3_kernel(const DecArgs a0) {
 }
 
 // ---- 8-bit, 1/3/4 bands: lane per BLOCK decode, in registers (counterpart of enc_px_kernel) -------------
-// Workgroup per index segment, lane per block (passes of 256 blocks).  Per pass: block bit positions from a scan
-// of the per-unit lengths; each lane reads the rung switches of its B units, rungs come from ONE packed 64-bit scan
-// (16 bits per band); the lane decodes its B units (LDS table), keeps the running sums packed four to a register;
-// the values entering the units come from ONE more packed scan of the unit totals; SWAR byte adds apply them and
-// the core band; bytes are permuted to pixel order and the four rows go straight to HBM (B dwords per lane and
-// row: 64 lanes write one contiguous run).  No pixel tile in LDS.
-__device__ __forceinline__ uint32_t swar_add8(uint32_t x, uint32_t y) {       // four independent byte adds
-    return ((x & 0x7f7f7f7fu) + (y & 0x7f7f7f7fu)) ^ ((x ^ y) & 0x80808080u);
+// Workgroup per index segment, lane per block (passes of 256 blocks).  The kernel is bound by VALU issue, not
+// by HBM, so everything here is about instructions per value:
+//   * the segment's bits are staged in LDS (padded with zero words: no bounds checks on the decode path) and all
+//     bit positions are kept relative to LDS address 0, so a refill is  lshr, and, ds_read2_b32, v_alignbit;
+//   * the code table holds the mag-sign-undone delta (and the step flag) as 32-bit entries in rung regions aligned
+//     to their size, so the entry address is ONE v_and_or of the bit buffer; the code length is ONE v_bfe_u32
+//     of a per-rung constant; the table itself is a compile-time constant copied from L2 with one 16-byte load;
+//   * running sums are kept two to a register as 16-bit lanes: entering values and core bands are added with
+//     v_pk_add_u16, bytes are gathered into pixel order with v_perm_b32 (3 per output dword);
+//   * the three workgroup scans (bit positions, rung deltas and unit totals, the last two packed 16 bits per
+//     band) use DPP row shifts/broadcasts, no LDS.
+// The four rows go straight to HBM (B dwords per lane and row: 64 lanes write one contiguous run).
+typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add16(uint32_t x, uint32_t y) {       // two independent 16-bit adds (v_pk_add_u16)
+    return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, x) + __builtin_bit_cast(u16x2_t, y)));
 }
 constexpr int curve_pos_of(uint64_t order, int x, int y) {      // inverse of the curve: visit index of pixel (x, y)
     for (int i = 0; i < 16; i++) if ((int)order_nib(order, i) == ((y << 2) | x)) return i;
     return 0;
 }
 
-// Bit reader for one 8-bit unit: the unit's bits (at most 8 + 16*9 = 152, plus up to 31 of misalignment) are
-// fetched as six dwords with independent loads and then consumed from registers -- no dependent memory round
-// trips on the decode path.
-template <typename PTR>
-struct QReader {
-    uint64_t buf; uint32_t n, q0, q1, q2, q3, q4;
-    __device__ __forceinline__ void init(PTR src, uint32_t endw, uint32_t pos) {
-        const uint32_t w = pos >> 5, sh = pos & 31;
-        const uint32_t d0 = w < endw ? src[w] : 0u;
-        q0 = w + 1 < endw ? src[w + 1] : 0u; q1 = w + 2 < endw ? src[w + 2] : 0u; q2 = w + 3 < endw ? src[w + 3] : 0u;
-        q3 = w + 4 < endw ? src[w + 4] : 0u; q4 = w + 5 < endw ? src[w + 5] : 0u;
-        buf = (uint64_t)(d0 >> sh); n = 32 - sh;
+// Decode table of the 8-bit lane-per-block kernel, built at compile time.  Region of rung r (1..7): entries
+// [4<<r, 8<<r), i.e. byte offset 16<<r, aligned to its own size.  Entry: bits 0..15 the value with mag-sign undone
+// (two's complement), bit 16 the top (rung) bit of the mag-sign value, bit 17 its low bit (the sign) -- the two
+// flags the step needs (reference QB3decode.h:285-289).
+struct PxDecTab { alignas(16) uint32_t e[1024]; };
+constexpr PxDecTab make_px_dec_tab() {
+    PxDecTab t{};
+    for (uint32_t r = 1; r < 8; r++) {
+        const uint32_t top = 1u << r, half = top >> 1;
+        for (uint32_t x = 0; x < (4u << r); x++) {
+            uint32_t v = 0;
+            if (!(x & 1)) v = (x & (top - 1)) >> 1;
+            else if (!(x & 2)) v = ((x >> 2) & (half - 1)) | half;
+            else v = ((x >> 2) & (top - 1)) | top;
+            if (v == top || v == top - 1) v ^= 2 * top - 1;
+            const uint32_t d = ((v >> 1) ^ (0u - (v & 1u))) & 0xffffu;
+            t.e[(4u << r) + x] = d | (((v >> r) & 1u) << 16) | ((v & 1u) << 17);
+        }
     }
-    __device__ __forceinline__ void ensure32() {        // after this at least 32 bits are valid
-        if (n < 32) { buf |= (uint64_t)q0 << n; n += 32; q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = 0; }
+    return t;
+}
+__device__ const PxDecTab px_dec_tab = make_px_dec_tab();
+
+__device__ __forceinline__ LdsWords lds_at(uint32_t byte_off) { return (LdsWords)(uintptr_t)byte_off; }
+// 32 stream bits starting at bit `pos` (counted from LDS address 0)
+__device__ __forceinline__ uint32_t lds_bits(uint32_t pos) {
+    LdsWords p = lds_at((pos >> 3) & ~3u);
+    return __builtin_amdgcn_alignbit(p[1], p[0], pos);
+}
+
+// wave-wide inclusive scan with DPP (row shifts inside the 16-lane rows, then the two row broadcasts of GFX9)
+__device__ __forceinline__ uint32_t wave_iscan32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return x;
+}
+// workgroup exclusive scan of NW independent 32-bit words per lane; ONE barrier; the scratch (NW*4 words) must not
+// be rewritten before the caller's next barrier
+template <int NW>
+__device__ __forceinline__ void block_exscan_dpp(uint32_t (&v)[NW], uint32_t *wsum) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        inc[k] = wave_iscan32(v[k]);
+        if (lane == 63) wsum[k * 4 + wave] = inc[k];
     }
-    __device__ __forceinline__ void skip(uint32_t k) { buf >>= k; n -= k; }
-};
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        uint32_t base = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) if (i < wave) base += wsum[k * 4 + i];
+        v[k] = base + inc[k] - v[k];
+    }
+}
 
 // rung switch of an 8-bit unit at bit `pos`: delta (mod 8); *cslen = bits consumed
-template <typename PTR>
-__device__ __forceinline__ uint32_t px_switch(PTR src, uint32_t endw, uint32_t pos, uint32_t *cslen, bool *signal) {
-    const uint32_t w = pos >> 5, sh = pos & 31;
-    const uint32_t d0 = w < endw ? src[w] : 0u, d1 = w + 1 < endw ? src[w + 1] : 0u;
-    uint32_t x = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+__device__ __forceinline__ uint32_t px_switch(uint32_t pos, uint32_t *cslen, bool *signal) {
+    uint32_t x = lds_bits(pos);
     *signal = false;
     if (!(x & 1)) { *cslen = 1; return 0; }
     x >>= 1;                                            // code at rung 2 (reference QB3decode.h:97-116)
@@ -1633,179 +1679,82 @@ __device__ __forceinline__ uint32_t px_switch(PTR src, uint32_t endw, uint32_t p
     return (m & 1) ? (8 - (m + 1) / 2) & 7 : m / 2 + 1;
 }
 
-// the 16 values of an 8-bit unit whose codes start at bit `gpos`; run[i] = running sum, packed 4 per register
-template <bool STEP, typename PTR>
-__device__ __forceinline__ void px_group(PTR src, uint32_t endw, uint32_t gpos, uint32_t rung, const uint16_t *dtab, uint32_t (&rp)[4]) {
-    QReader<PTR> rd;
-    rd.init(src, endw, gpos);
-    uint32_t g[16];
+// the 16 values of an 8-bit unit whose codes start at bit `gpos`: rp[k] = running sums of values 2k, 2k+1 as two
+// 16-bit lanes (low byte = the sum mod 256); returns the unit total (garbage above bit 7)
+template <bool STEP>
+__device__ __forceinline__ uint32_t px_group(uint32_t gpos, uint32_t rung, uint32_t (&rp)[8]) {
+    uint32_t acc = 0;
     if (rung == 0) {
-        rd.ensure32();
-        const uint32_t x = (uint32_t)rd.buf;
+        const uint32_t x = lds_bits(gpos);
         const uint32_t bits = (x & 1) ? (x >> 1) & 0xffffu : 0u;
 #pragma unroll
-        for (int i = 0; i < 16; i++) g[i] = (bits >> i) & 1u;
-    } else {
-        const uint16_t *tab = dtab + dec_tab_off(rung);
-        const uint32_t mask = (4u << rung) - 1;
-        uint32_t rb = 0;
-#pragma unroll
         for (int i = 0; i < 16; i++) {
-            if (i % 3 == 0) rd.ensure32();              // three codes are at most 27 bits
-            const uint32_t x = (uint32_t)rd.buf & mask;
-            const uint32_t e = tab[x];
-            rd.skip(rung + (x & 1) + ((x & 3) == 3));
-            g[i] = e & 0xfffu;
-            rb |= ((e >> rung) & 1u) << i;
+            acc -= (bits >> i) & 1u;                    // mag-sign 1 is -1
+            if (i & 1) rp[i >> 1] |= acc << 16; else rp[i >> 1] = acc & 0xffffu;
         }
-        if (STEP && (rb & (rb + 1)) == 0) {             // undo the step (reference QB3decode.h:285-289)
-            const uint32_t m = __popc(rb);
-#pragma unroll
-            for (int i = 0; i < 16; i++) if ((uint32_t)i == m) g[i] ^= 1u << rung;
-        }
+        return acc;
     }
-    uint32_t acc = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) rp[q] = 0;
+    const uint32_t base = 16u << rung, m2 = base - 4;   // table region and the mask of (rung+2 bits) << 2
+    const uint32_t K = rung * 0x11111111u + 0x20102010u; // code length by the low three bits, 4 bits each
+    uint32_t pos = gpos, buf = 0, fl = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        acc = (acc + ((g[i] >> 1) ^ (0u - (g[i] & 1u)))) & 0xffu;      // undo mag-sign, accumulate (mod 256)
-        rp[i >> 2] |= acc << (8 * (i & 3));
+        if (i % 3 == 0) buf = lds_bits(pos);            // three codes are at most 27 bits
+        const uint32_t t = buf << 2;
+        const uint32_t e = *lds_at((t & m2) | base);
+        const uint32_t len = __builtin_amdgcn_ubfe(K, t, 4);
+        buf >>= len; pos += len;
+        acc += e;
+        if (STEP) fl |= ((e >> 16) & 3u) << (2 * i);
+        if (i & 1) rp[i >> 1] |= acc << 16; else rp[i >> 1] = acc & 0xffffu;
     }
-}
-
-template <int B, bool RGB, uint64_t ORDER, bool STEP, typename PTR>
-__device__ __forceinline__ void dec_px_body(const DecArgs &a, PTR src, uint32_t endw, uint32_t cpos0, uint32_t g0, uint32_t nb_here,
-                                            uint64_t seg, uint64_t w0, uint64_t *wsum, uint64_t *carry, const uint8_t *ulen_s, const uint16_t *dtab) {
-    constexpr uint32_t UMASK = 7;
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, nbx = a.g.nbx;
-    const uint64_t stride = a.g.stride;
-    uint32_t cpos = cpos0;
-    bool bad = false;
-    const uint32_t npass = (nb_here + nthr - 1) / nthr;
-    for (uint32_t p = 0; p < npass; p++) {
-        const uint32_t sl = p * nthr + tid;
-        const bool act = sl < nb_here;
-        uint32_t ul[B], blen = 0;
+    if (STEP) {                                         // undo the step (reference QB3decode.h:285-289)
+        const uint32_t tb = fl & 0x55555555u, u = tb | (tb << 1);
+        const uint32_t m = __popc(tb);
+        if ((u & (u + 1)) == 0 && m < 16) {
+            // value m regains its rung bit: its delta moves by half a rung, away from zero; sums m.. follow
+            const uint32_t half = base >> 5;            // 1 << (rung - 1)
+            const uint32_t c16 = ((fl >> (2 * m + 1)) & 1u) ? (0u - half) & 0xffffu : half;
+            const uint32_t ge = 0xffff0000u >> (16 - m);// bit i set: value i >= m   (as a 16-bit mask in the low half)
 #pragma unroll
-        for (int c = 0; c < B; c++) { ul[c] = act ? ulen_s[sl * B + c] : 0u; blen += ul[c]; }
-        const uint64_t bex = block_exscan_1b<uint64_t>(blen, wsum);
-        if (tid == nthr - 1) carry[0] = bex + blen;                          // bits of this pass
-        // rung switches of the lane's units
-        uint32_t gpos[B], pos = cpos + (uint32_t)bex;
-        uint64_t dpk = 0;
-#pragma unroll
-        for (int c = 0; c < B; c++) {
-            gpos[c] = 0;
-            if (act) {
-                bool sig; uint32_t csl;
-                const uint32_t d = px_switch<PTR>(src, endw, pos, &csl, &sig);
-                gpos[c] = pos + csl;
-                if (sig && STEP) bad = true;                            // common-factor / index unit: not handled here
-                dpk |= (uint64_t)d << (16 * c);
-                pos += ul[c];
+            for (int k = 0; k < 8; k++) {
+                const uint32_t pair = (ge >> (2 * k)) & 3u;
+                rp[k] = pk_add16(rp[k], ((pair | (pair << 15)) & 0x00010001u) * c16);
             }
+            acc += c16;
         }
-        const uint64_t dex = block_exscan_1b<uint64_t>(dpk, wsum + 4) + dpk;  // inclusive, per band in 16-bit fields
-        // decode the units; running sums packed 4 per register, in curve order
-        uint32_t rp[B][4], rungs = 0;
-        uint64_t spk = 0;
-#pragma unroll
-        for (int c = 0; c < B; c++) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) rp[c][q] = 0;
-            if (act) {
-                const uint32_t rung = ((uint32_t)carry[1 + c] + (uint32_t)((dex >> (16 * c)) & 0xffffu)) & UMASK;
-                rungs |= rung << (4 * c);
-                px_group<STEP, PTR>(src, endw, gpos[c], rung, dtab, rp[c]);
-                spk |= (uint64_t)(rp[c][3] >> 24) << (16 * c);
-            }
-        }
-        const uint64_t sex = block_exscan_1b<uint64_t>(spk, wsum + 8);    // exclusive
-        uint32_t pv[B];
-#pragma unroll
-        for (int c = 0; c < B; c++) pv[c] = ((uint32_t)carry[1 + B + c] + (uint32_t)((sex >> (16 * c)) & 0xffffu)) & 0xffu;
-        __syncthreads();                                                 // everyone has read the carries
-        if (act && (sl == nb_here - 1 || tid == nthr - 1)) {                  // state leaving the pass
-#pragma unroll
-            for (int c = 0; c < B; c++) {
-                carry[1 + c] = (rungs >> (4 * c)) & 15u;
-                carry[1 + B + c] = (pv[c] + (uint32_t)((spk >> (16 * c)) & 0xffu)) & 0xffu;
-            }
-        }
-        if (act) {
-            // entering value, then the core band (reference QB3decode.h:560-567)
-#pragma unroll
-            for (int c = 0; c < B; c++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) rp[c][q] = swar_add8(rp[c][q], pv[c] * 0x01010101u);
-#pragma unroll
-            for (int c = 0; c < B; c++) {
-                constexpr int dummy = 0; (void)dummy;
-                const int cb = core_of<B, RGB>(c);
-                if (cb != c)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) rp[c][q] = swar_add8(rp[c][q], rp[cb][q]);
-            }
-            // curve order, band planar -> pixel order, band interleaved; store the four rows
-            const uint32_t g = g0 + sl, by = g / nbx, bx = g - by * nbx;
-            const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
-            uint8_t *p0 = (uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B;
-#pragma unroll
-            for (int y = 0; y < 4; y++) {
-                uint32_t ow[B];
-#pragma unroll
-                for (int k = 0; k < B; k++) ow[k] = 0;
-#pragma unroll
-                for (int x = 0; x < 4; x++)
-#pragma unroll
-                    for (int c = 0; c < B; c++) {
-                        const int i = curve_pos_of(ORDER, x, y), bi = x * B + c;
-                        ow[bi >> 2] |= ((rp[c][i >> 2] >> (8 * (i & 3))) & 0xffu) << (8 * (bi & 3));
-                    }
-                uint32_t *dst = (uint32_t *)(p0 + (uint64_t)y * stride);
-#pragma unroll
-                for (int k = 0; k < B; k++) dst[k] = ow[k];
-            }
-        }
-        __syncthreads();
-        cpos += (uint32_t)carry[0];
     }
-    if (bad) atomicOr(a.status, 1u);
-    if (tid == 0 && seg == a.g.nseg - 1) {      // reference: more than 7 unused bits at the end is a failure
-        const uint64_t used = (uint64_t)cpos + 32 * w0 - a.in_bit0;
-        if (used > a.in_bits) atomicOr(a.status, 4u);
-        else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
-    }
+    return acc;
 }
 
 template <int B, bool RGB, uint64_t ORDER, bool STEP>
 __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
-    const uint32_t nthr = blockDim.x;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t tid = threadIdx.x, NB = a.g.seg_blocks;
-    const uint64_t seg = blockIdx.x;
+    constexpr int NW = (B + 1) / 2;                     // 32-bit words of a scan packed 16 bits per band
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, NB = a.g.seg_blocks, nbx = a.g.nbx;
+    const uint64_t seg = blockIdx.x, stride = a.g.stride;
     const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
 
-    uint64_t *wsum = (uint64_t *)smem;                  // 16
-    uint64_t *carry = wsum + 16;                        // [0] pass bits, [1..B] rung, [1+B..2B] entering value
-    uint16_t *dtab = (uint16_t *)(carry + 16);          // 1024 entries
-    uint8_t *ulen_s = (uint8_t *)(dtab + 1024);         // NB*B bytes, padded to 8
+    uint32_t *tab = (uint32_t *)smem;                   // 4 KB, at LDS address 0 (the table addressing relies on it)
+    uint32_t *wsum = tab + 1024;                        // 3 scans x NW x 4 waves
+    uint32_t *carry = wsum + 32;                        // [0] pass bits, [1..B] rung, [1+B..2B] entering value
+    uint8_t *ulen_s = (uint8_t *)(carry + 16);          // NB*B bytes, padded to 8
     uint32_t *stage = (uint32_t *)(ulen_s + ((NB * B + 7) & ~7u));
-    fill_dec_tab(dtab);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
+    const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
 
     const uint64_t P0 = a.idx.bitpos[seg];
     const uint64_t P1 = (seg + 1 < a.g.nseg) ? a.idx.bitpos[seg + 1] : a.in_bits;
     const uint64_t w0 = (a.in_bit0 + P0) >> 5;
     const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
-    const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0 + 2;
-    const bool staged = ndw64 <= a.in_cap_dw;           // workgroup uniform
-    const uint32_t ndw = (uint32_t)ndw64;
-    if (staged)
-        for (uint32_t i = tid; i < ndw; i += nthr) stage[i] = (w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
-    const uint32_t endw_g = (uint32_t)((endw_abs - w0 < 0xffffffffull) ? endw_abs - w0 : 0xffffffffull);
+    const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0;
+    // the staging area holds the longest valid segment; an index that says otherwise is not ours
+    const bool fits = ndw64 <= a.in_cap_dw && lds0 == 0;
+    const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
+    for (uint32_t i = tid; i < ndw + 8; i += nthr) stage[i] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+    for (uint32_t i = tid; i < 256; i += nthr) ((uint4 *)tab)[i] = ((const uint4 *)px_dec_tab.e)[i];
     const uint8_t *ul = (const uint8_t *)a.idx.ulen + (uint64_t)g0 * B;
     for (uint32_t i = tid; i < nb_here * B; i += nthr) ulen_s[i] = ul[i];
     if (tid < B) {
@@ -1813,9 +1762,107 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
         carry[1 + B + tid] = ((const uint8_t *)a.idx.prev)[seg * B + tid];
     }
     __syncthreads();
-    const uint32_t cpos0 = (uint32_t)(a.in_bit0 + P0 - 32 * w0);
-    if (staged) dec_px_body<B, RGB, ORDER, STEP, LdsWords>(a, (LdsWords)stage, ndw, cpos0, g0, nb_here, seg, w0, wsum, carry, ulen_s, dtab);
-    else dec_px_body<B, RGB, ORDER, STEP, const uint32_t *>(a, a.in32 + w0, endw_g, cpos0, g0, nb_here, seg, w0, wsum, carry, ulen_s, dtab);
+    const uint32_t limit = stage_bit0 + 32 * ndw;       // no unit starts beyond the staged bits (8 zero words follow)
+    uint32_t cpos = stage_bit0 + (uint32_t)(a.in_bit0 + P0 - 32 * w0);
+    bool bad = !fits;
+    const uint32_t npass = (nb_here + nthr - 1) / nthr;
+    for (uint32_t p = 0; p < npass; p++) {
+        const uint32_t sl = p * nthr + tid;
+        const bool act = sl < nb_here;
+        uint32_t ul_[B], blen[1] = { 0 };
+#pragma unroll
+        for (int c = 0; c < B; c++) { ul_[c] = act ? ulen_s[sl * B + c] : 0u; blen[0] += ul_[c]; }
+        const uint32_t mybits = blen[0];
+        block_exscan_dpp<1>(blen, wsum);
+        if (tid == nthr - 1) carry[0] = blen[0] + mybits;                    // bits of this pass
+        // rung switches of the lane's units
+        uint32_t gpos[B], pos = cpos + blen[0], dpk[NW], dmine[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) dpk[k] = 0;
+#pragma unroll
+        for (int c = 0; c < B; c++) {
+            pos = pos < limit ? pos : limit;
+            bool sig; uint32_t csl;
+            const uint32_t d = px_switch(pos, &csl, &sig);
+            gpos[c] = pos + csl;
+            if (act && sig && STEP) bad = true;                              // common-factor / index unit: not handled here
+            dpk[c >> 1] |= (act ? d : 0u) << (16 * (c & 1));
+            pos += ul_[c];
+        }
+#pragma unroll
+        for (int k = 0; k < NW; k++) dmine[k] = dpk[k];
+        block_exscan_dpp<NW>(dpk, wsum + 4);
+        // decode the units; running sums in curve order, two 16-bit lanes per register
+        uint32_t rp[B][8], rungs = 0, spk[NW], smine[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) spk[k] = 0;
+#pragma unroll
+        for (int c = 0; c < B; c++) {
+            const uint32_t dinc = ((dpk[c >> 1] + dmine[c >> 1]) >> (16 * (c & 1))) & 0xffffu;     // inclusive
+            const uint32_t rung = (carry[1 + c] + dinc) & 7u;
+            rungs |= rung << (4 * c);
+            const uint32_t tot = px_group<STEP>(gpos[c], rung, rp[c]) & 0xffu;
+            spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
+        }
+#pragma unroll
+        for (int k = 0; k < NW; k++) smine[k] = spk[k];
+        block_exscan_dpp<NW>(spk, wsum + 4 + 4 * NW);                        // exclusive
+        uint32_t pv[B];
+#pragma unroll
+        for (int c = 0; c < B; c++) pv[c] = (carry[1 + B + c] + ((spk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 0xffu;
+        __syncthreads();                                                     // everyone has read the carries
+        if (act && (sl == nb_here - 1 || tid == nthr - 1)) {                 // state leaving the pass
+#pragma unroll
+            for (int c = 0; c < B; c++) {
+                carry[1 + c] = (rungs >> (4 * c)) & 15u;
+                carry[1 + B + c] = (pv[c] + ((smine[c >> 1] >> (16 * (c & 1))) & 0xffu)) & 0xffu;
+            }
+        }
+        if (act) {
+            // entering value, then the core band (reference QB3decode.h:560-567)
+#pragma unroll
+            for (int c = 0; c < B; c++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], pv[c] * 0x00010001u);
+#pragma unroll
+            for (int c = 0; c < B; c++) {
+                const int cb = core_of<B, RGB>(c);
+                if (cb != c)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], rp[cb][k]);
+            }
+            // curve order, band planar -> pixel order, band interleaved; store the four rows
+            const uint32_t g = g0 + sl, by = g / nbx, bx = g - by * nbx;
+            const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+            uint8_t *p0 = (uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B;
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                uint32_t *dst = (uint32_t *)(p0 + (uint64_t)y * stride);
+#pragma unroll
+                for (int k = 0; k < B; k++) {
+                    // byte j of output dword k is band (4k+j)%B of pixel x = (4k+j)/B: low byte of a 16-bit lane
+                    uint32_t half2[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int b0 = 4 * k + 2 * h, b1 = b0 + 1;
+                        const int i0 = curve_pos_of(ORDER, b0 / B, y), i1 = curve_pos_of(ORDER, b1 / B, y);
+                        // v_perm_b32: selector bytes 0..3 pick from the second operand, 4..7 from the first
+                        half2[h] = __builtin_amdgcn_perm(rp[b1 % B][i1 >> 1], rp[b0 % B][i0 >> 1],
+                                                         (uint32_t)((4 + 2 * (i1 & 1)) << 8 | (2 * (i0 & 1))));
+                    }
+                    dst[k] = __builtin_amdgcn_perm(half2[1], half2[0], 0x05040100u);
+                }
+            }
+        }
+        __syncthreads();
+        cpos += carry[0];
+    }
+    if (bad) atomicOr(a.status, fits ? 1u : 8u);
+    if (tid == 0 && seg == a.g.nseg - 1 && fits) {      // reference: more than 7 unused bits at the end is a failure
+        const uint64_t used = (uint64_t)(cpos - stage_bit0) + 32 * w0 - a.in_bit0;
+        if (used > a.in_bits) atomicOr(a.status, 4u);
+        else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
 }
 
 // Foreign stream: ONE lane walks the stream and rebuilds the index (bit position + band state at every
@@ -2179,7 +2226,10 @@ DecPlan plan_decode(const Geometry &g) {
     bool rgb = false;
     p.px = p.fast && px_eligible(g, &rgb);
     p.px_rgb = rgb;
-    p.lds_px = 8 * 32 + 2048 + (((size_t)NB * g.bands + 7) & ~(size_t)7) + 4 * (size_t)p.in_cap_dw;
+    // staging of the px kernel: the longest valid segment (every unit at its maximum) + the word the first unit
+    // starts in + 8 zero words, after the 4 KB table, the scan scratch and the unit lengths
+    p.px_cap_dw = (uint32_t)(((size_t)NB * g.bands * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
+    p.lds_px = 4096 + 4 * 32 + 4 * 16 + (((size_t)NB * g.bands + 7) & ~(size_t)7) + 4 * ((size_t)p.px_cap_dw + 8);
     return p;
 }
 
@@ -2244,7 +2294,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
     HIPCHK(hipMemsetAsync(a.status, 0, status_bytes, st));
     a.lane_dw = dec_lane_dwords(g);
     a.dpr = g.bands * g.tsz;
-    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = plan.in_cap_dw;
+    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = plan.px ? plan.px_cap_dw : plan.in_cap_dw;
     a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;
     switch (g.tsz) {

@@ -394,22 +394,22 @@ def _cli(*args):
 
 @pytest.mark.parametrize("case", [
     # (w, h, bands, dtype, gen, flags, reference mode, quanta, trim)
-    (203, 131, 3, 0, "NOISY3", [], 8, 1, False),            # cqb3 default: QB3M_BASE
-    (203, 131, 3, 0, "NOISY3", ["-f"], 7, 1, False),
-    (203, 131, 3, 0, "NOISY3", ["-b"], 5, 1, False),
+    (203, 131, 3, 0, "NOISY3", [], 4, 1, False),            # cqb3 default: QB3M_BASE
+    (203, 131, 3, 0, "NOISY3", ["-f"], 8, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-b"], 7, 1, False),
     (203, 131, 3, 0, "NOISY3", ["-l"], 0, 1, False),
-    (203, 131, 3, 0, "NOISY3", ["-b", "-l"], 1, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-b", "-l"], 3, 1, False),
     (203, 131, 3, 0, "NOISY3", ["-r"], 6, 1, False),
     (203, 131, 3, 0, "NOISY3", ["-l", "-r"], 2, 1, False),
-    (203, 131, 3, 0, "NOISY3", ["-b", "-r"], 4, 1, False),
-    (203, 131, 3, 0, "NOISY3", ["-b", "-l", "-r"], 3, 1, False),
-    (203, 131, 3, 0, "NOISY3", ["-m"], 8, 1, False),
-    (203, 131, 3, 0, "NOISY3", ["-m", "2,2,2"], 8, 1, False),
-    (203, 131, 3, 0, "NOISY3", ["-q", "5"], 8, 5, False),
-    (203, 131, 3, 0, "NOISY3", ["-q", "+4"], 8, 4, False),
-    (203, 131, 3, 0, "NOISY3", ["-t"], 8, 1, True),
-    (130, 67, 1, 2, "LANDSAT16", ["-b"], 5, 1, False),
-    (130, 67, 1, 2, "LANDSAT16", ["-t", "-f"], 7, 1, True),
+    (203, 131, 3, 0, "NOISY3", ["-b", "-r"], 5, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-b", "-l", "-r"], 1, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-m"], 4, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-m", "2,2,2"], 4, 1, False),
+    (203, 131, 3, 0, "NOISY3", ["-q", "5"], 4, 5, False),
+    (203, 131, 3, 0, "NOISY3", ["-q", "+4"], 4, 4, False),
+    (203, 131, 3, 0, "NOISY3", ["-t"], 4, 1, True),
+    (130, 67, 1, 2, "LANDSAT16", ["-b"], 7, 1, False),
+    (130, 67, 1, 2, "LANDSAT16", ["-t", "-f"], 8, 1, True),
 ], ids=lambda c: "%dx%dx%d-t%d%s" % (c[0], c[1], c[2], c[3], "".join(c[5])))
 def test_cli_pnm_roundtrip(qb3, oracle, tmp_path, case):
     """tools/cqb3x.cpp, the cqb3 counterpart (reference cqb3.cpp:405-493 encode, :276-323 decode): PNM in, the same
@@ -438,7 +438,7 @@ def test_cli_pnm_roundtrip(qb3, oracle, tmp_path, case):
     hh, ww = src.shape[:2]
     hdr = b"P%c\n%d %d\n%d\n" % (b"56"[b == 3], ww, hh, 255 if dt == 0 else 65535)
     assert back.startswith(hdr)
-    ref, _, _, _ = oracle.decode(want)
+    ref, _, _, _ = oracle.decode(want, identity=True)      # no CB chunk = identity map
     px = np.frombuffer(back[len(hdr):], dtype=np.uint8)
     if dt == 2:
         px = px.view(">u2").astype("<u2").view(np.uint8)
@@ -453,7 +453,7 @@ def test_cli_raw_and_errors(qb3, oracle, tmp_path):
     r = _cli("-s", "64,40,5,5", "-m", tmp_path / "a.raw")
     assert r.returncode == 0, r.stderr
     got = np.fromfile(tmp_path / "a.qb3", dtype=np.uint8)
-    assert np.array_equal(got, oracle.encode(img, 5, 8, cband=list(range(5))))
+    assert np.array_equal(got, oracle.encode(img, 5, 4, cband=list(range(5))))
     r = _cli("-d", "-s", tmp_path / "a.qb3")
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "a.raw").read_bytes() == img.tobytes()
