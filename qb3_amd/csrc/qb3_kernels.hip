@@ -70,6 +70,46 @@ template <uint32_t UB> __device__ __forceinline__ uint32_t cs_code(uint32_t delt
 }
 
 
+typedef const __attribute__((address_space(3))) uint32_t *LdsWords;   // explicit LDS pointer: loads become ds_read
+__device__ __forceinline__ LdsWords lds_at(uint32_t byte_off) { return (LdsWords)(uintptr_t)byte_off; }
+// 32 stream bits starting at bit `pos` (counted from LDS address 0)
+__device__ __forceinline__ uint32_t lds_bits(uint32_t pos) {
+    LdsWords p = lds_at((pos >> 3) & ~3u);
+    return __builtin_amdgcn_alignbit(p[1], p[0], pos);
+}
+
+// wave-wide inclusive scan with DPP (row shifts inside the 16-lane rows, then the two row broadcasts of GFX9)
+__device__ __forceinline__ uint32_t wave_iscan32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return x;
+}
+// workgroup exclusive scan of NW independent 32-bit words per lane; ONE barrier; the scratch (NW*4 words) must not
+// be rewritten before the caller's next barrier
+template <int NW>
+__device__ __forceinline__ void block_exscan_dpp(uint32_t (&v)[NW], uint32_t *wsum) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        inc[k] = wave_iscan32(v[k]);
+        if (lane == 63) wsum[k * 4 + wave] = inc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        uint32_t base = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) if (i < wave) base += wsum[k * 4 + i];
+        v[k] = base + inc[k] - v[k];
+    }
+}
+
+
 // ---- code tables in LDS, generated from the code rules (never transcribed) ---------------------------------
 // Encode: ENC_TAB_SIZE entries; rung r in 1..7 occupies [2^(r+1)-4, 2^(r+2)-4), indexed by the mag-sign value,
 // entry = len<<12 | code with the middle swap applied (reference QB3encode.h:30-33, 132-141).
@@ -465,38 +505,124 @@ template <typename T> __device__ __forceinline__ void apply_step(T (&v)[16], uin
 }
 // ------------------------------------------------------------------ 8-bit, 1/3/4 bands: lane per BLOCK, in registers
 // Specialisation of enc_kernel for the common rasters (uint8, grey / RGB / RGBA, width a multiple of 4, identity
-// or default R-G,G,B-G band map, Hilbert or Z curve).  Same bit stream, different organisation:
+// or default R-G,G,B-G band map, Hilbert or Z curve).  Same bit stream, different organisation.  The kernel is
+// bound by VALU issue (SQ_INSTS_VALU x 4 cycles / SIMD = its duration), so it is written for instruction count:
 //   * a lane owns a whole block: it loads the four rows of the block straight from HBM (B dwords per row: 64
 //     lanes x 4*B bytes are one contiguous run, so the loads are coalesced without an LDS tile) plus the one
 //     dword that holds the previous block's last visited pixel;
-//   * every byte position is a compile-time constant (band count and curve are template parameters), so the
-//     gather is shifts and masks on registers; the 16 mag-sign deltas of a band are kept packed, 4 per register;
-//   * rungs of the neighbouring block come from the neighbouring lane (__shfl_up, LDS only across waves); lane 0
-//     of the workgroup is the halo block (computes rungs only), so a chunk is 255 blocks;
-//   * one workgroup scan per chunk (block bit lengths), one LDS bit writer per lane running through all bands.
+//   * band count and curve are template parameters: v_perm_b32 gathers each band's bytes in curve order, four to
+//     a register, and band difference, running delta and mag-sign are byte-parallel (SWAR) on those registers;
+//   * the code table is a compile-time constant (code << 8 | length) copied from L2; a unit's bit string is six
+//     pieces of at most 27 bits, each built BACKWARDS with one v_lshl_or_b32 per value (the shift count is the
+//     entry itself: the hardware uses its low five bits) and its length is the low byte of the sum of the entries;
+//   * rungs of the neighbouring block come from the neighbouring lane (DPP wave shift, LDS only across waves);
+//     lane 0 of the workgroup is the halo block (computes rungs only), so a chunk is 255 blocks;
+//   * one workgroup scan per chunk (block bit lengths, DPP), one 32-bit LDS bit writer per lane.
 constexpr uint32_t order_nib(uint64_t order, int i) { return (uint32_t)(order >> (60 - 4 * i)) & 15u; }
-
-template <int B> __device__ __forceinline__ uint32_t px_byte(const uint32_t (&w)[4][B], int x, int y, int c) {
-    const int bi = x * B + c;
-    return (w[y][bi >> 2] >> ((bi & 3) * 8)) & 0xffu;
-}
 // core band of band c under the default map: R-G, G, B-G (, A)   (reference QB3encode.cpp:41-45)
 template <int B, bool RGB> constexpr int core_of(int c) { return (RGB && (c == 0 || c == 2)) ? 1 : c; }
+
+// Encode table of the px kernel, built at compile time: rung r (1..7) at entries [2<<r, 4<<r), indexed by the
+// mag-sign value; entry = code << 8 | length, middle swap applied (reference QB3encode.h:30-33, 132-141)
+struct PxEncTab { alignas(16) uint32_t e[512]; };
+constexpr PxEncTab make_px_enc_tab() {
+    PxEncTab t{};
+    for (uint32_t r = 1; r < 8; r++) {
+        const uint32_t top = 1u << r, half = top >> 1;
+        for (uint32_t m = 0; m < (2u << r); m++) {
+            uint32_t v = m;
+            if (v == top || v == top - 1) v ^= 2 * top - 1;
+            const uint32_t code = (v < half) ? (v << 1) : (v < top) ? (((v - half) << 2) | 1) : (((v - top) << 2) | 3);
+            t.e[(2u << r) + m] = (code << 8) | (r + (v >= half) + (v >= top));
+        }
+    }
+    return t;
+}
+__device__ const PxEncTab px_enc_tab = make_px_enc_tab();
+// rung-switch codes of 8-bit data (3-bit rungs): length in 4-bit fields, code in 8-bit fields, by delta
+constexpr uint32_t cs3_len_c(uint32_t d) {
+    if (d == 0) return 1;
+    const uint32_t m = (d < 4) ? 2 * (d - 1) : 2 * (8 - d) - 1;
+    return 3 + (m >= 2) + (m >= 4);
+}
+constexpr uint32_t cs3_code_c(uint32_t d) {
+    if (d == 0) return 0;
+    const uint32_t m = (d < 4) ? 2 * (d - 1) : 2 * (8 - d) - 1;
+    const uint32_t c = (m < 2) ? (m << 1) : (m < 4) ? (((m - 2) << 2) | 1) : (((m - 4) << 2) | 3);
+    return (c << 1) | 1;
+}
+constexpr uint32_t cs3_lens() { uint32_t v = 0; for (uint32_t d = 0; d < 8; d++) v |= cs3_len_c(d) << (4 * d); return v; }
+constexpr uint64_t cs3_codes() { uint64_t v = 0; for (uint32_t d = 0; d < 8; d++) v |= (uint64_t)cs3_code_c(d) << (8 * d); return v; }
+
+// four independent byte subtractions
+__device__ __forceinline__ uint32_t swar_sub8(uint32_t x, uint32_t y) {
+    return ((x | 0x80808080u) - (y & 0x7f7f7f7fu)) ^ (~(x ^ y) & 0x80808080u);
+}
+// mag-sign of four bytes (reference QB3common.h:127-130): (d << 1) ^ (d < 0 ? 0xff : 0)
+__device__ __forceinline__ uint32_t swar_mags8(uint32_t d) {
+    const uint32_t s = d & 0x80808080u, ff = (s << 1) - (s >> 7);
+    return ((d << 1) & 0xfefefefeu) ^ ff;
+}
+// bytes of band c at curve positions 4q..4q+3 from the block's rows (w[y][k] = dword k of row y)
+template <int B, uint64_t ORDER>
+__device__ __forceinline__ uint32_t gather_quad(const uint32_t (&w)[4][B], int q, int c) {
+    int ry[4], rk[4], rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int nib = (int)order_nib(ORDER, 4 * q + j), bi = (nib & 3) * B + c;
+        ry[j] = nib >> 2; rk[j] = bi >> 2; rb[j] = bi & 3;
+    }
+    auto same = [&](int i, int j) { return ry[i] == ry[j] && rk[i] == rk[j]; };
+    // at most two source registers: one v_perm_b32 (selector 0..3 = bytes of the second operand, 4..7 of the first)
+    int other = -1;
+    bool two = true;
+#pragma unroll
+    for (int j = 1; j < 4; j++)
+        if (!same(j, 0)) { if (other < 0) other = j; else if (!same(j, other)) two = false; }
+    if (two) {
+        uint32_t sel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sel |= (uint32_t)(same(j, 0) ? rb[j] : 4 + rb[j]) << (8 * j);
+        const int o = other < 0 ? 0 : other;
+        return __builtin_amdgcn_perm(w[ry[o]][rk[o]], w[ry[0]][rk[0]], sel);
+    }
+    const uint32_t lo = __builtin_amdgcn_perm(w[ry[1]][rk[1]], w[ry[0]][rk[0]], (uint32_t)((4 + rb[1]) << 8 | rb[0]));
+    const uint32_t hi = __builtin_amdgcn_perm(w[ry[3]][rk[3]], w[ry[2]][rk[2]], (uint32_t)((4 + rb[3]) << 8 | rb[2]));
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+// LDS bit writer with a 32-bit accumulator, for pieces of at most 27 bits
+struct LdsWriter32 {
+    uint32_t *buf;
+    uint32_t acc, n, w;
+    __device__ __forceinline__ void init(uint32_t *b, uint32_t bitpos) { buf = b; acc = 0; n = bitpos & 31; w = bitpos >> 5; }
+    __device__ __forceinline__ void put(uint32_t code, uint32_t len) {     // len <= 27, code < 2^len
+        acc |= code << n;
+        const uint32_t n2 = n + len;
+        if (n2 >= 32) {                                                    // then n >= 5
+            atomicOr(&buf[w], acc); w++;
+            acc = code >> (32 - n);
+            n = n2 - 32;
+        } else n = n2;
+    }
+    __device__ __forceinline__ void finish() { if (n) atomicOr(&buf[w], acc); }
+};
 
 template <int B, bool RGB, uint64_t ORDER, bool STEP>
 __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
-    constexpr uint32_t UB = 3, UMASK = 7;
+    constexpr uint32_t UMASK = 7;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
     const uint64_t stride = a.g.stride;
 
-    uint16_t *etab = (uint16_t *)smem;                      // 512 entries
-    uint32_t *wsum = (uint32_t *)(etab + 512);              // 64 dwords: scan scratch, [32..35] rungs of each wave's last lane
-    uint32_t *outbuf = wsum + 64;
-    fill_enc_tab(etab);
-    for (uint32_t i = tid; i < a.slot_dw; i += 256) outbuf[i] = 0;
+    uint32_t *etab = (uint32_t *)smem;                      // 512 entries
+    uint32_t *wsum = etab + 512;                            // 64 dwords: scan scratch, [32..35] rungs of each wave's last lane
+    uint32_t *outbuf = wsum + 64;                           // slot_dw dwords (a multiple of 4)
+    if (tid < 128) ((uint4 *)etab)[tid] = ((const uint4 *)px_enc_tab.e)[tid];
+    for (uint32_t i = tid; i < a.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
+    const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
 
     const uint32_t chunk = blockIdx.x;
     const int64_t gs = (int64_t)chunk * 255 - 1 + tid;     // lane 0 is the halo block
@@ -529,12 +655,16 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
             for (int k = 0; k < B; k++) w[r][k] = 0;
     }
 
-    // ---- per band: deltas in curve order, mag-sign, packed four to a register
+    // ---- per band: bytes in curve order, band difference, running delta, mag-sign -- four values per register
+    uint32_t cur[B][4];
+#pragma unroll
+    for (int c = 0; c < B; c++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[c][q] = gather_quad<B, ORDER>(w, q, c);
     uint32_t gp[B][4], usedv[B], lastv[B], pvv[B];
     uint32_t rp_packed = 0;
 #pragma unroll
     for (int c = 0; c < B; c++) {
-        constexpr int dummy = 0; (void)dummy;
         const int cb = core_of<B, RGB>(c);
         uint32_t prv;
         if (gblk == 0) prv = (uint32_t)a0.st.prev[c] & 0xffu;
@@ -543,26 +673,22 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
             if (cb != c) prv = (prv - ((pd >> (8 * (cb + 4 - B))) & 0xffu)) & 0xffu;
         }
         pvv[c] = prv;
-        uint32_t used = 0;
+        uint32_t x[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) gp[c][q] = 0;
+        for (int q = 0; q < 4; q++) x[q] = (cb != c) ? swar_sub8(cur[c][q], cur[cb][q]) : cur[c][q];
+        uint32_t u = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            constexpr uint32_t dummy2 = 0; (void)dummy2;
-            const uint32_t nib = order_nib(ORDER, i);
-            uint32_t v = px_byte<B>(w, nib & 3, nib >> 2, c);
-            if (cb != c) v = (v - px_byte<B>(w, nib & 3, nib >> 2, cb)) & 0xffu;
-            const uint32_t d = (v - prv) & 0xffu;
-            const uint32_t m = ((d << 1) ^ (0u - (d >> 7))) & 0xffu;       // mag-sign (reference QB3common.h:127-130)
-            used |= m;
-            gp[c][i >> 2] |= m << (8 * (i & 3));
-            prv = v;
+        for (int q = 0; q < 4; q++) {
+            const uint32_t before = q ? __builtin_amdgcn_alignbit(x[q], x[q - 1], 24) : ((x[0] << 8) | prv);
+            gp[c][q] = swar_mags8(swar_sub8(x[q], before));
+            u |= gp[c][q];
         }
-        usedv[c] = used; lastv[c] = prv;
-        rp_packed |= topbit32(used | 1) << (4 * c);
+        u |= u >> 16; u |= u >> 8; u &= 0xffu;
+        usedv[c] = u; lastv[c] = x[3] >> 24;
+        rp_packed |= topbit32(u | 1) << (4 * c);
     }
     // rungs of the previous block: neighbouring lane, or the last lane of the previous wave through LDS
-    uint32_t prp = __shfl_up(rp_packed, 1, 64);
+    uint32_t prp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rp_packed, 0x138, 0xf, 0xf, false);      // wave_shr:1
     if (lane == 63) wsum[32 + wave] = rp_packed;
     __syncthreads();
     if (lane == 0 && wave) prp = wsum[32 + wave - 1];
@@ -570,26 +696,25 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
 #pragma unroll
         for (int c = 0; c < B; c++) prp |= ((uint32_t)a0.st.rung[c] & 15u) << (4 * c); }
 
-    // ---- per band: the unit's bit string as six pieces of at most 27 bits (see enc_kernel)
-    uint32_t pc[B][6], plens[B], lens[B], blen = 0;
+    // ---- per band: the unit's bit string as six pieces of at most 27 bits; pl = piece length (low byte)
+    uint32_t pc[B][6], pl[B][6], lens[B], blen[1] = { 0 };
 #pragma unroll
     for (int c = 0; c < B; c++) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) pc[c][k] = 0;
-        plens[c] = 0; lens[c] = 0;
+        for (int k = 0; k < 6; k++) { pc[c][k] = 0; pl[c][k] = 0; }
+        lens[c] = 0;
         if (payload) {
             const uint32_t rung = (rp_packed >> (4 * c)) & 15u, prung = (prp >> (4 * c)) & 15u, used = usedv[c];
             const uint32_t delta = (rung - prung) & UMASK;
-            const uint32_t csl = cs_len<UB>(delta), csc = cs_code<UB>(delta);
-            uint32_t len = csl;
+            const uint32_t csl = __builtin_amdgcn_ubfe(cs3_lens(), 4 * delta, 4), csc = (uint32_t)(cs3_codes() >> (8 * delta)) & 0xffu;
             if (used <= 1) {
                 uint32_t bits = 0;
 #pragma unroll
                 for (int i = 0; i < 16; i++) bits |= ((gp[c][i >> 2] >> (8 * (i & 3))) & 1u) << i;
-                const uint32_t l = 1 + (used ? 16 : 0);
-                pc[c][0] = csc | (used << csl) | (bits << (csl + 1));
-                plens[c] = csl + l;
-                len += l;
+                // switch, the "not all zero" flag, then the 16 bits: split so that no piece exceeds 27 bits
+                pc[c][0] = csc | (used << csl); pl[c][0] = csl + 1;
+                pc[c][1] = bits; pl[c][1] = used ? 16 : 0;
+                lens[c] = pl[c][0] + pl[c][1];
             } else {
                 uint32_t g4[4] = {gp[c][0], gp[c][1], gp[c][2], gp[c][3]};
                 if (STEP) {     // clear the rung bit of the last value of a 1..10..0 rung-bit run (reference QB3encode.h:169-176)
@@ -602,32 +727,39 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
                         for (int q = 0; q < 4; q++) if ((n >> 2) == (uint32_t)q) g4[q] ^= (1u << rung) << (8 * (n & 3));
                     }
                 }
-                const uint16_t *tab = etab + enc_tab_off(rung);
-                uint32_t acc = csc, al = csl, k = 0, lsum = 0;
+                const uint32_t tb = etab_off + (8u << rung);         // byte address of the rung's table region
+                constexpr int first[7] = {0, 2, 5, 8, 11, 14, 16};  // piece k holds values first[k] .. first[k+1]-1
+                uint32_t lsum = 0;
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const uint32_t e = tab[(g4[i >> 2] >> (8 * (i & 3))) & 0xffu];
-                    const uint32_t l = e >> 12;
-                    acc |= (e & 0xfff) << al; al += l; lsum += l;
-                    if (i == 1 || i == 4 || i == 7 || i == 10 || i == 13 || i == 15) {
-                        pc[c][k] = acc; plens[c] |= al << (5 * k); k++; acc = 0; al = 0;
+                for (int k = 0; k < 6; k++) {
+                    uint32_t acc = 0, s = 0;
+#pragma unroll
+                    for (int i = first[k + 1] - 1; i >= first[k]; i--) {
+                        const uint32_t m = (g4[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                        const uint32_t e = *lds_at((m << 2) + tb);
+                        acc = (acc << (e & 31u)) | (e >> 8);
+                        s += e;
                     }
+                    if (k == 0) { acc = (acc << csl) | csc; s += csl; }
+                    pc[c][k] = acc; pl[c][k] = s & 0xffu; lsum += s & 0xffu;
                 }
-                len += lsum;
+                lens[c] = lsum;
             }
-            lens[c] = len; blen += len;
+            blen[0] += lens[c];
         }
     }
-    uint32_t total;
-    const uint32_t pos = block_exscan(blen, wsum, &total);
+    const uint32_t mybits = blen[0];
+    block_exscan_dpp<1>(blen, wsum);
+    const uint32_t pos = blen[0], total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    (void)mybits;
 
     if (payload) {
-        LdsWriter wr;
+        LdsWriter32 wr;
         wr.init(outbuf, pos);
 #pragma unroll
         for (int c = 0; c < B; c++)
 #pragma unroll
-            for (int k = 0; k < 6; k++) wr.put(pc[c][k], (plens[c] >> (5 * k)) & 31);
+            for (int k = 0; k < 6; k++) wr.put(pc[c][k], pl[c][k]);
         wr.finish();
         if (gblk == nblocks - 1) {
 #pragma unroll
@@ -649,9 +781,9 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
         }
     }
     __syncthreads();
-    const uint32_t nd = (total + 31) >> 5;
-    uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;
-    for (uint32_t d = tid; d < nd; d += 256) slot[d] = outbuf[d];
+    const uint32_t nd4 = (total + 127) >> 7;
+    uint4 *slot = (uint4 *)(a.scratch + (uint64_t)chunk * a.slot_dw);
+    for (uint32_t d = tid; d < nd4; d += 256) slot[d] = ((const uint4 *)outbuf)[d];
     if (tid == 0) a.chunk_bits[chunk] = total;
 }
 
@@ -1117,7 +1249,6 @@ __device__ __forceinline__ DecArgs dec_for_tile(DecArgs a, uint32_t t) {
 
 // LSB-first bit reader over aligned dword loads; reads past the stream end return zeros, like the
 // reference's iBits::peek (bitstream.h:39-50)
-typedef const __attribute__((address_space(3))) uint32_t *LdsWords;   // explicit LDS pointer: loads become ds_read
 template <typename PTR>
 struct ReaderT {
     PTR in;
@@ -1626,44 +1757,6 @@ constexpr PxDecTab make_px_dec_tab() {
 }
 __device__ const PxDecTab px_dec_tab = make_px_dec_tab();
 
-__device__ __forceinline__ LdsWords lds_at(uint32_t byte_off) { return (LdsWords)(uintptr_t)byte_off; }
-// 32 stream bits starting at bit `pos` (counted from LDS address 0)
-__device__ __forceinline__ uint32_t lds_bits(uint32_t pos) {
-    LdsWords p = lds_at((pos >> 3) & ~3u);
-    return __builtin_amdgcn_alignbit(p[1], p[0], pos);
-}
-
-// wave-wide inclusive scan with DPP (row shifts inside the 16-lane rows, then the two row broadcasts of GFX9)
-__device__ __forceinline__ uint32_t wave_iscan32(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);     // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);     // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
-    return x;
-}
-// workgroup exclusive scan of NW independent 32-bit words per lane; ONE barrier; the scratch (NW*4 words) must not
-// be rewritten before the caller's next barrier
-template <int NW>
-__device__ __forceinline__ void block_exscan_dpp(uint32_t (&v)[NW], uint32_t *wsum) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc[NW];
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-        inc[k] = wave_iscan32(v[k]);
-        if (lane == 63) wsum[k * 4 + wave] = inc[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-        uint32_t base = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 3; i++) if (i < wave) base += wsum[k * 4 + i];
-        v[k] = base + inc[k] - v[k];
-    }
-}
-
 // rung switch of an 8-bit unit at bit `pos`: delta (mod 8); *cslen = bits consumed
 __device__ __forceinline__ uint32_t px_switch(uint32_t pos, uint32_t *cslen, bool *signal) {
     uint32_t x = lds_bits(pos);
@@ -2035,13 +2128,15 @@ static uint32_t max_unit_bits(uint32_t tsz, uint32_t mode = CM_FTL) {
 struct EncWs { size_t bits, off, gsum, seams, scratch, cwhas, cwval, centry, res, total; uint32_t slot_dw, ngroups; };
 static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
     EncWs w;
-    w.slot_dw = (uint32_t)((31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1);
+    // a multiple of 4 dwords: slots are 16-byte aligned (the px kernel copies them out as uint4)
+    w.slot_dw = (uint32_t)(((31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1 + 3) & ~(size_t)3);
     w.ngroups = (nchunks + SCAN_GROUP - 1) / SCAN_GROUP;
     size_t o = 0;
     w.bits = o; o += align8(4 * (size_t)nchunks);
     w.off = o; o += 8 * (size_t)nchunks;
     w.gsum = o; o += 8 * ((size_t)w.ngroups + 1);
     w.seams = o; o += 8 * (size_t)nchunks;
+    o = (o + 15) & ~(size_t)15;
     w.scratch = o; o += align8(4 * (size_t)nchunks * w.slot_dw);
     const size_t nb = g.mode == CM_BEST ? (size_t)nchunks * g.bands : 0;
     w.cwhas = o; o += align8(nb);
@@ -2075,7 +2170,7 @@ EncPlan plan_encode(const Geometry &g) {
         p.threads = 256; p.slots = 256; p.nbp = 255;
         p.nchunks = (uint32_t)((g.nblocks + 254) / 255);
         const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp);
-        p.lds_bytes = 1024 + 256 + 4 * (size_t)L.slot_dw;
+        p.lds_bytes = 2048 + 256 + 4 * (size_t)L.slot_dw;
         p.ws_bytes = L.total;
         return p;
     }

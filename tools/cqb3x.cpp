@@ -126,11 +126,12 @@ int do_encode(const Options &o) {
         r.px.swap(file);
     } else if (!parse_pnm(file, r))
         return fail("input is not a binary PNM (P5/P6); use -s for headerless rasters");
-    const size_t px_bytes = r.bands * kTypeSize[r.type], stride = r.w * px_bytes;
+    // the encoder's line stride is in values, not bytes (QB3.h: "in dtype units"; reference cqb3.cpp:393,406)
+    const size_t px_bytes = r.bands * kTypeSize[r.type], stride = r.w * r.bands;
     size_t offset = 0;
     if (o.trim) {           // drop the first column/line when that leaves the larger multiple of 4 (cqb3.cpp:393-402)
         if (r.w % 4 > 1) offset += px_bytes;
-        if (r.h % 4 > 1) offset += stride;
+        if (r.h % 4 > 1) offset += stride * kTypeSize[r.type];
         r.w -= r.w % 4; r.h -= r.h % 4;
         if (o.verbose) printf("Trimmed to %zux%zu\n", r.w, r.h);
     }
