@@ -1160,7 +1160,8 @@ __device__ __forceinline__ uint64_t chunk_start(const EncArgs &a, uint32_t k) {
 
 // Concatenate: one WAVE per chunk reads the chunk's slot, funnel-shifts it to its bit position and stores the
 // dwords that lie wholly inside the chunk; the first and last shifted dword go to the seam table.
-__global__ void enc_concat_kernel(const EncArgs a0) {
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));     // four dwords at any dword address
+__global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (chunk >= a.nchunks) return;
@@ -1168,15 +1169,52 @@ __global__ void enc_concat_kernel(const EncArgs a0) {
     const uint32_t total = a.chunk_bits[chunk];
     const uint32_t phase = (uint32_t)(G & 31), nsrc = (total + 31) >> 5;
     const uint32_t nd = (phase + total + 31) >> 5, tailbits = (phase + total) & 31;
-    const uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;
+    const uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;    // 16-byte aligned (slot_dw is a multiple of 4)
+    const uint4 *slot4 = (const uint4 *)slot;
     uint32_t *gout = a.out32 + (G >> 5);
-    for (uint32_t d = lane; d < nd; d += 64) {
-        const uint32_t lo = d < nsrc ? slot[d] : 0u, prv = (d > 0 && d - 1 < nsrc) ? slot[d - 1] : 0u;
-        const uint32_t v = phase ? (uint32_t)((((uint64_t)lo << 32) | prv) >> (32 - phase)) : lo;
-        const bool shared = (d == 0 && phase) || (d == nd - 1 && tailbits);
-        if (!shared) gout[d] = v;
-        if (d == 0) a.seams[2 * chunk] = v;
-        if (d == nd - 1) a.seams[2 * chunk + 1] = v;
+    // a lane moves four dwords per step (one 16-byte load, the next one already in flight): memory-level parallelism
+    // is what this copy needs.  Output dword d = source dwords d-1, d funnel-shifted by the chunk's bit phase.
+    const uint32_t ng = (nd + 3) >> 2, sh = (32 - phase) & 31;
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if (lane < ng && 4 * lane < nsrc) cur = slot4[lane];
+    uint32_t before = 0;                                                // lane 0: the dword before its group
+    for (uint32_t g = lane; g < ng; g += 64) {
+        const uint32_t gn = g + 64;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        uint32_t before_n = 0;
+        if (gn < ng && 4 * gn < nsrc) nxt = slot4[gn];
+        if (lane == 0 && gn < ng && 4 * gn - 1 < nsrc) before_n = slot[4 * gn - 1];
+        const uint32_t d = 4 * g;
+        uint32_t s[4] = { cur.x, cur.y, cur.z, cur.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (d + k >= nsrc) s[k] = 0;        // the slot is only defined up to nsrc
+        uint32_t prv = __shfl_up(s[3], 1, 64);
+        if (lane == 0) prv = before;
+        uint32_t v[4];
+        if (phase) {
+            v[0] = __builtin_amdgcn_alignbit(s[0], prv, sh);
+#pragma unroll
+            for (int k = 1; k < 4; k++) v[k] = __builtin_amdgcn_alignbit(s[k], s[k - 1], sh);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = s[k];
+        }
+        if (d > 0 && d + 4 < nd) {                                      // no seam dword in the group
+            u32x4_a4 o = { v[0], v[1], v[2], v[3] };
+            *(u32x4_a4 *)(gout + d) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t dd = d + k;
+                if (dd < nd) {
+                    const bool shared = (dd == 0 && phase) || (dd == nd - 1 && tailbits);
+                    if (!shared) gout[dd] = v[k];
+                    if (dd == 0) a.seams[2 * chunk] = v[k];
+                    if (dd == nd - 1) a.seams[2 * chunk + 1] = v[k];
+                }
+            }
+        }
+        cur = nxt; before = before_n;
     }
 }
 
