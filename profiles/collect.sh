@@ -1,0 +1,15 @@
+#!/bin/bash
+# profiles/collect.sh TAG -- the three rocprofv3 runs behind profiles/TAG_* (run on the GPU box from the repo root).
+# Counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa tracing next to --pmc).
+set -e
+TAG=${1:-rXX}
+OUT=gpurun_out/prof_$TAG
+CMD="bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $CMD > /dev/null 2> $OUT/fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $CMD > /dev/null 2> $OUT/write.log
+PROFILE_CMD="python3 $CMD" python3 profiles/summarise.py $TAG $OUT/trace $OUT/fetch $OUT/write
+cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc_hbm.csv profiles/pmc_traffic.json $OUT/
+grep '^{' $OUT/bench_under_rocprof.json > $OUT/${TAG}_bench_under_rocprof.json || true

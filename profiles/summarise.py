@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""profiles/summarise.py -- turn rocprofv3 output into the summaries committed under profiles/.
+
+    python3 profiles/summarise.py TAG TRACE_DIR FETCH_DIR WRITE_DIR
+
+TRACE_DIR  output of  rocprofv3 --kernel-trace --stats -d TRACE_DIR -o t --output-format csv -- python3 bench.py ...
+FETCH_DIR  output of  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d ... -- python3 bench.py ...     (own pass)
+WRITE_DIR  output of  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d ... -- python3 bench.py ...     (own pass)
+
+Writes profiles/TAG_kernel_stats.csv, profiles/TAG_pmc_hbm.csv and refreshes profiles/pmc_traffic.json (what
+bench.py reports as roofline.traffic).  Counter unit and the gfx950 correction follow MI355X_MICROARCH.md:
+FETCH_SIZE / WRITE_SIZE are KiB per dispatch; FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950 (x2),
+WRITE_SIZE is exact.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+# library profile names (qb3x_profile_names) by a substring of the kernel symbol
+KEYS = [("enc_px_kernel", "enc_units"), ("enc_kernel", "enc_units"), ("enc_best_kernel", "enc_best"), ("best_scan", "enc_best_scan"),
+        ("enc_scan2", "enc_scan2"), ("enc_scan", "enc_scan"), ("enc_concat", "enc_concat"), ("enc_seam", "enc_seams"),
+        ("write_header", "write_header"), ("dec_px_kernel", "dec_units"), ("dec3_kernel", "dec_units"),
+        ("dec_index_serial", "dec_index_serial"), ("dec_kernel", "dec_segments")]
+
+
+def key_of(name):
+    if "qb3dev" not in name:
+        return None
+    for sub, key in KEYS:
+        if sub in name:
+            return key
+    return None
+
+
+def find(d, suffix):
+    m = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not m:
+        raise SystemExit("no %s under %s" % (suffix, d))
+    return m[0]
+
+
+def kernel_stats(trace_dir):
+    rows = list(csv.DictReader(open(find(trace_dir, "kernel_trace.csv"))))
+    acc = collections.defaultdict(list)
+    for r in rows:
+        acc[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = []
+    for name, d in acc.items():
+        if "qb3dev" in name:
+            out.append((name, len(d), sum(d), sum(d) / len(d), min(d), max(d)))
+    out.sort(key=lambda t: -t[2])
+    return out
+
+
+def pmc(d, counter):
+    rows = list(csv.DictReader(open(find(d, "counter_collection.csv"))))
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] == counter:
+            k = key_of(r["Kernel_Name"])
+            if k:
+                acc[k].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    tag, trace_dir, fetch_dir, write_dir = sys.argv[1:5]
+    cmd = os.environ.get("PROFILE_CMD", "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline")
+    stats = kernel_stats(trace_dir)
+    with open(os.path.join(HERE, tag + "_kernel_stats.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- %s   (MI355X)\n" % cmd)
+        f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs\n")
+        for name, n, tot, avg, lo, hi in stats:
+            f.write('"%s",%d,%d,%.1f,%d,%d\n' % (name, n, tot, avg, lo, hi))
+    fetch, nf = pmc(fetch_dir, "FETCH_SIZE")
+    write, _ = pmc(write_dir, "WRITE_SIZE")
+    traffic = {}
+    with open(os.path.join(HERE, tag + "_pmc_hbm.csv"), "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- %s\n" % cmd)
+        f.write("# counter unit: KiB per dispatch (average over the dispatches seen). gfx950 correction per "
+                "MI355X_MICROARCH.md: FETCH_SIZE x2, WRITE_SIZE x1\n")
+        f.write("kernel,dispatches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_per_launch_corrected\n")
+        for k in sorted(set(fetch) | set(write)):
+            fk, wk = fetch.get(k, 0.0), write.get(k, 0.0)
+            b = int(round((2 * fk + wk) * 1024))
+            f.write("%s,%d,%.1f,%.1f,%d\n" % (k, nf.get(k, 0), fk, wk, b))
+            traffic[k] = {"hbm_bytes_per_launch": b, "fetch_KiB": fk, "write_KiB": wk, "source": "profiles/%s_pmc_hbm.csv" % tag}
+    with open(os.path.join(HERE, "pmc_traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+    for name, n, tot, avg, lo, hi in stats:
+        print("%-28s calls %3d avg %9.1f us" % (key_of(name), n, avg / 1e3))
+
+
+if __name__ == "__main__":
+    main()

@@ -1751,8 +1751,9 @@ __global__ void dec3_kernel(const DecArgs a0) {
 }
 
 // ---- 8-bit, 1/3/4 bands: lane per BLOCK decode, in registers (counterpart of enc_px_kernel) -------------
-// Workgroup per index segment, lane per block (passes of 256 blocks).  The kernel is bound by VALU issue, not
-// by HBM, so everything here is about instructions per value:
+// WAVE per index segment (64 blocks), lane per block; the waves of a workgroup share the code table and nothing
+// else, so there is one barrier and every wave hides the others' memory latency.  The kernel is bound by VALU
+// issue, not by HBM, so everything here is about instructions per value:
 //   * the segment's bits are staged in LDS (padded with zero words: no bounds checks on the decode path) and all
 //     bit positions are kept relative to LDS address 0, so a refill is  lshr, and, ds_read2_b32, v_alignbit;
 //   * the code table holds the mag-sign-undone delta (and the step flag) as 32-bit entries in rung regions aligned
@@ -1760,7 +1761,7 @@ __global__ void dec3_kernel(const DecArgs a0) {
 //     of a per-rung constant; the table itself is a compile-time constant copied from L2 with one 16-byte load;
 //   * running sums are kept two to a register as 16-bit lanes: entering values and core bands are added with
 //     v_pk_add_u16, bytes are gathered into pixel order with v_perm_b32 (3 per output dword);
-//   * the three workgroup scans (bit positions, rung deltas and unit totals, the last two packed 16 bits per
+//   * the three wave scans (bit positions, rung deltas and unit totals, the last two packed 16 bits per
 //     band) use DPP row shifts/broadcasts, no LDS.
 // The four rows go straight to HBM (B dwords per lane and row: 64 lanes write one contiguous run).
 typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
@@ -1863,18 +1864,21 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NW = (B + 1) / 2;                     // 32-bit words of a scan packed 16 bits per band
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x, NB = a.g.seg_blocks, nbx = a.g.nbx;
-    const uint64_t seg = blockIdx.x, stride = a.g.stride;
-    const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
-    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t NB = a.g.seg_blocks, nbx = a.g.nbx;  // NB <= 64: a WAVE owns a segment, nothing is shared but the table
+    const uint64_t stride = a.g.stride;
 
     uint32_t *tab = (uint32_t *)smem;                   // 4 KB, at LDS address 0 (the table addressing relies on it)
-    uint32_t *wsum = tab + 1024;                        // 3 scans x NW x 4 waves
-    uint32_t *carry = wsum + 32;                        // [0] pass bits, [1..B] rung, [1+B..2B] entering value
-    uint8_t *ulen_s = (uint8_t *)(carry + 16);          // NB*B bytes, padded to 8
-    uint32_t *stage = (uint32_t *)(ulen_s + ((NB * B + 7) & ~7u));
+    uint32_t *stage = tab + 1024 + wave * (a.in_cap_dw + 8);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
     const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
+    for (uint32_t i = tid; i < 256; i += blockDim.x) ((uint4 *)tab)[i] = ((const uint4 *)px_dec_tab.e)[i];
+    __syncthreads();                                    // the only workgroup barrier
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    if (seg >= a.g.nseg) return;
+    const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
+    const bool act = lane < nb_here;
 
     const uint64_t P0 = a.idx.bitpos[seg];
     const uint64_t P1 = (seg + 1 < a.g.nseg) ? a.idx.bitpos[seg + 1] : a.in_bits;
@@ -1884,113 +1888,91 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     // the staging area holds the longest valid segment; an index that says otherwise is not ours
     const bool fits = ndw64 <= a.in_cap_dw && lds0 == 0;
     const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
-    for (uint32_t i = tid; i < ndw + 8; i += nthr) stage[i] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
-    for (uint32_t i = tid; i < 256; i += nthr) ((uint4 *)tab)[i] = ((const uint4 *)px_dec_tab.e)[i];
-    const uint8_t *ul = (const uint8_t *)a.idx.ulen + (uint64_t)g0 * B;
-    for (uint32_t i = tid; i < nb_here * B; i += nthr) ulen_s[i] = ul[i];
-    if (tid < B) {
-        carry[1 + tid] = a.idx.rung[seg * B + tid];
-        carry[1 + B + tid] = ((const uint8_t *)a.idx.prev)[seg * B + tid];
+    for (uint32_t i = lane; i < ndw + 8; i += 64) stage[i] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+    uint32_t ul_[B], blen = 0;
+    {
+        const uint8_t *ul = (const uint8_t *)a.idx.ulen + ((uint64_t)g0 + lane) * B;
+#pragma unroll
+        for (int c = 0; c < B; c++) { ul_[c] = act ? ul[c] : 0u; blen += ul_[c]; }
     }
-    __syncthreads();
+    // the wave reads what its own lanes staged: LDS operations of a wave execute in order, the fence is for the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
     const uint32_t limit = stage_bit0 + 32 * ndw;       // no unit starts beyond the staged bits (8 zero words follow)
-    uint32_t cpos = stage_bit0 + (uint32_t)(a.in_bit0 + P0 - 32 * w0);
+    const uint32_t cpos = stage_bit0 + (uint32_t)(a.in_bit0 + P0 - 32 * w0);
     bool bad = !fits;
-    const uint32_t npass = (nb_here + nthr - 1) / nthr;
-    for (uint32_t p = 0; p < npass; p++) {
-        const uint32_t sl = p * nthr + tid;
-        const bool act = sl < nb_here;
-        uint32_t ul_[B], blen[1] = { 0 };
+    const uint32_t binc = wave_iscan32(blen);           // inclusive: lane 63 holds the bits of the segment
+    // rung switches of the lane's units
+    uint32_t gpos[B], pos = cpos + binc - blen, dpk[NW];
 #pragma unroll
-        for (int c = 0; c < B; c++) { ul_[c] = act ? ulen_s[sl * B + c] : 0u; blen[0] += ul_[c]; }
-        const uint32_t mybits = blen[0];
-        block_exscan_dpp<1>(blen, wsum);
-        if (tid == nthr - 1) carry[0] = blen[0] + mybits;                    // bits of this pass
-        // rung switches of the lane's units
-        uint32_t gpos[B], pos = cpos + blen[0], dpk[NW], dmine[NW];
+    for (int k = 0; k < NW; k++) dpk[k] = 0;
 #pragma unroll
-        for (int k = 0; k < NW; k++) dpk[k] = 0;
+    for (int c = 0; c < B; c++) {
+        pos = pos < limit ? pos : limit;
+        bool sig; uint32_t csl;
+        const uint32_t d = px_switch(pos, &csl, &sig);
+        gpos[c] = pos + csl;
+        if (act && sig && STEP) bad = true;             // common-factor / index unit: not handled here
+        dpk[c >> 1] |= (act ? d : 0u) << (16 * (c & 1));
+        pos += ul_[c];
+    }
+#pragma unroll
+    for (int k = 0; k < NW; k++) dpk[k] = wave_iscan32(dpk[k]);                 // inclusive, 16 bits per band
+    // decode the units; running sums in curve order, two 16-bit lanes per register
+    uint32_t rp[B][8], spk[NW], sinc[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) spk[k] = 0;
+#pragma unroll
+    for (int c = 0; c < B; c++) {
+        const uint32_t rung = ((uint32_t)a.idx.rung[seg * B + c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 7u;
+        const uint32_t tot = px_group<STEP>(gpos[c], rung, rp[c]) & 0xffu;
+        spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
+    }
+#pragma unroll
+    for (int k = 0; k < NW; k++) sinc[k] = wave_iscan32(spk[k]);
+    if (act) {
+        // entering value, then the core band (reference QB3decode.h:560-567)
 #pragma unroll
         for (int c = 0; c < B; c++) {
-            pos = pos < limit ? pos : limit;
-            bool sig; uint32_t csl;
-            const uint32_t d = px_switch(pos, &csl, &sig);
-            gpos[c] = pos + csl;
-            if (act && sig && STEP) bad = true;                              // common-factor / index unit: not handled here
-            dpk[c >> 1] |= (act ? d : 0u) << (16 * (c & 1));
-            pos += ul_[c];
+            const uint32_t pv = (uint32_t)((const uint8_t *)a.idx.prev)[seg * B + c] + (((sinc[c >> 1] - spk[c >> 1]) >> (16 * (c & 1))) & 0xffffu);
+#pragma unroll
+            for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], (pv & 0xffu) * 0x00010001u);
         }
-#pragma unroll
-        for (int k = 0; k < NW; k++) dmine[k] = dpk[k];
-        block_exscan_dpp<NW>(dpk, wsum + 4);
-        // decode the units; running sums in curve order, two 16-bit lanes per register
-        uint32_t rp[B][8], rungs = 0, spk[NW], smine[NW];
-#pragma unroll
-        for (int k = 0; k < NW; k++) spk[k] = 0;
 #pragma unroll
         for (int c = 0; c < B; c++) {
-            const uint32_t dinc = ((dpk[c >> 1] + dmine[c >> 1]) >> (16 * (c & 1))) & 0xffffu;     // inclusive
-            const uint32_t rung = (carry[1 + c] + dinc) & 7u;
-            rungs |= rung << (4 * c);
-            const uint32_t tot = px_group<STEP>(gpos[c], rung, rp[c]) & 0xffu;
-            spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
+            const int cb = core_of<B, RGB>(c);
+            if (cb != c)
+#pragma unroll
+                for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], rp[cb][k]);
         }
+        // curve order, band planar -> pixel order, band interleaved; store the four rows
+        const uint32_t g = g0 + lane, by = g / nbx, bx = g - by * nbx;
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        uint8_t *p0 = (uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B;
 #pragma unroll
-        for (int k = 0; k < NW; k++) smine[k] = spk[k];
-        block_exscan_dpp<NW>(spk, wsum + 4 + 4 * NW);                        // exclusive
-        uint32_t pv[B];
+        for (int y = 0; y < 4; y++) {
+            uint32_t *dst = (uint32_t *)(p0 + (uint64_t)y * stride);
 #pragma unroll
-        for (int c = 0; c < B; c++) pv[c] = (carry[1 + B + c] + ((spk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 0xffu;
-        __syncthreads();                                                     // everyone has read the carries
-        if (act && (sl == nb_here - 1 || tid == nthr - 1)) {                 // state leaving the pass
+            for (int k = 0; k < B; k++) {
+                // byte j of output dword k is band (4k+j)%B of pixel x = (4k+j)/B: low byte of a 16-bit lane
+                uint32_t half2[2];
 #pragma unroll
-            for (int c = 0; c < B; c++) {
-                carry[1 + c] = (rungs >> (4 * c)) & 15u;
-                carry[1 + B + c] = (pv[c] + ((smine[c >> 1] >> (16 * (c & 1))) & 0xffu)) & 0xffu;
-            }
-        }
-        if (act) {
-            // entering value, then the core band (reference QB3decode.h:560-567)
-#pragma unroll
-            for (int c = 0; c < B; c++)
-#pragma unroll
-                for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], pv[c] * 0x00010001u);
-#pragma unroll
-            for (int c = 0; c < B; c++) {
-                const int cb = core_of<B, RGB>(c);
-                if (cb != c)
-#pragma unroll
-                    for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], rp[cb][k]);
-            }
-            // curve order, band planar -> pixel order, band interleaved; store the four rows
-            const uint32_t g = g0 + sl, by = g / nbx, bx = g - by * nbx;
-            const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
-            uint8_t *p0 = (uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B;
-#pragma unroll
-            for (int y = 0; y < 4; y++) {
-                uint32_t *dst = (uint32_t *)(p0 + (uint64_t)y * stride);
-#pragma unroll
-                for (int k = 0; k < B; k++) {
-                    // byte j of output dword k is band (4k+j)%B of pixel x = (4k+j)/B: low byte of a 16-bit lane
-                    uint32_t half2[2];
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int b0 = 4 * k + 2 * h, b1 = b0 + 1;
-                        const int i0 = curve_pos_of(ORDER, b0 / B, y), i1 = curve_pos_of(ORDER, b1 / B, y);
-                        // v_perm_b32: selector bytes 0..3 pick from the second operand, 4..7 from the first
-                        half2[h] = __builtin_amdgcn_perm(rp[b1 % B][i1 >> 1], rp[b0 % B][i0 >> 1],
-                                                         (uint32_t)((4 + 2 * (i1 & 1)) << 8 | (2 * (i0 & 1))));
-                    }
-                    dst[k] = __builtin_amdgcn_perm(half2[1], half2[0], 0x05040100u);
+                for (int h = 0; h < 2; h++) {
+                    const int b0 = 4 * k + 2 * h, b1 = b0 + 1;
+                    const int i0 = curve_pos_of(ORDER, b0 / B, y), i1 = curve_pos_of(ORDER, b1 / B, y);
+                    // v_perm_b32: selector bytes 0..3 pick from the second operand, 4..7 from the first
+                    half2[h] = __builtin_amdgcn_perm(rp[b1 % B][i1 >> 1], rp[b0 % B][i0 >> 1],
+                                                     (uint32_t)((4 + 2 * (i1 & 1)) << 8 | (2 * (i0 & 1))));
                 }
+                dst[k] = __builtin_amdgcn_perm(half2[1], half2[0], 0x05040100u);
             }
         }
-        __syncthreads();
-        cpos += carry[0];
     }
     if (bad) atomicOr(a.status, fits ? 1u : 8u);
-    if (tid == 0 && seg == a.g.nseg - 1 && fits) {      // reference: more than 7 unused bits at the end is a failure
-        const uint64_t used = (uint64_t)(cpos - stage_bit0) + 32 * w0 - a.in_bit0;
+    if (lane == 63 && seg == a.g.nseg - 1 && fits) {    // reference: more than 7 unused bits at the end is a failure
+        const uint64_t used = (uint64_t)(cpos + binc - stage_bit0) + 32 * w0 - a.in_bit0;
         if (used > a.in_bits) atomicOr(a.status, 4u);
         else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
     }
@@ -2124,6 +2106,9 @@ uint32_t seg_blocks_for(const Geometry &g) {
     if (g.mode != CM_BEST) {      // one segment = the blocks of one decoder workgroup, at most 256
         static const uint32_t knob = [] { const char *e = getenv("QB3_SEG_BLOCKS"); int k = e ? atoi(e) : 0; return (uint32_t)(k < 0 ? 0 : k); }();
         if (knob) return knob;                                                  // tuning knob, process wide
+        // 8-bit grey/RGB/RGBA: the lane-per-block decoder gives a segment to a WAVE (a function of type and band
+        // count only: encoder and decoder must agree whatever kernel either of them ends up using)
+        if (g.tsz == 1 && (g.bands == 1 || g.bands == 3 || g.bands == 4)) return 64;
         uint32_t threads, bpp, passes;
         fast_geometry(g.bands, g.tsz, &threads, &bpp, &passes);
         while (passes > 1 && bpp * passes > 256) passes--;
@@ -2362,15 +2347,15 @@ DecPlan plan_decode(const Geometry &g) {
     // staging of the px kernel: the longest valid segment (every unit at its maximum) + the word the first unit
     // starts in + 8 zero words, after the 4 KB table, the scan scratch and the unit lengths
     p.px_cap_dw = (uint32_t)(((size_t)NB * g.bands * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
-    p.lds_px = 4096 + 4 * 32 + 4 * 16 + (((size_t)NB * g.bands + 7) & ~(size_t)7) + 4 * ((size_t)p.px_cap_dw + 8);
+    p.px = p.px && NB <= 64;
+    p.lds_px = 4096 + 4 * 4 * ((size_t)p.px_cap_dw + 8);       // table + four waves' staging
     return p;
 }
 
 template <int B, bool RGB>
 static void launch_dec_px_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    const uint32_t nt = a.g.seg_blocks >= 256 ? 256u : ((a.g.seg_blocks + 63) / 64) * 64;
-    dim3 grid((uint32_t)a.g.nseg, a.ntiles), block(nt);
+    dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
     if (!z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, false>), grid, block, plan.lds_px, st, a);
     else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);
     else if (z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, false>), grid, block, plan.lds_px, st, a);
