@@ -71,6 +71,8 @@ struct EncPlan {
     uint32_t nbp;           // payload blocks per chunk
     bool px;                // 8-bit 1/3/4-band register-resident kernel applies (lane per block)
     bool px_rgb;            //   ... with the default R-G,G,B-G map (else identity)
+    bool px16;              // 16-bit register-resident kernel applies (lane per block and band group)
+    uint32_t px16_bg, px16_ng;      //   ... bands per lane (1..4), lanes per block
 };
 EncPlan plan_encode(const Geometry &g);
 
@@ -102,7 +104,9 @@ struct DecPlan {
     // 8-bit 1/3/4-band lane-per-block kernel
     bool px, px_rgb;
     size_t lds_px;
-    uint32_t px_cap_dw;     // staging capacity (dwords) of the 8-bit lane-per-block kernel
+    uint32_t px_cap_dw;     // staging capacity (dwords) of the lane-per-block kernels, per wave
+    bool px16;              // 16-bit lane-per-(block, band group) kernel applies
+    uint32_t px16_bg, px16_ng;
 };
 DecPlan plan_decode(const Geometry &g);
 

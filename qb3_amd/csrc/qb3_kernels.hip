@@ -199,6 +199,7 @@ struct EncArgs {
     uint32_t hdr_len;       // container header bytes to stamp in front of the stream (write_header_kernel)
     uint8_t hdr[64];
     uint32_t flags;         // tuning switches (QB3_ENC_FLAGS): bit 0 = codes from the LDS table instead of the rule
+    uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups per block (lanes per block), magic of it
     EncResult *res;
     BandState st;
     IndexView idx;
@@ -787,6 +788,246 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
     if (tid == 0) a.chunk_bits[chunk] = total;
 }
 
+// ------------------------------------------------------------------ 16-bit: lane per (block, band group), in registers
+// The 16-bit counterpart of enc_px_kernel.  A lane owns BG <= 4 bands of one block (bands = NG x BG: 8-band data
+// is two lanes per block); units of a block are consecutive in the stream, so lane order is still stream order.
+// Two values per register: v_perm_b32 gathers curve-ordered pairs, band difference / running delta / mag-sign are
+// packed 16-bit operations (v_pk_sub_u16, v_pk_lshlrev_b16, v_pk_ashrrev_i16).  Rungs up to 7 use the same
+// compile-time code table as the 8-bit kernel, higher rungs the code rule in ALU (no middle swap above rung 7);
+// pieces are 64 bits wide (three codes of at most 17 bits).  Slot 0 of a workgroup (its first NG lanes) is the halo
+// block, so a chunk is 256/NG - 1 blocks.
+typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t x, uint32_t y) {
+    return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, x) - __builtin_bit_cast(u16x2_t, y)));
+}
+__device__ __forceinline__ uint32_t pk_mags16(uint32_t d) {       // (d << 1) ^ (d >> 15), two 16-bit lanes
+    const u16x2_t a = __builtin_bit_cast(u16x2_t, d) << (u16x2_t)(uint16_t)1;
+    const i16x2_t s = __builtin_bit_cast(i16x2_t, d) >> (i16x2_t)(int16_t)15;
+    return __builtin_bit_cast(uint32_t, a) ^ __builtin_bit_cast(uint32_t, s);
+}
+// values 2k, 2k+1 (curve order) of band c of the lane's group; w[y][j] = dword j of the lane's row y, halfword
+// x*BG + c of it is band c of pixel x
+template <int BG, uint64_t ORDER>
+__device__ __forceinline__ uint32_t gather_pair16(const uint32_t (&w)[4][2 * BG], int k, int c) {
+    const int n0 = (int)order_nib(ORDER, 2 * k), n1 = (int)order_nib(ORDER, 2 * k + 1);
+    const int h0 = (n0 & 3) * BG + c, h1 = (n1 & 3) * BG + c;
+    const uint32_t sel = (uint32_t)(2 * (h0 & 1)) | (uint32_t)(2 * (h0 & 1) + 1) << 8 |
+                         (uint32_t)(4 + 2 * (h1 & 1)) << 16 | (uint32_t)(4 + 2 * (h1 & 1) + 1) << 24;
+    return __builtin_amdgcn_perm(w[n1 >> 2][h1 >> 1], w[n0 >> 2][h0 >> 1], sel);
+}
+
+template <int BG, bool RGB, uint64_t ORDER, bool STEP>
+__global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    constexpr uint32_t UB = 4, UMASK = 15;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx, B = a.g.bands, NG = a.px_ng, S = 256 / NG;
+    const uint64_t stride = a.g.stride;                     // in values
+    const uint32_t slot = fastdiv(tid, NG, a.px_magic_ng), grp = tid - slot * NG, band0 = grp * BG;
+
+    uint32_t *etab = (uint32_t *)smem;                      // 512 entries
+    uint32_t *wsum = etab + 512;                            // 64 dwords of scan scratch
+    uint32_t *rp_s = wsum + 64;                             // 256: every lane's packed rungs
+    uint32_t *outbuf = rp_s + 256;                          // slot_dw dwords (a multiple of 4)
+    if (tid < 128) ((uint4 *)etab)[tid] = ((const uint4 *)px_enc_tab.e)[tid];
+    for (uint32_t i = tid; i < a.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
+    const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
+
+    const uint32_t chunk = blockIdx.x;
+    const int64_t gs = (int64_t)chunk * (S - 1) - 1 + slot; // slot 0 is the halo block
+    const bool valid = slot < S && gs >= 0 && gs < (int64_t)nblocks, payload = valid && slot >= 1;
+    const uint32_t gblk = valid ? (uint32_t)gs : 0u;
+
+    // ---- load the lane's bands of the block (4 rows) and of the previous block's last visited pixel
+    uint32_t w[4][2 * BG], pvals[BG];
+    constexpr uint32_t n15 = order_nib(ORDER, 15);
+#pragma unroll
+    for (int c = 0; c < BG; c++) pvals[c] = 0;
+    if (valid) {
+        const uint32_t by = gblk / nbx, bx = gblk - by * nbx;
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        const uint16_t *p0 = (const uint16_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B + band0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint16_t *rowp = p0 + (uint64_t)r * stride;
+            if (BG % 2 == 0) {      // a pixel's BG values are whole dwords; pixels are B values apart
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const uint32_t *q = (const uint32_t *)(rowp + (uint64_t)x * B);
+#pragma unroll
+                    for (int d = 0; d < BG / 2; d++) w[r][x * (BG / 2) + d] = q[d];
+                }
+            } else {                // BG == bands: the row of the block is contiguous
+                const uint32_t *q = (const uint32_t *)rowp;
+#pragma unroll
+                for (int k = 0; k < 2 * BG; k++) w[r][k] = q[k];
+            }
+        }
+        if (gblk) {
+            const uint32_t pb = gblk - 1, pby = pb / nbx, pbx = pb - pby * nbx;
+            const uint32_t py0 = (4 * pby + 4 > a.g.h) ? a.g.h - 4 : 4 * pby;
+            const uint16_t *q = (const uint16_t *)a.img + (uint64_t)(py0 + (n15 >> 2)) * stride + (uint64_t)(pbx * 4 + (n15 & 3)) * B + band0;
+#pragma unroll
+            for (int c = 0; c < BG; c++) pvals[c] = q[c];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int k = 0; k < 2 * BG; k++) w[r][k] = 0;
+    }
+
+    // ---- per band: values in curve order, band difference, running delta, mag-sign -- two values per register
+    uint32_t cur[BG][8];
+#pragma unroll
+    for (int c = 0; c < BG; c++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[c][k] = gather_pair16<BG, ORDER>(w, k, c);
+    uint32_t gp[BG][8], usedv[BG], lastv[BG], pvv[BG];
+    uint32_t rp_packed = 0;
+#pragma unroll
+    for (int c = 0; c < BG; c++) {
+        const int cb = core_of<BG, RGB>(c);
+        uint32_t prv;
+        if (gblk == 0) prv = (uint32_t)a0.st.prev[band0 + c] & 0xffffu;
+        else prv = (cb != c) ? (pvals[c] - pvals[cb]) & 0xffffu : pvals[c];
+        pvv[c] = prv;
+        uint32_t x[8], u = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = (cb != c) ? pk_sub16(cur[c][k], cur[cb][k]) : cur[c][k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t before = k ? __builtin_amdgcn_alignbit(x[k], x[k - 1], 16) : ((x[0] << 16) | prv);
+            gp[c][k] = pk_mags16(pk_sub16(x[k], before));
+            u |= gp[c][k];
+        }
+        u = (u | (u >> 16)) & 0xffffu;
+        usedv[c] = u; lastv[c] = x[7] >> 16;
+        rp_packed |= topbit32(u | 1) << (4 * c);
+    }
+    // rungs of the same bands of the previous block: NG lanes back
+    rp_s[tid] = rp_packed;
+    __syncthreads();
+    uint32_t prp = tid >= NG ? rp_s[tid - NG] : 0u;
+    if (gblk == 0) { prp = 0;
+#pragma unroll
+        for (int c = 0; c < BG; c++) prp |= ((uint32_t)a0.st.rung[band0 + c] & 15u) << (4 * c); }
+
+    // ---- per band: the unit's bit string as six pieces (64-bit), pl = piece length
+    uint64_t pc[BG][6];
+    uint32_t pl[BG][6], lens[BG], blen[1] = { 0 };
+#pragma unroll
+    for (int c = 0; c < BG; c++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pc[c][k] = 0; pl[c][k] = 0; }
+        lens[c] = 0;
+        if (payload) {
+            const uint32_t rung = (rp_packed >> (4 * c)) & 15u, prung = (prp >> (4 * c)) & 15u, used = usedv[c];
+            const uint32_t delta = (rung - prung) & UMASK;
+            const uint32_t csl = cs_len<UB>(delta), csc = cs_code<UB>(delta);
+            if (used <= 1) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) bits |= ((gp[c][i >> 1] >> (16 * (i & 1))) & 1u) << i;
+                pc[c][0] = csc | (used << csl); pl[c][0] = csl + 1;
+                pc[c][1] = bits; pl[c][1] = used ? 16 : 0;
+                lens[c] = pl[c][0] + pl[c][1];
+            } else {
+                uint32_t g8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) g8[k] = gp[c][k];
+                if (STEP) {     // clear the rung bit of the last value of a 1..10..0 rung-bit run (reference QB3encode.h:169-176)
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) bits |= ((g8[i >> 1] >> (16 * (i & 1) + rung)) & 1u) << i;
+                    if ((bits & (bits + 1)) == 0) {
+                        const uint32_t n = __popc(bits) - 1;        // index of the value to change
+#pragma unroll
+                        for (int k = 0; k < 8; k++) if ((n >> 1) == (uint32_t)k) g8[k] ^= (1u << rung) << (16 * (n & 1));
+                    }
+                }
+                constexpr int first[7] = {0, 2, 5, 8, 11, 14, 16};  // piece k holds values first[k] .. first[k+1]-1
+                uint32_t lsum = 0;
+                if (rung <= 7) {                                     // all values below 256: the code table
+                    const uint32_t tb = etab_off + (8u << rung);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        uint32_t acc = 0, s = 0;
+#pragma unroll
+                        for (int i = first[k + 1] - 1; i >= first[k]; i--) {
+                            const uint32_t m = (g8[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                            const uint32_t e = *lds_at((m << 2) + tb);
+                            acc = (acc << (e & 31u)) | (e >> 8);
+                            s += e;
+                        }
+                        s &= 0xffu;
+                        uint64_t a64 = acc;
+                        if (k == 0) { a64 = (a64 << csl) | csc; s += csl; }
+                        pc[c][k] = a64; pl[c][k] = s; lsum += s;
+                    }
+                } else {                                             // the code rule (reference QB3encode.h:30-33), no swap above rung 7
+                    const uint32_t top = 1u << rung, half = top >> 1;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        uint64_t acc = 0;
+                        uint32_t s = 0;
+#pragma unroll
+                        for (int i = first[k + 1] - 1; i >= first[k]; i--) {
+                            const uint32_t m = (g8[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                            const bool c1 = m >= half, c2 = m >= top;
+                            const uint32_t code = c2 ? (((m - top) << 2) | 3u) : c1 ? (((m - half) << 2) | 1u) : (m << 1);
+                            const uint32_t len = rung + c1 + c2;
+                            acc = (acc << len) | code;
+                            s += len;
+                        }
+                        if (k == 0) { acc = (acc << csl) | csc; s += csl; }
+                        pc[c][k] = acc; pl[c][k] = s; lsum += s;
+                    }
+                }
+                lens[c] = lsum;
+            }
+            blen[0] += lens[c];
+        }
+    }
+    block_exscan_dpp<1>(blen, wsum);
+    const uint32_t pos = blen[0], total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+
+    if (payload) {
+        LdsWriter wr;
+        wr.init(outbuf, pos);
+#pragma unroll
+        for (int c = 0; c < BG; c++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) wr.put64(pc[c][k], pl[c][k]);
+        wr.finish();
+        if (gblk == nblocks - 1) {
+#pragma unroll
+            for (int c = 0; c < BG; c++) { a.res->prev[band0 + c] = lastv[c]; a.res->rung[band0 + c] = (rp_packed >> (4 * c)) & 15u; a.res->cf[band0 + c] = a0.st.cf[band0 + c]; }
+        }
+        if (a.have_idx) {
+            uint16_t *ul = (uint16_t *)a.idx.ulen + (uint64_t)gblk * B + band0;
+#pragma unroll
+            for (int c = 0; c < BG; c++) ul[c] = (uint16_t)lens[c];
+            const uint32_t seg = gblk / a.g.seg_blocks;
+            if (seg * a.g.seg_blocks == gblk) {
+#pragma unroll
+                for (int c = 0; c < BG; c++) {
+                    ((uint16_t *)a.idx.prev)[(uint64_t)seg * B + band0 + c] = (uint16_t)pvv[c];
+                    a.idx.rung[(uint64_t)seg * B + band0 + c] = (uint8_t)((prp >> (4 * c)) & 15u);
+                }
+                if (grp == 0) a.idx.bitpos[seg] = ((uint64_t)chunk << 32) | pos;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nd4 = (total + 127) >> 7;
+    uint4 *slotp = (uint4 *)(a.scratch + (uint64_t)chunk * a.slot_dw);
+    for (uint32_t d = tid; d < nd4; d += 256) slotp[d] = ((const uint4 *)outbuf)[d];
+    if (tid == 0) a.chunk_bits[chunk] = total;
+}
+
 // ------------------------------------------------------------------ common-factor + index coding (BEST)
 // Reference: encode_best (QB3encode.h:617-724), cfgenc (:283-361), ienc (:557-613).  A unit can be coded
 // plainly, as common factor times a smaller group, or as up to eight distinct values plus indices.  The only
@@ -1265,6 +1506,7 @@ struct DecArgs {
     uint32_t dpr;
     // unit-parallel kernel (dec3_kernel)
     uint32_t bpp, passes, in_cap_dw, magic_bpp, magic_dpr;
+    uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups (lanes) per block
     // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
     uint32_t ntiles;
     uint64_t ts_in, ts_img, ts_idx;
@@ -1764,7 +2006,6 @@ __global__ void dec3_kernel(const DecArgs a0) {
 //   * the three wave scans (bit positions, rung deltas and unit totals, the last two packed 16 bits per
 //     band) use DPP row shifts/broadcasts, no LDS.
 // The four rows go straight to HBM (B dwords per lane and row: 64 lanes write one contiguous run).
-typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add16(uint32_t x, uint32_t y) {       // two independent 16-bit adds (v_pk_add_u16)
     return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, x) + __builtin_bit_cast(u16x2_t, y)));
 }
@@ -1978,6 +2219,212 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     }
 }
 
+// ---- 16-bit: wave per index segment, lane per (block, band group) -- counterpart of enc_px16_kernel -------
+// Same organisation as dec_px_kernel; a lane decodes the BG <= 4 units of its band group.  Rungs up to 7 go through
+// the same table (values below 256), higher rungs decode by the code rule from a 64-bit buffer (three codes of at
+// most 17 bits per refill).  Lane = block * NG + group, i.e. stream order, so bit positions are one DPP scan; the
+// per-band scans (rung deltas, unit totals) run over the lanes of one group: DPP when NG = 1, a strided shuffle
+// scan otherwise.
+__device__ __forceinline__ uint32_t px16_switch(uint32_t pos, uint32_t *cslen, bool *signal) {
+    uint32_t x = lds_bits(pos);
+    *signal = false;
+    if (!(x & 1)) { *cslen = 1; return 0; }
+    x >>= 1;                                            // code at rung 3 (reference QB3decode.h:97-116)
+    uint32_t m, len;
+    if (!(x & 1)) { m = (x & 7) >> 1; len = 3; }
+    else if (!(x & 2)) { m = ((x >> 2) & 3) | 4; len = 4; }
+    else { m = ((x >> 2) & 7) | 8; len = 5; }
+    *cslen = 1 + len;
+    if (m == 14) { *signal = true; return 0; }
+    return (m & 1) ? (16 - (m + 1) / 2) & 15 : m / 2 + 1;
+}
+
+// 16 values of a 16-bit unit at bit `gpos`: rp[k] = running sums of values 2k, 2k+1 (16-bit lanes); returns the total
+template <bool STEP>
+__device__ __forceinline__ uint32_t px16_group(uint32_t gpos, uint32_t rung, uint32_t (&rp)[8]) {
+    if (rung < 8) return px_group<STEP>(gpos, rung, rp);     // values below 256: the table path of the 8-bit kernel
+    const uint32_t top = 1u << rung, half = top >> 1;
+    uint32_t pos = gpos, acc = 0, fl = 0;
+    uint64_t buf = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i % 3 == 0) {                               // three codes are at most 51 bits
+            LdsWords p = lds_at((pos >> 3) & ~3u);
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            buf = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, pos) << 32) | __builtin_amdgcn_alignbit(d1, d0, pos);
+        }
+        const uint32_t x = (uint32_t)buf;
+        const bool c1 = x & 1, c2 = (x & 3) == 3;
+        const uint32_t len = rung + c1 + c2;
+        const uint32_t v = c2 ? (((x >> 2) & (top - 1)) | top) : c1 ? (((x >> 2) & (half - 1)) | half) : ((x & (top - 1)) >> 1);
+        buf >>= len; pos += len;
+        acc += (v >> 1) ^ (0u - (v & 1u));              // undo mag-sign, accumulate (mod 2^16 in the packed lanes)
+        if (STEP) fl |= ((uint32_t)c2 | ((v & 1u) << 1)) << (2 * i);
+        if (i & 1) rp[i >> 1] |= acc << 16; else rp[i >> 1] = acc & 0xffffu;
+    }
+    if (STEP) {                                         // undo the step (reference QB3decode.h:285-289), as in px_group
+        const uint32_t tb = fl & 0x55555555u, u = tb | (tb << 1);
+        const uint32_t m = __popc(tb);
+        if ((u & (u + 1)) == 0 && m < 16) {
+            const uint32_t c16 = ((fl >> (2 * m + 1)) & 1u) ? (0u - half) & 0xffffu : half;
+            const uint32_t ge = 0xffff0000u >> (16 - m);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t pair = (ge >> (2 * k)) & 3u;
+                rp[k] = pk_add16(rp[k], ((pair | (pair << 15)) & 0x00010001u) * c16);
+            }
+            acc += c16;
+        }
+    }
+    return acc;
+}
+
+// inclusive scan over the lanes of the same band group (stride NG), NW words per lane
+template <int NW>
+__device__ __forceinline__ void group_iscan(uint32_t (&v)[NW], uint32_t NG) {
+    if (NG == 1) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) v[k] = wave_iscan32(v[k]);
+        return;
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t d = NG; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const uint32_t y = __shfl_up(v[k], d, 64);
+            if (lane >= d) v[k] += y;
+        }
+    }
+}
+
+template <int BG, bool RGB, uint64_t ORDER, bool STEP>
+__global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int NW = (BG + 1) / 2;                    // 32-bit words of a scan packed 16 bits per band
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t NB = a.g.seg_blocks, nbx = a.g.nbx, B = a.g.bands, NG = a.px_ng;    // NB * NG <= 64
+    const uint64_t stride = a.g.stride;                 // in values
+    const uint32_t slot = fastdiv(lane, NG, a.px_magic_ng), grp = lane - slot * NG, band0 = grp * BG;
+
+    uint32_t *tab = (uint32_t *)smem;                   // 4 KB, at LDS address 0 (the table addressing relies on it)
+    uint32_t *stage = tab + 1024 + wave * (a.in_cap_dw + 16);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
+    const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
+    for (uint32_t i = tid; i < 256; i += blockDim.x) ((uint4 *)tab)[i] = ((const uint4 *)px_dec_tab.e)[i];
+    __syncthreads();                                    // the only workgroup barrier
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    if (seg >= a.g.nseg) return;
+    const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
+    const bool act = slot < nb_here;
+
+    const uint64_t P0 = a.idx.bitpos[seg];
+    const uint64_t P1 = (seg + 1 < a.g.nseg) ? a.idx.bitpos[seg + 1] : a.in_bits;
+    const uint64_t w0 = (a.in_bit0 + P0) >> 5;
+    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
+    const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0;
+    const bool fits = ndw64 <= a.in_cap_dw && lds0 == 0;
+    const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
+    for (uint32_t i = lane; i < ndw + 16; i += 64) stage[i] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;   // 16 zero words follow
+    uint32_t ul_[BG], blen = 0;
+    {
+        const uint16_t *ul = (const uint16_t *)a.idx.ulen + ((uint64_t)g0 + slot) * B + band0;
+#pragma unroll
+        for (int c = 0; c < BG; c++) { ul_[c] = act ? ul[c] : 0u; blen += ul_[c]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const uint32_t limit = stage_bit0 + 32 * ndw;
+    const uint32_t cpos = stage_bit0 + (uint32_t)(a.in_bit0 + P0 - 32 * w0);
+    bool bad = !fits;
+    const uint32_t binc = wave_iscan32(blen);           // lanes are in stream order
+    uint32_t gpos[BG], pos = cpos + binc - blen, dpk[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) dpk[k] = 0;
+#pragma unroll
+    for (int c = 0; c < BG; c++) {
+        pos = pos < limit ? pos : limit;
+        bool sig; uint32_t csl;
+        const uint32_t d = px16_switch(pos, &csl, &sig);
+        gpos[c] = pos + csl;
+        if (act && sig && STEP) bad = true;             // common-factor / index unit: not handled here
+        dpk[c >> 1] |= (act ? d : 0u) << (16 * (c & 1));
+        pos += ul_[c];
+    }
+    group_iscan<NW>(dpk, NG);                           // inclusive, 16 bits per band
+    uint32_t rp[BG][8], spk[NW], sinc[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) spk[k] = 0;
+#pragma unroll
+    for (int c = 0; c < BG; c++) {
+        const uint32_t rung = ((uint32_t)a.idx.rung[seg * B + band0 + c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 15u;
+        const uint32_t tot = px16_group<STEP>(gpos[c], rung, rp[c]) & 0xffffu;
+        spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
+    }
+    {   // per-band scan of the unit totals modulo 2^16: the two halves of a word must not carry into each other
+        uint32_t lo[NW], hi[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) { lo[k] = spk[k] & 0xffffu; hi[k] = spk[k] >> 16; }
+        group_iscan<NW>(lo, NG);
+        group_iscan<NW>(hi, NG);
+#pragma unroll
+        for (int k = 0; k < NW; k++) sinc[k] = (lo[k] & 0xffffu) | (hi[k] << 16);
+    }
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < BG; c++) {
+            const uint32_t excl = ((sinc[c >> 1] >> (16 * (c & 1))) - (spk[c >> 1] >> (16 * (c & 1)))) & 0xffffu;
+            const uint32_t pv = ((uint32_t)((const uint16_t *)a.idx.prev)[seg * B + band0 + c] + excl) & 0xffffu;
+#pragma unroll
+            for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], pv * 0x00010001u);
+        }
+#pragma unroll
+        for (int c = 0; c < BG; c++) {
+            const int cb = core_of<BG, RGB>(c);
+            if (cb != c)
+#pragma unroll
+                for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], rp[cb][k]);
+        }
+        const uint32_t g = g0 + slot, by = g / nbx, bx = g - by * nbx;
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        uint16_t *p0 = (uint16_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B + band0;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            uint16_t *rowp = p0 + (uint64_t)y * stride;
+            uint32_t ow[2 * BG];
+#pragma unroll
+            for (int j = 0; j < 2 * BG; j++) {          // halfwords 2j, 2j+1 of the lane's row: band h % BG of pixel h / BG
+                const int h0 = 2 * j, h1 = 2 * j + 1;
+                const int i0 = curve_pos_of(ORDER, h0 / BG, y), i1 = curve_pos_of(ORDER, h1 / BG, y);
+                const uint32_t sel = (uint32_t)(2 * (i0 & 1)) | (uint32_t)(2 * (i0 & 1) + 1) << 8 |
+                                     (uint32_t)(4 + 2 * (i1 & 1)) << 16 | (uint32_t)(4 + 2 * (i1 & 1) + 1) << 24;
+                ow[j] = __builtin_amdgcn_perm(rp[h1 % BG][i1 >> 1], rp[h0 % BG][i0 >> 1], sel);
+            }
+            if (BG % 2 == 0) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    uint32_t *q = (uint32_t *)(rowp + (uint64_t)x * B);
+#pragma unroll
+                    for (int d = 0; d < BG / 2; d++) q[d] = ow[x * (BG / 2) + d];
+                }
+            } else {
+                uint32_t *q = (uint32_t *)rowp;
+#pragma unroll
+                for (int k = 0; k < 2 * BG; k++) q[k] = ow[k];
+            }
+        }
+    }
+    if (bad) atomicOr(a.status, fits ? 1u : 8u);
+    if (lane == 63 && seg == a.g.nseg - 1 && fits) {
+        const uint64_t used = (uint64_t)(cpos + binc - stage_bit0) + 32 * w0 - a.in_bit0;
+        if (used > a.in_bits) atomicOr(a.status, 4u);
+        else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
+}
+
 // Foreign stream: ONE lane walks the stream and rebuilds the index (bit position + band state at every
 // segment start).  Latency bound by construction.
 template <typename T, int MODE>
@@ -2102,6 +2549,12 @@ static void fast_geometry(uint32_t bands, uint32_t tsz, uint32_t *threads, uint3
 }
 // Blocks per index segment.  A function of stream-intrinsic properties only (bands, value size, mode): encoder
 // and decoder must agree on it whatever their strides, band maps or buffer alignments are.
+// 16-bit lane-per-block kernels: bands = ng x bg, bg <= 4 bands per lane (0: no such split)
+static void px16_split(uint32_t B, uint32_t *bg, uint32_t *ng) {
+    *bg = B <= 4 ? B : (B % 4 == 0) ? 4 : (B % 2 == 0) ? 2 : 0;
+    *ng = *bg ? B / *bg : 0;
+}
+
 uint32_t seg_blocks_for(const Geometry &g) {
     if (g.mode != CM_BEST) {      // one segment = the blocks of one decoder workgroup, at most 256
         static const uint32_t knob = [] { const char *e = getenv("QB3_SEG_BLOCKS"); int k = e ? atoi(e) : 0; return (uint32_t)(k < 0 ? 0 : k); }();
@@ -2109,6 +2562,11 @@ uint32_t seg_blocks_for(const Geometry &g) {
         // 8-bit grey/RGB/RGBA: the lane-per-block decoder gives a segment to a WAVE (a function of type and band
         // count only: encoder and decoder must agree whatever kernel either of them ends up using)
         if (g.tsz == 1 && (g.bands == 1 || g.bands == 3 || g.bands == 4)) return 64;
+        if (g.tsz == 2) {       // 16-bit: a wave = 64 lanes of (block, band group)
+            uint32_t bg, ng;
+            px16_split(g.bands, &bg, &ng);
+            if (bg) return 64 / ng;
+        }
         uint32_t threads, bpp, passes;
         fast_geometry(g.bands, g.tsz, &threads, &bpp, &passes);
         while (passes > 1 && bpp * passes > 256) passes--;
@@ -2185,15 +2643,44 @@ static bool px_eligible(const Geometry &g, bool *rgb) {
     return (ident || def) && !getenv("QB3_NO_PX");
 }
 
+// 16-bit lane-per-(block, band group) kernels: bands = NG x BG with BG <= 4; a group must be whole dwords per
+// pixel unless it is the whole pixel (BG = bands = 1 or 3)
+static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *ng) {
+    if (g.tsz != 2 || g.mode == CM_BEST || getenv("QB3_NO_PX")) return false;
+    if ((g.w & 3) || (g.stride & 1) || g.h < 4) return false;
+    if (g.order != HILBERT && g.order != ZCURVE) return false;
+    const uint32_t B = g.bands;
+    px16_split(B, bg, ng);
+    if (!*bg) return false;
+    bool ident = true, def = B == 3 || B == 4;
+    for (uint32_t c = 0; c < B; c++) {
+        ident = ident && g.cband[c] == c;
+        def = def && g.cband[c] == ((c == 0 || c == 2) ? 1u : c);
+    }
+    *rgb = def && !ident;
+    return ident || def;
+}
+
 EncPlan plan_encode(const Geometry &g) {
     EncPlan p;
     const uint32_t dpr = g.bands * g.tsz;
     p.px = px_eligible(g, &p.px_rgb);
+    p.px16 = false; p.px16_bg = p.px16_ng = 0;
     if (p.px) {
         p.threads = 256; p.slots = 256; p.nbp = 255;
         p.nchunks = (uint32_t)((g.nblocks + 254) / 255);
         const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp);
         p.lds_bytes = 2048 + 256 + 4 * (size_t)L.slot_dw;
+        p.ws_bytes = L.total;
+        return p;
+    }
+    bool rgb16 = false;
+    if (px16_eligible(g, &rgb16, &p.px16_bg, &p.px16_ng)) {
+        p.px16 = true; p.px_rgb = rgb16;
+        p.threads = 256; p.slots = 256 / p.px16_ng; p.nbp = p.slots - 1;
+        p.nchunks = (uint32_t)((g.nblocks + p.nbp - 1) / p.nbp);
+        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp);
+        p.lds_bytes = 2048 + 256 + 1024 + 4 * (size_t)L.slot_dw;
         p.ws_bytes = L.total;
         return p;
     }
@@ -2219,6 +2706,23 @@ static void launch_enc_px_b(const EncArgs &a, const EncPlan &plan, hipStream_t s
     else if (!z && step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_bytes, st, a);
     else if (z && !step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, ZCURVE, false>), grid, block, plan.lds_bytes, st, a);
     else hipLaunchKernelGGL((enc_px_kernel<B, RGB, ZCURVE, true>), grid, block, plan.lds_bytes, st, a);
+}
+template <int BG, bool RGB>
+static void launch_enc_px16_b(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
+    dim3 grid(plan.nchunks, a.ntiles), block(256);
+    if (!z && !step) hipLaunchKernelGGL((enc_px16_kernel<BG, RGB, HILBERT, false>), grid, block, plan.lds_bytes, st, a);
+    else if (!z && step) hipLaunchKernelGGL((enc_px16_kernel<BG, RGB, HILBERT, true>), grid, block, plan.lds_bytes, st, a);
+    else if (z && !step) hipLaunchKernelGGL((enc_px16_kernel<BG, RGB, ZCURVE, false>), grid, block, plan.lds_bytes, st, a);
+    else hipLaunchKernelGGL((enc_px16_kernel<BG, RGB, ZCURVE, true>), grid, block, plan.lds_bytes, st, a);
+}
+static void launch_enc_px16(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    switch (plan.px16_bg) {
+    case 1: launch_enc_px16_b<1, false>(a, plan, st); break;
+    case 2: launch_enc_px16_b<2, false>(a, plan, st); break;
+    case 3: if (plan.px_rgb) launch_enc_px16_b<3, true>(a, plan, st); else launch_enc_px16_b<3, false>(a, plan, st); break;
+    default: if (plan.px_rgb) launch_enc_px16_b<4, true>(a, plan, st); else launch_enc_px16_b<4, false>(a, plan, st); break;
+    }
 }
 static void launch_enc_px(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     if (a.g.bands == 1) launch_enc_px_b<1, false>(a, plan, st);
@@ -2247,6 +2751,9 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
     } else if (plan.px && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0) {
         ProfScope ps("enc_units", st);
         launch_enc_px(a, plan, st);
+    } else if (plan.px16 && sizeof(T) == 2 && ((uintptr_t)a.img & 3) == 0) {
+        ProfScope ps("enc_units", st);
+        launch_enc_px16(a, plan, st);
     } else {
         ProfScope ps("enc_units", st);
         if (step) hipLaunchKernelGGL((enc_kernel<T, true>), grid, block, plan.lds_bytes, st, a);
@@ -2292,6 +2799,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.scratch = (uint32_t *)(w + L.scratch);
     a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry);
     a.slot_dw = L.slot_dw;
+    a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.res = (EncResult *)(w + L.res);
     a.st = st_in;
     a.have_idx = index != nullptr;
@@ -2349,6 +2857,12 @@ DecPlan plan_decode(const Geometry &g) {
     p.px_cap_dw = (uint32_t)(((size_t)NB * g.bands * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
     p.px = p.px && NB <= 64;
     p.lds_px = 4096 + 4 * 4 * ((size_t)p.px_cap_dw + 8);       // table + four waves' staging
+    p.px16 = false; p.px16_bg = p.px16_ng = 0;
+    bool rgb16 = false;
+    if (!p.px && p.fast && px16_eligible(g, &rgb16, &p.px16_bg, &p.px16_ng) && NB * p.px16_ng <= 64) {
+        p.px16 = true; p.px_rgb = rgb16;
+        p.lds_px = 4096 + 4 * 4 * ((size_t)p.px_cap_dw + 16);
+    }
     return p;
 }
 
@@ -2360,6 +2874,23 @@ static void launch_dec_px_b(const DecArgs &a, const DecPlan &plan, hipStream_t s
     else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);
     else if (z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, false>), grid, block, plan.lds_px, st, a);
     else hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, true>), grid, block, plan.lds_px, st, a);
+}
+template <int BG, bool RGB>
+static void launch_dec_px16_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
+    const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
+    dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
+    if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, false>), grid, block, plan.lds_px, st, a);
+    else if (!z && step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);
+    else if (z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, ZCURVE, false>), grid, block, plan.lds_px, st, a);
+    else hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, ZCURVE, true>), grid, block, plan.lds_px, st, a);
+}
+static void launch_dec_px16(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
+    switch (plan.px16_bg) {
+    case 1: launch_dec_px16_b<1, false>(a, plan, st); break;
+    case 2: launch_dec_px16_b<2, false>(a, plan, st); break;
+    case 3: if (plan.px_rgb) launch_dec_px16_b<3, true>(a, plan, st); else launch_dec_px16_b<3, false>(a, plan, st); break;
+    default: if (plan.px_rgb) launch_dec_px16_b<4, true>(a, plan, st); else launch_dec_px16_b<4, false>(a, plan, st); break;
+    }
 }
 static void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     if (a.g.bands == 1) launch_dec_px_b<1, false>(a, plan, st);
@@ -2376,6 +2907,9 @@ static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild,
     if (plan.px && MODE != CM_BEST && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0) {
         ProfScope ps("dec_units", st);
         launch_dec_px(a, plan, st);
+    } else if (plan.px16 && MODE != CM_BEST && sizeof(T) == 2 && ((uintptr_t)a.img & 3) == 0) {
+        ProfScope ps("dec_units", st);
+        launch_dec_px16(a, plan, st);
     } else if (plan.fast && MODE != CM_BEST) {
         ProfScope ps("dec_units", st);
         hipLaunchKernelGGL((dec3_kernel<T, MODE == CM_BASE>), dim3((uint32_t)a.g.nseg, a.ntiles), dim3(plan.threads2), plan.lds2_bytes, st, a);
@@ -2412,7 +2946,8 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
     HIPCHK(hipMemsetAsync(a.status, 0, status_bytes, st));
     a.lane_dw = dec_lane_dwords(g);
     a.dpr = g.bands * g.tsz;
-    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = plan.px ? plan.px_cap_dw : plan.in_cap_dw;
+    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16) ? plan.px_cap_dw : plan.in_cap_dw;
+    a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;
     switch (g.tsz) {

@@ -55,6 +55,23 @@ CASES = [
     (1024, 64, 3, 0, "NOISY3", 6),
     (2048, 8, 4, 0, "RANDOM", 7),
     (4096, 12, 1, 0, "GRAD", 0),
+    # 16-bit with width % 4 == 0 and 1-4 bands or an even band count take the lane-per-(block, band group) kernels:
+    # every group shape (1, 2, 3, 4 bands per lane; 1, 2, 3, 4, 8 lanes per block), rungs below and above 8,
+    # signed data, shifted last rows, several chunks
+    (256, 37, 1, 2, "LANDSAT16", 3),
+    (512, 64, 2, 2, "LANDSAT16", 4),
+    (256, 50, 3, 2, "LANDSAT16", 5),
+    (256, 64, 4, 3, "DEM", 6),
+    (128, 44, 6, 2, "NOISY3", 7),
+    (512, 128, 8, 2, "LANDSAT16", 3),
+    (64, 36, 12, 3, "DEM", 8),
+    (128, 20, 16, 2, "RANDOM", 9),
+    (1024, 16, 3, 2, "RANDOM", 10),
+    (256, 256, 4, 2, "NOISY3", 11),
+    (64, 64, 2, 3, "TERRACE", 4),
+    (128, 64, 3, 2, "CONST", 0),
+    (96, 32, 10, 2, "FEW", 5),
+    (64, 20, 14, 2, "PALETTE", 6),
 ]
 
 
