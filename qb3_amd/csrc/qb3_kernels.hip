@@ -891,12 +891,14 @@ __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
     for (int c = 0; c < BG; c++) {
         const int cb = core_of<BG, RGB>(c);
         uint32_t prv;
+        // the R-G, G, B-G map applies to the first three bands of the image: group 0 only
+        const bool diff = cb != c && grp == 0;
         if (gblk == 0) prv = (uint32_t)a0.st.prev[band0 + c] & 0xffffu;
-        else prv = (cb != c) ? (pvals[c] - pvals[cb]) & 0xffffu : pvals[c];
+        else prv = diff ? (pvals[c] - pvals[cb]) & 0xffffu : pvals[c];
         pvv[c] = prv;
         uint32_t x[8], u = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = (cb != c) ? pk_sub16(cur[c][k], cur[cb][k]) : cur[c][k];
+        for (int k = 0; k < 8; k++) x[k] = (cb != c) ? pk_sub16(cur[c][k], diff ? cur[cb][k] : 0u) : cur[c][k];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t before = k ? __builtin_amdgcn_alignbit(x[k], x[k - 1], 16) : ((x[0] << 16) | prv);
@@ -2384,9 +2386,9 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
 #pragma unroll
         for (int c = 0; c < BG; c++) {
             const int cb = core_of<BG, RGB>(c);
-            if (cb != c)
+            if (cb != c)        // the R-G, G, B-G map applies to the first three bands of the image: group 0 only
 #pragma unroll
-                for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], rp[cb][k]);
+                for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], grp == 0 ? rp[cb][k] : 0u);
         }
         const uint32_t g = g0 + slot, by = g / nbx, bx = g - by * nbx;
         const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
@@ -2652,7 +2654,8 @@ static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *
     const uint32_t B = g.bands;
     px16_split(B, bg, ng);
     if (!*bg) return false;
-    bool ident = true, def = B == 3 || B == 4;
+    // identity, or R-G, G, B-G on the first three bands (they must sit in one lane: 3 or 4 bands per group)
+    bool ident = true, def = *bg >= 3;
     for (uint32_t c = 0; c < B; c++) {
         ident = ident && g.cband[c] == c;
         def = def && g.cband[c] == ((c == 0 || c == 2) ? 1u : c);

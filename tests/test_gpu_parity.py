@@ -489,3 +489,18 @@ def test_cli_raw_and_errors(qb3, oracle, tmp_path):
         assert r.returncode == 0 and (tmp_path / "t.raw").read_bytes() == ref.tobytes()
     (tmp_path / "l.qb3").write_bytes(got.tobytes() + b"\0\0")      # two spare bytes at the end: over-long, fails
     assert _cli("-d", "-s", tmp_path / "l.qb3", tmp_path / "l.raw").returncode == 1
+
+
+@pytest.mark.parametrize("mode", [FTL, BASE, BASE_Z])
+@pytest.mark.parametrize("case", [(256, 64, 8, 2, "LANDSAT16", 3, [1, 1, 1, 3, 4, 5, 6, 7]), (128, 36, 12, 3, "DEM", 5, [1, 1, 1] + list(range(3, 12))),
+                                  (64, 64, 16, 2, "NOISY3", 6, [1, 1, 1] + list(range(3, 16))), (128, 64, 4, 2, "LANDSAT16", 7, [1, 1, 1, 3]),
+                                  (128, 64, 8, 2, "LANDSAT16", 8, [0, 1, 2, 3, 5, 5, 5, 7]), (64, 32, 6, 2, "LANDSAT16", 9, [1, 1, 1, 3, 4, 5])],
+                         ids=lambda c: "%dx%dx%d-t%d" % c[:4] if isinstance(c, tuple) else None)
+def test_band_maps_on_multiband_16bit(qb3, oracle, case, mode):
+    """SURVEY.md B-1 recommends {1,1,1,3,4,5,6,7} for the 8-band configuration: R-G,G,B-G on the first three bands
+    inside a 16-bit band group takes the lane-per-block kernels, other maps the generic ones; all must match"""
+    w, h, b, dt, gen, seed, cband = case
+    img = oracle.generate(w, h, b, dt, gen, seed)
+    ref = check_encode(qb3, oracle, img, dt, mode, cband=cband)
+    out, dims, dtype, m = qb3.decode(ref)
+    assert np.array_equal(out, img.view(np.uint8).ravel())
