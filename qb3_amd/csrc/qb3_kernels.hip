@@ -1509,6 +1509,7 @@ struct DecArgs {
     // unit-parallel kernel (dec3_kernel)
     uint32_t bpp, passes, in_cap_dw, magic_bpp, magic_dpr;
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups (lanes) per block
+    uint32_t totals_only;           // lane-per-block kernels: write the segments' per-band sums to idx.prev, no pixels
     // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
     uint32_t ntiles;
     uint64_t ts_in, ts_img, ts_idx;
@@ -2175,6 +2176,13 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     }
 #pragma unroll
     for (int k = 0; k < NW; k++) sinc[k] = wave_iscan32(spk[k]);
+    if (a.totals_only) { // foreign stream, first pass: leave the segment's per-band sums where the entering values go
+        if (lane == 63)
+#pragma unroll
+            for (int c = 0; c < B; c++) ((uint8_t *)a.idx.prev)[seg * B + c] = (uint8_t)(sinc[c >> 1] >> (16 * (c & 1)));
+        if (bad) atomicOr(a.status, fits ? 1u : 8u);
+        return;
+    }
     if (act) {
         // entering value, then the core band (reference QB3decode.h:560-567)
 #pragma unroll
@@ -2375,6 +2383,13 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
 #pragma unroll
         for (int k = 0; k < NW; k++) sinc[k] = (lo[k] & 0xffffu) | (hi[k] << 16);
     }
+    if (a.totals_only) { // foreign stream, first pass: the last lane of every band group holds the group's sums
+        if (lane >= 64 - NG)
+#pragma unroll
+            for (int c = 0; c < BG; c++) ((uint16_t *)a.idx.prev)[seg * B + band0 + c] = (uint16_t)(sinc[c >> 1] >> (16 * (c & 1)));
+        if (bad) atomicOr(a.status, fits ? 1u : 8u);
+        return;
+    }
     if (act) {
 #pragma unroll
         for (int c = 0; c < BG; c++) {
@@ -2424,6 +2439,133 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
         const uint64_t used = (uint64_t)(cpos + binc - stage_bit0) + 32 * w0 - a.in_bit0;
         if (used > a.in_bits) atomicOr(a.status, 4u);
         else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
+}
+
+// ---- foreign streams, 8/16-bit FTL/BASE: rebuild the index without decoding values --------------------------
+// The stream has no restart points, so unit positions can only be found by walking it; what CAN be parallel is
+// everything else.  dec_walk_kernel walks unit LENGTHS only (a code's length is its rung plus what its low two bits
+// say, reference QB3decode.h:119-129): one wave per tile, the stream staged through LDS in windows by all lanes,
+// then every lane runs the same walk (uniform control flow and LDS broadcast reads; the next stream word is always
+// already in a register).  It writes the per-unit lengths and each segment's bit position and rungs.  The values
+// entering the segments then come from the parallel decoder itself: one pass in TOTALS mode leaves every segment's
+// per-band sum in idx.prev, prev_scan_kernel turns the sums into exclusive prefixes, the normal pass follows.
+template <uint32_t UB>
+__global__ void __launch_bounds__(64) dec_walk_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    constexpr uint32_t WIN = 4096, UMASK = (1u << UB) - 1, NRUNG = 1u << UB;
+    constexpr uint32_t MAXU = UB + 2 + 16 * ((8u << (UB - 3)) + 1);    // longest unit: 149 bits (8-bit), 278 (16-bit)
+    static_assert(MAXU == (UB == 3 ? 149u : 278u), "unit length bound");
+    __shared__ uint32_t win[WIN + 4];
+    const uint32_t lane = threadIdx.x, B = a.g.bands, NB = a.g.seg_blocks, nblocks = (uint32_t)a.g.nblocks;
+    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
+    uint64_t R = 0;                         // current rungs, 4 bits per band
+    uint64_t P = a.in_bit0;                 // bit position, from a.in32
+    P = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)P);       // < 32
+    uint32_t gb = 0, inseg = 0;
+    uint64_t seg = 0;
+    bool bad = false;
+    while (gb < nblocks) {
+        const uint64_t w0 = P >> 5;         // stage the window that starts in the word of P
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < WIN + 4; i += 64) win[i] = (w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // bit reader over the window: 64-bit buffer, the next word prefetched
+        // (readfirstlane: the words are the same in every lane -- keep the whole walk in scalar registers, a dependent
+        // scalar instruction issues twice as fast as a dependent vector one)
+        uint32_t wp = (uint32_t)(P - 32 * w0) >> 5;
+        const uint32_t sh = (uint32_t)P & 31;
+        uint64_t buf = (uint64_t)((uint32_t)__builtin_amdgcn_readfirstlane(win[wp]) >> sh);     // the builtin returns int
+        uint32_t n = 32 - sh;
+        // the next word is requested one refill ahead and only moved to a scalar register when it is consumed, so the
+        // LDS latency is off the walk
+        uint32_t nxt_v = win[++wp];
+        auto refill = [&]() {
+            if (n <= 32) { buf |= (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(nxt_v) << n; n += 32; nxt_v = win[++wp]; }   // wp <= WIN + 3 by the loop bound
+        };
+        // walk whole blocks while the longest possible block still fits in the window
+        while (gb < nblocks && 32 * wp + B * MAXU + 64 <= 32 * WIN) {
+            if (inseg == 0) {
+                if (lane == 0) {
+                    a.idx.bitpos[seg] = 32 * (w0 + wp) - n - a.in_bit0;
+                    for (uint32_t c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)((R >> (4 * c)) & 15u);
+                }
+                seg++;
+            }
+            if (++inseg == NB) inseg = 0;
+            for (uint32_t c = 0; c < B; c++) {
+                refill();                                   // >= 33 bits: the switch code is at most UB + 2
+                uint32_t x = (uint32_t)buf, ulen;
+                uint32_t rung = (uint32_t)(R >> (4 * c)) & 15u;
+                if (!(x & 1)) ulen = 1;
+                else {                                      // code at rung UB - 1 (reference QB3decode.h:97-116)
+                    constexpr uint32_t r = UB - 1, half = 1u << (r - 1), top = 1u << r;
+                    x >>= 1;
+                    uint32_t m, len;
+                    if (!(x & 1)) { m = (x & (top - 1)) >> 1; len = r; }
+                    else if (!(x & 2)) { m = ((x >> 2) & (half - 1)) | half; len = r + 1; }
+                    else { m = ((x >> 2) & (top - 1)) | top; len = r + 2; }
+                    ulen = 1 + len;
+                    if (m == NRUNG - 2) bad = true;         // signal: a common-factor stream, not for this walker
+                    const uint32_t delta = (m & 1) ? (NRUNG - (m + 1) / 2) & UMASK : m / 2 + 1;
+                    rung = (rung + delta) & UMASK;
+                    R = (R & ~(15ull << (4 * c))) | ((uint64_t)rung << (4 * c));
+                }
+                buf >>= ulen; n -= ulen;
+                if (rung == 0) {                            // one flag, then 16 raw bits
+                    refill();
+                    const uint32_t l = ((uint32_t)buf & 1) ? 17 : 1;
+                    buf >>= l; n -= l; ulen += l;
+                } else {
+                    uint32_t glen = 0;
+                    const uint32_t kr = rung * 0x01010101u + 0x02000100u;    // code length by the low two bits: r, r+1, r, r+2
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        if (UB == 3 ? (i % 3 == 0) : true) refill();     // 3 x 9 bits, or one code of up to 17
+                        const uint32_t len = (kr >> (((uint32_t)buf & 3u) << 3)) & 0xffu;
+                        buf >>= len; n -= len; glen += len;
+                    }
+                    ulen += glen;
+                }
+                if (lane == 0) {
+                    if (UB == 3) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * B + c] = (uint8_t)ulen;
+                    else ((uint16_t *)a.idx.ulen)[(uint64_t)gb * B + c] = (uint16_t)ulen;
+                }
+            }
+            gb++;
+        }
+        P = 32 * (w0 + wp) - n;
+    }
+    if (bad && lane == 0) atomicOr(a.status, 1u);
+}
+
+// idx.prev holds every segment's per-band sum of values: make it the value entering the segment (exclusive prefix,
+// modulo the value width; a stream starts from zero).  One workgroup per tile.
+template <typename T>
+__global__ void __launch_bounds__(1024) prev_scan_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, B = a.g.bands;
+    const uint64_t nseg = a.g.nseg, per = (nseg + 1023) / 1024;
+    const uint64_t s0 = (uint64_t)tid * per, s1 = (s0 + per < nseg) ? s0 + per : nseg;
+    T *prev = (T *)a.idx.prev;
+    for (uint32_t c = 0; c < B; c++) {
+        uint32_t sum = 0;
+        for (uint64_t s = s0; s < s1; s++) sum += prev[s * B + c];
+        part[tid] = sum;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {           // inclusive scan of the partial sums
+            const uint32_t y = tid >= d ? part[tid - d] : 0u;
+            __syncthreads();
+            part[tid] += y;
+            __syncthreads();
+        }
+        uint32_t run = part[tid] - sum;
+        for (uint64_t s = s0; s < s1; s++) { const uint32_t t = prev[s * B + c]; prev[s * B + c] = (T)run; run += t; }
+        __syncthreads();
     }
 }
 
@@ -2903,7 +3045,23 @@ static void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st)
 
 template <typename T, int MODE>
 static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st) {
-    if (rebuild) {
+    const bool use_px = plan.px && MODE != CM_BEST && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0;
+    const bool use_px16 = plan.px16 && MODE != CM_BEST && sizeof(T) == 2 && ((uintptr_t)a.img & 3) == 0;
+    if (rebuild && (use_px || use_px16) && !getenv("QB3_SLOW_INDEX")) {
+        // foreign stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
+        // produce the values entering the segments (totals pass + scan)
+        {
+            ProfScope ps("dec_index_serial", st);
+            if (sizeof(T) == 1) hipLaunchKernelGGL(dec_walk_kernel<3>, dim3(a.ntiles), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(dec_walk_kernel<4>, dim3(a.ntiles), dim3(64), 0, st, a);
+        }
+        ProfScope ps("dec_index_prev", st);
+        DecArgs t = a;
+        t.totals_only = 1;
+        if (use_px) launch_dec_px(t, plan, st); else launch_dec_px16(t, plan, st);
+        if (sizeof(T) == 1) hipLaunchKernelGGL(prev_scan_kernel<uint8_t>, dim3(a.ntiles), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL(prev_scan_kernel<uint16_t>, dim3(a.ntiles), dim3(1024), 0, st, a);
+    } else if (rebuild) {
         ProfScope ps("dec_index_serial", st);
         hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(a.ntiles), dim3(64), 0, st, a);
     }
@@ -2951,6 +3109,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
     a.dpr = g.bands * g.tsz;
     a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16) ? plan.px_cap_dw : plan.in_cap_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
+    a.totals_only = 0;
     a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;
     switch (g.tsz) {
