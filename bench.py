@@ -34,8 +34,8 @@ ANCHOR_C2 = 434747055       # reference stream size for 16384x16384x3 NOISY3 see
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=16384, help="raster edge in pixels (default: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -97,8 +97,10 @@ def main():
     if rank == 0 and args.size == 16384 and nbytes != ANCHOR_C2:
         sys.exit(f"bench.py: stream is {nbytes} bytes, the reference produces {ANCHOR_C2} -- not bit-identical")
 
+    # HIP events around the long kernels only inside the timed region (level 2): an event pair costs more than the
+    # microsecond kernels take; those are timed in two extra, untimed steps afterwards
     qdev.profile_reset()
-    qdev.profile_enable(True)
+    qdev.profile_enable(2)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -106,11 +108,23 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     qdev.profile_enable(False)
+    timed_kernels = set(qdev.profile_report())
+    qdev.profile_enable(1)
+    prof_small = {}
+    before = qdev.profile_report()
+    for _ in range(2):
+        step()
+    fence()
+    qdev.profile_enable(False)
+    for name, (ms, cnt) in qdev.profile_report().items():
+        if name not in timed_kernels:
+            prof_small[name] = (ms, cnt)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    prof = qdev.profile_report()
+    prof = dict(before)             # the long kernels: exactly what the timed region saw
+    prof.update(prof_small)         # the microsecond kernels: from the two untimed steps
 
     # ---- the workload's only exchange: containers to rank 0 (variable-size gather), timed on its own
     gather = None
@@ -136,7 +150,8 @@ def main():
     kernels = {}
     for name, (ms, cnt) in prof.items():
         avg = ms / max(cnt, 1)
-        kernels[name] = {"avg_ms": round(avg, 4), "launches": int(cnt), "GBps_algorithmic": round(algo_bytes / avg / 1e6, 1) if avg > 0 else None}
+        kernels[name] = {"avg_ms": round(avg, 4), "launches": int(cnt), "GBps_algorithmic": round(algo_bytes / avg / 1e6, 1) if avg > 0 else None,
+                         "in_timed_region": name in timed_kernels}
     enc_ms = sum(kernels[k]["avg_ms"] for k in ("enc_units", "enc_scan", "enc_concat", "enc_seams") if k in kernels)
     dec_ms = sum(kernels[k]["avg_ms"] for k in ("dec_index_serial", "dec_segments", "dec_units") if k in kernels)
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None

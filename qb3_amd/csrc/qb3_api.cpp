@@ -809,7 +809,7 @@ QB3_API int qb3x_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 QB3_API const char *qb3x_last_error(void) { return last_error(); }
-QB3_API void qb3x_profile_enable(int on) { prof_enable(on != 0); }
+QB3_API void qb3x_profile_enable(int level) { prof_enable(level < 0 ? 0 : level); }
 QB3_API void qb3x_profile_reset(void) { prof_reset(); }
 QB3_API int qb3x_profile_get(const char *kernel, double *total_ms, uint64_t *count) { return prof_get(kernel, total_ms, count) ? 1 : 0; }
 QB3_API int qb3x_profile_names(char *buf, size_t bufsize) { return prof_names(buf, bufsize); }

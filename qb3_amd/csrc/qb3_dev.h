@@ -123,7 +123,7 @@ int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, ui
 int launch_dequantize(void *img, const Geometry &g, int dtype, uint64_t q, void *stream);
 
 // Optional per-kernel timing with HIP events recorded on the launch stream (off by default).
-void prof_enable(bool on);
+void prof_enable(int level);        // 0 off, 1 every kernel, 2 the long kernels only (less event traffic)
 void prof_reset();
 void prof_collect();                                    // call after the stream was synchronised
 bool prof_get(const char *name, double *total_ms, uint64_t *count);

@@ -2630,11 +2630,13 @@ void set_error(const char *what, int e) {
 namespace qb3dev {
 struct ProfPending { const char *name; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
-static bool g_prof_on = false;
+static int g_prof_level = 0;
 static std::vector<ProfPending> g_prof_pending;
 static std::vector<hipEvent_t> g_prof_pool;
 static std::map<std::string, std::pair<double, uint64_t>> g_prof_acc;
-void prof_enable(bool on) { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_on = on; }
+void prof_enable(int level) { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_level = level; }
+// level 2 skips the microsecond kernels: two events per kernel cost more than those kernels take
+static bool prof_minor(const char *n) { const std::string s(n); return s == "enc_scan" || s == "enc_seams" || s == "enc_best_scan"; }
 void prof_reset() { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_acc.clear(); }
 static hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -2646,7 +2648,7 @@ struct ProfScope {      // records an event before and after the launches made i
     hipStream_t st; hipEvent_t a = nullptr, b = nullptr; const char *name; bool on;
     ProfScope(const char *n, hipStream_t s) : st(s), name(n) {
         std::lock_guard<std::mutex> l(g_prof_mu);
-        on = g_prof_on;
+        on = g_prof_level == 1 || (g_prof_level >= 2 && !prof_minor(n));
         if (on) { a = prof_event(); b = prof_event(); (void)hipEventRecord(a, st); }
     }
     ~ProfScope() {

@@ -99,7 +99,8 @@ class DeviceDecoder:
 
 
 def profile_enable(on=True):
-    lib.qb3x_profile_enable(1 if on else 0)
+    """True / 1: every kernel; 2: skip the microsecond kernels (less event traffic in a timed loop); False / 0: off."""
+    lib.qb3x_profile_enable(int(on))
 
 
 def profile_reset():
