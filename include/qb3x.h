@@ -58,6 +58,17 @@ size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t src_pitch,
 size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
                          void *d_dst, size_t dst_pitch, const void *d_index, void *stream);
 
+/* Self-indexing containers (off by default: the container then differs from the reference's by one chunk).
+ * When on, qb3_encode / qb3x_encode_device put a coarse restart table -- at most 64 KB: the bit position and band
+ * state at every N-th block -- into the container as an ignorable chunk "ix" in front of "DT".  The reference's
+ * decoder steps over it (lower-case chunk, QB3decode.cpp:251-255; its length field counts from the chunk start,
+ * which is how that decoder skips) and decodes the same pixels; this library's decoder uses it when no out-of-band
+ * index is given, so that qb3_read_data / qb3x_decode_device(d_index = NULL) walk the stream with thousands of
+ * waves instead of one.  qb3_max_encoded_size() grows by 64 KB while the switch is on.  Not written for RLE0
+ * modes, narrow images and STORED output.  A decoder handle for the device flavour needs a host copy of the
+ * container up to its "DT" mark (up to 64 KB + 80 bytes instead of 64 bytes). */
+void qb3x_set_encoder_index_chunk(encsp p, int on);
+
 /* Compatibility switches. */
 #define QB3X_REF_CBAND0 1u      /* decoder: reproduce reference defect (no CB chunk => every band adds band 0,
                                    reference QB3decode.cpp:138 + QB3decode.h:560-567) instead of identity */

@@ -60,6 +60,7 @@ _PROTOS = {
     # include/qb3x.h
     "qb3x_device_count": (C.c_int, []),
     "qb3x_index_size": (_sz, [_vp]),
+    "qb3x_set_encoder_index_chunk": (None, [_vp, C.c_int]),
     "qb3x_decoder_index_size": (_sz, [_vp]),
     "qb3x_encode_device": (_sz, [_vp, _vp, _vp, _vp, _vp]),
     "qb3x_decode_device": (_sz, [_vp, _vp, _vp, _vp, _vp]),
@@ -89,7 +90,7 @@ def _np_ptr(a):
     return a.ctypes.data_as(_vp)
 
 
-def encode(img, dtype, mode=QB3M_FTL, cband=None, stride=0, quanta=1, away=False):
+def encode(img, dtype, mode=QB3M_FTL, cband=None, stride=0, quanta=1, away=False, index_chunk=False):
     """qb3_create_encoder .. qb3_encode on a numpy image of shape (h, w, bands); returns the container bytes."""
     import numpy as np
     h, w, b = img.shape
@@ -98,6 +99,8 @@ def encode(img, dtype, mode=QB3M_FTL, cband=None, stride=0, quanta=1, away=False
         raise ValueError("qb3_create_encoder refused the parameters")
     try:
         lib.qb3_set_encoder_mode(p, mode)
+        if index_chunk:
+            lib.qb3x_set_encoder_index_chunk(p, 1)
         if cband is not None:
             arr = (_sz * b)(*cband)
             lib.qb3_set_encoder_coreband(p, b, arr)

@@ -60,7 +60,8 @@ struct encs {
     qb3_mode mode;
     qb3_dtype type;
     bool away;
-    DevBuf d_img, d_out, d_ws, d_q;
+    bool ix_chunk;          // qb3x_set_encoder_index_chunk: embed the coarse restart table ("ix")
+    DevBuf d_img, d_out, d_ws, d_q, d_idx;
 };
 
 struct decs {
@@ -75,7 +76,9 @@ struct decs {
     uint8_t *s_start;       // the pointer given to qb3_read_start
     bool saw_cb;            // a CB chunk was present
     unsigned compat;
-    DevBuf d_in, d_img, d_ws;
+    size_t ix_off;          // coarse restart table found in the container: offset of its entries from s_start (0: none)
+    uint32_t ix_K, ix_blocks, ix_E;
+    DevBuf d_in, d_img, d_ws, d_ix;
 };
 
 // ---------------------------------------------------------------- small host bit writer for headers
@@ -87,7 +90,24 @@ struct HdrWriter {
 };
 
 // reference QB3encode.cpp:189-268: main header, then CB / QV / SC chunks as needed, then DT
-static size_t write_headers(const encs *p, uint8_t *dst) {
+// The coarse restart table for a geometry: K entries of E bytes, one per `blocks` blocks, so that the chunk fits
+// its 16-bit length.  chunk = "ix", length, version, flags, 2 reserved bytes, blocks (4 bytes), entries.
+struct IxLayout { uint32_t K = 0, blocks = 0, E = 0, flags = 0; size_t chunk = 0; };
+static IxLayout ix_layout(const Geometry &g) {
+    IxLayout L;
+    L.E = ix_entry_bytes(g);
+    const uint64_t kmax = (65535 - 12) / L.E;
+    const uint64_t spe = (g.nseg + kmax - 1) / kmax;            // fine segments per entry
+    L.blocks = (uint32_t)(spe * g.seg_blocks);
+    L.K = (uint32_t)((g.nseg + spe - 1) / spe);
+    L.chunk = 12 + (size_t)L.K * L.E;
+    L.flags = g.mode == CM_BEST ? 1 : 0;                        // bit 0: entries carry the common factors
+    return L;
+}
+
+// ix: when given, the chunk head is written and the function returns BEFORE the entries (the caller owns
+// entries + "DT"); otherwise the header ends with "DT" as in the reference
+static size_t write_headers(const encs *p, uint8_t *dst, const IxLayout *ix = nullptr) {
     HdrWriter w(dst);
     w.put(0x80334251u, 4);
     w.put(p->xsize - 1, 2); w.put(p->ysize - 1, 2); w.put(p->nbands - 1, 1);
@@ -105,6 +125,14 @@ static size_t write_headers(const encs *p, uint8_t *dst) {
     if (p->order != ZCURVE && p->mode != QB3M_STORED) {
         w.sig("SC"); w.put(8, 2); w.put(p->order ? p->order : HILBERT, 8);
     }
+    if (ix) {
+        // an ignorable chunk (lower case): its length counts from the chunk start, which is how the reference skips
+        // unknown chunks (QB3decode.cpp:254-255), so its decoder steps over it
+        w.sig("ix"); w.put(ix->chunk, 2);
+        w.put(1, 1); w.put(ix->flags, 1); w.put(0, 2);
+        w.put(ix->blocks, 4);
+        return w.n;
+    }
     w.sig("DT");
     return w.n;
 }
@@ -117,7 +145,7 @@ QB3_API encsp qb3_create_encoder(size_t w, size_t h, size_t b, qb3_dtype dt) {
         return nullptr;
     encs *p = new encs();
     p->xsize = w; p->ysize = h; p->nbands = b; p->type = dt;
-    p->stride = 0; p->order = 0; p->quanta = 1; p->away = false; p->mode = QB3M_DEFAULT; p->error = 0;
+    p->stride = 0; p->order = 0; p->quanta = 1; p->away = false; p->mode = QB3M_DEFAULT; p->error = 0; p->ix_chunk = false;
     for (size_t c = 0; c < QB3_MAXBANDS; c++) p->cband[c] = c < b ? c : 0;
     if (b == 3 || b == 4) p->cband[0] = p->cband[2] = 1;
     qb3_reset_encoder(p);
@@ -163,7 +191,7 @@ QB3_API bool qb3_set_encoder_quanta(encsp p, uint64_t q, bool away) {
 QB3_API size_t qb3_max_encoded_size(const encsp p) {
     size_t n = 16 * ((p->xsize + 3) / 4) * ((p->ysize + 3) / 4) * p->nbands;
     double bits_per_value = 17.0 / 16.0 + 8 * szof(p->type);
-    return 1024 + static_cast<size_t>(bits_per_value * n / 8);
+    return 1024 + static_cast<size_t>(bits_per_value * n / 8) + (p->ix_chunk ? 65536 : 0);
 }
 
 QB3_API qb3_mode qb3_set_encoder_mode(encsp p, qb3_mode mode) {
@@ -284,7 +312,8 @@ static size_t stored_encode_host(encsp p, const void *source, void *destination)
 // `hdr`.  On success *bits receives the stream length; the handle's band state is updated when `carry`.
 // d_index may be null.  Synchronises the stream.
 static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, uint8_t *d_out, size_t hdr,
-                                 void *d_index, hipStream_t st, bool carry, uint64_t *bits, const uint8_t *hdrbytes) {
+                                 void *d_index, hipStream_t st, bool carry, uint64_t *bits, const uint8_t *hdrbytes,
+                                 size_t hdr_stamp, const IxTable &ix) {
     EncPlan plan = plan_encode(g);
     if (!p->d_ws.ensure(plan.ws_bytes)) return false;
     BandState bs;
@@ -295,7 +324,7 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     uint32_t *out32 = (uint32_t *)(d_out + (hdr & ~(size_t)3));
     EncResult res;
     const uint8_t *dres = (const uint8_t *)p->d_ws.p + plan.ws_bytes - sizeof(EncResult);
-    if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st, TileBatch(), hdrbytes, (uint32_t)hdr)) return false;
+    if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st, TileBatch(), hdrbytes, (uint32_t)hdr_stamp, ix)) return false;
     hipError_t e = hipMemcpyAsync(&res, dres, sizeof(res), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
@@ -330,8 +359,8 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     const qb3_mode mode = p->mode;
     const bool rle = is_rle_mode(mode);
     if (rle) p->mode = (qb3_mode)((int)mode - 2);       // RLE is a post pass over the base mode's stream
-    uint8_t hdrbuf[64];
-    const size_t hdr = write_headers(p, hdrbuf);
+    uint8_t hdrbuf[80];
+    size_t hdr = write_headers(p, hdrbuf);                // (with the coarse index chunk: redone below, once the geometry is known)
     if (p->error) return 0;                               // stale error blocks the handle until reset
     if (!device_ok()) { p->error = QB3E_LIBERR; if (rle) p->mode = mode; return 0; }
 
@@ -379,8 +408,22 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     // check_info (reference QB3encode.h:364-373); cband is kept in range by the setter
     if (g.w < 4 || g.h < 4) { p->error = 1; if (rle) p->mode = mode; return 0; }
 
+    // optional coarse restart table inside the container (not with RLE0, whose post pass rewrites the container)
+    IxLayout ixl;
+    IxTable ixt;
+    size_t hdr_stamp = hdr;                               // header bytes prepared on the host
+    if (p->ix_chunk && !narrow && !rle) {
+        ixl = ix_layout(g);
+        hdr_stamp = write_headers(p, hdrbuf, &ixl);
+        hdr = hdr_stamp + (size_t)ixl.K * ixl.E + 2;      // entries, then "DT": both written by ix_fill_kernel
+        ixt.entries = out_dev + hdr_stamp; ixt.K = ixl.K; ixt.blocks = ixl.blocks; ixt.entry_bytes = ixl.E;
+        if (!d_index) {                                   // the table is a sample of the index: make one
+            if (!p->d_idx.ensure(index_bytes(g))) { p->error = QB3E_LIBERR; return 0; }
+            d_index = p->d_idx.p;
+        }
+    }
     uint64_t bits = 0;
-    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits, hdrbuf)) {   // the index describes the block stream, RLE0 wrapped or not
+    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits, hdrbuf, hdr_stamp, ixt)) {   // the index describes the block stream, RLE0 wrapped or not
         p->error = QB3E_LIBERR; if (rle) p->mode = mode; return 0;
     }
     p->error = 0;
@@ -406,8 +449,8 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     }
     if (raw_size(p) > len) {
         if (on_host) {
-            memcpy(host_dst, hdrbuf, hdr);
-            HIPOK(hipMemcpyAsync((uint8_t *)host_dst + hdr, out_dev + hdr, len - hdr, hipMemcpyDeviceToHost, st));
+            memcpy(host_dst, hdrbuf, hdr_stamp);
+            HIPOK(hipMemcpyAsync((uint8_t *)host_dst + hdr_stamp, out_dev + hdr_stamp, len - hdr_stamp, hipMemcpyDeviceToHost, st));
             HIPOK(hipStreamSynchronize(st));
         }       // device flavour: the header was stamped by write_header_kernel, in stream order
         return len;
@@ -432,6 +475,8 @@ QB3_API size_t qb3x_encode_device(encsp p, const void *d_src, void *d_dst, void 
     if (!p || !d_src || !d_dst || ((uintptr_t)d_dst & 3)) { if (p) p->error = QB3E_EINV; return 0; }
     return encode_common(p, nullptr, nullptr, d_src, d_dst, d_index, (hipStream_t)stream);
 }
+
+QB3_API void qb3x_set_encoder_index_chunk(encsp p, int on) { if (p) p->ix_chunk = on != 0; }
 
 QB3_API size_t qb3x_index_size(const encsp p) {
     if (!p || p->xsize < 4 || p->ysize < 4) return 0;
@@ -543,6 +588,7 @@ QB3_API decsp qb3_read_start(void *source, size_t source_size, size_t *image_siz
     p->s_start = (uint8_t *)source;
     p->s_in = p->s_start + 11; p->s_size = source_size - 11;
     p->saw_cb = false; p->compat = 0;
+    p->ix_off = 0; p->ix_K = p->ix_blocks = p->ix_E = 0;
     image_size[0] = p->xsize; image_size[1] = p->ysize; image_size[2] = p->nbands;
     if (mode <= (int)QB3M_CF_RLE) p->order = ZCURVE;
     return p;
@@ -599,6 +645,16 @@ QB3_API bool qb3_read_info(decsp p) {
         } else {
             // the reference skips an ignorable (lower case) chunk by `len` bytes from the chunk start
             // (QB3decode.cpp:254-255); a zero length would never terminate there, treat it as an error
+            if (c0 == 'i' && c1 == 'x' && len >= 12 && rd(pos + 4) == 1 && p->mode != QB3M_STORED) {
+                // this library's coarse restart table (include/qb3x.h): remember where the entries are, check later
+                const size_t tsz = szof(p->type);
+                const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * ((rd(pos + 5) & 1) ? 2 : 1)));
+                const size_t off = (size_t)(p->s_in - p->s_start) + pos + 12;
+                if ((len - 12) % E == 0 && pos + len <= n) {
+                    p->ix_off = off; p->ix_E = E; p->ix_K = (len - 12) / E;
+                    p->ix_blocks = rd(pos + 8) | (rd(pos + 9) << 8) | (rd(pos + 10) << 16) | (rd(pos + 11) << 24);
+                }
+            }
             if ((c0 & 0x20) && len) pos += len;
             else p->error = QB3E_UNKN;
         }
@@ -619,12 +675,12 @@ QB3_API size_t qb3x_decoder_index_size(const decsp p) {
 
 // Decode the block stream at d_stream (+ byte offset off inside a 4-byte aligned device buffer) into d_img.
 static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_buf, size_t off, size_t nbytes,
-                                 void *d_img, const void *d_index, hipStream_t st) {
+                                 void *d_img, const void *d_index, hipStream_t st, const IxTable &ix = IxTable()) {
     DecPlan plan = plan_decode(g);
     if (!p->d_ws.ensure(plan.ws_bytes)) return false;
     uint32_t *d_status = nullptr;
     const uint32_t *in32 = (const uint32_t *)(d_buf + (off & ~(size_t)3));
-    if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st))
+    if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st, TileBatch(), nullptr, ix))
         return false;
     uint32_t status = 0;
     hipError_t e = hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st);
@@ -706,7 +762,19 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
         if (!p->d_img.ensure((size_t)g.w * g.h * g.bands * tsz)) { p->error = QB3E_LIBERR; return 0; }
         img_dev = p->d_img.p;
     }
-    if (!decode_blocks_device(p, g, dev_buf, off, nbytes, img_dev, d_index, st)) {
+    // a coarse restart table inside the container stands in for a missing index (not under RLE0: positions there are
+    // those of the expanded stream, which is what the table holds, but keep the legacy modes on the plain path)
+    IxTable ixt;
+    if (!d_index && p->ix_K && !rle && !narrow) {
+        const size_t bytes = (size_t)p->ix_K * p->ix_E;
+        if (on_host) {
+            if (!p->d_ix.ensure(bytes)) { p->error = QB3E_LIBERR; return 0; }
+            HIPOK(hipMemcpyAsync(p->d_ix.p, p->s_start + p->ix_off, bytes, hipMemcpyHostToDevice, st));
+            ixt.entries = (uint8_t *)p->d_ix.p;
+        } else ixt.entries = (uint8_t *)d_src + p->ix_off;
+        ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E;
+    }
+    if (!decode_blocks_device(p, g, dev_buf, off, nbytes, img_dev, d_index, st, ixt)) {
         if (p->error == QB3E_OK) p->error = QB3E_LIBERR;
         return 0;
     }

@@ -76,6 +76,15 @@ struct EncPlan {
 };
 EncPlan plan_encode(const Geometry &g);
 
+// Optional coarse restart table carried INSIDE the container as an ignorable chunk ("ix", include/qb3x.h): K entries,
+// one per `blocks` blocks: [bit position, 6 bytes][rung, 1 byte per band][prev, tsz bytes per band][cf, the same,
+// common-factor modes only].  With it a stream that arrives without the out-of-band index is walked by K waves.
+struct IxTable {
+    uint8_t *entries = nullptr;     // device pointer (encode: where to write them, "DT" follows; decode: where they are)
+    uint32_t K = 0, blocks = 0, entry_bytes = 0;
+};
+uint32_t ix_entry_bytes(const Geometry &g);
+
 // Batched tiles: n images/streams laid out at fixed byte pitches, processed by one set of launches (blockIdx.y).
 // n == 0 means a single image.  ws_pitch = plan.ws_bytes of one tile; idx_pitch = index_bytes of one tile.
 struct TileBatch { uint32_t n = 0; uint64_t src_pitch = 0, dst_pitch = 0, ws_pitch = 0, idx_pitch = 0; };
@@ -88,9 +97,11 @@ struct TileBatch { uint32_t n = 0; uint64_t src_pitch = 0, dst_pitch = 0, ws_pit
 //   ws         workspace of plan.ws_bytes; the EncResult is its LAST sizeof(EncResult) bytes
 //   index      optional decode index (nullptr = none)
 // Launches on `stream`, does not synchronise.  Returns hipError_t as int.
+// ix: entries == nullptr when no chunk is wanted
 int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
                   const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb = TileBatch(),
-                  const uint8_t *hdr = nullptr, uint32_t hdr_len = 0);     // hdr: container header stamped before each stream
+                  const uint8_t *hdr = nullptr, uint32_t hdr_len = 0,      // hdr: container header stamped before each stream
+                  const IxTable &ix = IxTable());
 
 struct DecPlan {
     uint32_t threads;       // lanes per workgroup, one index segment per lane
@@ -116,7 +127,8 @@ DecPlan plan_decode(const Geometry &g);
 // Returns hipError_t as int; does not synchronise.
 int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
                   void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb = TileBatch(),
-                  const uint64_t *tile_bits = nullptr);    // tile_bits: device array, stream length of each tile in bits
+                  const uint64_t *tile_bits = nullptr,     // tile_bits: device array, stream length of each tile in bits
+                  const IxTable &ix = IxTable());
 
 // Elementwise helpers on device buffers (quantisation, reference QB3encode.cpp:137-186 / QB3decode.cpp:77-107)
 int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, uint64_t q, bool away, void *stream);

@@ -197,9 +197,12 @@ struct EncArgs {
     uint32_t ntiles;
     uint64_t ts_img, ts_out, ts_ws, ts_idx;     // batched tiles: byte strides from tile to tile (blockIdx.y = tile)
     uint32_t hdr_len;       // container header bytes to stamp in front of the stream (write_header_kernel)
-    uint8_t hdr[64];
+    uint32_t hdr_back;      // distance from the container start to the stream start (= hdr_len without an index chunk)
+    uint8_t hdr[80];        // at most 11 + 20 (CB) + 12 (QV) + 12 (SC) + 12 (ix head) bytes
     uint32_t flags;         // tuning switches (QB3_ENC_FLAGS): bit 0 = codes from the LDS table instead of the rule
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups per block (lanes per block), magic of it
+    uint8_t *ix_dst;                // coarse index chunk: where the entries go (null: none), "DT" right after them
+    uint32_t ix_K, ix_spe, ix_E;    //   ... entries, fine segments per entry, bytes per entry
     EncResult *res;
     BandState st;
     IndexView idx;
@@ -1491,8 +1494,30 @@ __global__ void enc_seam_kernel(const EncArgs a0) {
 __global__ void write_header_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     // the stream starts at out32 + out_bit0/8; the header ends there
-    uint8_t *end = (uint8_t *)a.out32 + (a.out_bit0 >> 3);
-    if (threadIdx.x < a.hdr_len) end[(int)threadIdx.x - (int)a.hdr_len] = a0.hdr[threadIdx.x];
+    // (with a coarse index chunk the prepared bytes are followed by its entries and "DT": hdr_back > hdr_len)
+    uint8_t *start = (uint8_t *)a.out32 + (a.out_bit0 >> 3) - a.hdr_back;
+    for (uint32_t i = threadIdx.x; i < a.hdr_len; i += blockDim.x) start[i] = a0.hdr[i];
+}
+
+// The coarse index chunk: every ix_spe-th segment entry of the (finished) index, packed little endian, then "DT"
+__global__ void ix_fill_kernel(const EncArgs a) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, B = a.g.bands, tsz = a.g.tsz;
+    if (k == 0) { uint8_t *dt = a.ix_dst + (uint64_t)a.ix_K * a.ix_E; dt[0] = 'D'; dt[1] = 'T'; }
+    if (k >= a.ix_K) return;
+    const uint64_t s = (uint64_t)k * a.ix_spe;
+    uint8_t *e = a.ix_dst + (uint64_t)k * a.ix_E;
+    const uint64_t bp = a.idx.bitpos[s];
+    for (uint32_t i = 0; i < 6; i++) e[i] = (uint8_t)(bp >> (8 * i));
+    e += 6;
+    for (uint32_t c = 0; c < B; c++) e[c] = a.idx.rung[s * B + c];
+    e += B;
+    const uint8_t *pv = (const uint8_t *)a.idx.prev + s * B * tsz;
+    for (uint32_t i = 0; i < B * tsz; i++) e[i] = pv[i];
+    if (a.g.mode == CM_BEST) {
+        e += B * tsz;
+        const uint8_t *cf = (const uint8_t *)a.idx.cf + s * B * tsz;
+        for (uint32_t i = 0; i < B * tsz; i++) e[i] = cf[i];
+    }
 }
 
 // ------------------------------------------------------------------ decode
@@ -1510,6 +1535,8 @@ struct DecArgs {
     uint32_t bpp, passes, in_cap_dw, magic_bpp, magic_dpr;
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups (lanes) per block
     uint32_t totals_only;           // lane-per-block kernels: write the segments' per-band sums to idx.prev, no pixels
+    const uint8_t *ix;              // coarse index chunk found in the container (null: none): restart points for the walk
+    uint32_t ix_K, ix_blocks, ix_E;
     // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
     uint32_t ntiles;
     uint64_t ts_in, ts_img, ts_idx;
@@ -2461,11 +2488,21 @@ __global__ void __launch_bounds__(64) dec_walk_kernel(const DecArgs a0) {
     const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
     uint64_t R = 0;                         // current rungs, 4 bits per band
     uint64_t P = a.in_bit0;                 // bit position, from a.in32
-    P = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)P);       // < 32
-    uint32_t gb = 0, inseg = 0;
+    uint32_t gb = 0, gb_end = nblocks, inseg = 0;
     uint64_t seg = 0;
+    if (a.ix) {                             // restart point blockIdx.y of the container's coarse table
+        const uint8_t *e = a.ix + (uint64_t)blockIdx.y * a.ix_E;
+        uint64_t bp = 0;
+        for (uint32_t i = 0; i < 6; i++) bp |= (uint64_t)e[i] << (8 * i);
+        P += bp;
+        for (uint32_t c = 0; c < B; c++) R |= (uint64_t)(e[6 + c] & 15u) << (4 * c);
+        gb = blockIdx.y * a.ix_blocks;
+        gb_end = (nblocks - gb < a.ix_blocks) ? nblocks : gb + a.ix_blocks;
+        seg = gb / NB;
+    }
+    P = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(P >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)P);
     bool bad = false;
-    while (gb < nblocks) {
+    while (gb < gb_end) {
         const uint64_t w0 = P >> 5;         // stage the window that starts in the word of P
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2487,7 +2524,7 @@ __global__ void __launch_bounds__(64) dec_walk_kernel(const DecArgs a0) {
             if (n <= 32) { buf |= (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(nxt_v) << n; n += 32; nxt_v = win[++wp]; }   // wp <= WIN + 3 by the loop bound
         };
         // walk whole blocks while the longest possible block still fits in the window
-        while (gb < nblocks && 32 * wp + B * MAXU + 64 <= 32 * WIN) {
+        while (gb < gb_end && 32 * wp + B * MAXU + 64 <= 32 * WIN) {
             if (inseg == 0) {
                 if (lane == 0) {
                     a.idx.bitpos[seg] = 32 * (w0 + wp) - n - a.in_bit0;
@@ -2579,14 +2616,29 @@ __global__ void dec_index_serial(const DecArgs a0) {
     __shared__ uint32_t st_rung[MAXBANDS];
     const uint32_t bands = a.g.bands, S = a.g.seg_blocks;
     for (uint32_t c = 0; c < bands; c++) { st_prev[c] = 0; st_cf[c] = 0; st_rung[c] = 0; }
+    const uint32_t nblocks = (uint32_t)a.g.nblocks;
+    uint32_t gb0 = 0, gb_end = nblocks;
+    uint64_t seg = 0, bp = 0;
+    if (a.ix) {                             // restart point blockIdx.y of the container's coarse table
+        const uint8_t *e = a.ix + (uint64_t)blockIdx.y * a.ix_E;
+        for (uint32_t i = 0; i < 6; i++) bp |= (uint64_t)e[i] << (8 * i);
+        const uint8_t *pv = e + 6 + bands, *cf = pv + bands * sizeof(T);
+        for (uint32_t c = 0; c < bands; c++) {
+            st_rung[c] = e[6 + c];
+            uint64_t v = 0, f = 0;
+            for (uint32_t i = 0; i < sizeof(T); i++) { v |= (uint64_t)pv[c * sizeof(T) + i] << (8 * i); if (MODE == CM_BEST) f |= (uint64_t)cf[c * sizeof(T) + i] << (8 * i); }
+            st_prev[c] = v; st_cf[c] = f;
+        }
+        gb0 = blockIdx.y * a.ix_blocks;
+        gb_end = (nblocks - gb0 < a.ix_blocks) ? nblocks : gb0 + a.ix_blocks;
+        seg = gb0 / S;
+    }
     Reader rd;
-    rd.init(a.in32, a.in_bit0, a.in_bit0 + a.in_bits);
+    rd.init(a.in32, a.in_bit0 + bp, a.in_bit0 + a.in_bits);
     T g[16];
     bool ok = true;
     uint32_t inseg = 0;
-    uint64_t seg = 0;
-    const uint32_t nblocks = (uint32_t)a.g.nblocks;
-    for (uint32_t gb = 0; gb < nblocks && ok; gb++) {
+    for (uint32_t gb = gb0; gb < gb_end && ok; gb++) {
         if (inseg == 0) {
             a.idx.bitpos[seg] = rd.position() - a.in_bit0;
             for (uint32_t c = 0; c < bands; c++) {
@@ -2723,6 +2775,7 @@ uint32_t seg_blocks_for(const Geometry &g) {
     uint32_t s = units / g.bands;
     return s ? s : 1;
 }
+uint32_t ix_entry_bytes(const Geometry &g) { return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)); }
 uint32_t ulen_size_for(uint32_t tsz, uint32_t mode) { return mode == CM_BEST ? 0 : (tsz == 1 ? 1 : 2); }
 
 static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
@@ -2922,6 +2975,7 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
         ProfScope ps("enc_seams", st);
         hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256, nt), dim3(256), 0, st, a);
         if (a.hdr_len) hipLaunchKernelGGL(write_header_kernel, dim3(1, nt), dim3(64), 0, st, a);
+        if (a.ix_dst && a.have_idx && nt == 1) hipLaunchKernelGGL(ix_fill_kernel, dim3((a.ix_K + 255) / 256), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -2929,10 +2983,13 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
 
 int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
                   const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb,
-                  const uint8_t *hdr, uint32_t hdr_len) {
+                  const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix) {
     EncArgs a;
+    a.ix_dst = ix.entries; a.ix_K = ix.K; a.ix_E = ix.entry_bytes;
+    a.ix_spe = g.seg_blocks ? ix.blocks / g.seg_blocks : 0;
     a.ntiles = tb.n ? tb.n : 1; a.ts_img = tb.src_pitch; a.ts_out = tb.dst_pitch; a.ts_ws = tb.ws_pitch; a.ts_idx = tb.idx_pitch;
-    a.hdr_len = hdr_len <= 64 ? hdr_len : 0;
+    a.hdr_len = hdr_len <= sizeof(a.hdr) ? hdr_len : 0;
+    a.hdr_back = a.hdr_len + (ix.entries ? ix.K * ix.entry_bytes + 2 : 0);
     for (uint32_t i = 0; i < a.hdr_len; i++) a.hdr[i] = hdr[i];
     a.g = g; a.img = img; a.out32 = out32; a.out_bit0 = out_bit0;
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
@@ -3054,8 +3111,9 @@ static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild,
         // produce the values entering the segments (totals pass + scan)
         {
             ProfScope ps("dec_index_serial", st);
-            if (sizeof(T) == 1) hipLaunchKernelGGL(dec_walk_kernel<3>, dim3(a.ntiles), dim3(64), 0, st, a);
-            else hipLaunchKernelGGL(dec_walk_kernel<4>, dim3(a.ntiles), dim3(64), 0, st, a);
+            const dim3 wg(a.ntiles, a.ix ? a.ix_K : 1);
+            if (sizeof(T) == 1) hipLaunchKernelGGL(dec_walk_kernel<3>, wg, dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(dec_walk_kernel<4>, wg, dim3(64), 0, st, a);
         }
         ProfScope ps("dec_index_prev", st);
         DecArgs t = a;
@@ -3065,7 +3123,7 @@ static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild,
         else hipLaunchKernelGGL(prev_scan_kernel<uint16_t>, dim3(a.ntiles), dim3(1024), 0, st, a);
     } else if (rebuild) {
         ProfScope ps("dec_index_serial", st);
-        hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(a.ntiles), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(a.ntiles, a.ix ? a.ix_K : 1), dim3(64), 0, st, a);
     }
     if (plan.px && MODE != CM_BEST && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0) {
         ProfScope ps("dec_units", st);
@@ -3094,9 +3152,15 @@ static int launch_decode_t(const DecArgs &a, const DecPlan &plan, bool rebuild, 
 
 int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
                   void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb,
-                  const uint64_t *tile_bits) {
+                  const uint64_t *tile_bits, const IxTable &ix) {
     hipStream_t st = (hipStream_t)stream;
     DecArgs a;
+    // the container's coarse restart table is usable when it matches this geometry and this library's segments
+    a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = 0;
+    if (ix.entries && !tb.n && ix.blocks && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&
+        ix.K == (g.nblocks + ix.blocks - 1) / ix.blocks) {
+        a.ix = ix.entries; a.ix_K = ix.K; a.ix_blocks = ix.blocks; a.ix_E = ix.entry_bytes;
+    }
     a.g = g; a.in32 = in32; a.in_bit0 = in_bit0; a.in_bits = in_bits; a.img = img;
     a.ntiles = tb.n ? tb.n : 1; a.ts_in = tb.src_pitch; a.ts_img = tb.dst_pitch; a.tile_bits = tile_bits;
     uint8_t *w = (uint8_t *)ws;

@@ -21,12 +21,14 @@ def _stream_ptr():
 class DeviceEncoder:
     """One encoder handle bound to the current device; output and index buffers are reused across calls."""
 
-    def __init__(self, w, h, bands, dtype, mode=QB3M_FTL, cband=None, want_index=True):
+    def __init__(self, w, h, bands, dtype, mode=QB3M_FTL, cband=None, want_index=True, index_chunk=False):
         self.w, self.h, self.bands, self.dtype = w, h, bands, dtype
         self.p = lib.qb3_create_encoder(w, h, bands, dtype)
         if not self.p:
             raise ValueError("qb3_create_encoder refused the parameters")
         self.mode = lib.qb3_set_encoder_mode(self.p, mode)
+        if index_chunk:             # self-indexing container (qb3x.h): one more chunk, up to 64 KB
+            lib.qb3x_set_encoder_index_chunk(self.p, 1)
         if cband is not None:
             arr = (_sz * bands)(*cband)
             lib.qb3_set_encoder_coreband(self.p, bands, arr)
@@ -64,9 +66,15 @@ class DeviceEncoder:
 
 
 class DeviceDecoder:
-    """Decoder for one device-resident container.  `header` is a host copy of (at least) its first 64 bytes."""
+    """Decoder for one device-resident container.  `header` is a host copy of the container up to its "DT" mark: the
+    first 64 bytes, or HEADER_MAX bytes if it may carry the coarse index chunk; a device tensor holding the container
+    is accepted too (the wrapper copies what it needs)."""
+
+    HEADER_MAX = 65536 + 96
 
     def __init__(self, header, nbytes):
+        if torch.is_tensor(header):
+            header = header[:min(int(nbytes), self.HEADER_MAX)].cpu().numpy()
         self.hdr = np.ascontiguousarray(header, dtype=np.uint8)
         dims = (_sz * 3)()
         self.p = lib.qb3_read_start(self.hdr.ctypes.data_as(_vp), nbytes, dims)

@@ -504,3 +504,84 @@ def test_band_maps_on_multiband_16bit(qb3, oracle, case, mode):
     ref = check_encode(qb3, oracle, img, dt, mode, cband=cband)
     out, dims, dtype, m = qb3.decode(ref)
     assert np.array_equal(out, img.view(np.uint8).ravel())
+
+
+IX_CASES = [
+    # w, h, bands, dtype, gen, seed, mode
+    (512, 512, 3, 0, "NOISY3", 1, FTL),          # 8-bit lane-per-block kernels, length walker
+    (509, 203, 3, 0, "NOISY3", 2, BASE),         # odd size: generic kernels, value walker
+    (256, 256, 8, 2, "LANDSAT16", 3, BASE),      # 16-bit groups
+    (1024, 64, 1, 0, "GRAD", 0, BASE_Z),
+    (256, 128, 1, 5, "DEM", 4, FTL),             # 32-bit: generic
+    (128, 128, 1, 7, "DEM", 4, 5),               # 64-bit common factor: entries carry cf
+    (96, 64, 1, 5, "TERRACE", 4, 5),
+    (64, 48, 3, 0, "PALETTE", 3, 1),
+    (2048, 2048, 3, 0, "NOISY3", 5, FTL),        # more segments than entries fit: several segments per entry
+]
+
+
+@pytest.mark.parametrize("case", IX_CASES, ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % (c[0], c[1], c[2], c[3], c[4], c[6]))
+def test_index_chunk(qb3, oracle, case):
+    """qb3x_set_encoder_index_chunk: the container gains one ignorable chunk ("ix") and nothing else changes; the
+    reference's decoder (the oracle restates its skip rule, QB3decode.cpp:251-255) steps over it; this library
+    decodes through it, host and device flavour"""
+    import torch
+    from qb3_amd import synth, device as qdev
+    w, h, b, dt, gen, seed, mode = case
+    cb = None if b in (1, 3, 4) else [1, 1, 1] + list(range(3, b))
+    img = oracle.generate(w, h, b, dt, gen, seed)
+    ref = oracle.encode(img, dt, mode, cband=cb)
+    got = qb3.encode(img, dt, mode, cband=cb, index_chunk=True)
+    plain = qb3.encode(img, dt, mode, cband=cb)
+    assert np.array_equal(plain, ref)
+    # same container with one chunk inserted in front of "DT"
+    extra = len(got) - len(ref)
+    assert extra >= 12 + 6 and extra <= 65535
+    dt_at = len(ref) - (len(ref) - bytes(ref).index(b"DT", 11))
+    assert bytes(got[:dt_at]) == bytes(ref[:dt_at]) and bytes(got[dt_at:dt_at + 2]) == b"ix"
+    assert int(got[dt_at + 2]) | int(got[dt_at + 3]) << 8 == extra
+    assert bytes(got[dt_at + extra:]) == bytes(ref[dt_at:])
+    raw = img.view(np.uint8).ravel()
+    out, _, _, _ = oracle.decode(got, identity=True)
+    assert out is not None and np.array_equal(out, raw), "the reference decoder must step over the chunk"
+    out, dims, dtype, m = qb3.decode(got)
+    assert np.array_equal(out, raw)
+    # device flavour: container made on the device, decoded with and without the out-of-band index
+    enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cb, index_chunk=True)
+    dimg = synth.generate(w, h, b, dt, gen, seed)
+    dst, n, index = enc.encode(dimg)
+    assert n == len(got) and np.array_equal(dst[:n].cpu().numpy(), got)
+    dec = qdev.DeviceDecoder(dst, n)
+    draw = dimg.reshape(-1).view(torch.uint8)
+    assert torch.equal(dec.decode(dst, index=None), draw)
+    assert torch.equal(dec.decode(dst, index=index), draw)
+
+
+def test_index_chunk_not_written_where_it_cannot_be(qb3, oracle):
+    """RLE0 modes (the post pass rewrites the container), narrow images and STORED output carry no chunk"""
+    img = oracle.generate(96, 64, 1, 5, "TERRACE", 4)
+    for mode in (2, 3, 6, 7):
+        assert np.array_equal(qb3.encode(img, 5, mode, index_chunk=True), oracle.encode(img, 5, mode))
+    narrow = oracle.generate(2, 40, 3, 0, "NOISY3", 1)
+    assert np.array_equal(qb3.encode(narrow, 0, FTL, index_chunk=True), oracle.encode(narrow, 0, FTL))
+    noise = oracle.generate(64, 64, 3, 0, "RANDOM", 1)         # incompressible: falls back to STORED
+    assert np.array_equal(qb3.encode(noise, 0, FTL, index_chunk=True), oracle.encode(noise, 0, FTL))
+
+
+def test_index_chunk_is_checked_not_trusted(qb3, oracle):
+    """a table that does not fit the geometry is ignored (serial walk), a damaged one cannot crash the decoder"""
+    img = oracle.generate(256, 256, 3, 0, "NOISY3", 9)
+    got = qb3.encode(img, 0, FTL, index_chunk=True)
+    at = bytes(got).index(b"ix", 11)
+    bad = got.copy()
+    bad[at + 8] ^= 1                    # blocks per entry no longer a multiple of the segment size
+    out, _, _, _ = qb3.decode(bad)
+    assert np.array_equal(out, img.ravel())
+    worse = got.copy()
+    worse[at + 12 + 2] ^= 0x55          # a bit position pointing elsewhere: wrong pixels or a reported failure, no crash
+    try:
+        qb3.decode(worse)
+    except RuntimeError:
+        pass
+    out, _, _, _ = qb3.decode(got)      # and the handle-free API is still healthy
+    assert np.array_equal(out, img.ravel())
