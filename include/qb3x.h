@@ -66,7 +66,9 @@ size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch,
  * index is given, so that qb3_read_data / qb3x_decode_device(d_index = NULL) walk the stream with thousands of
  * waves instead of one.  qb3_max_encoded_size() grows by 64 KB while the switch is on.  Not written for RLE0
  * modes, narrow images and STORED output.  A decoder handle for the device flavour needs a host copy of the
- * container up to its "DT" mark (up to 64 KB + 80 bytes instead of 64 bytes). */
+ * container up to its "DT" mark (up to 64 KB + 80 bytes instead of 64 bytes).
+ * Callers that only know the reference API (LD_PRELOAD, relinked tools) can set QB3X_INDEX_CHUNK=1 in the
+ * environment: it is read when an encoder handle is created. */
 void qb3x_set_encoder_index_chunk(encsp p, int on);
 
 /* Compatibility switches. */

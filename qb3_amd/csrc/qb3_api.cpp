@@ -145,7 +145,8 @@ QB3_API encsp qb3_create_encoder(size_t w, size_t h, size_t b, qb3_dtype dt) {
         return nullptr;
     encs *p = new encs();
     p->xsize = w; p->ysize = h; p->nbands = b; p->type = dt;
-    p->stride = 0; p->order = 0; p->quanta = 1; p->away = false; p->mode = QB3M_DEFAULT; p->error = 0; p->ix_chunk = false;
+    p->stride = 0; p->order = 0; p->quanta = 1; p->away = false; p->mode = QB3M_DEFAULT; p->error = 0;
+    { const char *e = getenv("QB3X_INDEX_CHUNK"); p->ix_chunk = e && atoi(e) != 0; }     // for callers that only know the reference API
     for (size_t c = 0; c < QB3_MAXBANDS; c++) p->cband[c] = c < b ? c : 0;
     if (b == 3 || b == 4) p->cband[0] = p->cband[2] = 1;
     qb3_reset_encoder(p);
