@@ -448,7 +448,8 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
             }
         }
     }
-    if (raw_size(p) > len) {
+    // (the coarse index chunk does not take part in the decision: the same inputs give the same kind of container)
+    if (raw_size(p) > len - (ixt.entries ? ixl.chunk : 0)) {
         if (on_host) {
             memcpy(host_dst, hdrbuf, hdr_stamp);
             HIPOK(hipMemcpyAsync((uint8_t *)host_dst + hdr_stamp, out_dev + hdr_stamp, len - hdr_stamp, hipMemcpyDeviceToHost, st));
