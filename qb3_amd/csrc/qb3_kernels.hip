@@ -2585,25 +2585,22 @@ template <typename T>
 __global__ void __launch_bounds__(1024) prev_scan_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x, B = a.g.bands;
+    const uint32_t tid = threadIdx.x, B = a.g.bands, c = blockIdx.y;       // one workgroup per tile and band
     const uint64_t nseg = a.g.nseg, per = (nseg + 1023) / 1024;
     const uint64_t s0 = (uint64_t)tid * per, s1 = (s0 + per < nseg) ? s0 + per : nseg;
     T *prev = (T *)a.idx.prev;
-    for (uint32_t c = 0; c < B; c++) {
-        uint32_t sum = 0;
-        for (uint64_t s = s0; s < s1; s++) sum += prev[s * B + c];
-        part[tid] = sum;
+    uint32_t sum = 0;
+    for (uint64_t s = s0; s < s1; s++) sum += prev[s * B + c];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {               // inclusive scan of the partial sums
+        const uint32_t y = tid >= d ? part[tid - d] : 0u;
         __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {           // inclusive scan of the partial sums
-            const uint32_t y = tid >= d ? part[tid - d] : 0u;
-            __syncthreads();
-            part[tid] += y;
-            __syncthreads();
-        }
-        uint32_t run = part[tid] - sum;
-        for (uint64_t s = s0; s < s1; s++) { const uint32_t t = prev[s * B + c]; prev[s * B + c] = (T)run; run += t; }
+        part[tid] += y;
         __syncthreads();
     }
+    uint32_t run = part[tid] - sum;
+    for (uint64_t s = s0; s < s1; s++) { const uint32_t t = prev[s * B + c]; prev[s * B + c] = (T)run; run += t; }
 }
 
 // Foreign stream: ONE lane walks the stream and rebuilds the index (bit position + band state at every
@@ -3115,12 +3112,15 @@ static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild,
             if (sizeof(T) == 1) hipLaunchKernelGGL(dec_walk_kernel<3>, wg, dim3(64), 0, st, a);
             else hipLaunchKernelGGL(dec_walk_kernel<4>, wg, dim3(64), 0, st, a);
         }
-        ProfScope ps("dec_index_prev", st);
-        DecArgs t = a;
-        t.totals_only = 1;
-        if (use_px) launch_dec_px(t, plan, st); else launch_dec_px16(t, plan, st);
-        if (sizeof(T) == 1) hipLaunchKernelGGL(prev_scan_kernel<uint8_t>, dim3(a.ntiles), dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL(prev_scan_kernel<uint16_t>, dim3(a.ntiles), dim3(1024), 0, st, a);
+        {
+            ProfScope ps("dec_index_prev", st);
+            DecArgs t = a;
+            t.totals_only = 1;
+            if (use_px) launch_dec_px(t, plan, st); else launch_dec_px16(t, plan, st);
+        }
+        ProfScope ps("dec_index_scan", st);
+        if (sizeof(T) == 1) hipLaunchKernelGGL(prev_scan_kernel<uint8_t>, dim3(a.ntiles, a.g.bands), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL(prev_scan_kernel<uint16_t>, dim3(a.ntiles, a.g.bands), dim3(1024), 0, st, a);
     } else if (rebuild) {
         ProfScope ps("dec_index_serial", st);
         hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(a.ntiles, a.ix ? a.ix_K : 1), dim3(64), 0, st, a);
