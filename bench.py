@@ -155,12 +155,14 @@ def main():
     enc_ms = sum(kernels[k]["avg_ms"] for k in ("enc_units", "enc_scan", "enc_concat", "enc_seams") if k in kernels)
     dec_ms = sum(kernels[k]["avg_ms"] for k in ("dec_index_serial", "dec_segments", "dec_units") if k in kernels)
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
-    traffic = None
+    traffic = valu = None
     try:
         if args.size != 16384:
             raise OSError("PMC traffic was collected for the 16384 workload only")
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+            rec = json.load(f).get(dom, {})
+        traffic = rec.get("hbm_bytes_per_launch")
+        valu = rec.get("valu")
     except (OSError, ValueError):
         pass
     roofline = None
@@ -168,7 +170,10 @@ def main():
         achieved = algo_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": algo_bytes}
+                    "algorithmic_bytes_per_launch": algo_bytes,
+                    # what actually limits the kernel (rocprofv3 SQ counters of the same workload, profiles/): the share of
+                    # its duration in which the SIMDs issue vector instructions -- integer bit packing, no MFMA
+                    "valu": valu}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

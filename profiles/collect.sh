@@ -10,6 +10,7 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $CMD > /dev/null 2> $OUT/fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $CMD > /dev/null 2> $OUT/write.log
-PROFILE_CMD="python3 $CMD" python3 profiles/summarise.py $TAG $OUT/trace $OUT/fetch $OUT/write
-cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc_hbm.csv profiles/pmc_traffic.json $OUT/
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/sq -o s --output-format csv -- python3 $CMD > /dev/null 2> $OUT/sq.log
+PROFILE_CMD="python3 $CMD" python3 profiles/summarise.py $TAG $OUT/trace $OUT/fetch $OUT/write $OUT/sq
+cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc_hbm.csv profiles/${TAG}_sq.csv profiles/pmc_traffic.json $OUT/
 grep '^{' $OUT/bench_under_rocprof.json > $OUT/${TAG}_bench_under_rocprof.json || true
