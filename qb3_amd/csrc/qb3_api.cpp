@@ -879,6 +879,8 @@ QB3_API int qb3x_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 QB3_API const char *qb3x_last_error(void) { return last_error(); }
+// not in qb3x.h: a tuning aid (phase time stamps of dec_px_kernel's first `nwaves` waves, 8 x uint64 each)
+QB3_API void qb3x_debug_set_stamps(void *d_buf, unsigned nwaves) { dbg_set_stamps(d_buf, nwaves); }
 QB3_API void qb3x_profile_enable(int level) { prof_enable(level < 0 ? 0 : level); }
 QB3_API void qb3x_profile_reset(void) { prof_reset(); }
 QB3_API int qb3x_profile_get(const char *kernel, double *total_ms, uint64_t *count) { return prof_get(kernel, total_ms, count) ? 1 : 0; }

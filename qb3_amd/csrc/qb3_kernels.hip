@@ -1535,6 +1535,8 @@ struct DecArgs {
     uint32_t bpp, passes, in_cap_dw, magic_bpp, magic_dpr;
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups (lanes) per block
     uint32_t totals_only;           // lane-per-block kernels: write the segments' per-band sums to idx.prev, no pixels
+    uint64_t *stamps;               // debugging: per-wave phase time stamps (null: off), see dbg_set_stamps
+    uint32_t stamps_n;
     const uint8_t *ix;              // coarse index chunk found in the container (null: none): restart points for the walk
     uint32_t ix_K, ix_blocks, ix_E;
     // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
@@ -2134,6 +2136,7 @@ template <int B, bool RGB, uint64_t ORDER, bool STEP>
 __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t t_start = a0.stamps ? clock64() : 0;
     constexpr int NW = (B + 1) / 2;                     // 32-bit words of a scan packed 16 bits per band
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t NB = a.g.seg_blocks, nbx = a.g.nbx;  // NB <= 64: a WAVE owns a segment, nothing is shared but the table
@@ -2143,34 +2146,59 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     uint32_t *stage = tab + 1024 + wave * (a.in_cap_dw + 8);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
     const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
+    // Loads that depend on nothing but the segment number go out first -- positions, unit lengths, entering rungs and
+    // values -- so that their round trips overlap the table copy and its barrier (in-kernel time stamps: a wave spends
+    // 45 % of its life waiting for memory before it can start, the two dependent trips "position, then stream words").
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    const bool live = seg < a.g.nseg;
+    const uint64_t segc = live ? seg : 0;
+    const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
+    const bool act = live && lane < nb_here;
+    const uint64_t P0 = a.idx.bitpos[segc];
+    const uint64_t P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
+    uint32_t ul_[B], rg0[B], pv0[B], blen = 0;
+    {
+        const uint8_t *ul = (const uint8_t *)a.idx.ulen + ((uint64_t)g0 + lane) * B;
+#pragma unroll
+        for (int c = 0; c < B; c++) {
+            ul_[c] = act ? ul[c] : 0u;
+            rg0[c] = a.idx.rung[segc * B + c];
+            pv0[c] = ((const uint8_t *)a.idx.prev)[segc * B + c];
+        }
+    }
     for (uint32_t i = tid; i < 256; i += blockDim.x) ((uint4 *)tab)[i] = ((const uint4 *)px_dec_tab.e)[i];
     __syncthreads();                                    // the only workgroup barrier
-    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
-    if (seg >= a.g.nseg) return;
-    const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
-    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
-    const bool act = lane < nb_here;
-
-    const uint64_t P0 = a.idx.bitpos[seg];
-    const uint64_t P1 = (seg + 1 < a.g.nseg) ? a.idx.bitpos[seg + 1] : a.in_bits;
+    if (!live) return;
+    const bool stamp = a0.stamps && seg < a0.stamps_n && lane == 0;
+    if (stamp) { a0.stamps[seg * 8 + 0] = t_start; a0.stamps[seg * 8 + 1] = clock64(); }
     const uint64_t w0 = (a.in_bit0 + P0) >> 5;
     const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
     const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0;
     // the staging area holds the longest valid segment; an index that says otherwise is not ours
     const bool fits = ndw64 <= a.in_cap_dw && lds0 == 0;
     const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
-    for (uint32_t i = lane; i < ndw + 8; i += 64) stage[i] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
-    uint32_t ul_[B], blen = 0;
-    {
-        const uint8_t *ul = (const uint8_t *)a.idx.ulen + ((uint64_t)g0 + lane) * B;
+    for (uint32_t base = 0; base < ndw + 8; base += 512) {          // eight loads in flight per lane, then eight LDS stores
+        uint32_t sw[8];
 #pragma unroll
-        for (int c = 0; c < B; c++) { ul_[c] = act ? ul[c] : 0u; blen += ul_[c]; }
+        for (int k = 0; k < 8; k++) {
+            const uint32_t i = base + lane + 64 * k;
+            sw[k] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t i = base + lane + 64 * k;
+            if (i < ndw + 8) stage[i] = sw[k];
+        }
     }
+#pragma unroll
+    for (int c = 0; c < B; c++) blen += ul_[c];
     // the wave reads what its own lanes staged: LDS operations of a wave execute in order, the fence is for the compiler
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    if (stamp) a0.stamps[seg * 8 + 2] = clock64();
     const uint32_t limit = stage_bit0 + 32 * ndw;       // no unit starts beyond the staged bits (8 zero words follow)
     const uint32_t cpos = stage_bit0 + (uint32_t)(a.in_bit0 + P0 - 32 * w0);
     bool bad = !fits;
@@ -2191,18 +2219,20 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     }
 #pragma unroll
     for (int k = 0; k < NW; k++) dpk[k] = wave_iscan32(dpk[k]);                 // inclusive, 16 bits per band
+    if (stamp) a0.stamps[seg * 8 + 3] = clock64();
     // decode the units; running sums in curve order, two 16-bit lanes per register
     uint32_t rp[B][8], spk[NW], sinc[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) spk[k] = 0;
 #pragma unroll
     for (int c = 0; c < B; c++) {
-        const uint32_t rung = ((uint32_t)a.idx.rung[seg * B + c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 7u;
+        const uint32_t rung = (rg0[c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 7u;
         const uint32_t tot = px_group<STEP>(gpos[c], rung, rp[c]) & 0xffu;
         spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
     }
 #pragma unroll
     for (int k = 0; k < NW; k++) sinc[k] = wave_iscan32(spk[k]);
+    if (stamp) a0.stamps[seg * 8 + 4] = clock64();
     if (a.totals_only) { // foreign stream, first pass: leave the segment's per-band sums where the entering values go
         if (lane == 63)
 #pragma unroll
@@ -2214,7 +2244,7 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
         // entering value, then the core band (reference QB3decode.h:560-567)
 #pragma unroll
         for (int c = 0; c < B; c++) {
-            const uint32_t pv = (uint32_t)((const uint8_t *)a.idx.prev)[seg * B + c] + (((sinc[c >> 1] - spk[c >> 1]) >> (16 * (c & 1))) & 0xffffu);
+            const uint32_t pv = pv0[c] + (((sinc[c >> 1] - spk[c >> 1]) >> (16 * (c & 1))) & 0xffffu);
 #pragma unroll
             for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], (pv & 0xffu) * 0x00010001u);
         }
@@ -2248,6 +2278,7 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
             }
         }
     }
+    if (stamp) a0.stamps[seg * 8 + 5] = clock64();
     if (bad) atomicOr(a.status, fits ? 1u : 8u);
     if (lane == 63 && seg == a.g.nseg - 1 && fits) {    // reference: more than 7 unused bits at the end is a failure
         const uint64_t used = (uint64_t)(cpos + binc - stage_bit0) + 32 * w0 - a.in_bit0;
@@ -2255,7 +2286,6 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
         else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
     }
 }
-
 // ---- 16-bit: wave per index segment, lane per (block, band group) -- counterpart of enc_px16_kernel -------
 // Same organisation as dec_px_kernel; a lane decodes the BG <= 4 units of its band group.  Rungs up to 7 go through
 // the same table (values below 256), higher rungs decode by the code rule from a 64-bit buffer (three codes of at
@@ -2666,6 +2696,9 @@ __global__ void dec_index_serial(const DecArgs a0) {
 
 // ------------------------------------------------------------------ host side of the kernels
 static thread_local char g_err[256] = "";
+static uint64_t *g_stamps = nullptr;        // debugging aid (qb3x_debug_set_stamps): phase time stamps of the first waves
+static uint32_t g_stamps_n = 0;
+void dbg_set_stamps(void *d_buf, uint32_t nwaves) { g_stamps = (uint64_t *)d_buf; g_stamps_n = nwaves; }
 const char *last_error() { return g_err; }
 void set_error(const char *what, int e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, e ? hipGetErrorString((hipError_t)e) : "failed");
@@ -3176,6 +3209,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
     a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16) ? plan.px_cap_dw : plan.in_cap_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.totals_only = 0;
+    a.stamps = g_stamps; a.stamps_n = g_stamps_n;
     a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;
     switch (g.tsz) {
