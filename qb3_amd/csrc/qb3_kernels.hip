@@ -318,15 +318,26 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, u
 
     // ---- stage the 4-row tile: coalesced dword loads, [row][slot][pixel][band] as in memory
     const uint8_t *imgb = (const uint8_t *)a.img;
-    for (uint32_t r = 0; r < 4; r++)
-        for (uint32_t j = tid; j < rowdw; j += nthr) {
-            const uint32_t s = fastdiv(j, dpr, a.magic_dpr), d = j - s * dpr;
-            const uint8_t *p = imgb + (slot_base[s] + (uint64_t)r * stride) * sizeof(T) + 4 * d;
-            uint32_t v;
-            if (((uintptr_t)p & 3) == 0) v = *(const uint32_t *)p;
-            else v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-            tile[r * rowdw + j] = v;
+    // (four loads in flight per thread before the LDS stores: a load-store-load-store loop pays one memory round trip
+    // per element)
+    for (uint32_t j0 = 0; j0 < rowdw; j0 += nthr) {
+        const uint32_t j = j0 + tid;
+        const bool in = j < rowdw;
+        const uint32_t s = fastdiv(in ? j : 0, dpr, a.magic_dpr), d = (in ? j : 0) - s * dpr;
+        const uint8_t *p0 = imgb + slot_base[s] * sizeof(T) + 4 * d;
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) {
+            const uint8_t *p = p0 + (uint64_t)r * stride * sizeof(T);
+            v[r] = 0;
+            if (in) {
+                if (((uintptr_t)p & 3) == 0) v[r] = *(const uint32_t *)p;
+                else v[r] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+            }
         }
+#pragma unroll
+        for (uint32_t r = 0; r < 4; r++) if (in) tile[r * rowdw + j] = v[r];
+    }
     __syncthreads();
 
     // ---- per unit: gather in curve order, band difference, delta, mag-sign, rung
@@ -1915,7 +1926,13 @@ __global__ void dec3_kernel(const DecArgs a0) {
     const bool staged = ndw64 <= a.in_cap_dw;          // workgroup uniform
     const uint32_t ndw = (uint32_t)ndw64;
     if (staged)
-        for (uint32_t i = tid; i < ndw; i += nthr) stage[i] = (w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+        for (uint32_t base = 0; base < ndw; base += 4 * nthr) {        // four loads in flight per thread, then four LDS stores
+            uint32_t sw[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t i = base + tid + q * nthr; sw[q] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t i = base + tid + q * nthr; if (i < ndw) stage[i] = sw[q]; }
+        }
     const uint32_t endw_g = (uint32_t)((endw_abs - w0 < 0xffffffffull) ? endw_abs - w0 : 0xffffffffull);
     for (uint32_t sl = tid; sl < nb_here; sl += nthr) {
         const uint32_t g = g0 + sl, by = g / nbx, bx = g - by * nbx;
@@ -2378,28 +2395,49 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
     uint32_t *stage = tab + 1024 + wave * (a.in_cap_dw + 16);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
     const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
+    // loads that depend on nothing but the segment number go out first; their round trips overlap the table copy and
+    // its barrier (see dec_px_kernel)
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    const bool live = seg < a.g.nseg;
+    const uint64_t segc = live ? seg : 0;
+    const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
+    const bool act = live && slot < nb_here;
+    const uint64_t P0 = a.idx.bitpos[segc];
+    const uint64_t P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
+    uint32_t ul_[BG], rg0[BG], pv0[BG], blen = 0;
+    {
+        const uint16_t *ul = (const uint16_t *)a.idx.ulen + ((uint64_t)g0 + slot) * B + band0;
+#pragma unroll
+        for (int c = 0; c < BG; c++) {
+            ul_[c] = act ? ul[c] : 0u;
+            rg0[c] = a.idx.rung[segc * B + band0 + c];
+            pv0[c] = ((const uint16_t *)a.idx.prev)[segc * B + band0 + c];
+        }
+    }
     for (uint32_t i = tid; i < 256; i += blockDim.x) ((uint4 *)tab)[i] = ((const uint4 *)px_dec_tab.e)[i];
     __syncthreads();                                    // the only workgroup barrier
-    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
-    if (seg >= a.g.nseg) return;
-    const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
-    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
-    const bool act = slot < nb_here;
-
-    const uint64_t P0 = a.idx.bitpos[seg];
-    const uint64_t P1 = (seg + 1 < a.g.nseg) ? a.idx.bitpos[seg + 1] : a.in_bits;
+    if (!live) return;
     const uint64_t w0 = (a.in_bit0 + P0) >> 5;
     const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
     const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0;
     const bool fits = ndw64 <= a.in_cap_dw && lds0 == 0;
     const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
-    for (uint32_t i = lane; i < ndw + 16; i += 64) stage[i] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;   // 16 zero words follow
-    uint32_t ul_[BG], blen = 0;
-    {
-        const uint16_t *ul = (const uint16_t *)a.idx.ulen + ((uint64_t)g0 + slot) * B + band0;
+    for (uint32_t base = 0; base < ndw + 16; base += 512) {         // eight loads in flight per lane, then eight LDS stores; 16 zero words follow
+        uint32_t sw[8];
 #pragma unroll
-        for (int c = 0; c < BG; c++) { ul_[c] = act ? ul[c] : 0u; blen += ul_[c]; }
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = base + lane + 64 * q;
+            sw[q] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = base + lane + 64 * q;
+            if (i < ndw + 16) stage[i] = sw[q];
+        }
     }
+#pragma unroll
+    for (int c = 0; c < BG; c++) blen += ul_[c];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2427,7 +2465,7 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
     for (int k = 0; k < NW; k++) spk[k] = 0;
 #pragma unroll
     for (int c = 0; c < BG; c++) {
-        const uint32_t rung = ((uint32_t)a.idx.rung[seg * B + band0 + c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 15u;
+        const uint32_t rung = (rg0[c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 15u;
         const uint32_t tot = px16_group<STEP>(gpos[c], rung, rp[c]) & 0xffffu;
         spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
     }
@@ -2451,7 +2489,7 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
 #pragma unroll
         for (int c = 0; c < BG; c++) {
             const uint32_t excl = ((sinc[c >> 1] >> (16 * (c & 1))) - (spk[c >> 1] >> (16 * (c & 1)))) & 0xffffu;
-            const uint32_t pv = ((uint32_t)((const uint16_t *)a.idx.prev)[seg * B + band0 + c] + excl) & 0xffffu;
+            const uint32_t pv = (pv0[c] + excl) & 0xffffu;
 #pragma unroll
             for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], pv * 0x00010001u);
         }
@@ -2536,7 +2574,13 @@ __global__ void __launch_bounds__(64) dec_walk_kernel(const DecArgs a0) {
         const uint64_t w0 = P >> 5;         // stage the window that starts in the word of P
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < WIN + 4; i += 64) win[i] = (w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+        for (uint32_t base = 0; base < WIN + 4; base += 1024) {        // sixteen loads in flight per lane
+            uint32_t sw[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) { const uint32_t i = base + lane + 64 * q; sw[q] = (i < WIN + 4 && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u; }
+#pragma unroll
+            for (int q = 0; q < 16; q++) { const uint32_t i = base + lane + 64 * q; if (i < WIN + 4) win[i] = sw[q]; }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
