@@ -201,6 +201,8 @@ struct EncArgs {
     uint8_t hdr[80];        // at most 11 + 20 (CB) + 12 (QV) + 12 (SC) + 12 (ix head) bytes
     uint32_t flags;         // tuning switches (QB3_ENC_FLAGS): bit 0 = codes from the LDS table instead of the rule
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups per block (lanes per block), magic of it
+    uint64_t *stamps;               // debugging: per-workgroup phase time stamps of enc_px_kernel (null: off)
+    uint32_t stamps_n;
     uint8_t *ix_dst;                // coarse index chunk: where the entries go (null: none), "DT" right after them
     uint32_t ix_K, ix_spe, ix_E;    //   ... entries, fine segments per entry, bytes per entry
     EncResult *res;
@@ -628,6 +630,7 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     constexpr uint32_t UMASK = 7;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint64_t t_start = a0.stamps ? clock64() : 0;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
     const uint64_t stride = a.g.stride;
@@ -635,11 +638,15 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
     uint32_t *etab = (uint32_t *)smem;                      // 512 entries
     uint32_t *wsum = etab + 512;                            // 64 dwords: scan scratch, [32..35] rungs of each wave's last lane
     uint32_t *outbuf = wsum + 64;                           // slot_dw dwords (a multiple of 4)
-    if (tid < 128) ((uint4 *)etab)[tid] = ((const uint4 *)px_enc_tab.e)[tid];
+    // the code table is asked for now and written to LDS only before the first barrier: its round trip runs beside the
+    // pixel loads instead of in front of them
+    const uint4 tabv = ((const uint4 *)px_enc_tab.e)[tid & 127];
     for (uint32_t i = tid; i < a.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
     const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
 
     const uint32_t chunk = blockIdx.x;
+    const bool stamp = a0.stamps && chunk < a0.stamps_n && threadIdx.x == 64;
+    if (stamp) a0.stamps[chunk * 8 + 0] = t_start;
     const int64_t gs = (int64_t)chunk * 255 - 1 + tid;     // lane 0 is the halo block
     const bool valid = gs >= 0 && gs < (int64_t)nblocks, payload = valid && tid >= 1;
     const uint32_t gblk = valid ? (uint32_t)gs : 0u;
@@ -670,6 +677,7 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
             for (int k = 0; k < B; k++) w[r][k] = 0;
     }
 
+    if (stamp) a0.stamps[chunk * 8 + 1] = clock64();
     // ---- per band: bytes in curve order, band difference, running delta, mag-sign -- four values per register
     uint32_t cur[B][4];
 #pragma unroll
@@ -702,15 +710,18 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
         usedv[c] = u; lastv[c] = x[3] >> 24;
         rp_packed |= topbit32(u | 1) << (4 * c);
     }
+    if (stamp) a0.stamps[chunk * 8 + 2] = clock64() + (rp_packed & 0);
     // rungs of the previous block: neighbouring lane, or the last lane of the previous wave through LDS
     uint32_t prp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rp_packed, 0x138, 0xf, 0xf, false);      // wave_shr:1
     if (lane == 63) wsum[32 + wave] = rp_packed;
+    if (tid < 128) ((uint4 *)etab)[tid] = tabv;
     __syncthreads();
     if (lane == 0 && wave) prp = wsum[32 + wave - 1];
     if (gblk == 0) { prp = 0;
 #pragma unroll
         for (int c = 0; c < B; c++) prp |= ((uint32_t)a0.st.rung[c] & 15u) << (4 * c); }
 
+    if (stamp) a0.stamps[chunk * 8 + 3] = clock64();
     // ---- per band: the unit's bit string as six pieces of at most 27 bits; pl = piece length (low byte)
     uint32_t pc[B][6], pl[B][6], lens[B], blen[1] = { 0 };
 #pragma unroll
@@ -763,11 +774,13 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
             blen[0] += lens[c];
         }
     }
+    if (stamp) a0.stamps[chunk * 8 + 4] = clock64() + (blen[0] & 0);
     const uint32_t mybits = blen[0];
     block_exscan_dpp<1>(blen, wsum);
     const uint32_t pos = blen[0], total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     (void)mybits;
 
+    if (stamp) a0.stamps[chunk * 8 + 5] = clock64();
     if (payload) {
         LdsWriter32 wr;
         wr.init(outbuf, pos);
@@ -795,11 +808,13 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
             }
         }
     }
+    if (stamp) a0.stamps[chunk * 8 + 6] = clock64();
     __syncthreads();
     const uint32_t nd4 = (total + 127) >> 7;
     uint4 *slot = (uint4 *)(a.scratch + (uint64_t)chunk * a.slot_dw);
     for (uint32_t d = tid; d < nd4; d += 256) slot[d] = ((const uint4 *)outbuf)[d];
     if (tid == 0) a.chunk_bits[chunk] = total;
+    if (stamp) a0.stamps[chunk * 8 + 7] = clock64();
 }
 
 // ------------------------------------------------------------------ 16-bit: lane per (block, band group), in registers
@@ -845,7 +860,7 @@ __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
     uint32_t *wsum = etab + 512;                            // 64 dwords of scan scratch
     uint32_t *rp_s = wsum + 64;                             // 256: every lane's packed rungs
     uint32_t *outbuf = rp_s + 256;                          // slot_dw dwords (a multiple of 4)
-    if (tid < 128) ((uint4 *)etab)[tid] = ((const uint4 *)px_enc_tab.e)[tid];
+    const uint4 tabv = ((const uint4 *)px_enc_tab.e)[tid & 127];     // written to LDS before the first barrier, see enc_px_kernel
     for (uint32_t i = tid; i < a.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
     const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
 
@@ -925,6 +940,7 @@ __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
     }
     // rungs of the same bands of the previous block: NG lanes back
     rp_s[tid] = rp_packed;
+    if (tid < 128) ((uint4 *)etab)[tid] = tabv;
     __syncthreads();
     uint32_t prp = tid >= NG ? rp_s[tid - NG] : 0u;
     if (gblk == 0) { prp = 0;
@@ -3078,6 +3094,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry);
     a.slot_dw = L.slot_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
+    a.stamps = g_stamps; a.stamps_n = g_stamps_n;
     a.res = (EncResult *)(w + L.res);
     a.st = st_in;
     a.have_idx = index != nullptr;
