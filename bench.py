@@ -171,8 +171,9 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": algo_bytes,
-                    # what actually limits the kernel (rocprofv3 SQ counters of the same workload, profiles/): the share of
-                    # its duration in which the SIMDs issue vector instructions -- integer bit packing, no MFMA
+                    # where the time goes besides HBM (rocprofv3 SQ counters of the same workload, profiles/): the share of the
+                    # kernel's duration in which the SIMDs issue vector instructions and the LDS pipe is busy -- integer bit
+                    # packing, no MFMA; the rest is memory latency the resident waves do not cover
                     "valu": valu}
 
     cpu = None

@@ -1448,46 +1448,51 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     // a lane moves four dwords per step (one 16-byte load, the next one already in flight): memory-level parallelism
     // is what this copy needs.  Output dword d = source dwords d-1, d funnel-shifted by the chunk's bit phase.
     const uint32_t ng = (nd + 3) >> 2, sh = (32 - phase) & 31;
-    uint4 cur = make_uint4(0, 0, 0, 0);
-    if (lane < ng && 4 * lane < nsrc) cur = slot4[lane];
-    uint32_t before = 0;                                                // lane 0: the dword before its group
-    for (uint32_t g = lane; g < ng; g += 64) {
-        const uint32_t gn = g + 64;
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        uint32_t before_n = 0;
-        if (gn < ng && 4 * gn < nsrc) nxt = slot4[gn];
-        if (lane == 0 && gn < ng && 4 * gn - 1 < nsrc) before_n = slot[4 * gn - 1];
-        const uint32_t d = 4 * g;
-        uint32_t s[4] = { cur.x, cur.y, cur.z, cur.w };
+    constexpr int NQ = 4;                                               // 16-byte loads in flight per lane
+    for (uint32_t gb = 0; gb < ng; gb += 64 * NQ) {
+        uint4 cur[NQ];
+        uint32_t before[NQ];                                            // lane 0: the dword before its group
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (d + k >= nsrc) s[k] = 0;        // the slot is only defined up to nsrc
-        uint32_t prv = __shfl_up(s[3], 1, 64);
-        if (lane == 0) prv = before;
-        uint32_t v[4];
-        if (phase) {
-            v[0] = __builtin_amdgcn_alignbit(s[0], prv, sh);
-#pragma unroll
-            for (int k = 1; k < 4; k++) v[k] = __builtin_amdgcn_alignbit(s[k], s[k - 1], sh);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = s[k];
+        for (int q = 0; q < NQ; q++) {
+            const uint32_t g = gb + 64 * q + lane;
+            cur[q] = make_uint4(0, 0, 0, 0); before[q] = 0;
+            if (g < ng && 4 * g < nsrc) cur[q] = slot4[g];
+            if (lane == 0 && g && g < ng && 4 * g - 1 < nsrc) before[q] = slot[4 * g - 1];
         }
-        if (d > 0 && d + 4 < nd) {                                      // no seam dword in the group
-            u32x4_a4 o = { v[0], v[1], v[2], v[3] };
-            *(u32x4_a4 *)(gout + d) = o;
-        } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t dd = d + k;
-                if (dd < nd) {
-                    const bool shared = (dd == 0 && phase) || (dd == nd - 1 && tailbits);
-                    if (!shared) gout[dd] = v[k];
-                    if (dd == 0) a.seams[2 * chunk] = v[k];
-                    if (dd == nd - 1) a.seams[2 * chunk + 1] = v[k];
+        for (int q = 0; q < NQ; q++) {
+            const uint32_t g = gb + 64 * q + lane, d = 4 * g;
+            uint32_t s[4] = { cur[q].x, cur[q].y, cur[q].z, cur[q].w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (d + k >= nsrc) s[k] = 0;    // the slot is only defined up to nsrc
+            uint32_t prv = __shfl_up(s[3], 1, 64);
+            if (lane == 0) prv = before[q];
+            if (g >= ng) continue;
+            uint32_t v[4];
+            if (phase) {
+                v[0] = __builtin_amdgcn_alignbit(s[0], prv, sh);
+#pragma unroll
+                for (int k = 1; k < 4; k++) v[k] = __builtin_amdgcn_alignbit(s[k], s[k - 1], sh);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = s[k];
+            }
+            if (d > 0 && d + 4 < nd) {                                  // no seam dword in the group
+                u32x4_a4 o = { v[0], v[1], v[2], v[3] };
+                *(u32x4_a4 *)(gout + d) = o;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t dd = d + k;
+                    if (dd < nd) {
+                        const bool shared = (dd == 0 && phase) || (dd == nd - 1 && tailbits);
+                        if (!shared) gout[dd] = v[k];
+                        if (dd == 0) a.seams[2 * chunk] = v[k];
+                        if (dd == nd - 1) a.seams[2 * chunk + 1] = v[k];
+                    }
                 }
             }
         }
-        cur = nxt; before = before_n;
     }
 }
 
