@@ -523,7 +523,7 @@ template <typename T> __device__ __forceinline__ void apply_step(T (&v)[16], uin
 // ------------------------------------------------------------------ 8-bit, 1/3/4 bands: lane per BLOCK, in registers
 // Specialisation of enc_kernel for the common rasters (uint8, grey / RGB / RGBA, width a multiple of 4, identity
 // or default R-G,G,B-G band map, Hilbert or Z curve).  Same bit stream, different organisation.  The kernel is
-// bound by VALU issue (SQ_INSTS_VALU x 4 cycles / SIMD = its duration), so it is written for instruction count:
+// bound by instruction issue and memory latency, not by HBM bandwidth, so it is written for instruction count:
 //   * a lane owns a whole block: it loads the four rows of the block straight from HBM (B dwords per row: 64
 //     lanes x 4*B bytes are one contiguous run, so the loads are coalesced without an LDS tile) plus the one
 //     dword that holds the previous block's last visited pixel;
