@@ -2064,8 +2064,9 @@ __global__ void dec3_kernel(const DecArgs a0) {
 
 // ---- 8-bit, 1/3/4 bands: lane per BLOCK decode, in registers (counterpart of enc_px_kernel) -------------
 // WAVE per index segment (64 blocks), lane per block; the waves of a workgroup share the code table and nothing
-// else, so there is one barrier and every wave hides the others' memory latency.  The kernel is bound by VALU
-// issue, not by HBM, so everything here is about instructions per value:
+// else, so there is one barrier and every wave hides the others' memory latency.  The kernel is bound by memory
+// latency, the LDS pipe and instruction issue, not by HBM bandwidth, so everything here is about instructions and LDS
+// accesses per value:
 //   * the segment's bits are staged in LDS (padded with zero words: no bounds checks on the decode path) and all
 //     bit positions are kept relative to LDS address 0, so a refill is  lshr, and, ds_read2_b32, v_alignbit;
 //   * the code table holds the mag-sign-undone delta (and the step flag) as 32-bit entries in rung regions aligned
