@@ -201,6 +201,7 @@ struct EncArgs {
     uint8_t hdr[80];        // at most 11 + 20 (CB) + 12 (QV) + 12 (SC) + 12 (ix head) bytes
     uint32_t flags;         // tuning switches (QB3_ENC_FLAGS): bit 0 = codes from the LDS table instead of the rule
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups per block (lanes per block), magic of it
+    uint32_t px_aligned;            // lane-per-block kernels: every row of every block is dword aligned (plain dword loads)
     uint64_t *stamps;               // debugging: per-workgroup phase time stamps of enc_px_kernel (null: off)
     uint32_t stamps_n;
     uint8_t *ix_dst;                // coarse index chunk: where the entries go (null: none), "DT" right after them
@@ -655,20 +656,47 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
     uint32_t w[4][B];
     uint32_t pd = 0;
     constexpr uint32_t n15 = order_nib(ORDER, 15);
+    // Rows need not be dword aligned (odd widths and strides, the shifted last column, any pointer): a row is read as the
+    // aligned dwords that cover it -- one more than it has when it is not aligned -- and funnel-shifted into place.
+    // Nothing is read beyond the aligned dword that holds the row's last byte.
+    auto load_row = [&](const uint8_t *p, uint32_t (&row)[B]) {
+        const uint32_t sh = 8 * ((uint32_t)(uintptr_t)p & 3);
+        const uint32_t *q = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+        uint32_t d[B + 1];
+#pragma unroll
+        for (int t = 0; t < B; t++) d[t] = q[t];
+        d[B] = sh ? q[B] : 0u;
+#pragma unroll
+        for (int t = 0; t < B; t++) row[t] = __builtin_amdgcn_alignbit(d[t + 1], d[t], sh);
+    };
     if (valid) {
         const uint32_t by = gblk / nbx, bx = gblk - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;     // last column / row is shifted, not padded
         const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
-        const uint8_t *p0 = (const uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t *rp = (const uint32_t *)(p0 + (uint64_t)r * stride);
-#pragma unroll
-            for (int k = 0; k < B; k++) w[r][k] = rp[k];
-        }
+        const uint8_t *p0 = (const uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)x0 * B;
+        const uint8_t *pp = nullptr;      // the four bytes that end the previous block's row holding its last visited pixel
         if (gblk) {
             const uint32_t pb = gblk - 1, pby = pb / nbx, pbx = pb - pby * nbx;
+            const uint32_t px0 = (4 * pbx + 4 > a.g.w) ? a.g.w - 4 : 4 * pbx;
             const uint32_t py0 = (4 * pby + 4 > a.g.h) ? a.g.h - 4 : 4 * pby;
-            pd = *(const uint32_t *)((const uint8_t *)a.img + (uint64_t)(py0 + (n15 >> 2)) * stride + (uint64_t)pbx * 4 * B + 4 * (B - 1));
+            pp = (const uint8_t *)a.img + (uint64_t)(py0 + (n15 >> 2)) * stride + (uint64_t)px0 * B + 4 * (B - 1);
+        }
+        if (a.px_aligned) {             // workgroup uniform: width, stride and pointer are multiples of 4
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t *rp = (const uint32_t *)(p0 + (uint64_t)r * stride);
+#pragma unroll
+                for (int t = 0; t < B; t++) w[r][t] = rp[t];
+            }
+            if (gblk) pd = *(const uint32_t *)pp;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) load_row(p0 + (uint64_t)r * stride, w[r]);
+            if (gblk) {
+                const uint32_t sh = 8 * ((uint32_t)(uintptr_t)pp & 3);
+                const uint32_t *q = (const uint32_t *)((uintptr_t)pp & ~(uintptr_t)3);
+                pd = __builtin_amdgcn_alignbit(sh ? q[1] : 0u, q[0], sh);
+            }
         }
     } else {
 #pragma unroll
@@ -1567,6 +1595,7 @@ struct DecArgs {
     uint32_t bpp, passes, in_cap_dw, magic_bpp, magic_dpr;
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups (lanes) per block
     uint32_t totals_only;           // lane-per-block kernels: write the segments' per-band sums to idx.prev, no pixels
+    uint32_t px_aligned;            // lane-per-block kernels: every row of every block is dword aligned (plain dword stores)
     uint64_t *stamps;               // debugging: per-wave phase time stamps (null: off), see dbg_set_stamps
     uint32_t stamps_n;
     const uint8_t *ix;              // coarse index chunk found in the container (null: none): restart points for the walk
@@ -2296,11 +2325,12 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
         }
         // curve order, band planar -> pixel order, band interleaved; store the four rows
         const uint32_t g = g0 + lane, by = g / nbx, bx = g - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;     // last column / row is shifted, not padded
         const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
-        uint8_t *p0 = (uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B;
+        uint8_t *p0 = (uint8_t *)a.img + (uint64_t)y0 * stride + (uint64_t)x0 * B;
 #pragma unroll
         for (int y = 0; y < 4; y++) {
-            uint32_t *dst = (uint32_t *)(p0 + (uint64_t)y * stride);
+            uint32_t ow[B];
 #pragma unroll
             for (int k = 0; k < B; k++) {
                 // byte j of output dword k is band (4k+j)%B of pixel x = (4k+j)/B: low byte of a 16-bit lane
@@ -2313,7 +2343,24 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
                     half2[h] = __builtin_amdgcn_perm(rp[b1 % B][i1 >> 1], rp[b0 % B][i0 >> 1],
                                                      (uint32_t)((4 + 2 * (i1 & 1)) << 8 | (2 * (i0 & 1))));
                 }
-                dst[k] = __builtin_amdgcn_perm(half2[1], half2[0], 0x05040100u);
+                ow[k] = __builtin_amdgcn_perm(half2[1], half2[0], 0x05040100u);
+            }
+            uint8_t *row = p0 + (uint64_t)y * stride;
+            const uint32_t al = a.px_aligned ? 0u : (uint32_t)(uintptr_t)row & 3;     // px_aligned: wave uniform
+            if (al == 0) {
+#pragma unroll
+                for (int k = 0; k < B; k++) ((uint32_t *)row)[k] = ow[k];
+            } else {        // unaligned row: head bytes, the aligned dwords inside it, tail bytes -- only the row's own 4*B bytes
+                const uint32_t head = 4 - al, sh = 8 * head;            // bytes before the first aligned dword
+#pragma unroll
+                for (uint32_t t = 0; t < 3; t++) if (t < head) row[t] = (uint8_t)(ow[0] >> (8 * t));
+                uint32_t *mid = (uint32_t *)(row + head);
+#pragma unroll
+                for (int k = 0; k + 1 < B; k++) mid[k] = __builtin_amdgcn_alignbit(ow[k + 1], ow[k], sh);
+                uint8_t *tail = row + head + 4 * (B - 1);               // the last `al` bytes
+                const uint32_t last = ow[B - 1] >> sh;
+#pragma unroll
+                for (uint32_t t = 0; t < 3; t++) if (t < al) tail[t] = (uint8_t)(last >> (8 * t));
             }
         }
     }
@@ -2927,7 +2974,7 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
 // Hilbert or Z curve, identity or default RGB(A) band map
 static bool px_eligible(const Geometry &g, bool *rgb) {
     if (g.tsz != 1 || !(g.bands == 1 || g.bands == 3 || g.bands == 4) || g.mode == CM_BEST) return false;
-    if ((g.w & 3) || (g.stride & 3) || g.h < 4) return false;
+    if (g.w < 4 || g.h < 4) return false;                  // any width, stride and pointer: rows are read and written unaligned
     if (g.order != HILBERT && g.order != ZCURVE) return false;
     bool ident = true, def = g.bands >= 3;
     for (uint32_t c = 0; c < g.bands; c++) {
@@ -3044,7 +3091,7 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
             ProfScope ps("enc_best_units", st);
             hipLaunchKernelGGL((enc_best_kernel<T, 1>), grid, block, plan.lds_bytes, st, a);
         }
-    } else if (plan.px && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0) {
+    } else if (plan.px && sizeof(T) == 1) {
         ProfScope ps("enc_units", st);
         launch_enc_px(a, plan, st);
     } else if (plan.px16 && sizeof(T) == 2 && ((uintptr_t)a.img & 3) == 0) {
@@ -3101,6 +3148,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.slot_dw = L.slot_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.stamps = g_stamps; a.stamps_n = g_stamps_n;
+    a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.src_pitch & 3);
     a.res = (EncResult *)(w + L.res);
     a.st = st_in;
     a.have_idx = index != nullptr;
@@ -3201,7 +3249,7 @@ static void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st)
 
 template <typename T, int MODE>
 static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st) {
-    const bool use_px = plan.px && MODE != CM_BEST && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0;
+    const bool use_px = plan.px && MODE != CM_BEST && sizeof(T) == 1;
     const bool use_px16 = plan.px16 && MODE != CM_BEST && sizeof(T) == 2 && ((uintptr_t)a.img & 3) == 0;
     if (rebuild && (use_px || use_px16) && !getenv("QB3_SLOW_INDEX")) {
         // foreign stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
@@ -3225,7 +3273,7 @@ static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild,
         ProfScope ps("dec_index_serial", st);
         hipLaunchKernelGGL((dec_index_serial<T, MODE>), dim3(a.ntiles, a.ix ? a.ix_K : 1), dim3(64), 0, st, a);
     }
-    if (plan.px && MODE != CM_BEST && sizeof(T) == 1 && ((uintptr_t)a.img & 3) == 0) {
+    if (plan.px && MODE != CM_BEST && sizeof(T) == 1) {
         ProfScope ps("dec_units", st);
         launch_dec_px(a, plan, st);
     } else if (plan.px16 && MODE != CM_BEST && sizeof(T) == 2 && ((uintptr_t)a.img & 3) == 0) {
@@ -3277,6 +3325,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.totals_only = 0;
     a.stamps = g_stamps; a.stamps_n = g_stamps_n;
+    a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.dst_pitch & 3);
     a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;
     switch (g.tsz) {

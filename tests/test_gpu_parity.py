@@ -47,8 +47,8 @@ CASES = [
     (64, 64, 16, 0, "NOISY3", 11),
     (32, 32, 16, 6, "RANDOM", 12),
     (256, 256, 3, 0, "CONST", 0),
-    # 8-bit 1/3/4 bands with width % 4 == 0 take the lane-per-block kernels; heights that need a shifted last row,
-    # more than one 255-block chunk, all three band counts
+    # 8-bit 1/3/4 bands take the lane-per-block kernels (any width: the odd sizes above read and write unaligned rows);
+    # heights that need a shifted last row, more than one 255-block chunk, all three band counts
     (64, 37, 3, 0, "NOISY3", 3),
     (128, 50, 4, 0, "NOISY3", 4),
     (256, 19, 1, 0, "NOISY3", 5),
@@ -585,3 +585,29 @@ def test_index_chunk_is_checked_not_trusted(qb3, oracle):
         pass
     out, _, _, _ = qb3.decode(got)      # and the handle-free API is still healthy
     assert np.array_equal(out, img.ravel())
+
+
+@pytest.mark.parametrize("mode", [FTL, BASE])
+@pytest.mark.parametrize("off", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(251, 37, 3), (64, 20, 4), (509, 12, 1)])
+def test_unaligned_device_pointers(qb3, oracle, shape, off, mode):
+    """the 8-bit lane-per-block kernels read and write rows at any alignment: odd widths, and rasters that start at an
+    odd address inside a device buffer (source and destination)"""
+    import torch
+    from qb3_amd import synth, device as qdev
+    w, h, b = shape
+    img = synth.generate(w, h, b, 0, "NOISY3", 11)
+    raw = img.reshape(-1)
+    buf = torch.zeros(raw.numel() + 8, dtype=torch.uint8, device="cuda")
+    src = buf[off:off + raw.numel()]
+    src.copy_(raw)
+    enc = qdev.DeviceEncoder(w, h, b, 0, mode=mode)
+    dst, n, index = enc.encode(src)
+    ref = oracle.encode(img.cpu().numpy(), 0, mode)
+    assert n == len(ref) and np.array_equal(dst[:n].cpu().numpy(), ref)
+    dec = qdev.DeviceDecoder(dst, n)
+    guard = torch.full((raw.numel() + 8,), 0xA5, dtype=torch.uint8, device="cuda")
+    out = guard[off:off + raw.numel()]
+    dec.decode(dst, out=out, index=index)
+    assert torch.equal(out, raw)
+    assert bool((guard[:off] == 0xA5).all()) and bool((guard[off + raw.numel():] == 0xA5).all()), "wrote outside the raster"
