@@ -24,6 +24,7 @@
 //
 // No MFMA anywhere: this is integer bit packing, bounded by VALU/LDS issue and, ultimately, HBM.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "qb3_dev.h"
 
 namespace qb3dev {
@@ -902,30 +903,45 @@ __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
     constexpr uint32_t n15 = order_nib(ORDER, 15);
 #pragma unroll
     for (int c = 0; c < BG; c++) pvals[c] = 0;
+    // N dwords starting at a halfword address: when it is not dword aligned (odd strides, the shifted last column, odd
+    // widths) the N+1 aligned dwords covering them are read and funnel-shifted; nothing is read beyond the aligned dword
+    // holding the last halfword
+    auto load_dw = [&](const uint16_t *p, uint32_t *dst, auto nconst) {
+        constexpr int N = decltype(nconst)::value;
+        if (a.px_aligned) {                 // workgroup uniform
+            const uint32_t *q = (const uint32_t *)p;
+#pragma unroll
+            for (int t = 0; t < N; t++) dst[t] = q[t];
+        } else {
+            const uint32_t sh = 8 * ((uint32_t)(uintptr_t)p & 2);
+            const uint32_t *q = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+            uint32_t d[N + 1];
+#pragma unroll
+            for (int t = 0; t < N; t++) d[t] = q[t];
+            d[N] = sh ? q[N] : 0u;
+#pragma unroll
+            for (int t = 0; t < N; t++) dst[t] = __builtin_amdgcn_alignbit(d[t + 1], d[t], sh);
+        }
+    };
     if (valid) {
         const uint32_t by = gblk / nbx, bx = gblk - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;     // last column / row is shifted, not padded
         const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
-        const uint16_t *p0 = (const uint16_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B + band0;
+        const uint16_t *p0 = (const uint16_t *)a.img + (uint64_t)y0 * stride + (uint64_t)x0 * B + band0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const uint16_t *rowp = p0 + (uint64_t)r * stride;
             if (BG % 2 == 0) {      // a pixel's BG values are whole dwords; pixels are B values apart
 #pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const uint32_t *q = (const uint32_t *)(rowp + (uint64_t)x * B);
-#pragma unroll
-                    for (int d = 0; d < BG / 2; d++) w[r][x * (BG / 2) + d] = q[d];
-                }
-            } else {                // BG == bands: the row of the block is contiguous
-                const uint32_t *q = (const uint32_t *)rowp;
-#pragma unroll
-                for (int k = 0; k < 2 * BG; k++) w[r][k] = q[k];
-            }
+                for (int x = 0; x < 4; x++) load_dw(rowp + (uint64_t)x * B, &w[r][x * (BG / 2)], std::integral_constant<int, (BG / 2 ? BG / 2 : 1)>());
+            } else                  // BG == bands: the row of the block is contiguous
+                load_dw(rowp, &w[r][0], std::integral_constant<int, 2 * BG>());
         }
         if (gblk) {
             const uint32_t pb = gblk - 1, pby = pb / nbx, pbx = pb - pby * nbx;
+            const uint32_t px0 = (4 * pbx + 4 > a.g.w) ? a.g.w - 4 : 4 * pbx;
             const uint32_t py0 = (4 * pby + 4 > a.g.h) ? a.g.h - 4 : 4 * pby;
-            const uint16_t *q = (const uint16_t *)a.img + (uint64_t)(py0 + (n15 >> 2)) * stride + (uint64_t)(pbx * 4 + (n15 & 3)) * B + band0;
+            const uint16_t *q = (const uint16_t *)a.img + (uint64_t)(py0 + (n15 >> 2)) * stride + (uint64_t)(px0 + (n15 & 3)) * B + band0;
 #pragma unroll
             for (int c = 0; c < BG; c++) pvals[c] = q[c];
         }
@@ -2570,8 +2586,24 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
                 for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], grp == 0 ? rp[cb][k] : 0u);
         }
         const uint32_t g = g0 + slot, by = g / nbx, bx = g - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;     // last column / row is shifted, not padded
         const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
-        uint16_t *p0 = (uint16_t *)a.img + (uint64_t)y0 * stride + (uint64_t)bx * 4 * B + band0;
+        uint16_t *p0 = (uint16_t *)a.img + (uint64_t)y0 * stride + (uint64_t)x0 * B + band0;
+        // N dwords to a halfword address: aligned dwords when it is dword aligned, else a head halfword, the aligned dwords
+        // inside and a tail halfword -- never a byte outside the N dwords' own place
+        auto store_dw = [&](uint16_t *p, const uint32_t *src, auto nconst) {
+            constexpr int N = decltype(nconst)::value;
+            if (a.px_aligned || !((uintptr_t)p & 2)) {
+#pragma unroll
+                for (int t = 0; t < N; t++) ((uint32_t *)p)[t] = src[t];
+            } else {
+                p[0] = (uint16_t)src[0];
+                uint32_t *mid = (uint32_t *)(p + 1);
+#pragma unroll
+                for (int t = 0; t + 1 < N; t++) mid[t] = __builtin_amdgcn_alignbit(src[t + 1], src[t], 16);
+                p[2 * N - 1] = (uint16_t)(src[N - 1] >> 16);
+            }
+        };
 #pragma unroll
         for (int y = 0; y < 4; y++) {
             uint16_t *rowp = p0 + (uint64_t)y * stride;
@@ -2586,16 +2618,9 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
             }
             if (BG % 2 == 0) {
 #pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    uint32_t *q = (uint32_t *)(rowp + (uint64_t)x * B);
-#pragma unroll
-                    for (int d = 0; d < BG / 2; d++) q[d] = ow[x * (BG / 2) + d];
-                }
-            } else {
-                uint32_t *q = (uint32_t *)rowp;
-#pragma unroll
-                for (int k = 0; k < 2 * BG; k++) q[k] = ow[k];
-            }
+                for (int x = 0; x < 4; x++) store_dw(rowp + (uint64_t)x * B, &ow[x * (BG / 2)], std::integral_constant<int, (BG / 2 ? BG / 2 : 1)>());
+            } else
+                store_dw(rowp, &ow[0], std::integral_constant<int, 2 * BG>());
         }
     }
     if (bad) atomicOr(a.status, fits ? 1u : 8u);
@@ -2989,7 +3014,7 @@ static bool px_eligible(const Geometry &g, bool *rgb) {
 // pixel unless it is the whole pixel (BG = bands = 1 or 3)
 static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *ng) {
     if (g.tsz != 2 || g.mode == CM_BEST || getenv("QB3_NO_PX")) return false;
-    if ((g.w & 3) || (g.stride & 1) || g.h < 4) return false;
+    if (g.w < 4 || g.h < 4) return false;                  // any width and stride: rows are read and written at halfword alignment
     if (g.order != HILBERT && g.order != ZCURVE) return false;
     const uint32_t B = g.bands;
     px16_split(B, bg, ng);
@@ -3094,7 +3119,7 @@ static int launch_encode_t(const EncArgs &a, const EncPlan &plan, hipStream_t st
     } else if (plan.px && sizeof(T) == 1) {
         ProfScope ps("enc_units", st);
         launch_enc_px(a, plan, st);
-    } else if (plan.px16 && sizeof(T) == 2 && ((uintptr_t)a.img & 3) == 0) {
+    } else if (plan.px16 && sizeof(T) == 2 && ((uintptr_t)a.img & 1) == 0) {
         ProfScope ps("enc_units", st);
         launch_enc_px16(a, plan, st);
     } else {
@@ -3250,7 +3275,7 @@ static void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st)
 template <typename T, int MODE>
 static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st) {
     const bool use_px = plan.px && MODE != CM_BEST && sizeof(T) == 1;
-    const bool use_px16 = plan.px16 && MODE != CM_BEST && sizeof(T) == 2 && ((uintptr_t)a.img & 3) == 0;
+    const bool use_px16 = plan.px16 && MODE != CM_BEST && sizeof(T) == 2 && ((uintptr_t)a.img & 1) == 0;
     if (rebuild && (use_px || use_px16) && !getenv("QB3_SLOW_INDEX")) {
         // foreign stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
         // produce the values entering the segments (totals pass + scan)
@@ -3276,7 +3301,7 @@ static int launch_decode_tm(const DecArgs &a, const DecPlan &plan, bool rebuild,
     if (plan.px && MODE != CM_BEST && sizeof(T) == 1) {
         ProfScope ps("dec_units", st);
         launch_dec_px(a, plan, st);
-    } else if (plan.px16 && MODE != CM_BEST && sizeof(T) == 2 && ((uintptr_t)a.img & 3) == 0) {
+    } else if (plan.px16 && MODE != CM_BEST && sizeof(T) == 2 && ((uintptr_t)a.img & 1) == 0) {
         ProfScope ps("dec_units", st);
         launch_dec_px16(a, plan, st);
     } else if (plan.fast && MODE != CM_BEST) {
