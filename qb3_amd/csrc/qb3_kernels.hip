@@ -1114,6 +1114,12 @@ __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
 template <typename T> __device__ __forceinline__ T mdiv_t(T v, T cf) { return (T)((T)((T)(mabs_t<T>(v) / cf) << 1) - (T)(v & 1)); }
 
 template <typename T> __device__ __forceinline__ T gcf_t(const T (&g)[16]) {      // gcd of the non-zero magnitudes (QB3encode.h:98-126)
+    // a magnitude of 1 settles it; so does an odd value next to an even one... only the first is cheap to see in every
+    // lane at once, and on noisy data it spares most lanes the divergent Euclid loop
+    bool one = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) one = one || mabs_t<T>(g[i]) == 1;
+    if (one) return 1;
     T x = 0;
 #pragma unroll 1
     for (uint32_t i = 0; i < 16 && x != 1; i++) {
@@ -1209,7 +1215,19 @@ __device__ __forceinline__ void best_analyse(const T (&g)[16], uint32_t rung, ui
     }
     // index coding (QB3encode.h:557-613)
     u.idx = 0xffffffffu;
+    // (first count the distinct values with plain comparisons, in registers and the same in every lane: more than 8
+    // means no index coding, and the search below -- small arrays indexed at run time, divergent -- is skipped)
+    uint32_t distinct = 0;
     if (rung > 3 && rung < 63) {
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            bool seen = false;
+#pragma unroll
+            for (uint32_t j = 0; j < i; j++) seen = seen || g[j] == g[i];
+            distinct += !seen;
+        }
+    }
+    if (rung > 3 && rung < 63 && distinct <= 8) {
         T val[8]; uint32_t cnt[8], n = 0;
         bool fits = true;
 #pragma unroll 1
