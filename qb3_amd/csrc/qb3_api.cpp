@@ -433,7 +433,13 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     if (rle) {
         // byte-serial post pass on the host (reference QB3encode.cpp:536-565)
         p->mode = mode;
-        if (len <= maxsz / 2) {
+        // ... and only worth a trip to the host when the stream has a run of four zero bytes at all (probed on the device)
+        int has_run = 1;
+        if (len <= maxsz / 2 && len - hdr >= 4) {
+            uint8_t *flag = (uint8_t *)p->d_ws.p;       // the workspace is idle now; its first word serves as the flag
+            if (zero_run_probe(out_dev, hdr, len - hdr, flag, &has_run, st)) has_run = 1;
+        }
+        if (len <= maxsz / 2 && has_run) {
             std::vector<uint8_t> data(len - hdr);
             HIPOK(hipMemcpyAsync(data.data(), out_dev + hdr, data.size(), hipMemcpyDeviceToHost, st));
             HIPOK(hipStreamSynchronize(st));

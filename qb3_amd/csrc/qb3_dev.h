@@ -130,6 +130,9 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
                   const uint64_t *tile_bits = nullptr,     // tile_bits: device array, stream length of each tile in bits
                   const IxTable &ix = IxTable());
 
+// RLE0 can only win on a stream with a run of four zero bytes: *has_run says whether bytes [off, off+nbytes) of d_buf have one
+int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, int *has_run, void *stream);
+
 // Elementwise helpers on device buffers (quantisation, reference QB3encode.cpp:137-186 / QB3decode.cpp:77-107)
 int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, uint64_t q, bool away, void *stream);
 int launch_dequantize(void *img, const Geometry &g, int dtype, uint64_t q, void *stream);

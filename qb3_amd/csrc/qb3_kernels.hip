@@ -24,6 +24,7 @@
 //
 // No MFMA anywhere: this is integer bit packing, bounded by VALU/LDS issue and, ultimately, HBM.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <type_traits>
 #include "qb3_dev.h"
 
@@ -2850,6 +2851,27 @@ __global__ void dec_index_serial(const DecArgs a0) {
     if (!ok) atomicOr(a.status, 1u);
 }
 
+// RLE0 (reference QB3encode.cpp:536-565) can only shorten a stream that holds a run of four zero bytes; looking for one
+// on the device spares the host pass (a copy of the whole stream over PCIe and a byte loop) whenever there is none.
+__global__ void zero_run_probe_kernel(const uint32_t *buf, uint64_t first_byte, uint64_t end_byte, uint32_t *flag) {
+    const uint64_t ndw = (end_byte + 3) >> 2;
+    bool found = false;
+    for (uint64_t d = (first_byte >> 2) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndw; d += (uint64_t)gridDim.x * blockDim.x) {
+        // bytes outside [first_byte, end_byte) count as non-zero
+        auto dw = [&](uint64_t i) -> uint32_t {
+            if (i >= ndw) return 0xffffffffu;
+            uint32_t v = buf[i];
+            if (4 * i < first_byte) v |= 0xffffffffu >> (8 * (4 - (uint32_t)(first_byte - 4 * i)));
+            if (4 * i + 4 > end_byte) v |= 0xffffffffu << (8 * (uint32_t)(end_byte - 4 * i));
+            return v;
+        };
+        const uint32_t cur = dw(d), nxt = dw(d + 1);
+        found = found || cur == 0 || __builtin_amdgcn_alignbit(nxt, cur, 8) == 0 || __builtin_amdgcn_alignbit(nxt, cur, 16) == 0 ||
+                __builtin_amdgcn_alignbit(nxt, cur, 24) == 0;
+    }
+    if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 // ------------------------------------------------------------------ host side of the kernels
 static thread_local char g_err[256] = "";
 static uint64_t *g_stamps = nullptr;        // debugging aid (qb3x_debug_set_stamps): phase time stamps of the first waves
@@ -3339,6 +3361,21 @@ static int launch_decode_t(const DecArgs &a, const DecPlan &plan, bool rebuild, 
     case CM_BASE: return launch_decode_tm<T, CM_BASE>(a, plan, rebuild, st);
     default: return launch_decode_tm<T, CM_BEST>(a, plan, rebuild, st);
     }
+}
+
+// *has_run = 1 when bytes [off, off + nbytes) of the dword-aligned device buffer hold four consecutive zero bytes.
+// d_flag: one device word of scratch.  Synchronises the stream.
+int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, int *has_run, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(d_flag, 0, 4, st));
+    const uint64_t ndw = (off + nbytes + 3) / 4 - off / 4;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, (ndw + 255) / 256 ? (ndw + 255) / 256 : 1);
+    hipLaunchKernelGGL(zero_run_probe_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *)d_buf, (uint64_t)off, (uint64_t)(off + nbytes), (uint32_t *)d_flag);
+    uint32_t f = 0;
+    HIPCHK(hipMemcpyAsync(&f, d_flag, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *has_run = (int)f;
+    return 0;
 }
 
 int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
