@@ -101,3 +101,42 @@ def _encode_strided(qb3, buf, w, h, b, dt, mode, cb, stride, chunk=False):
         return dst[:n].copy()
     finally:
         L.qb3_destroy_encoder(p)
+
+
+@pytest.mark.parametrize("case", [(64, 48, 3, 0, "NOISY3", 8), (128, 36, 1, 0, "GRAD", 4), (96, 64, 8, 2, "LANDSAT16", 4), (64, 64, 1, 5, "DEM", 8),
+                                  (64, 64, 1, 7, "DEM", 5), (64, 48, 3, 0, "PALETTE", 5), (40, 44, 4, 0, "NOISY3", 0), (61, 35, 3, 0, "NOISY3", 8)],
+                         ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % c)
+def test_damaged_streams_fail_or_decode_but_never_fault(qb3, oracle, case):
+    """bit flips, byte smashes and truncations of valid containers: every decoder kernel bounds what it reads by the
+    stream length and what it writes by the geometry, so the call returns -- pixels or an error -- and the process and
+    the GPU stay healthy (checked by decoding the intact stream again afterwards)"""
+    w, h, b, dt, gen, mode = case
+    img = oracle.generate(w, h, b, dt, gen, 7)
+    good = oracle.encode(img, dt, mode, cband=None if b in (1, 3, 4) else list(range(b)))
+    chunked = qb3.encode(img, dt, mode if mode not in (2, 3, 6, 7) else 5, cband=None if b in (1, 3, 4) else list(range(b)), index_chunk=True)
+    rng = random.Random(99)
+    data0 = bytes(good).index(b"DT", 11) + 2
+    outcomes = {"ok": 0, "error": 0}
+    for trial in range(40):
+        base = good if trial % 3 else chunked
+        s = base.copy()
+        lo = data0 if base is good else 11          # the self-indexing container: damage the restart table too
+        kind = trial % 4
+        if kind == 0:
+            for _ in range(rng.randrange(1, 4)):
+                at = rng.randrange(lo, len(s)); s[at] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            at = rng.randrange(lo, len(s)); n = min(len(s) - at, rng.randrange(1, 64)); s[at:at + n] = rng.randrange(256)
+        elif kind == 2:
+            s = s[:rng.randrange(lo + 1, len(s))].copy()
+        else:
+            s = np.concatenate([s, np.frombuffer(bytes(rng.randrange(256) for _ in range(rng.randrange(1, 40))), dtype=np.uint8)])
+        try:
+            out, dims, dtype, m = qb3.decode(s)
+            assert out.size == w * h * b * oracle.TYPESIZE[dt]
+            outcomes["ok"] += 1
+        except (RuntimeError, ValueError):
+            outcomes["error"] += 1
+    out, _, _, _ = qb3.decode(good)
+    want, _, _, _ = oracle.decode(good, identity=True)
+    assert np.array_equal(out, want), outcomes
