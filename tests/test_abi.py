@@ -150,3 +150,49 @@ def test_block_coding_fails_loudly_without_gpu(qb3, oracle):
     s = oracle.encode(img, 0, 8)
     with pytest.raises(RuntimeError):
         qb3.decode(s)
+
+
+def test_headers_compile_as_c_and_cpp_and_link(tmp_path):
+    """include/QB3.h is the drop-in header: a C caller and a C++ caller that use every reference entry point must compile
+    against it and link against qb3_amd/libQB3.so (nothing is run: no GPU here)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc, libdir = os.path.join(root, "include"), os.path.join(root, "qb3_amd")
+    src = r'''
+#include "QB3.h"
+#include "qb3x.h"
+#include <stddef.h>
+int main(void) {
+    size_t dims[3], map[3] = {1, 1, 2};
+    unsigned char in[48] = {0}, out[2048];
+    encsp e = qb3_create_encoder(4, 4, 3, QB3_U8);
+    if (!e) return 1;
+    qb3_set_encoder_mode(e, QB3M_FTL);
+    qb3_set_encoder_coreband(e, 3, map);
+    qb3_set_encoder_quanta(e, 1, 0);
+    qb3_set_encoder_stride(e, 0);
+    size_t n = qb3_max_encoded_size(e) <= sizeof(out) ? qb3_encode(e, in, out) : 0;
+    int st = qb3_get_encoder_state(e);
+    qb3_reset_encoder(e);
+    qb3_destroy_encoder(e);
+    decsp d = n ? qb3_read_start(out, n, dims) : 0;
+    if (d) {
+        qb3_read_info(d);
+        (void)qb3_get_type(d); (void)qb3_get_mode(d); (void)qb3_get_quanta(d); (void)qb3_get_order(d);
+        (void)qb3_get_coreband(d, map); (void)qb3_decoded_size(d);
+        qb3_set_decoder_stride(d, 0);
+        qb3_read_data(d, in);
+        qb3_destroy_decoder(d);
+    }
+    (void)qb3x_device_count(); (void)qb3x_last_error();
+    return st;
+}
+'''
+    for compiler, name, std in (("gcc", "caller.c", "-std=c99"), ("g++", "caller.cpp", "-std=c++11")):
+        path = tmp_path / name
+        path.write_text(src)
+        exe = tmp_path / (name + ".out")
+        r = subprocess.run([compiler, std, "-Wall", "-Werror", "-I", inc, str(path), "-L", libdir, "-lQB3",
+                            "-Wl,-rpath," + libdir, "-o", str(exe)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
