@@ -611,3 +611,36 @@ def test_unaligned_device_pointers(qb3, oracle, shape, off, mode):
     dec.decode(dst, out=out, index=index)
     assert torch.equal(out, raw)
     assert bool((guard[:off] == 0xA5).all()) and bool((guard[off + raw.numel():] == 0xA5).all()), "wrote outside the raster"
+
+
+def test_handles_are_independent_across_threads(qb3, oracle):
+    """handles share nothing.  Four host threads, each with its own encoder and decoder handles and its own
+    raster, code concurrently (ctypes drops the GIL inside the library); every stream must equal the oracle's"""
+    import threading
+    cases = [(256, 128, 3, 0, "NOISY3", 8), (200, 100, 1, 5, "DEM", 4), (128, 128, 8, 2, "LANDSAT16", 8), (96, 64, 1, 7, "DEM", 5)]
+    imgs = [oracle.generate(w, h, b, dt, gen, 30 + i) for i, (w, h, b, dt, gen, m) in enumerate(cases)]
+    refs = [oracle.encode(img, c[3], c[5], cband=None if c[2] in (1, 3, 4) else list(range(c[2]))) for img, c in zip(imgs, cases)]
+    errors = []
+
+    def work(i):
+        w, h, b, dt, gen, mode = cases[i]
+        cb = None if b in (1, 3, 4) else list(range(b))
+        try:
+            for _ in range(8):
+                got = qb3.encode(imgs[i], dt, mode, cband=cb)
+                if not np.array_equal(got, refs[i]):
+                    errors.append("thread %d: stream differs" % i)
+                    return
+                out, _, _, _ = qb3.decode(got)
+                if not np.array_equal(out, imgs[i].view(np.uint8).ravel()):
+                    errors.append("thread %d: pixels differ" % i)
+                    return
+        except Exception as e:      # noqa: BLE001 -- report whatever a worker thread hit
+            errors.append("thread %d: %r" % (i, e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
