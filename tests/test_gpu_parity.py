@@ -333,34 +333,44 @@ def test_overlong_stream_fails_like_the_reference(qb3, oracle):
     qb3.decode(s)
 
 
-def test_tiles_api(qb3, oracle):
+@pytest.mark.parametrize("shape", [(256, 256, 3, 0), (251, 121, 3, 0), (130, 67, 8, 2), (61, 35, 1, 5)],
+                         ids=lambda c: "%dx%dx%d-t%d" % c)
+def test_tiles_api(qb3, oracle, shape):
+    """one call, several tiles: aligned 8-bit tiles, tiles whose size makes every pitch odd (unaligned rows and tile
+    starts), 16-bit groups, a 32-bit tile through the generic kernels; with the index and without"""
     import ctypes as C
     import torch
     from qb3_amd import synth
     L = qb3.lib
-    w = h = 256
+    w, h, b, dt = shape
+    tsz = oracle.TYPESIZE[dt]
     n = 6
-    imgs = torch.stack([synth.generate(w, h, 3, 0, "NOISY3", 1000 + t) for t in range(n)])
-    p = L.qb3_create_encoder(w, h, 3, 0)
+    gen = "NOISY3" if dt == 0 else ("LANDSAT16" if dt == 2 else "DEM")
+    imgs = torch.stack([synth.generate(w, h, b, dt, gen, 1000 + t) for t in range(n)])
+    p = L.qb3_create_encoder(w, h, b, dt)
     pitch = (L.qb3_max_encoded_size(p) + 3) // 4 * 4
     isz = L.qb3x_index_size(p)
     dst = torch.zeros(n * pitch, dtype=torch.uint8, device="cuda")
     idx = torch.zeros(n * isz, dtype=torch.uint8, device="cuda")
     sizes = (C.c_size_t * n)()
-    assert L.qb3x_encode_tiles(p, imgs.data_ptr(), n, w * h * 3, dst.data_ptr(), pitch, idx.data_ptr(), sizes, None) == n
+    raw = w * h * b * tsz
+    assert L.qb3x_encode_tiles(p, imgs.data_ptr(), n, raw, dst.data_ptr(), pitch, idx.data_ptr(), sizes, None) == n
     L.qb3_destroy_encoder(p)
     host = dst.cpu().numpy()
     for t in range(n):
-        ref = oracle.encode(imgs[t].cpu().numpy(), 0, 8)
+        ref = oracle.encode(imgs[t].cpu().numpy().view(oracle.NPTYPE[dt]), dt, 8)
         assert sizes[t] == len(ref) and np.array_equal(host[t * pitch:t * pitch + sizes[t]], ref)
     dims = (C.c_size_t * 3)()
     hdr = host[:64].copy()
     d = L.qb3_read_start(hdr.ctypes.data, sizes[0], dims)
     assert L.qb3_read_info(d)
-    out = torch.zeros_like(imgs)
-    assert L.qb3x_decode_tiles(d, dst.data_ptr(), n, pitch, sizes, out.data_ptr(), w * h * 3, idx.data_ptr(), None) == n
+    if b not in (1, 3, 4):
+        L.qb3x_set_decoder_compat(d, 0)     # identity map when the container has no CB chunk (the default)
+    for index in (idx.data_ptr(), None):
+        out = torch.zeros_like(imgs)
+        assert L.qb3x_decode_tiles(d, dst.data_ptr(), n, pitch, sizes, out.data_ptr(), raw, index, None) == n
+        assert torch.equal(out, imgs)
     L.qb3_destroy_decoder(d)
-    assert torch.equal(out, imgs)
 
 
 @pytest.mark.parametrize("case", [(2048, 2048, 1, 7, "TERRACE", 4, 1), (2048, 2048, 1, 7, "TERRACE", 4, 5), (2048, 1024, 3, 0, "NOISY3", 2, 8),
