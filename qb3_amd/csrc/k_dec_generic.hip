@@ -1,0 +1,403 @@
+// qb3_amd/csrc/k_dec_generic.hip -- generic decoders: unit-parallel (dec3_kernel), lane per segment (dec_kernel), serial index rebuild
+#include "qb3_kernels.h"
+
+namespace qb3dev {
+
+// Lane per index segment.
+template <typename T, int MODE>
+__global__ void dec_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t bands = a.g.bands, S = a.g.seg_blocks, nbx = a.g.nbx;
+    const uint64_t seg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= a.g.nseg) return;
+    // per-lane LDS: scratch block [y][x][band] then band state
+    uint32_t *lane_mem = (uint32_t *)smem + (size_t)threadIdx.x * a.lane_dw;
+    T *blk = (T *)lane_mem;
+    T *prev = blk + 16 * bands;
+    T *pcf = prev + bands;
+    uint8_t *rungs = (uint8_t *)(pcf + bands);
+    for (uint32_t c = 0; c < bands; c++) {
+        prev[c] = ((const T *)a.idx.prev)[seg * bands + c];
+        pcf[c] = (MODE == CM_BEST) ? ((const T *)a.idx.cf)[seg * bands + c] : (T)0;
+        rungs[c] = a.idx.rung[seg * bands + c];
+    }
+    Reader rd;
+    rd.init(a.in32, a.in_bit0 + a.idx.bitpos[seg], a.in_bit0 + a.in_bits);
+    const uint64_t order = a.g.order;
+    const uint32_t gend = (uint32_t)(((seg + 1) * S < a.g.nblocks) ? (seg + 1) * S : a.g.nblocks);
+    bool ok = true;
+    T g[16];
+    for (uint32_t gb = (uint32_t)(seg * S); gb < gend && ok; gb++) {
+        for (uint32_t c = 0; c < bands; c++) {
+            uint32_t rung = rungs[c];
+            T cf = pcf[c];
+            ok = parse_unit<T, MODE, Reader>(rd, rung, cf, g) && ok;
+            rungs[c] = (uint8_t)rung;
+            pcf[c] = cf;
+            T prv = prev[c];
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) {
+                const uint32_t nib = curve_nib(order, i);
+                prv = (T)(prv + smag_t<T>(g[i]));
+                blk[nib * bands + c] = prv;
+            }
+            prev[c] = prv;
+        }
+        // add the core band back, sequentially in place like the strip epilogue (reference QB3decode.h:560-567)
+        for (uint32_t c = 0; c < bands; c++) {
+            const uint32_t cb = a0.g.cband[c];
+            if (cb != c)
+                for (uint32_t i = 0; i < 16; i++) blk[i * bands + c] = (T)(blk[i * bands + c] + blk[i * bands + cb]);
+        }
+        const uint32_t by = gb / nbx, bx = gb - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        for (uint32_t y = 0; y < 4; y++) {
+            uint8_t *dst = (uint8_t *)a.img + ((uint64_t)(y0 + y) * a.g.stride + (uint64_t)x0 * bands) * sizeof(T);
+            const uint32_t *srow = lane_mem + y * a.dpr;
+            if (((uintptr_t)dst & 3) == 0)
+                for (uint32_t d = 0; d < a.dpr; d++) ((uint32_t *)dst)[d] = srow[d];
+            else
+                for (uint32_t d = 0; d < 4 * a.dpr; d++) dst[d] = ((const uint8_t *)srow)[d];
+        }
+    }
+    if (!ok) atomicOr(a.status, 1u);
+    if (seg == a.g.nseg - 1) {
+        // reference: fails when more than 7 bits are left (QB3decode.h:411,569,740); also flag overruns
+        const uint64_t used = rd.position() - a.in_bit0;
+        if (used > a.in_bits) atomicOr(a.status, 4u);
+        else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
+}
+
+// ---- unit-parallel decode (FTL / BASE, band maps whose core bands are themselves core) ------------------
+// One workgroup per index segment (= NB blocks).  Nothing in it is serial: the index carries the bit length of
+// every unit, so
+//   positions   exclusive scan of block lengths, plus the unit lengths inside the block
+//   rungs       each lane reads its own rung-switch code; the rung is the entry rung of the band plus the
+//               per-band scan of the switch deltas (mod 2^UB)
+//   values      lane per unit decodes its 16 codes, undoes step and mag-sign; the value entering the unit is
+//               the band's entry value plus the per-band scan of the unit totals
+// Lanes are ordered band-major inside a pass (lane = band*BPP + block) so that a per-band scan is a plain
+// workgroup scan minus its value at the band's first lane.  The compressed range is staged in LDS with
+// coalesced loads, pixels are assembled in an LDS tile laid out like the image and stored as coalesced dwords.
+// same, with ONE barrier: the scratch must not be rewritten before the caller's next barrier (use distinct areas)
+template <typename V>
+__device__ __forceinline__ V block_exscan_1b(V v, V *wsum) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    V x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        V y = __shfl_up(x, d, 64);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    V base = 0;
+    for (uint32_t i = 0; i < wave; i++) base += wsum[i];
+    return (V)(base + x - v);
+}
+
+// reads the rung-switch code at bit `pos`: returns the delta (mod 2^UB), sets *gpos to the first value code
+template <typename T, typename PTR>
+__device__ __forceinline__ uint32_t dec3_switch(PTR src, uint32_t endw, uint32_t pos, uint32_t *gpos, bool *signal) {
+    constexpr uint32_t UB = UBits<T>::v;
+    ReaderT<PTR> rd;
+    rd.in = src; rd.endw = endw; rd.wp = pos >> 5;
+    const uint32_t sh = pos & 31;
+    rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
+    uint32_t delta = 0;
+    *signal = false;
+    if (rd.get(1)) delta = get_switch_noflag<UB, ReaderT<PTR>>(rd, *signal);
+    *gpos = (uint32_t)rd.position();
+    return delta;
+}
+
+// decodes the 16 values at bit `gpos`; run[i] = sum of the first i+1 deltas in curve order.
+// Rungs 1..7 go through the LDS table (one read per value, three values per refill of the bit buffer).
+template <typename T, bool STEP, typename PTR>
+__device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos, uint32_t rung, const uint16_t *dtab, T (&run)[16]) {
+    ReaderT<PTR> rd;
+    rd.in = src; rd.endw = endw; rd.wp = gpos >> 5;
+    const uint32_t sh = gpos & 31;
+    rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
+    if (rung >= 1 && rung < 8) {
+        const uint16_t *tab = dtab + dec_tab_off(rung);
+        const uint32_t mask = (4u << rung) - 1;
+        uint32_t rb = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            if (i % 3 == 0) rd.ensure(32);          // three codes are at most 27 bits
+            const uint32_t x = (uint32_t)rd.buf & mask;
+            const uint32_t e = tab[x];              // value: off the critical path, the reads pipeline
+            rd.skip(rung + (x & 1) + ((x & 3) == 3));   // length from the two flag bits alone (QB3decode.h:119-129)
+            run[i] = (T)(e & 0xfff);
+            rb |= ((e >> rung) & 1) << i;
+        }
+        if (STEP && (rb & (rb + 1)) == 0) {         // undo the step (reference QB3decode.h:285-289)
+            const uint32_t m = __popc(rb);
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) if (i == m) run[i] ^= (T)((T)1 << rung);
+        }
+    } else
+        get_group<T, STEP, ReaderT<PTR>>(rd, rung, run);
+    T acc = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) { acc = (T)(acc + smag_t<T>(run[i])); run[i] = acc; }
+}
+
+template <typename T, bool STEP>
+__global__ void dec3_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t bands = a.g.bands, NB = a.g.seg_blocks, dpr = a.dpr, nbx = a.g.nbx, BPP = a.bpp;
+    const uint64_t seg = blockIdx.x;
+    const uint32_t g0 = (uint32_t)(seg * NB);
+    const uint32_t nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
+    const uint64_t stride = a.g.stride;
+
+    // LDS carve (8-byte aligned pieces)
+    uint64_t *slot_base = (uint64_t *)smem;
+    uint64_t *wsum = slot_base + NB;                   // 16: scan scratch
+    uint64_t *cprev = wsum + 16;                       // MAXBANDS: value entering the pass, per band
+    uint64_t *ebaseT = cprev + MAXBANDS;               // MAXBANDS: scan value at the band's first lane (totals)
+    uint32_t *crung = (uint32_t *)(ebaseT + MAXBANDS); // MAXBANDS
+    uint32_t *ebase = crung + MAXBANDS;                // MAXBANDS (deltas)
+    uint32_t *bpos = ebase + MAXBANDS;                 // BPP (+pad)
+    uint32_t *stage = bpos + ((BPP + 1) & ~1u);
+    uint32_t *tile = stage + a.in_cap_dw;
+    uint16_t *ulen_s = (uint16_t *)(tile + 4 * NB * dpr);   // BPP*bands (padded to 8 bytes)
+    uint16_t *dtab = ulen_s + ((BPP * bands + 3) & ~3u);    // DEC_TAB_SIZE + pad
+    fill_dec_tab(dtab);
+
+    // the compressed range of this segment, in bits from a.in32
+    const uint64_t P0 = a.idx.bitpos[seg];
+    const uint64_t P1 = (seg + 1 < a.g.nseg) ? a.idx.bitpos[seg + 1] : a.in_bits;
+    const uint64_t w0 = (a.in_bit0 + P0) >> 5;
+    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
+    const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0 + 2;
+    const bool staged = ndw64 <= a.in_cap_dw;          // workgroup uniform
+    const uint32_t ndw = (uint32_t)ndw64;
+    if (staged)
+        for (uint32_t base = 0; base < ndw; base += 4 * nthr) {        // four loads in flight per thread, then four LDS stores
+            uint32_t sw[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t i = base + tid + q * nthr; sw[q] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t i = base + tid + q * nthr; if (i < ndw) stage[i] = sw[q]; }
+        }
+    const uint32_t endw_g = (uint32_t)((endw_abs - w0 < 0xffffffffull) ? endw_abs - w0 : 0xffffffffull);
+    for (uint32_t sl = tid; sl < nb_here; sl += nthr) {
+        const uint32_t g = g0 + sl, by = g / nbx, bx = g - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        slot_base[sl] = (uint64_t)y0 * stride + (uint64_t)x0 * bands;
+    }
+    if (tid < bands) {
+        cprev[tid] = (uint64_t)((const T *)a.idx.prev)[seg * bands + tid];
+        crung[tid] = a.idx.rung[seg * bands + tid];
+    }
+    uint32_t cpos = (uint32_t)(a.in_bit0 + P0 - 32 * w0);     // bit position of the pass, relative to word w0
+    const uint32_t c = fastdiv(tid, BPP, a.magic_bpp), b = tid - c * BPP;
+    const uint32_t cb = a0.g.cband[c < MAXBANDS ? c : 0];
+    const uint64_t order = a.g.order;
+    T *tt = (T *)tile;
+    const uint32_t rowel = NB * 4 * bands;       // tile elements per pixel row
+    bool bad = false;
+    __syncthreads();
+
+    for (uint32_t p = 0; p < a.passes; p++) {
+        const uint32_t pb0 = p * BPP;
+        const uint32_t nbp = pb0 >= nb_here ? 0 : ((nb_here - pb0 < BPP) ? nb_here - pb0 : BPP);
+        // unit lengths of this pass (contiguous in the table)
+        const uint64_t ubase = ((uint64_t)g0 + pb0) * bands;
+        if (a.g.ulen_sz == 1) for (uint32_t i = tid; i < nbp * bands; i += nthr) ulen_s[i] = ((const uint8_t *)a.idx.ulen)[ubase + i];
+        else for (uint32_t i = tid; i < nbp * bands; i += nthr) ulen_s[i] = ((const uint16_t *)a.idx.ulen)[ubase + i];
+        __syncthreads();
+        uint32_t blen = 0;
+        if (tid < nbp) for (uint32_t k = 0; k < bands; k++) blen += ulen_s[tid * bands + k];
+        const uint32_t bex = (uint32_t)block_exscan_v<uint64_t>(blen, wsum);
+        if (tid < nbp) bpos[tid] = cpos + bex;
+        if (tid == nthr - 1) wsum[15] = bex + blen;        // pass total (lane nthr-1 holds the inclusive sum)
+        __syncthreads();
+        const uint32_t ptotal = (uint32_t)wsum[15];
+        const bool act = c < bands && b < nbp;
+        const uint32_t sl = pb0 + b;
+        uint32_t pos = 0, gpos = 0, delta = 0;
+        if (act) {
+            pos = bpos[b];
+            for (uint32_t k = 0; k < c; k++) pos += ulen_s[b * bands + k];
+            bool sig;
+            delta = staged ? dec3_switch<T, LdsWords>((LdsWords)stage, ndw, pos, &gpos, &sig)
+                           : dec3_switch<T, const uint32_t *>(a.in32 + w0, endw_g, pos, &gpos, &sig);
+            if (sig && STEP) bad = true;       // common-factor / index unit in a BASE stream: not handled here
+        }
+        // per-band scan of the rung deltas
+        const uint32_t dex = (uint32_t)block_exscan_v<uint64_t>(act ? delta : 0u, wsum);
+        if (act && b == 0) ebase[c] = dex;
+        __syncthreads();
+        T run[16];
+        T usum = 0;
+        uint32_t rung = 0;
+        if (act) {
+            rung = (crung[c] + dex + delta - ebase[c]) & UMASK;
+            if (staged) dec3_group<T, STEP, LdsWords>((LdsWords)stage, ndw, gpos, rung, dtab, run);
+            else dec3_group<T, STEP, const uint32_t *>(a.in32 + w0, endw_g, gpos, rung, dtab, run);
+            usum = run[15];
+        }
+        // per-band scan of the unit totals -> value entering each unit
+        const uint64_t sex = block_exscan_v<uint64_t>(act ? (uint64_t)usum : 0ull, wsum);
+        if (act && b == 0) ebaseT[c] = sex;
+        __syncthreads();
+        T pv = 0;
+        if (act) {
+            pv = (T)(cprev[c] + sex - ebaseT[c]);
+            if (cb == c) {
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t nib = curve_nib(order, i);
+                    tt[sl * 4 * bands + c + ((nib >> 2) * rowel + (nib & 3) * bands)] = (T)(run[i] + pv);
+                }
+            }
+        }
+        __syncthreads();            // core bands are in the tile; every read of crung/cprev is done
+        if (act) {
+            if (cb != c) {
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t nib = curve_nib(order, i);
+                    const uint32_t e = sl * 4 * bands + ((nib >> 2) * rowel + (nib & 3) * bands);
+                    tt[e + c] = (T)(run[i] + pv + tt[e + cb]);
+                }
+            }
+            if (b == nbp - 1) { crung[c] = rung; cprev[c] = (uint64_t)(T)(pv + usum); }
+        }
+        cpos += ptotal;
+        __syncthreads();
+    }
+    if (bad) atomicOr(a.status, 1u);
+    if (tid == 0 && seg == a.g.nseg - 1) {      // reference: more than 7 unused bits at the end is a failure
+        const uint64_t used = (uint64_t)cpos + 32 * w0 - a.in_bit0;
+        if (used > a.in_bits) atomicOr(a.status, 4u);
+        else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
+
+    // ---- store the tile rows, coalesced dwords
+    const uint32_t rowdw = nb_here * dpr;
+    for (uint32_t r = 0; r < 4; r++)
+        for (uint32_t j = tid; j < rowdw; j += nthr) {
+            const uint32_t sl = fastdiv(j, dpr, a.magic_dpr), d = j - sl * dpr;
+            uint8_t *dst = (uint8_t *)a.img + (slot_base[sl] + (uint64_t)r * stride) * sizeof(T) + 4 * d;
+            const uint32_t v = tile[r * NB * dpr + j];
+            if (((uintptr_t)dst & 3) == 0) *(uint32_t *)dst = v;
+            else { dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); dst[3] = (uint8_t)(v >> 24); }
+        }
+}
+
+// Foreign stream: ONE lane walks the stream and rebuilds the index (bit position + band state at every
+// segment start).  Latency bound by construction.
+template <typename T, int MODE>
+__global__ void dec_index_serial(const DecArgs a0) {
+    if (threadIdx.x) return;
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);       // one lane per tile
+    __shared__ uint64_t st_prev[MAXBANDS], st_cf[MAXBANDS];
+    __shared__ uint32_t st_rung[MAXBANDS];
+    const uint32_t bands = a.g.bands, S = a.g.seg_blocks;
+    for (uint32_t c = 0; c < bands; c++) { st_prev[c] = 0; st_cf[c] = 0; st_rung[c] = 0; }
+    const uint32_t nblocks = (uint32_t)a.g.nblocks;
+    uint32_t gb0 = 0, gb_end = nblocks;
+    uint64_t seg = 0, bp = 0;
+    if (a.ix) {                             // restart point blockIdx.y of the container's coarse table
+        const uint8_t *e = a.ix + (uint64_t)blockIdx.y * a.ix_E;
+        for (uint32_t i = 0; i < 6; i++) bp |= (uint64_t)e[i] << (8 * i);
+        const uint8_t *pv = e + 6 + bands, *cf = pv + bands * sizeof(T);
+        for (uint32_t c = 0; c < bands; c++) {
+            st_rung[c] = e[6 + c];
+            uint64_t v = 0, f = 0;
+            for (uint32_t i = 0; i < sizeof(T); i++) { v |= (uint64_t)pv[c * sizeof(T) + i] << (8 * i); if (MODE == CM_BEST) f |= (uint64_t)cf[c * sizeof(T) + i] << (8 * i); }
+            st_prev[c] = v; st_cf[c] = f;
+        }
+        gb0 = blockIdx.y * a.ix_blocks;
+        gb_end = (nblocks - gb0 < a.ix_blocks) ? nblocks : gb0 + a.ix_blocks;
+        seg = gb0 / S;
+    }
+    Reader rd;
+    rd.init(a.in32, a.in_bit0 + bp, a.in_bit0 + a.in_bits);
+    T g[16];
+    bool ok = true;
+    uint32_t inseg = 0;
+    for (uint32_t gb = gb0; gb < gb_end && ok; gb++) {
+        if (inseg == 0) {
+            a.idx.bitpos[seg] = rd.position() - a.in_bit0;
+            for (uint32_t c = 0; c < bands; c++) {
+                ((T *)a.idx.prev)[seg * bands + c] = (T)st_prev[c];
+                if (MODE == CM_BEST) ((T *)a.idx.cf)[seg * bands + c] = (T)st_cf[c];
+                a.idx.rung[seg * bands + c] = (uint8_t)st_rung[c];
+            }
+            seg++;
+        }
+        if (++inseg == S) inseg = 0;
+        for (uint32_t c = 0; c < bands; c++) {
+            uint32_t rung = st_rung[c];
+            T cf = (T)st_cf[c];
+            const uint64_t ustart = rd.position();
+            ok = parse_unit<T, MODE, Reader>(rd, rung, cf, g) && ok;
+            if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint8_t)(rd.position() - ustart);
+            else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint16_t)(rd.position() - ustart);
+            T sum = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) sum = (T)(sum + smag_t<T>(g[i]));
+            st_prev[c] = (T)((T)st_prev[c] + sum);
+            st_cf[c] = cf;
+            st_rung[c] = rung;
+        }
+    }
+    if (!ok) atomicOr(a.status, 1u);
+}
+
+template <typename T>
+static void launch_dec_generic_t(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
+    if (plan.fast && a.g.mode != CM_BEST) {
+        const dim3 grid((uint32_t)a.g.nseg, a.ntiles), block(plan.threads2);
+        if (a.g.mode == CM_BASE) hipLaunchKernelGGL((dec3_kernel<T, true>), grid, block, plan.lds2_bytes, st, a);
+        else hipLaunchKernelGGL((dec3_kernel<T, false>), grid, block, plan.lds2_bytes, st, a);
+        return;
+    }
+    const dim3 grid(plan.nwg, a.ntiles), block(plan.threads);
+    switch (a.g.mode) {
+    case CM_FTL: hipLaunchKernelGGL((dec_kernel<T, CM_FTL>), grid, block, plan.lds_bytes, st, a); break;
+    case CM_BASE: hipLaunchKernelGGL((dec_kernel<T, CM_BASE>), grid, block, plan.lds_bytes, st, a); break;
+    default: hipLaunchKernelGGL((dec_kernel<T, CM_BEST>), grid, block, plan.lds_bytes, st, a); break;
+    }
+}
+void launch_dec_generic(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
+    switch (a.g.tsz) {
+    case 1: launch_dec_generic_t<uint8_t>(a, plan, st); break;
+    case 2: launch_dec_generic_t<uint16_t>(a, plan, st); break;
+    case 4: launch_dec_generic_t<uint32_t>(a, plan, st); break;
+    default: launch_dec_generic_t<uint64_t>(a, plan, st); break;
+    }
+}
+template <typename T>
+static void launch_dec_index_serial_t(const DecArgs &a, hipStream_t st) {
+    const dim3 grid(a.ntiles, a.ix ? a.ix_K : 1), block(64);
+    switch (a.g.mode) {
+    case CM_FTL: hipLaunchKernelGGL((dec_index_serial<T, CM_FTL>), grid, block, 0, st, a); break;
+    case CM_BASE: hipLaunchKernelGGL((dec_index_serial<T, CM_BASE>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((dec_index_serial<T, CM_BEST>), grid, block, 0, st, a); break;
+    }
+}
+void launch_dec_index_serial(const DecArgs &a, hipStream_t st) {
+    switch (a.g.tsz) {
+    case 1: launch_dec_index_serial_t<uint8_t>(a, st); break;
+    case 2: launch_dec_index_serial_t<uint16_t>(a, st); break;
+    case 4: launch_dec_index_serial_t<uint32_t>(a, st); break;
+    default: launch_dec_index_serial_t<uint64_t>(a, st); break;
+    }
+}
+
+}  // namespace qb3dev

@@ -1,0 +1,267 @@
+// qb3_amd/csrc/k_dec_px16.hip -- 16-bit decoder, wave per segment, lane per (block, band group)
+#include "qb3_px.h"
+
+namespace qb3dev {
+
+// ---- 16-bit: wave per index segment, lane per (block, band group) -- counterpart of enc_px16_kernel -------
+// Same organisation as dec_px_kernel; a lane decodes the BG <= 4 units of its band group.  Rungs up to 7 go through
+// the same table (values below 256), higher rungs decode by the code rule from a 64-bit buffer (three codes of at
+// most 17 bits per refill).  Lane = block * NG + group, i.e. stream order, so bit positions are one DPP scan; the
+// per-band scans (rung deltas, unit totals) run over the lanes of one group: DPP when NG = 1, a strided shuffle
+// scan otherwise.
+__device__ __forceinline__ uint32_t px16_switch(uint32_t pos, uint32_t *cslen, bool *signal) {
+    uint32_t x = lds_bits(pos);
+    *signal = false;
+    if (!(x & 1)) { *cslen = 1; return 0; }
+    x >>= 1;                                            // code at rung 3 (reference QB3decode.h:97-116)
+    uint32_t m, len;
+    if (!(x & 1)) { m = (x & 7) >> 1; len = 3; }
+    else if (!(x & 2)) { m = ((x >> 2) & 3) | 4; len = 4; }
+    else { m = ((x >> 2) & 7) | 8; len = 5; }
+    *cslen = 1 + len;
+    if (m == 14) { *signal = true; return 0; }
+    return (m & 1) ? (16 - (m + 1) / 2) & 15 : m / 2 + 1;
+}
+
+// 16 values of a 16-bit unit at bit `gpos`: rp[k] = running sums of values 2k, 2k+1 (16-bit lanes); returns the total
+template <bool STEP>
+__device__ __forceinline__ uint32_t px16_group(uint32_t gpos, uint32_t rung, uint32_t (&rp)[8]) {
+    if (rung < 8) return px_group<STEP>(gpos, rung, rp);     // values below 256: the table path of the 8-bit kernel
+    const uint32_t top = 1u << rung, half = top >> 1;
+    uint32_t pos = gpos, acc = 0, fl = 0;
+    uint64_t buf = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i % 3 == 0) {                               // three codes are at most 51 bits
+            LdsWords p = lds_at((pos >> 3) & ~3u);
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            buf = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, pos) << 32) | __builtin_amdgcn_alignbit(d1, d0, pos);
+        }
+        const uint32_t x = (uint32_t)buf;
+        const bool c1 = x & 1, c2 = (x & 3) == 3;
+        const uint32_t len = rung + c1 + c2;
+        const uint32_t v = c2 ? (((x >> 2) & (top - 1)) | top) : c1 ? (((x >> 2) & (half - 1)) | half) : ((x & (top - 1)) >> 1);
+        buf >>= len; pos += len;
+        acc += (v >> 1) ^ (0u - (v & 1u));              // undo mag-sign, accumulate (mod 2^16 in the packed lanes)
+        if (STEP) fl |= ((uint32_t)c2 | ((v & 1u) << 1)) << (2 * i);
+        if (i & 1) rp[i >> 1] |= acc << 16; else rp[i >> 1] = acc & 0xffffu;
+    }
+    if (STEP) {                                         // undo the step (reference QB3decode.h:285-289), as in px_group
+        const uint32_t tb = fl & 0x55555555u, u = tb | (tb << 1);
+        const uint32_t m = __popc(tb);
+        if ((u & (u + 1)) == 0 && m < 16) {
+            const uint32_t c16 = ((fl >> (2 * m + 1)) & 1u) ? (0u - half) & 0xffffu : half;
+            const uint32_t ge = 0xffff0000u >> (16 - m);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t pair = (ge >> (2 * k)) & 3u;
+                rp[k] = pk_add16(rp[k], ((pair | (pair << 15)) & 0x00010001u) * c16);
+            }
+            acc += c16;
+        }
+    }
+    return acc;
+}
+
+// inclusive scan over the lanes of the same band group (stride NG), NW words per lane
+template <int NW>
+__device__ __forceinline__ void group_iscan(uint32_t (&v)[NW], uint32_t NG) {
+    if (NG == 1) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) v[k] = wave_iscan32(v[k]);
+        return;
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t d = NG; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const uint32_t y = __shfl_up(v[k], d, 64);
+            if (lane >= d) v[k] += y;
+        }
+    }
+}
+
+template <int BG, bool RGB, uint64_t ORDER, bool STEP>
+__global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int NW = (BG + 1) / 2;                    // 32-bit words of a scan packed 16 bits per band
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t NB = a.g.seg_blocks, nbx = a.g.nbx, B = a.g.bands, NG = a.px_ng;    // NB * NG <= 64
+    const uint64_t stride = a.g.stride;                 // in values
+    const uint32_t slot = fastdiv(lane, NG, a.px_magic_ng), grp = lane - slot * NG, band0 = grp * BG;
+
+    uint32_t *tab = (uint32_t *)smem;                   // 4 KB, at LDS address 0 (the table addressing relies on it)
+    uint32_t *stage = tab + 1024 + wave * (a.in_cap_dw + 16);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
+    const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
+    // loads that depend on nothing but the segment number go out first; their round trips overlap the table copy and
+    // its barrier (see dec_px_kernel)
+    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
+    const bool live = seg < a.g.nseg;
+    const uint64_t segc = live ? seg : 0;
+    const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
+    const bool act = live && slot < nb_here;
+    const uint64_t P0 = a.idx.bitpos[segc];
+    const uint64_t P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
+    uint32_t ul_[BG], rg0[BG], pv0[BG], blen = 0;
+    {
+        const uint16_t *ul = (const uint16_t *)a.idx.ulen + ((uint64_t)g0 + slot) * B + band0;
+#pragma unroll
+        for (int c = 0; c < BG; c++) {
+            ul_[c] = act ? ul[c] : 0u;
+            rg0[c] = a.idx.rung[segc * B + band0 + c];
+            pv0[c] = ((const uint16_t *)a.idx.prev)[segc * B + band0 + c];
+        }
+    }
+    for (uint32_t i = tid; i < 256; i += blockDim.x) ((uint4 *)tab)[i] = ((const uint4 *)px_dec_tab.e)[i];
+    __syncthreads();                                    // the only workgroup barrier
+    if (!live) return;
+    const uint64_t w0 = (a.in_bit0 + P0) >> 5;
+    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
+    const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0;
+    const bool fits = ndw64 <= a.in_cap_dw && lds0 == 0;
+    const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
+    for (uint32_t base = 0; base < ndw + 16; base += 512) {         // eight loads in flight per lane, then eight LDS stores; 16 zero words follow
+        uint32_t sw[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = base + lane + 64 * q;
+            sw[q] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = base + lane + 64 * q;
+            if (i < ndw + 16) stage[i] = sw[q];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < BG; c++) blen += ul_[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const uint32_t limit = stage_bit0 + 32 * ndw;
+    const uint32_t cpos = stage_bit0 + (uint32_t)(a.in_bit0 + P0 - 32 * w0);
+    bool bad = !fits;
+    const uint32_t binc = wave_iscan32(blen);           // lanes are in stream order
+    uint32_t gpos[BG], pos = cpos + binc - blen, dpk[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) dpk[k] = 0;
+#pragma unroll
+    for (int c = 0; c < BG; c++) {
+        pos = pos < limit ? pos : limit;
+        bool sig; uint32_t csl;
+        const uint32_t d = px16_switch(pos, &csl, &sig);
+        gpos[c] = pos + csl;
+        if (act && sig && STEP) bad = true;             // common-factor / index unit: not handled here
+        dpk[c >> 1] |= (act ? d : 0u) << (16 * (c & 1));
+        pos += ul_[c];
+    }
+    group_iscan<NW>(dpk, NG);                           // inclusive, 16 bits per band
+    uint32_t rp[BG][8], spk[NW], sinc[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) spk[k] = 0;
+#pragma unroll
+    for (int c = 0; c < BG; c++) {
+        const uint32_t rung = (rg0[c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 15u;
+        const uint32_t tot = px16_group<STEP>(gpos[c], rung, rp[c]) & 0xffffu;
+        spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
+    }
+    {   // per-band scan of the unit totals modulo 2^16: the two halves of a word must not carry into each other
+        uint32_t lo[NW], hi[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) { lo[k] = spk[k] & 0xffffu; hi[k] = spk[k] >> 16; }
+        group_iscan<NW>(lo, NG);
+        group_iscan<NW>(hi, NG);
+#pragma unroll
+        for (int k = 0; k < NW; k++) sinc[k] = (lo[k] & 0xffffu) | (hi[k] << 16);
+    }
+    if (a.totals_only) { // foreign stream, first pass: the last lane of every band group holds the group's sums
+        if (lane >= 64 - NG)
+#pragma unroll
+            for (int c = 0; c < BG; c++) ((uint16_t *)a.idx.prev)[seg * B + band0 + c] = (uint16_t)(sinc[c >> 1] >> (16 * (c & 1)));
+        if (bad) atomicOr(a.status, fits ? 1u : 8u);
+        return;
+    }
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < BG; c++) {
+            const uint32_t excl = ((sinc[c >> 1] >> (16 * (c & 1))) - (spk[c >> 1] >> (16 * (c & 1)))) & 0xffffu;
+            const uint32_t pv = (pv0[c] + excl) & 0xffffu;
+#pragma unroll
+            for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], pv * 0x00010001u);
+        }
+#pragma unroll
+        for (int c = 0; c < BG; c++) {
+            const int cb = core_of<BG, RGB>(c);
+            if (cb != c)        // the R-G, G, B-G map applies to the first three bands of the image: group 0 only
+#pragma unroll
+                for (int k = 0; k < 8; k++) rp[c][k] = pk_add16(rp[c][k], grp == 0 ? rp[cb][k] : 0u);
+        }
+        const uint32_t g = g0 + slot, by = g / nbx, bx = g - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;     // last column / row is shifted, not padded
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        uint16_t *p0 = (uint16_t *)a.img + (uint64_t)y0 * stride + (uint64_t)x0 * B + band0;
+        // N dwords to a halfword address: aligned dwords when it is dword aligned, else a head halfword, the aligned dwords
+        // inside and a tail halfword -- never a byte outside the N dwords' own place
+        auto store_dw = [&](uint16_t *p, const uint32_t *src, auto nconst) {
+            constexpr int N = decltype(nconst)::value;
+            if (a.px_aligned || !((uintptr_t)p & 2)) {
+#pragma unroll
+                for (int t = 0; t < N; t++) ((uint32_t *)p)[t] = src[t];
+            } else {
+                p[0] = (uint16_t)src[0];
+                uint32_t *mid = (uint32_t *)(p + 1);
+#pragma unroll
+                for (int t = 0; t + 1 < N; t++) mid[t] = __builtin_amdgcn_alignbit(src[t + 1], src[t], 16);
+                p[2 * N - 1] = (uint16_t)(src[N - 1] >> 16);
+            }
+        };
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            uint16_t *rowp = p0 + (uint64_t)y * stride;
+            uint32_t ow[2 * BG];
+#pragma unroll
+            for (int j = 0; j < 2 * BG; j++) {          // halfwords 2j, 2j+1 of the lane's row: band h % BG of pixel h / BG
+                const int h0 = 2 * j, h1 = 2 * j + 1;
+                const int i0 = curve_pos_of(ORDER, h0 / BG, y), i1 = curve_pos_of(ORDER, h1 / BG, y);
+                const uint32_t sel = (uint32_t)(2 * (i0 & 1)) | (uint32_t)(2 * (i0 & 1) + 1) << 8 |
+                                     (uint32_t)(4 + 2 * (i1 & 1)) << 16 | (uint32_t)(4 + 2 * (i1 & 1) + 1) << 24;
+                ow[j] = __builtin_amdgcn_perm(rp[h1 % BG][i1 >> 1], rp[h0 % BG][i0 >> 1], sel);
+            }
+            if (BG % 2 == 0) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) store_dw(rowp + (uint64_t)x * B, &ow[x * (BG / 2)], std::integral_constant<int, (BG / 2 ? BG / 2 : 1)>());
+            } else
+                store_dw(rowp, &ow[0], std::integral_constant<int, 2 * BG>());
+        }
+    }
+    if (bad) atomicOr(a.status, fits ? 1u : 8u);
+    if (lane == 63 && seg == a.g.nseg - 1 && fits) {
+        const uint64_t used = (uint64_t)(cpos + binc - stage_bit0) + 32 * w0 - a.in_bit0;
+        if (used > a.in_bits) atomicOr(a.status, 4u);
+        else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
+}
+
+template <int BG, bool RGB>
+static void launch_dec_px16_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
+    const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
+    dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
+    if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, false>), grid, block, plan.lds_px, st, a);
+    else if (!z && step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);
+    else if (z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, ZCURVE, false>), grid, block, plan.lds_px, st, a);
+    else hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, ZCURVE, true>), grid, block, plan.lds_px, st, a);
+}
+void launch_dec_px16(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
+    switch (plan.px16_bg) {
+    case 1: launch_dec_px16_b<1, false>(a, plan, st); break;
+    case 2: launch_dec_px16_b<2, false>(a, plan, st); break;
+    case 3: if (plan.px_rgb) launch_dec_px16_b<3, true>(a, plan, st); else launch_dec_px16_b<3, false>(a, plan, st); break;
+    default: if (plan.px_rgb) launch_dec_px16_b<4, true>(a, plan, st); else launch_dec_px16_b<4, false>(a, plan, st); break;
+    }
+}
+
+}  // namespace qb3dev

@@ -1,0 +1,187 @@
+// qb3_amd/csrc/k_enc_post.hip -- after the chunks are coded: offsets (scan), concatenation, seams, header, index chunks
+#include "qb3_kernels.h"
+
+namespace qb3dev {
+
+// Exclusive scan of the chunk bit counts, one workgroup per SCAN_GROUP chunks (4 per thread); the per-group sums
+// are folded in by the consumers.  64-bit offsets: a 16384^2 x 3 stream exceeds 2^32 bits.
+__global__ void enc_scan_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, i0 = blockIdx.x * SCAN_GROUP + 4 * tid;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = (i0 + k < a.nchunks) ? a.chunk_bits[i0 + k] : 0; sum += v[k]; }
+    uint32_t total;
+    uint64_t off = block_exscan(sum, wsum, &total);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i0 + k < a.nchunks) { a.chunk_off[i0 + k] = off; off += v[k]; }
+    if (tid == 0) a.group_sum[blockIdx.x] = total;
+}
+
+// Second level: exclusive scan of the group sums in place (one workgroup); entry [ngroups] gets the total.
+__global__ void enc_scan2_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    __shared__ uint64_t wsum64[16];
+    __shared__ uint64_t carry;
+    const uint32_t ngroups = (a.nchunks + SCAN_GROUP - 1) / SCAN_GROUP;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ngroups; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < ngroups ? a.group_sum[i] : 0ull;
+        const uint64_t ex = block_exscan_v<uint64_t>(v, wsum64);
+        const uint64_t c0 = carry;
+        if (i < ngroups) a.group_sum[i] = c0 + ex;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry = c0 + ex + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.group_sum[ngroups] = carry;
+}
+
+// start of chunk k in the stream, in bits (k == nchunks: the stream length)
+__device__ __forceinline__ uint64_t chunk_start(const EncArgs &a, uint32_t k) {
+    if (k >= a.nchunks) return a.group_sum[(a.nchunks + SCAN_GROUP - 1) / SCAN_GROUP];
+    return a.group_sum[k / SCAN_GROUP] + a.chunk_off[k];
+}
+
+// Concatenate: one WAVE per chunk reads the chunk's slot, funnel-shifts it to its bit position and stores the
+// dwords that lie wholly inside the chunk; the first and last shifted dword go to the seam table.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));     // four dwords at any dword address
+__global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (chunk >= a.nchunks) return;
+    const uint64_t G = (uint64_t)a.out_bit0 + chunk_start(a, chunk);
+    const uint32_t total = a.chunk_bits[chunk];
+    const uint32_t phase = (uint32_t)(G & 31), nsrc = (total + 31) >> 5;
+    const uint32_t nd = (phase + total + 31) >> 5, tailbits = (phase + total) & 31;
+    const uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;    // 16-byte aligned (slot_dw is a multiple of 4)
+    const uint4 *slot4 = (const uint4 *)slot;
+    uint32_t *gout = a.out32 + (G >> 5);
+    // a lane moves four dwords per step (one 16-byte load, the next one already in flight): memory-level parallelism
+    // is what this copy needs.  Output dword d = source dwords d-1, d funnel-shifted by the chunk's bit phase.
+    const uint32_t ng = (nd + 3) >> 2, sh = (32 - phase) & 31;
+    constexpr int NQ = 4;                                               // 16-byte loads in flight per lane
+    for (uint32_t gb = 0; gb < ng; gb += 64 * NQ) {
+        uint4 cur[NQ];
+        uint32_t before[NQ];                                            // lane 0: the dword before its group
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const uint32_t g = gb + 64 * q + lane;
+            cur[q] = make_uint4(0, 0, 0, 0); before[q] = 0;
+            if (g < ng && 4 * g < nsrc) cur[q] = slot4[g];
+            if (lane == 0 && g && g < ng && 4 * g - 1 < nsrc) before[q] = slot[4 * g - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const uint32_t g = gb + 64 * q + lane, d = 4 * g;
+            uint32_t s[4] = { cur[q].x, cur[q].y, cur[q].z, cur[q].w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (d + k >= nsrc) s[k] = 0;    // the slot is only defined up to nsrc
+            uint32_t prv = __shfl_up(s[3], 1, 64);
+            if (lane == 0) prv = before[q];
+            if (g >= ng) continue;
+            uint32_t v[4];
+            if (phase) {
+                v[0] = __builtin_amdgcn_alignbit(s[0], prv, sh);
+#pragma unroll
+                for (int k = 1; k < 4; k++) v[k] = __builtin_amdgcn_alignbit(s[k], s[k - 1], sh);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = s[k];
+            }
+            if (d > 0 && d + 4 < nd) {                                  // no seam dword in the group
+                u32x4_a4 o = { v[0], v[1], v[2], v[3] };
+                *(u32x4_a4 *)(gout + d) = o;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t dd = d + k;
+                    if (dd < nd) {
+                        const bool shared = (dd == 0 && phase) || (dd == nd - 1 && tailbits);
+                        if (!shared) gout[dd] = v[k];
+                        if (dd == 0) a.seams[2 * chunk] = v[k];
+                        if (dd == nd - 1) a.seams[2 * chunk + 1] = v[k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One thread per chunk boundary: a dword that holds the end of one chunk and the start of the next is the OR of
+// their edge dwords; the thread of the FIRST boundary inside a dword assembles it.  The same launch turns the
+// chunk-relative index positions into stream positions and publishes the stream length.
+__global__ void enc_seam_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    if (a.have_idx)
+        for (uint64_t sgi = k; sgi < a.g.nseg; sgi += nthreads) {
+            const uint64_t v = a.idx.bitpos[sgi];
+            a.idx.bitpos[sgi] = chunk_start(a, (uint32_t)(v >> 32)) + (v & 0xffffffffu);
+        }
+    if (k > a.nchunks) return;
+    const uint64_t Ek = (uint64_t)a.out_bit0 + chunk_start(a, k);
+    if (k == a.nchunks) a.res->total_bits = Ek - a.out_bit0;
+    if ((Ek & 31) == 0) return;
+    const uint64_t d = Ek >> 5;
+    if (k > 0) { const uint64_t Ep = (uint64_t)a.out_bit0 + chunk_start(a, k - 1); if ((Ep >> 5) == d && (Ep & 31)) return; }
+    uint32_t v = k > 0 ? a.seams[2 * (k - 1) + 1] : 0u;
+    for (uint32_t j = k; j < a.nchunks; j++) {
+        v |= a.seams[2 * j];
+        const uint64_t En = (uint64_t)a.out_bit0 + chunk_start(a, j + 1);
+        if ((En >> 5) != d || (En & 31) == 0) break;       // chunk j reaches the end of the dword
+    }
+    a.out32[d] = v;
+}
+
+// Writes the container header in front of every tile's stream (after enc_seam_kernel, which owns the first dword).
+__global__ void write_header_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    // the stream starts at out32 + out_bit0/8; the header ends there
+    // (with a coarse index chunk the prepared bytes are followed by its entries and "DT": hdr_back > hdr_len)
+    uint8_t *start = (uint8_t *)a.out32 + (a.out_bit0 >> 3) - a.hdr_back;
+    for (uint32_t i = threadIdx.x; i < a.hdr_len; i += blockDim.x) start[i] = a0.hdr[i];
+}
+
+// The coarse index chunk: every ix_spe-th segment entry of the (finished) index, packed little endian, then "DT"
+__global__ void ix_fill_kernel(const EncArgs a) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, B = a.g.bands, tsz = a.g.tsz;
+    if (k == 0) { uint8_t *dt = a.ix_dst + (uint64_t)a.ix_K * a.ix_E; dt[0] = 'D'; dt[1] = 'T'; }
+    if (k >= a.ix_K) return;
+    const uint64_t s = (uint64_t)k * a.ix_spe;
+    uint8_t *e = a.ix_dst + (uint64_t)k * a.ix_E;
+    const uint64_t bp = a.idx.bitpos[s];
+    for (uint32_t i = 0; i < 6; i++) e[i] = (uint8_t)(bp >> (8 * i));
+    e += 6;
+    for (uint32_t c = 0; c < B; c++) e[c] = a.idx.rung[s * B + c];
+    e += B;
+    const uint8_t *pv = (const uint8_t *)a.idx.prev + s * B * tsz;
+    for (uint32_t i = 0; i < B * tsz; i++) e[i] = pv[i];
+    if (a.g.mode == CM_BEST) {
+        e += B * tsz;
+        const uint8_t *cf = (const uint8_t *)a.idx.cf + s * B * tsz;
+        for (uint32_t i = 0; i < B * tsz; i++) e[i] = cf[i];
+    }
+}
+
+void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    const uint32_t nt = a.ntiles;
+    {
+        ProfScope ps("enc_scan", st);
+        hipLaunchKernelGGL(enc_scan_kernel, dim3((plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP, nt), dim3(SCAN_GROUP / 4), 0, st, a);
+        hipLaunchKernelGGL(enc_scan2_kernel, dim3(1, nt), dim3(1024), 0, st, a);
+    }
+    {
+        ProfScope ps("enc_concat", st);
+        hipLaunchKernelGGL(enc_concat_kernel, dim3((plan.nchunks + 3) / 4, nt), dim3(256), 0, st, a);
+    }
+    ProfScope ps("enc_seams", st);
+    hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256, nt), dim3(256), 0, st, a);
+    if (a.hdr_len) hipLaunchKernelGGL(write_header_kernel, dim3(1, nt), dim3(64), 0, st, a);
+    if (a.ix_dst && a.have_idx && nt == 1) hipLaunchKernelGGL(ix_fill_kernel, dim3((a.ix_K + 255) / 256), dim3(256), 0, st, a);
+}
+
+}  // namespace qb3dev

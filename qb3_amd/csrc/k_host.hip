@@ -1,0 +1,511 @@
+// qb3_amd/csrc/k_host.hip -- host side of the kernels: plans, workspace layout, launch orchestration, profiling, small elementwise kernels
+#include "qb3_kernels.h"
+
+namespace qb3dev {
+
+// RLE0 (reference QB3encode.cpp:536-565) can only shorten a stream that holds a run of four zero bytes; looking for one
+// on the device spares the host pass (a copy of the whole stream over PCIe and a byte loop) whenever there is none.
+__global__ void zero_run_probe_kernel(const uint32_t *buf, uint64_t first_byte, uint64_t end_byte, uint32_t *flag) {
+    const uint64_t ndw = (end_byte + 3) >> 2;
+    bool found = false;
+    for (uint64_t d = (first_byte >> 2) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndw; d += (uint64_t)gridDim.x * blockDim.x) {
+        // bytes outside [first_byte, end_byte) count as non-zero
+        auto dw = [&](uint64_t i) -> uint32_t {
+            if (i >= ndw) return 0xffffffffu;
+            uint32_t v = buf[i];
+            if (4 * i < first_byte) v |= 0xffffffffu >> (8 * (4 - (uint32_t)(first_byte - 4 * i)));
+            if (4 * i + 4 > end_byte) v |= 0xffffffffu << (8 * (uint32_t)(end_byte - 4 * i));
+            return v;
+        };
+        const uint32_t cur = dw(d), nxt = dw(d + 1);
+        found = found || cur == 0 || __builtin_amdgcn_alignbit(nxt, cur, 8) == 0 || __builtin_amdgcn_alignbit(nxt, cur, 16) == 0 ||
+                __builtin_amdgcn_alignbit(nxt, cur, 24) == 0;
+    }
+    if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+// ------------------------------------------------------------------ host side of the kernels
+static thread_local char g_err[256] = "";
+const char *last_error() { return g_err; }
+void set_error(const char *what, int e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, e ? hipGetErrorString((hipError_t)e) : "failed");
+}
+
+// debugging switches: read once, the first time any handle plans a launch
+const Tuning &tuning() {
+    static const Tuning t = [] {
+        auto on = [](const char *name) { const char *e = getenv(name); return e && e[0] && e[0] != '0'; };
+        Tuning v;
+        v.no_px = on("QB3_NO_PX");                   // generic kernels also where a lane-per-block kernel applies
+        v.slow_index = on("QB3_SLOW_INDEX");         // index-less streams: the one-lane index rebuild instead of the walkers
+        v.no_single_pass = on("QB3_NO_SINGLE_PASS"); // 8-bit lane-per-block encoder: slots + concatenate instead of look-back
+        return v;
+    }();
+    return t;
+}
+
+// ---- per-kernel timing: hipEvents recorded on the launch stream, resolved after the caller's sync
+}  // namespace qb3dev
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+namespace qb3dev {
+struct ProfPending { const char *name; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
+static int g_prof_level = 0;
+static std::vector<ProfPending> g_prof_pending;
+static std::vector<hipEvent_t> g_prof_pool;
+static std::map<std::string, std::pair<double, uint64_t>> g_prof_acc;
+void prof_enable(int level) { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_level = level; }
+// level 2 skips the microsecond kernels: two events per kernel cost more than those kernels take
+static bool prof_minor(const char *n) { const std::string s(n); return s == "enc_scan" || s == "enc_seams" || s == "enc_best_scan"; }
+void prof_reset() { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_acc.clear(); }
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+ProfScope::ProfScope(const char *n, hipStream_t s) : st(s), name(n) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    on = g_prof_level == 1 || (g_prof_level >= 2 && !prof_minor(n));
+    if (on) { a = prof_event(); b = prof_event(); (void)hipEventRecord(a, st); }
+}
+ProfScope::~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, st);
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    g_prof_pending.push_back({name, a, b});
+}
+// Resolves the event pairs that have completed; a pair still in flight (another thread's stream) stays pending.
+void prof_collect() {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    std::vector<ProfPending> keep;
+    for (auto &p : g_prof_pending) {
+        float ms = 0;
+        const hipError_t e = hipEventElapsedTime(&ms, p.a, p.b);
+        if (e == hipErrorNotReady) { keep.push_back(p); continue; }
+        if (e == hipSuccess) { auto &acc = g_prof_acc[p.name]; acc.first += ms; acc.second++; }
+        g_prof_pool.push_back(p.a); g_prof_pool.push_back(p.b);
+    }
+    (void)hipGetLastError();       // hipErrorNotReady is not an error of the caller's
+    g_prof_pending.swap(keep);
+}
+bool prof_get(const char *name, double *total_ms, uint64_t *count) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    auto it = g_prof_acc.find(name);
+    if (it == g_prof_acc.end()) return false;
+    *total_ms = it->second.first; *count = it->second.second;
+    return true;
+}
+int prof_names(char *buf, size_t n) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    std::string s;
+    for (auto &kv : g_prof_acc) { if (!s.empty()) s += ","; s += kv.first; }
+    snprintf(buf, n, "%s", s.c_str());
+    return (int)g_prof_acc.size();
+}
+
+
+// Decoder workgroup geometry of the unit-parallel kernel: threads, blocks per pass, passes
+static void fast_geometry(uint32_t bands, uint32_t tsz, uint32_t *threads, uint32_t *bpp, uint32_t *passes) {
+    *threads = tsz == 8 ? 128 : 256;
+    *bpp = *threads / bands;
+    uint32_t k = (uint32_t)(16384 / ((size_t)*bpp * bands * tsz * 16));    // keep the pixel tile near 16 KB
+    *passes = k < 1 ? 1 : (k > 3 ? 3 : k);
+}
+// Blocks per index segment.  A function of stream-intrinsic properties only (bands, value size, mode): encoder
+// and decoder must agree on it whatever their strides, band maps or buffer alignments are.
+// 16-bit lane-per-block kernels: bands = ng x bg, bg <= 4 bands per lane (0: no such split)
+static void px16_split(uint32_t B, uint32_t *bg, uint32_t *ng) {
+    *bg = B <= 4 ? B : (B % 4 == 0) ? 4 : (B % 2 == 0) ? 2 : 0;
+    *ng = *bg ? B / *bg : 0;
+}
+
+uint32_t seg_blocks_for(const Geometry &g) {
+    if (g.mode != CM_BEST) {      // one segment = the blocks of one decoder workgroup, at most 256
+        // 8-bit grey/RGB/RGBA: the lane-per-block decoder gives a segment to a WAVE (a function of type and band
+        // count only: encoder and decoder must agree whatever kernel either of them ends up using)
+        if (g.tsz == 1 && (g.bands == 1 || g.bands == 3 || g.bands == 4)) return 64;
+        if (g.tsz == 2) {       // 16-bit: a wave = 64 lanes of (block, band group)
+            uint32_t bg, ng;
+            px16_split(g.bands, &bg, &ng);
+            if (bg) return 64 / ng;
+        }
+        uint32_t threads, bpp, passes;
+        fast_geometry(g.bands, g.tsz, &threads, &bpp, &passes);
+        while (passes > 1 && bpp * passes > 256) passes--;
+        return bpp * passes;
+    }
+    // common-factor modes: a lane walks the segment serially, keep it short (12 units)
+    uint32_t s = 12 / g.bands;
+    return s ? s : 1;
+}
+uint32_t ix_entry_bytes(const Geometry &g) { return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)); }
+uint32_t ulen_size_for(uint32_t tsz, uint32_t mode) { return mode == CM_BEST ? 0 : (tsz == 1 ? 1 : 2); }
+
+static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
+size_t index_bytes(const Geometry &g) {
+    const size_t n = (size_t)g.nseg * g.bands;
+    return align8(8 * (size_t)g.nseg) + 2 * align8(n * g.tsz) + align8(n) + align8((size_t)g.nblocks * g.bands * g.ulen_sz);
+}
+IndexView index_view(const Geometry &g, void *base) {
+    IndexView v;
+    uint8_t *p = (uint8_t *)base;
+    const size_t n = (size_t)g.nseg * g.bands;
+    v.bitpos = (uint64_t *)p; p += align8(8 * (size_t)g.nseg);
+    v.prev = p; p += align8(n * g.tsz);
+    v.cf = p; p += align8(n * g.tsz);
+    v.rung = p; p += align8(n);
+    v.ulen = g.ulen_sz ? p : nullptr;
+    return v;
+}
+
+uint32_t magic_div(uint32_t d) { return d == 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); }   // exact for n*d < 2^32/d-ish, n small
+
+uint32_t max_unit_bits(uint32_t tsz, uint32_t mode) {
+    const uint32_t ub = tsz == 1 ? 3 : tsz == 2 ? 4 : tsz == 4 ? 5 : 6;
+    const uint32_t plain = ub + 2 + 16 * (8 * tsz + 1);
+    // common factor: signal + switch + 2 flags + own-rung switch + factor code + group
+    return mode == CM_BEST ? plain + 3 * ub + 8 + 8 * tsz + 2 : plain;
+}
+
+// encoder workspace layout (all 8-byte aligned), EncResult last
+struct EncWs { size_t bits, off, gsum, seams, scratch, cwhas, cwval, centry, res, total; uint32_t slot_dw, ngroups; };
+static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
+    EncWs w;
+    // a multiple of 4 dwords: slots are 16-byte aligned (the px kernel copies them out as uint4)
+    w.slot_dw = (uint32_t)(((31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1 + 3) & ~(size_t)3);
+    w.ngroups = (nchunks + SCAN_GROUP - 1) / SCAN_GROUP;
+    size_t o = 0;
+    w.bits = o; o += align8(4 * (size_t)nchunks);
+    w.off = o; o += 8 * (size_t)nchunks;
+    w.gsum = o; o += 8 * ((size_t)w.ngroups + 1);
+    w.seams = o; o += 8 * (size_t)nchunks;
+    o = (o + 15) & ~(size_t)15;
+    w.scratch = o; o += align8(4 * (size_t)nchunks * w.slot_dw);
+    const size_t nb = g.mode == CM_BEST ? (size_t)nchunks * g.bands : 0;
+    w.cwhas = o; o += align8(nb);
+    w.cwval = o; o += 8 * nb;
+    w.centry = o; o += 8 * nb;
+    w.res = o; o += sizeof(EncResult);
+    w.total = o;
+    return w;
+}
+
+// the 8-bit lane-per-block kernels need: uint8, 1/3/4 bands, rows of whole blocks at dword-aligned addresses,
+// Hilbert or Z curve, identity or default RGB(A) band map
+static bool px_eligible(const Geometry &g, bool *rgb) {
+    if (g.tsz != 1 || !(g.bands == 1 || g.bands == 3 || g.bands == 4) || g.mode == CM_BEST) return false;
+    if (g.w < 4 || g.h < 4) return false;                  // any width, stride and pointer: rows are read and written unaligned
+    if (g.order != HILBERT && g.order != ZCURVE) return false;
+    bool ident = true, def = g.bands >= 3;
+    for (uint32_t c = 0; c < g.bands; c++) {
+        ident = ident && g.cband[c] == c;
+        def = def && g.cband[c] == ((c == 0 || c == 2) ? 1u : c);
+    }
+    *rgb = def && !ident;
+    return (ident || def) && !tuning().no_px;
+}
+
+// 16-bit lane-per-(block, band group) kernels: bands = NG x BG with BG <= 4; a group must be whole dwords per
+// pixel unless it is the whole pixel (BG = bands = 1 or 3)
+static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *ng) {
+    if (g.tsz != 2 || g.mode == CM_BEST || tuning().no_px) return false;
+    if (g.w < 4 || g.h < 4) return false;                  // any width and stride: rows are read and written at halfword alignment
+    if (g.order != HILBERT && g.order != ZCURVE) return false;
+    const uint32_t B = g.bands;
+    px16_split(B, bg, ng);
+    if (!*bg) return false;
+    // identity, or R-G, G, B-G on the first three bands (they must sit in one lane: 3 or 4 bands per group)
+    bool ident = true, def = *bg >= 3;
+    for (uint32_t c = 0; c < B; c++) {
+        ident = ident && g.cband[c] == c;
+        def = def && g.cband[c] == ((c == 0 || c == 2) ? 1u : c);
+    }
+    *rgb = def && !ident;
+    return ident || def;
+}
+
+EncPlan plan_encode(const Geometry &g) {
+    EncPlan p;
+    const uint32_t dpr = g.bands * g.tsz;
+    p.px = px_eligible(g, &p.px_rgb);
+    p.px16 = false; p.px16_bg = p.px16_ng = 0;
+    if (p.px) {
+        p.threads = 256; p.slots = 256; p.nbp = 255;
+        p.nchunks = (uint32_t)((g.nblocks + 254) / 255);
+        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp);
+        p.lds_bytes = 2048 + 256 + 4 * (size_t)L.slot_dw;
+        p.ws_bytes = L.total;
+        return p;
+    }
+    bool rgb16 = false;
+    if (px16_eligible(g, &rgb16, &p.px16_bg, &p.px16_ng)) {
+        p.px16 = true; p.px_rgb = rgb16;
+        p.threads = 256; p.slots = 256 / p.px16_ng; p.nbp = p.slots - 1;
+        p.nchunks = (uint32_t)((g.nblocks + p.nbp - 1) / p.nbp);
+        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp);
+        p.lds_bytes = 2048 + 256 + 1024 + 4 * (size_t)L.slot_dw;
+        p.ws_bytes = L.total;
+        return p;
+    }
+    p.threads = g.tsz == 8 ? 128 : 256;
+    p.slots = p.threads / g.bands;
+    const uint32_t nbp = p.slots - 1;
+    p.nbp = nbp;
+    p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
+    const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1;
+    p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * ((outdw + 1) & ~(size_t)1);
+    if (g.mode == CM_BEST) p.lds_bytes += 12 * (size_t)p.slots * g.bands + 8;
+    p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp).total;
+    return p;
+}
+
+static int launch_encode_all(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    if (a.g.mode == CM_BEST) launch_enc_best(a, plan, st);
+    else if (plan.px && a.g.tsz == 1) { ProfScope ps("enc_units", st); launch_enc_px(a, plan, st); }
+    else if (plan.px16 && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0) { ProfScope ps("enc_units", st); launch_enc_px16(a, plan, st); }
+    else { ProfScope ps("enc_units", st); launch_enc_generic(a, plan, st); }
+    launch_enc_post(a, plan, st);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
+                  const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb,
+                  const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix) {
+    EncArgs a;
+    a.ix_dst = ix.entries; a.ix_K = ix.K; a.ix_E = ix.entry_bytes;
+    a.ix_spe = g.seg_blocks ? ix.blocks / g.seg_blocks : 0;
+    a.ntiles = tb.n ? tb.n : 1; a.ts_img = tb.src_pitch; a.ts_out = tb.dst_pitch; a.ts_ws = tb.ws_pitch; a.ts_idx = tb.idx_pitch;
+    a.hdr_len = hdr_len <= sizeof(a.hdr) ? hdr_len : 0;
+    a.hdr_back = a.hdr_len + (ix.entries ? ix.K * ix.entry_bytes + 2 : 0);
+    for (uint32_t i = 0; i < a.hdr_len; i++) a.hdr[i] = hdr[i];
+    a.g = g; a.img = img; a.out32 = out32; a.out_bit0 = out_bit0;
+    a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
+    a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
+    uint8_t *w = (uint8_t *)ws;
+    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp);
+    a.chunk_bits = (uint32_t *)(w + L.bits);
+    a.chunk_off = (uint64_t *)(w + L.off);
+    a.group_sum = (uint64_t *)(w + L.gsum);
+    a.seams = (uint32_t *)(w + L.seams);
+    a.scratch = (uint32_t *)(w + L.scratch);
+    a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry);
+    a.slot_dw = L.slot_dw;
+    a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
+    a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.src_pitch & 3);
+    a.res = (EncResult *)(w + L.res);
+    a.st = st_in;
+    a.have_idx = index != nullptr;
+    a.idx = index ? index_view(g, index) : IndexView{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (g.tsz != 1 && g.tsz != 2 && g.tsz != 4 && g.tsz != 8) { set_error("encode: bad value size", 0); return -1; }
+    return launch_encode_all(a, plan, (hipStream_t)stream);
+}
+
+// LDS dwords per decoder lane: 16*bands values + 2*bands state values + bands rung bytes.  The count is made
+// odd (conflict-free lane stride) for <= 4 byte values; 8-byte values need an 8-byte aligned lane base, so
+// there it is made 2 mod 4.
+static uint32_t dec_lane_dwords(const Geometry &g) {
+    uint32_t dw = (uint32_t)((16 * g.bands * g.tsz + 2 * g.bands * g.tsz + g.bands + 3) / 4);
+    if (g.tsz == 8) { dw = (dw + 1) & ~1u; if ((dw & 3) == 0) dw += 2; }
+    else dw |= 1;
+    return dw;
+}
+
+DecPlan plan_decode(const Geometry &g) {
+    DecPlan p;
+    // per lane: 16*bands values + 2*bands state values + bands rung bytes, rounded to an odd dword count
+    const uint32_t lane_dw = dec_lane_dwords(g);
+    uint32_t threads = 64;
+    while (threads > 1 && (size_t)threads * lane_dw * 4 > 48 * 1024) threads >>= 1;
+    p.threads = threads;
+    p.nwg = (uint32_t)((g.nseg + threads - 1) / threads);
+    p.lds_bytes = (size_t)threads * lane_dw * 4;
+    p.ws_bytes = align8(index_bytes(g)) + 64;          // per tile: rebuilt index + its share of the status words
+    // unit-parallel kernel: FTL/BASE with a per-unit length table, and every core band must itself be core
+    // (true for every map the encoder's setter can produce, reference QB3encode.cpp:70-72); anything else keeps
+    // the lane-per-segment kernel
+    bool simple = g.mode != CM_BEST && g.ulen_sz != 0;
+    for (uint32_t c = 0; c < g.bands; c++) simple = simple && g.cband[g.cband[c]] == g.cband[c];
+    fast_geometry(g.bands, g.tsz, &p.threads2, &p.bpp, &p.passes);
+    const uint32_t dpr = g.bands * g.tsz, NB = g.seg_blocks;
+    p.passes = (NB + p.bpp - 1) / p.bpp;
+    p.in_cap_dw = (NB * dpr * 4 + 8 + 1) & ~1u;         // room for a stream as large as the raw blocks
+    p.lds2_bytes = 8 * (size_t)NB + 8 * 16 + 8 * 2 * MAXBANDS + 4 * 2 * MAXBANDS + 4 * (size_t)((p.bpp + 1) & ~1u)
+                 + 4 * (size_t)p.in_cap_dw + 16 * (size_t)NB * dpr + align8(2 * (size_t)p.bpp * g.bands) + 2048;
+    p.fast = simple && p.lds2_bytes <= 64 * 1024;
+    // 8-bit lane-per-block kernel
+    bool rgb = false;
+    p.px = p.fast && px_eligible(g, &rgb);
+    p.px_rgb = rgb;
+    // staging of the px kernel: the longest valid segment (every unit at its maximum) + the word the first unit
+    // starts in + 8 zero words, after the 4 KB table, the scan scratch and the unit lengths
+    p.px_cap_dw = (uint32_t)(((size_t)NB * g.bands * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
+    p.px = p.px && NB <= 64;
+    p.lds_px = 4096 + 4 * 4 * ((size_t)p.px_cap_dw + 8);       // table + four waves' staging
+    p.px16 = false; p.px16_bg = p.px16_ng = 0;
+    bool rgb16 = false;
+    if (!p.px && p.fast && px16_eligible(g, &rgb16, &p.px16_bg, &p.px16_ng) && NB * p.px16_ng <= 64) {
+        p.px16 = true; p.px_rgb = rgb16;
+        p.lds_px = 4096 + 4 * 4 * ((size_t)p.px_cap_dw + 16);
+    }
+    return p;
+}
+
+static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st) {
+    const bool best = a.g.mode == CM_BEST;
+    const bool use_px = plan.px && !best && a.g.tsz == 1;
+    const bool use_px16 = plan.px16 && !best && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0;
+    if (rebuild && (use_px || use_px16) && !tuning().slow_index) {
+        // index-less stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
+        // produce the values entering the segments (totals pass + scan)
+        { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
+        {
+            ProfScope ps("dec_index_prev", st);
+            DecArgs t = a;
+            t.totals_only = 1;
+            if (use_px) launch_dec_px(t, plan, st); else launch_dec_px16(t, plan, st);
+        }
+        ProfScope ps("dec_index_scan", st);
+        launch_prev_scan(a, st);
+    } else if (rebuild) {
+        ProfScope ps("dec_index_serial", st);
+        launch_dec_index_serial(a, st);
+    }
+    if (use_px) { ProfScope ps("dec_units", st); launch_dec_px(a, plan, st); }
+    else if (use_px16) { ProfScope ps("dec_units", st); launch_dec_px16(a, plan, st); }
+    else { ProfScope ps(plan.fast && !best ? "dec_units" : "dec_segments", st); launch_dec_generic(a, plan, st); }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// *has_run = 1 when bytes [off, off + nbytes) of the dword-aligned device buffer hold four consecutive zero bytes.
+// d_flag: one device word of scratch.  Synchronises the stream.
+int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, int *has_run, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(d_flag, 0, 4, st));
+    const uint64_t ndw = (off + nbytes + 3) / 4 - off / 4;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, (ndw + 255) / 256 ? (ndw + 255) / 256 : 1);
+    hipLaunchKernelGGL(zero_run_probe_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *)d_buf, (uint64_t)off, (uint64_t)(off + nbytes), (uint32_t *)d_flag);
+    uint32_t f = 0;
+    HIPCHK(hipMemcpyAsync(&f, d_flag, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *has_run = (int)f;
+    return 0;
+}
+
+int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
+                  void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb,
+                  const uint64_t *tile_bits, const IxTable &ix) {
+    hipStream_t st = (hipStream_t)stream;
+    DecArgs a;
+    // the container's coarse restart table is usable when it matches this geometry and this library's segments
+    a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = 0;
+    if (ix.entries && !tb.n && ix.blocks && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&
+        ix.K == (g.nblocks + ix.blocks - 1) / ix.blocks) {
+        a.ix = ix.entries; a.ix_K = ix.K; a.ix_blocks = ix.blocks; a.ix_E = ix.entry_bytes;
+    }
+    a.g = g; a.in32 = in32; a.in_bit0 = in_bit0; a.in_bits = in_bits; a.img = img;
+    a.ntiles = tb.n ? tb.n : 1; a.ts_in = tb.src_pitch; a.ts_img = tb.dst_pitch; a.tile_bits = tile_bits;
+    uint8_t *w = (uint8_t *)ws;
+    const bool rebuild = index == nullptr;
+    // workspace: [status words, 64 bytes per 16 tiles][rebuilt indices, one per tile]
+    const size_t status_bytes = ((4 * (size_t)a.ntiles + 63) / 64) * 64;
+    a.status = (uint32_t *)w;
+    a.idx = index_view(g, rebuild ? (void *)(w + status_bytes) : const_cast<void *>(index));
+    a.ts_idx = rebuild ? align8(index_bytes(g)) : tb.idx_pitch;
+    HIPCHK(hipMemsetAsync(a.status, 0, status_bytes, st));
+    a.lane_dw = dec_lane_dwords(g);
+    a.dpr = g.bands * g.tsz;
+    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16) ? plan.px_cap_dw : plan.in_cap_dw;
+    a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
+    a.totals_only = 0;
+    a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.dst_pitch & 3);
+    a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
+    *status_out = a.status;
+    if (g.tsz != 1 && g.tsz != 2 && g.tsz != 4 && g.tsz != 8) { set_error("decode: bad value size", 0); return -1; }
+    return launch_decode_all(a, plan, rebuild, st);
+}
+
+}  // namespace qb3dev
+
+// ------------------------------------------------------------------ quantisation (elementwise, HBM bound)
+namespace qb3dev {
+
+// reference QB3encode.cpp:137-186: round to nearest; ties toward zero, or away from zero when `away`
+template <typename TS>
+__global__ void quantize_kernel(TS *dst, const TS *src, uint32_t rowvals, uint32_t rows, uint64_t stride, uint64_t quanta, int away) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)rowvals * rows) return;
+    const uint64_t y = i / rowvals, x = i - y * rowvals;
+    const TS v = src[y * stride + x], q = (TS)quanta;
+    TS r;
+    if (q == 2) r = away ? (TS)(v / 2 + v % 2) : (TS)(v / 2);
+    else if (q == 3) r = (TS)(v / 3 + (v % 3) / 2);
+    else if (q == 4) r = away ? (TS)(v / 4 + (v % 4) / 2) : (TS)(v / 4 + (v % 4) / 3);
+    else {
+        const TS m = (TS)(v % q);
+        const bool neg = v < (TS)0;
+        if (away) { const TS h = (TS)(q / 2 + q % 2); r = (TS)(v / q + (!neg & (m >= h)) - (neg & ((TS)(m + h) <= (TS)0))); }
+        else { const TS h = (TS)(q / 2); r = (TS)(v / q + (!neg & (m > h)) - (neg & ((TS)(m + h) < (TS)0))); }
+    }
+    dst[i] = r;
+}
+
+// reference QB3decode.cpp:77-107: multiply back, saturating
+template <typename TS>
+__global__ void dequantize_kernel(TS *img, uint32_t rowvals, uint32_t rows, uint64_t stride, uint64_t quanta) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)rowvals * rows) return;
+    const uint64_t y = i / rowvals, x = i - y * rowvals;
+    constexpr bool is_signed = (TS)-1 < (TS)0;
+    constexpr TS tmax = is_signed ? (TS)(((uint64_t)1 << (8 * sizeof(TS) - 1)) - 1) : (TS)~(TS)0;
+    constexpr TS tmin = is_signed ? (TS)((uint64_t)1 << (8 * sizeof(TS) - 1)) : (TS)0;
+    const TS q = (TS)quanta, mai = (TS)(tmax / q), mii = (TS)(tmin / q);
+    const TS v = img[y * stride + x];
+    TS r = (v <= mai) ? (TS)(v * q) : tmax;
+    if (is_signed && q > 2 && v < mii) r = tmin;
+    img[y * stride + x] = r;
+}
+
+template <typename TS> static int launch_q(void *dst, const void *src, const Geometry &g, uint64_t q, bool away, hipStream_t st) {
+    const uint64_t n = (uint64_t)g.w * g.bands * g.h;
+    hipLaunchKernelGGL(quantize_kernel<TS>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (TS *)dst, (const TS *)src,
+                       g.w * g.bands, g.h, g.stride, q, away ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("quantize", (int)e); return (int)e; }
+    return 0;
+}
+template <typename TS> static int launch_dq(void *img, const Geometry &g, uint64_t q, hipStream_t st) {
+    const uint64_t n = (uint64_t)g.w * g.bands * g.h;
+    hipLaunchKernelGGL(dequantize_kernel<TS>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (TS *)img, g.w * g.bands, g.h, g.stride, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dequantize", (int)e); return (int)e; }
+    return 0;
+}
+
+int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, uint64_t q, bool away, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+    case 0: return launch_q<uint8_t>(dst, src, g, q, away, st);   case 1: return launch_q<int8_t>(dst, src, g, q, away, st);
+    case 2: return launch_q<uint16_t>(dst, src, g, q, away, st);  case 3: return launch_q<int16_t>(dst, src, g, q, away, st);
+    case 4: return launch_q<uint32_t>(dst, src, g, q, away, st);  case 5: return launch_q<int32_t>(dst, src, g, q, away, st);
+    case 6: return launch_q<uint64_t>(dst, src, g, q, away, st);  case 7: return launch_q<int64_t>(dst, src, g, q, away, st);
+    }
+    return -1;
+}
+int launch_dequantize(void *img, const Geometry &g, int dtype, uint64_t q, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+    case 0: return launch_dq<uint8_t>(img, g, q, st);   case 1: return launch_dq<int8_t>(img, g, q, st);
+    case 2: return launch_dq<uint16_t>(img, g, q, st);  case 3: return launch_dq<int16_t>(img, g, q, st);
+    case 4: return launch_dq<uint32_t>(img, g, q, st);  case 5: return launch_dq<int32_t>(img, g, q, st);
+    case 6: return launch_dq<uint64_t>(img, g, q, st);  case 7: return launch_dq<int64_t>(img, g, q, st);
+    }
+    return -1;
+}
+
+}  // namespace qb3dev

@@ -160,7 +160,7 @@ QB3_API void qb3_reset_encoder(encsp p) {
 
 QB3_API void qb3_destroy_encoder(encsp p) {
     if (!p) return;
-    p->d_img.release(); p->d_out.release(); p->d_ws.release(); p->d_q.release();
+    p->d_img.release(); p->d_out.release(); p->d_ws.release(); p->d_q.release(); p->d_idx.release();
     delete p;
 }
 
@@ -562,7 +562,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
 // ---------------------------------------------------------------- decoder handle
 QB3_API void qb3_destroy_decoder(decsp p) {
     if (!p) return;
-    p->d_in.release(); p->d_img.release(); p->d_ws.release();
+    p->d_in.release(); p->d_img.release(); p->d_ws.release(); p->d_ix.release();
     delete p;
 }
 QB3_API size_t qb3_decoded_size(const decsp p) { return p->xsize * p->ysize * p->nbands * szof(p->type); }
@@ -885,8 +885,6 @@ QB3_API int qb3x_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 QB3_API const char *qb3x_last_error(void) { return last_error(); }
-// not in qb3x.h: a tuning aid (phase time stamps of dec_px_kernel's first `nwaves` waves, 8 x uint64 each)
-QB3_API void qb3x_debug_set_stamps(void *d_buf, unsigned nwaves) { dbg_set_stamps(d_buf, nwaves); }
 QB3_API void qb3x_profile_enable(int level) { prof_enable(level < 0 ? 0 : level); }
 QB3_API void qb3x_profile_reset(void) { prof_reset(); }
 QB3_API int qb3x_profile_get(const char *kernel, double *total_ms, uint64_t *count) { return prof_get(kernel, total_ms, count) ? 1 : 0; }

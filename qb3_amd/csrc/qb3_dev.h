@@ -138,7 +138,6 @@ int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, ui
 int launch_dequantize(void *img, const Geometry &g, int dtype, uint64_t q, void *stream);
 
 // Optional per-kernel timing with HIP events recorded on the launch stream (off by default).
-void dbg_set_stamps(void *d_buf, uint32_t nwaves);     // debugging: dec_px_kernel writes 8 clock64() stamps per wave
 void prof_enable(int level);        // 0 off, 1 every kernel, 2 the long kernels only (less event traffic)
 void prof_reset();
 void prof_collect();                                    // call after the stream was synchronised
