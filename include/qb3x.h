@@ -53,20 +53,33 @@ size_t qb3x_decode_device(decsp p, const void *d_src, void *d_dst, const void *d
 size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t src_pitch,
                          void *d_dst, size_t dst_pitch, void *d_index, size_t *sizes, void *stream);
 
-/* Batched decode of n containers that share the geometry/mode of handle p (parsed from tile 0);
- * sizes[i] = container size of tile i.  Returns the number of tiles decoded. */
+/* Batched decode of n containers of the image size and type of handle p (parsed from tile 0);
+ * sizes[i] = container size of tile i.  Tiles whose header matches tile 0's go through one set of launches; a tile
+ * of another kind -- a raw-stored tile in a batch of coded ones, as qb3x_encode_tiles writes for incompressible
+ * data, or the reverse -- is parsed and decoded on its own.  Returns the number of tiles decoded;
+ * qb3x_decode_tile_ok(p, i) then tells which (1 = tile i of the last call was decoded). */
 size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
                          void *d_dst, size_t dst_pitch, const void *d_index, void *stream);
+int qb3x_decode_tile_ok(const decsp p, size_t i);
 
-/* Self-indexing containers (off by default: the container then differs from the reference's by one chunk).
- * When on, qb3_encode / qb3x_encode_device put a coarse restart table -- at most 64 KB: the bit position and band
- * state at every N-th block -- into the container as an ignorable chunk "ix" in front of "DT".  The reference's
- * decoder steps over it (lower-case chunk, QB3decode.cpp:251-255; its length field counts from the chunk start,
- * which is how that decoder skips) and decodes the same pixels; this library's decoder uses it when no out-of-band
- * index is given, so that qb3_read_data / qb3x_decode_device(d_index = NULL) walk the stream with thousands of
- * waves instead of one.  qb3_max_encoded_size() grows by 64 KB while the switch is on.  Not written for RLE0
- * modes, narrow images and STORED output.  A decoder handle for the device flavour needs a host copy of the
- * container up to its "DT" mark (up to 64 KB + 80 bytes instead of 64 bytes).
+/* qb3_read_start for the device flavour: `header` is a host copy of the FIRST header_size bytes of a container of
+ * stream_size bytes (the parser never reads beyond the copy; qb3_read_info fails when the copy ends before the
+ * container's "DT" mark).  qb3x_header_size_bound(first bytes, how many) says how many bytes always suffice,
+ * from the container's first 11 bytes (0: not a QB3 container). */
+decsp qb3x_read_start(void *header, size_t header_size, size_t stream_size, size_t *image_size);
+size_t qb3x_header_size_bound(const void *container, size_t avail);
+
+/* Self-indexing containers (off by default: the container then differs from the reference's by a few chunks).
+ * When on, qb3_encode / qb3x_encode_device put a restart table -- the bit position and band state at about every
+ * 1024th unit, 0.1-0.2 % of a typical stream -- into the container in front of "DT", as ignorable (lower-case) chunks:
+ * "ix" chunks of at most 64 KB, each followed by a 4-byte pad chunk "zz".  The reference's decoder steps over them
+ * (QB3decode.cpp:251-255) and decodes the same pixels: it skips an unknown chunk by its length field counted from the
+ * chunk START, so the field holds the whole chunk size, and the pad makes the container parse the same for a reader
+ * that adds the 4 head bytes to it.  This library's decoder uses the table when no out-of-band index is given:
+ * qb3_read_data / qb3x_decode_device(d_index = NULL) then walk the stream from every entry at once (one lane each)
+ * instead of serially.  qb3_max_encoded_size() grows by the table's size while the switch is on.  Not written for
+ * RLE0 modes, narrow images and STORED output.  A decoder handle for the device flavour needs a host copy of the
+ * container up to its "DT" mark: qb3x_header_size_bound() bytes always suffice (qb3x_read_start).
  * Callers that only know the reference API (LD_PRELOAD, relinked tools) can set QB3X_INDEX_CHUNK=1 in the
  * environment: it is read when an encoder handle is created. */
 void qb3x_set_encoder_index_chunk(encsp p, int on);

@@ -312,7 +312,7 @@ __global__ void dec_index_serial(const DecArgs a0) {
     uint32_t gb0 = 0, gb_end = nblocks;
     uint64_t seg = 0, bp = 0;
     if (a.ix) {                             // restart point blockIdx.y of the container's coarse table
-        const uint8_t *e = a.ix + (uint64_t)blockIdx.y * a.ix_E;
+        const uint8_t *e = ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, blockIdx.y);
         for (uint32_t i = 0; i < 6; i++) bp |= (uint64_t)e[i] << (8 * i);
         const uint8_t *pv = e + 6 + bands, *cf = pv + bands * sizeof(T);
         for (uint32_t c = 0; c < bands; c++) {

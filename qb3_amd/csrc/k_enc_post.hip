@@ -146,17 +146,32 @@ __global__ void write_header_kernel(const EncArgs a0) {
     for (uint32_t i = threadIdx.x; i < a.hdr_len; i += blockDim.x) start[i] = a0.hdr[i];
 }
 
-// The coarse index chunk: every ix_spe-th segment entry of the (finished) index, packed little endian, then "DT"
+// The restart table: every ix_spe-th segment entry of the (finished) index, packed little endian, in chunks of
+// ix_per_chunk entries -- each a lower-case (ignorable) "ix" chunk followed by a 4-byte "zz" pad chunk -- then "DT".
+// Chunk head: "ix", length (the whole chunk: the reference skips unknown chunks by that many bytes from the chunk
+// start, QB3decode.cpp:254-255), version 2, flags (bit 0: entries carry the common factors), 2 reserved bytes,
+// blocks per entry.  The pad makes the container parse the same if a reader adds the 4 head bytes to the length.
 __global__ void ix_fill_kernel(const EncArgs a) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, B = a.g.bands, tsz = a.g.tsz;
-    if (k == 0) { uint8_t *dt = a.ix_dst + (uint64_t)a.ix_K * a.ix_E; dt[0] = 'D'; dt[1] = 'T'; }
     if (k >= a.ix_K) return;
+    const uint32_t c = k / a.ix_per_chunk, j = k - c * a.ix_per_chunk;
+    const uint32_t here = (a.ix_K - c * a.ix_per_chunk < a.ix_per_chunk) ? a.ix_K - c * a.ix_per_chunk : a.ix_per_chunk;   // entries of this chunk
+    uint8_t *chunk = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E);
+    if (j == 0) {
+        const uint32_t len = IX_HEAD + here * a.ix_E;
+        chunk[0] = 'i'; chunk[1] = 'x'; chunk[2] = (uint8_t)len; chunk[3] = (uint8_t)(len >> 8);
+        chunk[4] = 2; chunk[5] = a.g.mode == CM_BEST ? 1 : 0; chunk[6] = 0; chunk[7] = 0;
+        for (uint32_t i = 0; i < 4; i++) chunk[8 + i] = (uint8_t)(a.ix_blocks >> (8 * i));
+        uint8_t *pad = chunk + len;
+        pad[0] = 'z'; pad[1] = 'z'; pad[2] = 4; pad[3] = 0;
+        if (c * a.ix_per_chunk + here == a.ix_K) { pad[4] = 'D'; pad[5] = 'T'; }
+    }
     const uint64_t s = (uint64_t)k * a.ix_spe;
-    uint8_t *e = a.ix_dst + (uint64_t)k * a.ix_E;
+    uint8_t *e = chunk + IX_HEAD + (uint64_t)j * a.ix_E;
     const uint64_t bp = a.idx.bitpos[s];
     for (uint32_t i = 0; i < 6; i++) e[i] = (uint8_t)(bp >> (8 * i));
     e += 6;
-    for (uint32_t c = 0; c < B; c++) e[c] = a.idx.rung[s * B + c];
+    for (uint32_t c2 = 0; c2 < B; c2++) e[c2] = a.idx.rung[s * B + c2];
     e += B;
     const uint8_t *pv = (const uint8_t *)a.idx.prev + s * B * tsz;
     for (uint32_t i = 0; i < B * tsz; i++) e[i] = pv[i];

@@ -143,6 +143,19 @@ uint32_t seg_blocks_for(const Geometry &g) {
     return s ? s : 1;
 }
 uint32_t ix_entry_bytes(const Geometry &g) { return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)); }
+// one entry per about 1024 units (a whole number of index segments): 0.1-0.2 % of a typical stream, and short
+// enough walks that one lane per entry covers a 16384^2 raster in a fraction of a millisecond
+IxTable ix_layout(const Geometry &g) {
+    IxTable t;
+    if (!g.seg_blocks || !g.nseg) return t;
+    t.entry_bytes = ix_entry_bytes(g);
+    const uint64_t units_per_seg = (uint64_t)g.seg_blocks * g.bands;
+    const uint64_t spe = units_per_seg >= 1024 ? 1 : 1024 / units_per_seg;      // fine segments per entry
+    t.blocks = (uint32_t)(spe * g.seg_blocks);
+    t.K = (uint32_t)((g.nseg + spe - 1) / spe);
+    t.per_chunk = (65535 - IX_HEAD) / t.entry_bytes;
+    return t;
+}
 uint32_t ulen_size_for(uint32_t tsz, uint32_t mode) { return mode == CM_BEST ? 0 : (tsz == 1 ? 1 : 2); }
 
 static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
@@ -277,11 +290,11 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
                   const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb,
                   const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix) {
     EncArgs a;
-    a.ix_dst = ix.entries; a.ix_K = ix.K; a.ix_E = ix.entry_bytes;
+    a.ix_dst = ix.base; a.ix_K = ix.K; a.ix_E = ix.entry_bytes; a.ix_per_chunk = ix.per_chunk; a.ix_blocks = ix.blocks;
     a.ix_spe = g.seg_blocks ? ix.blocks / g.seg_blocks : 0;
     a.ntiles = tb.n ? tb.n : 1; a.ts_img = tb.src_pitch; a.ts_out = tb.dst_pitch; a.ts_ws = tb.ws_pitch; a.ts_idx = tb.idx_pitch;
     a.hdr_len = hdr_len <= sizeof(a.hdr) ? hdr_len : 0;
-    a.hdr_back = a.hdr_len + (ix.entries ? ix.K * ix.entry_bytes + 2 : 0);
+    a.hdr_back = a.hdr_len + (ix.base ? (uint32_t)ix_total_bytes(ix) + 2 : 0);
     for (uint32_t i = 0; i < a.hdr_len; i++) a.hdr[i] = hdr[i];
     a.g = g; a.img = img; a.out32 = out32; a.out_bit0 = out_bit0;
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
@@ -403,10 +416,11 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
     hipStream_t st = (hipStream_t)stream;
     DecArgs a;
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
-    a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = 0;
-    if (ix.entries && !tb.n && ix.blocks && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&
+    a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = a.ix_per_chunk = a.ix_pad = 0;
+    if (ix.base && !tb.n && ix.blocks && ix.per_chunk && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&
         ix.K == (g.nblocks + ix.blocks - 1) / ix.blocks) {
-        a.ix = ix.entries; a.ix_K = ix.K; a.ix_blocks = ix.blocks; a.ix_E = ix.entry_bytes;
+        a.ix = ix.base; a.ix_K = ix.K; a.ix_blocks = ix.blocks; a.ix_E = ix.entry_bytes; a.ix_per_chunk = ix.per_chunk;
+        a.ix_pad = ix.pads ? IX_PAD : 0;
     }
     a.g = g; a.in32 = in32; a.in_bit0 = in_bit0; a.in_bits = in_bits; a.img = img;
     a.ntiles = tb.n ? tb.n : 1; a.ts_in = tb.src_pitch; a.ts_img = tb.dst_pitch; a.tile_bits = tile_bits;

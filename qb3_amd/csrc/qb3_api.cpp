@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <vector>
 #include <limits>
+#include <thread>
+#include <algorithm>
 #include "../../include/QB3.h"
 #include "../../include/qb3x.h"
 #include "qb3_dev.h"
@@ -49,6 +51,94 @@ static bool device_ok() {
     return true;
 }
 
+// ---------------------------------------------------------------- host <-> device copies of the host-pointer API
+// The reference API hands over pageable host memory.  A plain hipMemcpyAsync from pageable memory goes through the
+// runtime's own bounce buffers on ONE host thread (measured: 11 GB/s, a fifth of the link).  Large copies here go
+// through a ring of pinned buffers instead, filled (or drained) by a few host threads while the previous slice is
+// on the link.
+struct Stager {
+    static constexpr size_t SLICE = 8u << 20, NSLOT = 4, MIN_BYTES = 4u << 20;
+    uint8_t *slot[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    bool ready = false, failed = false;
+    bool init() {
+        if (ready || failed) return ready;
+        for (size_t i = 0; i < NSLOT; i++) {
+            if (hipHostMalloc((void **)&slot[i], SLICE, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { failed = true; (void)hipGetLastError(); release(); return false; }
+        }
+        return ready = true;
+    }
+    void release() {
+        for (size_t i = 0; i < NSLOT; i++) {
+            if (slot[i]) (void)hipHostFree(slot[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            slot[i] = nullptr; ev[i] = nullptr;
+        }
+        ready = false;
+    }
+};
+// memcpy by a few threads (the copies are memory bound: one thread moves about 10 GB/s)
+static unsigned copy_threads() {
+    static const unsigned n = [] { unsigned h = std::thread::hardware_concurrency(); return h >= 16 ? 8u : h >= 8 ? 4u : h >= 4 ? 2u : 1u; }();
+    return n;
+}
+static void parallel_memcpy(uint8_t *dst, const uint8_t *src, size_t n) {
+    const unsigned T = copy_threads();
+    if (T <= 1 || n < (1u << 20)) { memcpy(dst, src, n); return; }
+    const size_t part = ((n + T - 1) / T + 4095) & ~(size_t)4095;
+    std::thread th[8];
+    unsigned started = 0;
+    for (unsigned t = 1; t < T && t * part < n; t++, started++)
+        th[started] = std::thread([=] { memcpy(dst + t * part, src + t * part, std::min(part, n - t * part)); });
+    memcpy(dst, src, std::min(part, n));
+    for (unsigned t = 0; t < started; t++) th[t].join();
+}
+// host -> device; returns once the host bytes have been consumed (the last slices may still be on the link)
+static bool upload(Stager &sg, void *d_dst, const void *h_src, size_t bytes, hipStream_t st) {
+    if (bytes < Stager::MIN_BYTES || !sg.init()) {
+        hipError_t e = hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { set_error("upload", (int)e); return false; }
+        return true;
+    }
+    size_t i = 0;
+    for (size_t off = 0; off < bytes; off += Stager::SLICE, i++) {
+        const size_t k = i % Stager::NSLOT, n = std::min(Stager::SLICE, bytes - off);
+        if (i >= Stager::NSLOT && hipEventSynchronize(sg.ev[k]) != hipSuccess) { set_error("upload: slot wait", 0); return false; }
+        parallel_memcpy(sg.slot[k], (const uint8_t *)h_src + off, n);
+        hipError_t e = hipMemcpyAsync((uint8_t *)d_dst + off, sg.slot[k], n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(sg.ev[k], st);
+        if (e != hipSuccess) { set_error("upload", (int)e); return false; }
+    }
+    return true;
+}
+// device -> host; returns when the bytes are in h_dst (synchronises the stream)
+static bool download(Stager &sg, void *h_dst, const void *d_src, size_t bytes, hipStream_t st) {
+    if (bytes < Stager::MIN_BYTES || !sg.init()) {
+        hipError_t e = hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("download", (int)e); return false; }
+        return true;
+    }
+    const size_t nsl = (bytes + Stager::SLICE - 1) / Stager::SLICE;
+    auto issue = [&](size_t i) -> hipError_t {
+        const size_t off = i * Stager::SLICE, n = std::min(Stager::SLICE, bytes - off);
+        hipError_t e = hipMemcpyAsync(sg.slot[i % Stager::NSLOT], (const uint8_t *)d_src + off, n, hipMemcpyDeviceToHost, st);
+        return e == hipSuccess ? hipEventRecord(sg.ev[i % Stager::NSLOT], st) : e;
+    };
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < std::min(nsl, (size_t)Stager::NSLOT) && e == hipSuccess; i++) e = issue(i);
+    for (size_t i = 0; i < nsl && e == hipSuccess; i++) {
+        e = hipEventSynchronize(sg.ev[i % Stager::NSLOT]);
+        if (e != hipSuccess) break;
+        const size_t off = i * Stager::SLICE, n = std::min(Stager::SLICE, bytes - off);
+        parallel_memcpy((uint8_t *)h_dst + off, sg.slot[i % Stager::NSLOT], n);
+        if (i + Stager::NSLOT < nsl) e = issue(i + Stager::NSLOT);
+    }
+    if (e != hipSuccess) { set_error("download", (int)e); return false; }
+    return true;
+}
+
 struct band_state { size_t prev, runbits, cf; };
 
 struct encs {
@@ -60,8 +150,9 @@ struct encs {
     qb3_mode mode;
     qb3_dtype type;
     bool away;
-    bool ix_chunk;          // qb3x_set_encoder_index_chunk: embed the coarse restart table ("ix")
+    bool ix_chunk;          // qb3x_set_encoder_index_chunk: embed the restart table ("ix" chunks)
     DevBuf d_img, d_out, d_ws, d_q, d_idx;
+    Stager stager;
 };
 
 struct decs {
@@ -76,9 +167,13 @@ struct decs {
     uint8_t *s_start;       // the pointer given to qb3_read_start
     bool saw_cb;            // a CB chunk was present
     unsigned compat;
-    size_t ix_off;          // coarse restart table found in the container: offset of its entries from s_start (0: none)
-    uint32_t ix_K, ix_blocks, ix_E;
+    size_t hdr_avail;       // bytes readable at s_start (the whole stream, or the header copy given to qb3x_read_start)
+    size_t ix_off;          // restart table found in the container: offset of its first chunk from s_start (0: none)
+    uint32_t ix_K, ix_blocks, ix_E, ix_per_chunk;
+    bool ix_pads, ix_bad;   // pad chunks behind the table chunks (version 2); the chunks seen do not form one table
+    std::vector<uint8_t> tile_ok;   // qb3x_decode_tiles: per tile outcome of the last call
     DevBuf d_in, d_img, d_ws, d_ix;
+    Stager stager;
 };
 
 // ---------------------------------------------------------------- small host bit writer for headers
@@ -89,25 +184,9 @@ struct HdrWriter {
     void sig(const char *s) { d[n++] = (uint8_t)s[0]; d[n++] = (uint8_t)s[1]; }
 };
 
-// reference QB3encode.cpp:189-268: main header, then CB / QV / SC chunks as needed, then DT
-// The coarse restart table for a geometry: K entries of E bytes, one per `blocks` blocks, so that the chunk fits
-// its 16-bit length.  chunk = "ix", length, version, flags, 2 reserved bytes, blocks (4 bytes), entries.
-struct IxLayout { uint32_t K = 0, blocks = 0, E = 0, flags = 0; size_t chunk = 0; };
-static IxLayout ix_layout(const Geometry &g) {
-    IxLayout L;
-    L.E = ix_entry_bytes(g);
-    const uint64_t kmax = (65535 - 12) / L.E;
-    const uint64_t spe = (g.nseg + kmax - 1) / kmax;            // fine segments per entry
-    L.blocks = (uint32_t)(spe * g.seg_blocks);
-    L.K = (uint32_t)((g.nseg + spe - 1) / spe);
-    L.chunk = 12 + (size_t)L.K * L.E;
-    L.flags = g.mode == CM_BEST ? 1 : 0;                        // bit 0: entries carry the common factors
-    return L;
-}
-
-// ix: when given, the chunk head is written and the function returns BEFORE the entries (the caller owns
-// entries + "DT"); otherwise the header ends with "DT" as in the reference
-static size_t write_headers(const encs *p, uint8_t *dst, const IxLayout *ix = nullptr) {
+// reference QB3encode.cpp:189-268: main header, then CB / QV / SC chunks as needed, then DT.
+// with_dt = false: the caller continues the header (the restart-table chunks and "DT" are written on the device)
+static size_t write_headers(const encs *p, uint8_t *dst, bool with_dt = true) {
     HdrWriter w(dst);
     w.put(0x80334251u, 4);
     w.put(p->xsize - 1, 2); w.put(p->ysize - 1, 2); w.put(p->nbands - 1, 1);
@@ -125,15 +204,7 @@ static size_t write_headers(const encs *p, uint8_t *dst, const IxLayout *ix = nu
     if (p->order != ZCURVE && p->mode != QB3M_STORED) {
         w.sig("SC"); w.put(8, 2); w.put(p->order ? p->order : HILBERT, 8);
     }
-    if (ix) {
-        // an ignorable chunk (lower case): its length counts from the chunk start, which is how the reference skips
-        // unknown chunks (QB3decode.cpp:254-255), so its decoder steps over it
-        w.sig("ix"); w.put(ix->chunk, 2);
-        w.put(1, 1); w.put(ix->flags, 1); w.put(0, 2);
-        w.put(ix->blocks, 4);
-        return w.n;
-    }
-    w.sig("DT");
+    if (with_dt) w.sig("DT");
     return w.n;
 }
 
@@ -160,7 +231,7 @@ QB3_API void qb3_reset_encoder(encsp p) {
 
 QB3_API void qb3_destroy_encoder(encsp p) {
     if (!p) return;
-    p->d_img.release(); p->d_out.release(); p->d_ws.release(); p->d_q.release(); p->d_idx.release();
+    p->d_img.release(); p->d_out.release(); p->d_ws.release(); p->d_q.release(); p->d_idx.release(); p->stager.release();
     delete p;
 }
 
@@ -189,11 +260,22 @@ QB3_API bool qb3_set_encoder_quanta(encsp p, uint64_t q, bool away) {
     return !bad;
 }
 
-QB3_API size_t qb3_max_encoded_size(const encsp p) {
+// reference QB3encode.cpp:112-118
+static size_t max_encoded_size_ref(const encs *p) {
     size_t n = 16 * ((p->xsize + 3) / 4) * ((p->ysize + 3) / 4) * p->nbands;
     double bits_per_value = 17.0 / 16.0 + 8 * szof(p->type);
-    return 1024 + static_cast<size_t>(bits_per_value * n / 8) + (p->ix_chunk ? 65536 : 0);
+    return 1024 + static_cast<size_t>(bits_per_value * n / 8);
 }
+static Geometry make_geometry(size_t w, size_t h, size_t bands, int dtype, size_t stride, uint64_t order, int mode,
+                              const size_t *cband_sz, const uint8_t *cband_u8);
+static bool is_rle_mode(int m) { return m == QB3M_RLE || m == QB3M_CF_RLE || m == QB3M_RLE_H || m == QB3M_CF_RLE_H; }
+// bytes the restart-table chunks add to a container of this handle (0: none would be written)
+static size_t ix_room(const encs *p) {
+    if (!p->ix_chunk || p->xsize < 4 || p->ysize < 4 || p->xsize * p->ysize <= 16 || is_rle_mode(p->mode) || p->mode == QB3M_STORED) return 0;
+    const Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, p->mode, p->cband, nullptr);
+    return ix_total_bytes(ix_layout(g));
+}
+QB3_API size_t qb3_max_encoded_size(const encsp p) { return max_encoded_size_ref(p) + ix_room(p); }
 
 QB3_API qb3_mode qb3_set_encoder_mode(encsp p, qb3_mode mode) {
     if ((int)mode >= 0 && (int)mode < (int)QB3M_END) p->mode = mode;
@@ -338,17 +420,25 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     return true;
 }
 
-static bool is_rle_mode(int m) { return m == QB3M_RLE || m == QB3M_CF_RLE || m == QB3M_RLE_H || m == QB3M_CF_RLE_H; }
+// Puts the caller's mode back on every exit but the ones that are meant to change it (the reference leaves a handle
+// at QB3M_STORED after a raw fallback, QB3encode.cpp:464, and demotes RLE modes only for the block pass, :495-506).
+struct ModeGuard {
+    encs *p; qb3_mode mode; bool armed = true;
+    ModeGuard(encs *h) : p(h), mode(h->mode) {}
+    ~ModeGuard() { if (armed) p->mode = mode; }
+};
 
 // Shared by qb3_encode (host buffers) and qb3x_encode_device (device buffers).
 // host_src/host_dst are null in the device flavour; d_src/d_dst are null in the host flavour.
 static size_t encode_common(encsp p, const void *host_src, void *host_dst, const void *d_src, void *d_dst,
                             void *d_index, hipStream_t st) {
     const bool on_host = host_src != nullptr;
-    const size_t tsz = szof(p->type);
+    const size_t tsz = szof(p->type), line = p->xsize * p->nbands * tsz;
+    const size_t src_stride_bytes = (p->stride ? p->stride : p->xsize * p->nbands) * tsz;
+    const size_t src_span = src_stride_bytes * (p->ysize - 1) + line;      // bytes from the first to the last pixel
     if (p->xsize * p->ysize <= 16) {        // tiny images are stored (reference QB3encode.cpp:490)
         if (on_host) return stored_encode_host(p, host_src, host_dst);
-        std::vector<uint8_t> tmp((p->stride ? p->stride : p->xsize * p->nbands) * tsz * p->ysize), out(64 + raw_size(p));
+        std::vector<uint8_t> tmp(src_span), out(64 + raw_size(p));
         if (!device_ok()) { p->error = QB3E_LIBERR; return 0; }
         HIPOK(hipMemcpyAsync(tmp.data(), d_src, tmp.size(), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
@@ -357,25 +447,26 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
         HIPOK(hipStreamSynchronize(st));
         return n;
     }
+    ModeGuard guard(p);
     const qb3_mode mode = p->mode;
     const bool rle = is_rle_mode(mode);
+    const size_t ixroom = ix_room(p);                    // before the RLE demotion: no table under RLE0
     if (rle) p->mode = (qb3_mode)((int)mode - 2);       // RLE is a post pass over the base mode's stream
     uint8_t hdrbuf[80];
-    size_t hdr = write_headers(p, hdrbuf);                // (with the coarse index chunk: redone below, once the geometry is known)
+    size_t hdr = write_headers(p, hdrbuf);
     if (p->error) return 0;                               // stale error blocks the handle until reset
-    if (!device_ok()) { p->error = QB3E_LIBERR; if (rle) p->mode = mode; return 0; }
+    if (!device_ok()) { p->error = QB3E_LIBERR; return 0; }
 
     // geometry, with the narrow-image stand-in where needed
     size_t w = p->xsize, h = p->ysize, stride = p->stride;
     const void *img_dev = d_src;
     std::vector<uint8_t> small;
     const bool narrow = w < 4 || h < 4;
-    const size_t src_stride_bytes = (p->stride ? p->stride : p->xsize * p->nbands) * tsz;
     if (narrow) {
         std::vector<uint8_t> tmp;
         const uint8_t *hs = (const uint8_t *)host_src;
         if (!on_host) {
-            tmp.resize(src_stride_bytes * p->ysize);
+            tmp.resize(src_span);
             HIPOK(hipMemcpyAsync(tmp.data(), d_src, tmp.size(), hipMemcpyDeviceToHost, st));
             HIPOK(hipStreamSynchronize(st));
             hs = tmp.data();
@@ -385,9 +476,9 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     }
     if (on_host || narrow) {
         const uint8_t *hs = narrow ? small.data() : (const uint8_t *)host_src;
-        const size_t bytes = narrow ? small.size() : src_stride_bytes * (p->ysize - 1) + p->xsize * p->nbands * tsz;
+        const size_t bytes = narrow ? small.size() : src_span;
         if (!p->d_img.ensure(bytes)) { p->error = QB3E_LIBERR; return 0; }
-        HIPOK(hipMemcpyAsync(p->d_img.p, hs, bytes, hipMemcpyHostToDevice, st));
+        if (!upload(p->stager, p->d_img.p, hs, bytes, st)) { p->error = QB3E_LIBERR; return 0; }
         img_dev = p->d_img.p;
     }
     Geometry g = make_geometry(w, h, p->nbands, p->type, stride, p->order, p->mode, p->cband, nullptr);
@@ -400,24 +491,23 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
         g.stride = (uint64_t)g.w * g.bands;
     }
     const bool carry = !narrow && p->quanta < 2;
-    const size_t maxsz = qb3_max_encoded_size(p);
+    const size_t maxsz = max_encoded_size_ref(p);         // the reference's bound: RLE0 decisions must not depend on the table
     uint8_t *out_dev = (uint8_t *)d_dst;
     if (on_host) {
-        if (!p->d_out.ensure(maxsz + 64)) { p->error = QB3E_LIBERR; return 0; }
+        if (!p->d_out.ensure(maxsz + ixroom + 64)) { p->error = QB3E_LIBERR; return 0; }
         out_dev = (uint8_t *)p->d_out.p;
     }
     // check_info (reference QB3encode.h:364-373); cband is kept in range by the setter
-    if (g.w < 4 || g.h < 4) { p->error = 1; if (rle) p->mode = mode; return 0; }
+    if (g.w < 4 || g.h < 4) { p->error = 1; return 0; }
 
-    // optional coarse restart table inside the container (not with RLE0, whose post pass rewrites the container)
-    IxLayout ixl;
+    // optional restart table inside the container (not with RLE0, whose post pass rewrites the container)
     IxTable ixt;
     size_t hdr_stamp = hdr;                               // header bytes prepared on the host
-    if (p->ix_chunk && !narrow && !rle) {
-        ixl = ix_layout(g);
-        hdr_stamp = write_headers(p, hdrbuf, &ixl);
-        hdr = hdr_stamp + (size_t)ixl.K * ixl.E + 2;      // entries, then "DT": both written by ix_fill_kernel
-        ixt.entries = out_dev + hdr_stamp; ixt.K = ixl.K; ixt.blocks = ixl.blocks; ixt.entry_bytes = ixl.E;
+    if (ixroom && !narrow) {
+        ixt = ix_layout(g);
+        hdr_stamp = write_headers(p, hdrbuf, false);
+        hdr = hdr_stamp + ix_total_bytes(ixt) + 2;        // chunks, then "DT": both written by ix_fill_kernel
+        ixt.base = out_dev + hdr_stamp;
         if (!d_index) {                                   // the table is a sample of the index: make one
             if (!p->d_idx.ensure(index_bytes(g))) { p->error = QB3E_LIBERR; return 0; }
             d_index = p->d_idx.p;
@@ -425,7 +515,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     }
     uint64_t bits = 0;
     if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits, hdrbuf, hdr_stamp, ixt)) {   // the index describes the block stream, RLE0 wrapped or not
-        p->error = QB3E_LIBERR; if (rle) p->mode = mode; return 0;
+        p->error = QB3E_LIBERR; return 0;
     }
     p->error = 0;
     const size_t len = hdr + (size_t)((bits + 7) / 8);
@@ -454,20 +544,19 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
             }
         }
     }
-    // (the coarse index chunk does not take part in the decision: the same inputs give the same kind of container)
-    if (raw_size(p) > len - (ixt.entries ? ixl.chunk : 0)) {
+    // (the restart table does not take part in the decision: the same inputs give the same kind of container)
+    if (raw_size(p) > len - (ixt.base ? ix_total_bytes(ixt) : 0)) {
         if (on_host) {
             memcpy(host_dst, hdrbuf, hdr_stamp);
-            HIPOK(hipMemcpyAsync((uint8_t *)host_dst + hdr_stamp, out_dev + hdr_stamp, len - hdr_stamp, hipMemcpyDeviceToHost, st));
-            HIPOK(hipStreamSynchronize(st));
-        }       // device flavour: the header was stamped by write_header_kernel, in stream order
+            if (!download(p->stager, (uint8_t *)host_dst + hdr_stamp, out_dev + hdr_stamp, len - hdr_stamp, st)) { p->error = QB3E_LIBERR; return 0; }
+        }       // device flavour: the header was written by write_header_kernel, in stream order
         return len;
     }
-    // not worth it: raw bypass (reference QB3encode.cpp:571-573)
+    // not worth it: raw bypass (reference QB3encode.cpp:571-573), which leaves the handle's mode at STORED
+    guard.armed = false;
     if (on_host) return stored_encode_host(p, host_src, host_dst);
     p->mode = QB3M_STORED;
     const size_t h2 = write_headers(p, hdrbuf);
-    const size_t line = p->xsize * p->nbands * tsz;
     HIPOK(hipMemcpyAsync(d_dst, hdrbuf, h2, hipMemcpyHostToDevice, st));
     HIPOK(hipMemcpy2DAsync((uint8_t *)d_dst + h2, line, d_src, src_stride_bytes, line, p->ysize, hipMemcpyDeviceToDevice, st));
     HIPOK(hipStreamSynchronize(st));
@@ -517,7 +606,11 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
     // host synchronisation.  Anything unusual takes the one-by-one path.
     const bool batchable = !is_rle_mode(mode) && mode != QB3M_STORED && p->quanta < 2 && p->xsize >= 4 && p->ysize >= 4 &&
                            p->xsize * p->ysize > 16 && !p->error && device_ok();
-    if (!batchable) return encode_tiles_loop(p, d_src, 0, n, src_pitch, d_dst, dst_pitch, d_index, isz, sizes, stream, mode);
+    if (!batchable) {
+        const size_t k = encode_tiles_loop(p, d_src, 0, n, src_pitch, d_dst, dst_pitch, d_index, isz, sizes, stream, mode);
+        if (mode != QB3M_STORED) p->mode = mode;
+        return k;
+    }
 
     uint8_t hdrbuf[64];
     const size_t hdr = write_headers(p, hdrbuf);
@@ -555,6 +648,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
             p->band[c].prev = (size_t)res[cnt - 1].prev[c]; p->band[c].runbits = res[cnt - 1].rung[c]; p->band[c].cf = (size_t)res[cnt - 1].cf[c];
         }
     }
+    p->mode = mode;         // a raw fallback of one tile must not turn the handle (and the next call) to QB3M_STORED
     p->error = 0;
     return done;
 }
@@ -562,7 +656,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
 // ---------------------------------------------------------------- decoder handle
 QB3_API void qb3_destroy_decoder(decsp p) {
     if (!p) return;
-    p->d_in.release(); p->d_img.release(); p->d_ws.release(); p->d_ix.release();
+    p->d_in.release(); p->d_img.release(); p->d_ws.release(); p->d_ix.release(); p->stager.release();
     delete p;
 }
 QB3_API size_t qb3_decoded_size(const decsp p) { return p->xsize * p->ysize * p->nbands * szof(p->type); }
@@ -578,9 +672,10 @@ QB3_API bool qb3_get_coreband(const decsp p, size_t *coreband) {
 QB3_API void qb3_set_decoder_stride(decsp p, size_t stride) { p->stride = stride; }
 QB3_API void qb3x_set_decoder_compat(decsp p, unsigned flags) { if (p) p->compat = flags; }
 
-// reference QB3decode.cpp:130-172
-QB3_API decsp qb3_read_start(void *source, size_t source_size, size_t *image_size) {
-    if (!source || source_size < 15 || !image_size) return nullptr;
+// reference QB3decode.cpp:130-172.  hdr_avail: bytes readable at `source` (the device flavour may hand over a copy of
+// the container's head only, with source_size still the size of the whole container)
+static decsp read_start_impl(void *source, size_t hdr_avail, size_t source_size, size_t *image_size) {
+    if (!source || source_size < 15 || hdr_avail < 15 || !image_size) return nullptr;
     const uint8_t *b = (const uint8_t *)source;
     if (b[0] != 'Q' || b[1] != 'B' || b[2] != '3' || b[3] != 0x80) return nullptr;
     const size_t nb = 1 + (size_t)b[8];
@@ -595,11 +690,31 @@ QB3_API decsp qb3_read_start(void *source, size_t source_size, size_t *image_siz
     memset(p->cband, 0, sizeof(p->cband));
     p->s_start = (uint8_t *)source;
     p->s_in = p->s_start + 11; p->s_size = source_size - 11;
+    p->hdr_avail = hdr_avail < source_size ? hdr_avail : source_size;
     p->saw_cb = false; p->compat = 0;
-    p->ix_off = 0; p->ix_K = p->ix_blocks = p->ix_E = 0;
+    p->ix_off = 0; p->ix_K = p->ix_blocks = p->ix_E = p->ix_per_chunk = 0; p->ix_pads = false; p->ix_bad = false;
     image_size[0] = p->xsize; image_size[1] = p->ysize; image_size[2] = p->nbands;
     if (mode <= (int)QB3M_CF_RLE) p->order = ZCURVE;
     return p;
+}
+QB3_API decsp qb3_read_start(void *source, size_t source_size, size_t *image_size) {
+    return read_start_impl(source, source_size, source_size, image_size);
+}
+QB3_API decsp qb3x_read_start(void *header, size_t header_size, size_t stream_size, size_t *image_size) {
+    return read_start_impl(header, header_size, stream_size, image_size);
+}
+// Upper bound of the bytes in front of the block stream of a container that starts with these (at least 11) bytes:
+// the fixed header, the reference's chunks and this library's restart-table chunks for the worst mode.
+QB3_API size_t qb3x_header_size_bound(const void *container, size_t avail) {
+    const uint8_t *b = (const uint8_t *)container;
+    if (!b || avail < 11 || b[0] != 'Q' || b[1] != 'B' || b[2] != '3' || b[3] != 0x80) return 0;
+    const size_t w = 1 + (size_t)(b[4] | (b[5] << 8)), h = 1 + (size_t)(b[6] | (b[7] << 8)), nb = 1 + (size_t)b[8];
+    const size_t tsz = szof(b[9]);
+    if (!tsz || nb > QB3_MAXBANDS) return 0;
+    // an entry covers at least 12 units (one common-factor segment) and takes at most 6 + bands * (1 + 2 * tsz) bytes
+    const size_t units = ((w + 3) / 4) * ((h + 3) / 4) * nb, E = 6 + nb * (1 + 2 * tsz);
+    const size_t K = units / 12 + 1, per_chunk = (65535 - IX_HEAD) / E;
+    return 128 + K * E + (K / per_chunk + 1) * (IX_HEAD + IX_PAD);
 }
 
 static bool valid_curve(uint64_t v) {
@@ -616,8 +731,14 @@ QB3_API bool qb3_read_info(decsp p) {
     }
     const uint8_t *s = p->s_in;
     const size_t n = p->s_size;
+    const size_t avail = p->hdr_avail > 11 ? p->hdr_avail - 11 : 0;           // bytes readable at s (<= n)
     size_t pos = 0;
-    auto rd = [&](size_t at) -> unsigned { return at < n ? s[at] : 0u; };     // reads past the end give zeros
+    bool short_copy = false;                                                   // the head copy ends before the header does
+    auto rd = [&](size_t at) -> unsigned {                                     // reads past the end give zeros
+        if (at < avail) return s[at];
+        if (at < n) short_copy = true;
+        return 0u;
+    };
     do {
         const unsigned c0 = rd(pos), c1 = rd(pos + 1), len = rd(pos + 2) | (rd(pos + 3) << 8);
         if (c0 == 'Q' && c1 == 'V') {
@@ -653,14 +774,24 @@ QB3_API bool qb3_read_info(decsp p) {
         } else {
             // the reference skips an ignorable (lower case) chunk by `len` bytes from the chunk start
             // (QB3decode.cpp:254-255); a zero length would never terminate there, treat it as an error
-            if (c0 == 'i' && c1 == 'x' && len >= 12 && rd(pos + 4) == 1 && p->mode != QB3M_STORED) {
-                // this library's coarse restart table (include/qb3x.h): remember where the entries are, check later
+            if (c0 == 'i' && c1 == 'x' && len >= IX_HEAD && (rd(pos + 4) == 1 || rd(pos + 4) == 2) && p->mode != QB3M_STORED) {
+                // this library's restart table (include/qb3x.h): a run of such chunks, all but the last of the same
+                // size, each followed by a 4-byte pad chunk (version 2).  Remember where it is, check it later.
                 const size_t tsz = szof(p->type);
                 const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * ((rd(pos + 5) & 1) ? 2 : 1)));
-                const size_t off = (size_t)(p->s_in - p->s_start) + pos + 12;
-                if ((len - 12) % E == 0 && pos + len <= n) {
-                    p->ix_off = off; p->ix_E = E; p->ix_K = (len - 12) / E;
-                    p->ix_blocks = rd(pos + 8) | (rd(pos + 9) << 8) | (rd(pos + 10) << 16) | (rd(pos + 11) << 24);
+                const uint32_t blocks = rd(pos + 8) | (rd(pos + 9) << 8) | (rd(pos + 10) << 16) | (rd(pos + 11) << 24);
+                const size_t at = (size_t)(p->s_in - p->s_start) + pos;
+                const bool v2 = rd(pos + 4) == 2;
+                if ((len - IX_HEAD) % E || pos + len > n) p->ix_bad = true;
+                else if (!p->ix_K) {        // the first chunk
+                    p->ix_off = at; p->ix_E = E; p->ix_blocks = blocks; p->ix_pads = v2;
+                    p->ix_per_chunk = p->ix_K = (len - IX_HEAD) / E;
+                } else {                    // a further one: in place, same shape, and only the last may be short
+                    const size_t full = IX_HEAD + (size_t)p->ix_per_chunk * E + (p->ix_pads ? IX_PAD : 0);
+                    const uint32_t here = (len - IX_HEAD) / E;
+                    if (!v2 || !p->ix_pads || E != p->ix_E || blocks != p->ix_blocks || p->ix_K % p->ix_per_chunk ||
+                        at != p->ix_off + (p->ix_K / p->ix_per_chunk) * full || here > p->ix_per_chunk) p->ix_bad = true;
+                    else p->ix_K += here;
                 }
             }
             if ((c0 & 0x20) && len) pos += len;
@@ -669,6 +800,8 @@ QB3_API bool qb3_read_info(decsp p) {
         if (pos > n) pos = n;
     } while (p->stage != 2 && QB3E_OK == p->error && pos < n);
     if (QB3E_OK == p->error && 2 != p->stage) p->error = QB3E_EINV;
+    if (short_copy && QB3E_OK == p->error) p->error = QB3E_EINV;               // qb3x_read_start: the head copy is too short
+    if (p->ix_bad) p->ix_K = 0;
     return QB3E_OK == p->error;
 }
 
@@ -715,7 +848,7 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
         if (p->s_size != total) { p->error = QB3E_EINV; return 0; }
         if (on_host) {
             if (!p->stride) memcpy(host_dst, p->s_in, total);
-            else for (size_t y = 0; y < p->ysize; y++) memcpy((uint8_t *)host_dst + y * p->stride, p->s_in + y * line, line);
+            else for (size_t y = 0; y < p->ysize; y++) memcpy((uint8_t *)host_dst + y * dst_stride, p->s_in + y * line, line);   // stride in values, as everywhere (QB3.h:146-148)
         } else {
             HIPOK(hipMemcpy2DAsync(d_dst, dst_stride, (const uint8_t *)d_src + data_off, line, line, p->ysize, hipMemcpyDeviceToDevice, st));
             HIPOK(hipStreamSynchronize(st));
@@ -748,7 +881,7 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
     if (on_host || rle) {
         const uint8_t *src = rle ? unrle.data() : p->s_in;
         if (!p->d_in.ensure(nbytes + 8)) { p->error = QB3E_LIBERR; return 0; }
-        HIPOK(hipMemcpyAsync(p->d_in.p, src, nbytes, hipMemcpyHostToDevice, st));
+        if (!upload(p->stager, p->d_in.p, src, nbytes, st)) { p->error = QB3E_LIBERR; return 0; }
         dev_buf = (const uint8_t *)p->d_in.p; off = 0;
     } else { dev_buf = (const uint8_t *)d_src; off = data_off; }
 
@@ -770,17 +903,17 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
         if (!p->d_img.ensure((size_t)g.w * g.h * g.bands * tsz)) { p->error = QB3E_LIBERR; return 0; }
         img_dev = p->d_img.p;
     }
-    // a coarse restart table inside the container stands in for a missing index (not under RLE0: positions there are
-    // those of the expanded stream, which is what the table holds, but keep the legacy modes on the plain path)
+    // a restart table inside the container stands in for a missing index (not under RLE0: the legacy modes keep
+    // the plain path)
     IxTable ixt;
     if (!d_index && p->ix_K && !rle && !narrow) {
-        const size_t bytes = (size_t)p->ix_K * p->ix_E;
+        ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads;
         if (on_host) {
+            const size_t bytes = ix_total_bytes(ixt);
             if (!p->d_ix.ensure(bytes)) { p->error = QB3E_LIBERR; return 0; }
             HIPOK(hipMemcpyAsync(p->d_ix.p, p->s_start + p->ix_off, bytes, hipMemcpyHostToDevice, st));
-            ixt.entries = (uint8_t *)p->d_ix.p;
-        } else ixt.entries = (uint8_t *)d_src + p->ix_off;
-        ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E;
+            ixt.base = (uint8_t *)p->d_ix.p;
+        } else ixt.base = (uint8_t *)d_src + p->ix_off;
     }
     if (!decode_blocks_device(p, g, dev_buf, off, nbytes, img_dev, d_index, st, ixt)) {
         if (p->error == QB3E_OK) p->error = QB3E_LIBERR;
@@ -803,8 +936,11 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
         return total;
     }
     if (on_host) {
-        HIPOK(hipMemcpy2DAsync(host_dst, dst_stride, img_dev, line, line, p->ysize, hipMemcpyDeviceToHost, st));
-        HIPOK(hipStreamSynchronize(st));
+        if (dst_stride == line) { if (!download(p->stager, host_dst, img_dev, total, st)) { p->error = QB3E_LIBERR; return 0; } }
+        else {
+            HIPOK(hipMemcpy2DAsync(host_dst, dst_stride, img_dev, line, line, p->ysize, hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+        }
     }
     return total;
 }
@@ -819,32 +955,61 @@ QB3_API size_t qb3x_decode_device(decsp p, const void *d_src, void *d_dst, const
     return decode_common(p, nullptr, d_src, d_dst, d_index, (hipStream_t)stream);
 }
 
-static size_t decode_tiles_loop(decsp p, const void *d_src, size_t first, size_t n, size_t src_pitch, const size_t *sizes,
-                                void *d_dst, size_t dst_pitch, const void *d_index, size_t isz, void *stream) {
-    const size_t hdr = (size_t)(p->s_in - p->s_start);
-    size_t done = 0;
-    for (size_t i = first; i < first + n; i++) {
-        if (sizes[i] <= hdr) continue;
-        p->s_size = sizes[i] - hdr; p->error = QB3E_OK;
-        done += 0 != qb3x_decode_device(p, (const uint8_t *)d_src + i * src_pitch, (uint8_t *)d_dst + i * dst_pitch,
-                                        d_index ? (const uint8_t *)d_index + i * isz : nullptr, stream);
+// One tile through its own header: a host copy of its head is parsed into a handle of its own (a batch may hold
+// containers of another kind than tile 0's: raw-stored tiles next to coded ones, QB3encode.cpp:571-573)
+static bool decode_tile_alone(decsp ref, const uint8_t *d_tile, size_t size, void *d_out, const void *d_index, hipStream_t st) {
+    if (size < 15) return false;
+    std::vector<uint8_t> head(std::min(size, (size_t)256));
+    if (hipMemcpyAsync(head.data(), d_tile, head.size(), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
+    const size_t need = std::min(size, qb3x_header_size_bound(head.data(), head.size()));
+    size_t dims[3];
+    decsp q = read_start_impl(head.data(), head.size(), size, dims);
+    if (q && !qb3_read_info(q) && need > head.size()) {      // a restart table longer than the first copy
+        qb3_destroy_decoder(q);
+        head.resize(need);
+        if (hipMemcpyAsync(head.data(), d_tile, head.size(), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
+        q = read_start_impl(head.data(), head.size(), size, dims);
+        if (q) (void)qb3_read_info(q);
     }
-    return done;
+    if (!q) return false;
+    bool ok = q->stage == 2 && q->error == QB3E_OK && dims[0] == ref->xsize && dims[1] == ref->ysize && dims[2] == ref->nbands && q->type == ref->type;
+    if (ok) {
+        q->stride = ref->stride; q->compat = ref->compat;
+        ok = 0 != qb3x_decode_device(q, d_tile, d_out, d_index, st);
+    }
+    qb3_destroy_decoder(q);
+    return ok;
 }
 
 QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
                                  void *d_dst, size_t dst_pitch, const void *d_index, void *stream) {
     if (!p || !d_src || !d_dst || !sizes || (src_pitch & 3) || ((uintptr_t)d_src & 3)) return 0;
     if (p->stage != 2 || p->error != QB3E_OK) return 0;
-    const size_t isz = d_index ? qb3x_decoder_index_size(p) : 0;
-    const size_t hdr = (size_t)(p->s_in - p->s_start), s_size0 = p->s_size;
+    const size_t hdr = (size_t)(p->s_in - p->s_start);
     hipStream_t st = (hipStream_t)stream;
-    // batched path (all tiles share the geometry, mode and header layout of tile 0); else one by one
+    p->tile_ok.assign(n, 0);
+    if (!n || !device_ok()) return 0;
+    // the mode byte of every tile: tiles of tile 0's kind go through one set of launches, the others one by one
+    std::vector<uint8_t> modes(n);
+    {
+        hipError_t e = hipMemcpy2DAsync(modes.data(), 1, (const uint8_t *)d_src + 10, src_pitch, 1, n, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("decode tiles: mode bytes", (int)e); p->error = QB3E_LIBERR; return 0; }
+    }
+    // the pitch of the caller's index array is the encoder's qb3x_index_size: a function of the image and of the coding
+    // mode, which a raw-stored tile 0 does not tell -- take it from the first coded tile
+    size_t isz = 0;
+    if (d_index && p->xsize >= 4 && p->ysize >= 4) {
+        int m = p->mode;
+        for (size_t i = 0; i < n && m == QB3M_STORED; i++) m = modes[i];
+        if (m != QB3M_STORED && m < (int)QB3M_END)
+            isz = index_bytes(make_geometry(p->xsize, p->ysize, p->nbands, p->type, 0, m <= (int)QB3M_CF_RLE ? ZCURVE : p->order, m, nullptr, p->cband));
+    }
     const bool batchable = !is_rle_mode(p->mode) && p->mode != QB3M_STORED && p->quanta <= 1 && p->xsize >= 4 && p->ysize >= 4 &&
-                           p->xsize * p->ysize >= 16 && device_ok();
+                           p->xsize * p->ysize >= 16;
+    auto in_batch = [&](size_t i) { return batchable && modes[i] == (uint8_t)p->mode && sizes[i] > hdr; };
     size_t done = 0;
-    if (!batchable) done = decode_tiles_loop(p, d_src, 0, n, src_pitch, sizes, d_dst, dst_pitch, d_index, isz, stream);
-    else {
+    if (batchable) {
         uint8_t cband[QB3_MAXBANDS];
         for (size_t c = 0; c < QB3_MAXBANDS; c++) cband[c] = p->cband[c];
         if (!p->saw_cb && !(p->compat & QB3X_REF_CBAND0)) for (size_t c = 0; c < p->nbands; c++) cband[c] = (uint8_t)c;
@@ -859,7 +1024,8 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
         std::vector<uint32_t> status(batch);
         for (size_t first = 0; first < n; first += batch) {
             const size_t cnt = (n - first < batch) ? n - first : batch;
-            for (size_t i = 0; i < cnt; i++) bits[i] = sizes[first + i] > hdr ? (uint64_t)(sizes[first + i] - hdr) * 8 : 0;
+            // a tile of another kind takes part with an empty stream: its lanes find nothing to read, its turn comes below
+            for (size_t i = 0; i < cnt; i++) bits[i] = in_batch(first + i) ? (uint64_t)(sizes[first + i] - hdr) * 8 : 0;
             hipError_t e = hipMemcpyAsync(p->d_in.p, bits.data(), 8 * cnt, hipMemcpyHostToDevice, st);
             if (e != hipSuccess) { set_error("decode tiles: upload of stream lengths", (int)e); p->error = QB3E_LIBERR; return done; }
             TileBatch tb;
@@ -872,12 +1038,18 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
             prof_collect();
-            for (size_t i = 0; i < cnt; i++) done += bits[i] && !(status[i] & 11);
+            for (size_t i = 0; i < cnt; i++) if (bits[i] && !(status[i] & 11)) { p->tile_ok[first + i] = 1; done++; }
         }
     }
-    p->s_size = s_size0;
+    for (size_t i = 0; i < n; i++) {
+        if (in_batch(i)) continue;
+        if (decode_tile_alone(p, (const uint8_t *)d_src + i * src_pitch, sizes[i], (uint8_t *)d_dst + i * dst_pitch,
+                              d_index ? (const uint8_t *)d_index + i * isz : nullptr, st)) { p->tile_ok[i] = 1; done++; }
+    }
     return done;
 }
+
+QB3_API int qb3x_decode_tile_ok(const decsp p, size_t i) { return (p && i < p->tile_ok.size()) ? p->tile_ok[i] : 0; }
 
 // ---------------------------------------------------------------- misc
 QB3_API int qb3x_device_count(void) {

@@ -76,14 +76,22 @@ struct EncPlan {
 };
 EncPlan plan_encode(const Geometry &g);
 
-// Optional coarse restart table carried INSIDE the container as an ignorable chunk ("ix", include/qb3x.h): K entries,
-// one per `blocks` blocks: [bit position, 6 bytes][rung, 1 byte per band][prev, tsz bytes per band][cf, the same,
-// common-factor modes only].  With it a stream that arrives without the out-of-band index is walked by K waves.
+// Optional restart table carried INSIDE the container as ignorable chunks ("ix", include/qb3x.h): K entries, one per
+// `blocks` blocks: [bit position, 6 bytes][rung, 1 byte per band][prev, tsz bytes per band][cf, the same,
+// common-factor modes only].  A chunk holds at most 64 KB, so the table is a run of chunks of `per_chunk` entries
+// (the last one may hold fewer), each [12-byte head][entries][4-byte "zz" pad chunk]; `base` points at the first
+// chunk's first byte.  With it a stream that arrives without the out-of-band index is walked from K points at once.
+constexpr uint32_t IX_HEAD = 12, IX_PAD = 4;
 struct IxTable {
-    uint8_t *entries = nullptr;     // device pointer (encode: where to write them, "DT" follows; decode: where they are)
-    uint32_t K = 0, blocks = 0, entry_bytes = 0;
+    uint8_t *base = nullptr;        // device pointer (encode: where the chunks go, "DT" follows; decode: where they are)
+    uint32_t K = 0, blocks = 0, entry_bytes = 0, per_chunk = 0;
+    bool pads = true;               // false: a version 1 table (one chunk, no pad chunk behind it)
 };
 uint32_t ix_entry_bytes(const Geometry &g);
+// the table this library writes for a geometry (needs seg_blocks, nseg, bands, tsz, mode); K == 0: none
+IxTable ix_layout(const Geometry &g);
+inline size_t ix_chunks(const IxTable &t) { return t.per_chunk ? (t.K + t.per_chunk - 1) / t.per_chunk : 0; }
+inline size_t ix_total_bytes(const IxTable &t) { return ix_chunks(t) * (IX_HEAD + (t.pads ? IX_PAD : 0)) + (size_t)t.K * t.entry_bytes; }
 
 // Batched tiles: n images/streams laid out at fixed byte pitches, processed by one set of launches (blockIdx.y).
 // n == 0 means a single image.  ws_pitch = plan.ws_bytes of one tile; idx_pitch = index_bytes of one tile.
@@ -97,7 +105,7 @@ struct TileBatch { uint32_t n = 0; uint64_t src_pitch = 0, dst_pitch = 0, ws_pit
 //   ws         workspace of plan.ws_bytes; the EncResult is its LAST sizeof(EncResult) bytes
 //   index      optional decode index (nullptr = none)
 // Launches on `stream`, does not synchronise.  Returns hipError_t as int.
-// ix: entries == nullptr when no chunk is wanted
+// ix: base == nullptr when no table is wanted
 int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
                   const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb = TileBatch(),
                   const uint8_t *hdr = nullptr, uint32_t hdr_len = 0,      // hdr: container header stamped before each stream

@@ -208,8 +208,9 @@ struct EncArgs {
     uint8_t hdr[80];        // at most 11 + 20 (CB) + 12 (QV) + 12 (SC) + 12 (ix head) bytes
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups per block (lanes per block), magic of it
     uint32_t px_aligned;            // lane-per-block kernels: every row of every block is dword aligned (plain dword loads)
-    uint8_t *ix_dst;                // coarse index chunk: where the entries go (null: none), "DT" right after them
+    uint8_t *ix_dst;                // restart table: where its first chunk goes (null: none), "DT" right after the last
     uint32_t ix_K, ix_spe, ix_E;    //   ... entries, fine segments per entry, bytes per entry
+    uint32_t ix_per_chunk, ix_blocks;   // ... entries per chunk, blocks per entry
     EncResult *res;
     BandState st;
     IndexView idx;
@@ -302,13 +303,19 @@ struct DecArgs {
     uint32_t totals_only;           // lane-per-block kernels: write the segments' per-band sums to idx.prev, no pixels
     uint32_t px_aligned;            // lane-per-block kernels: every row of every block is dword aligned (plain dword stores)
     const uint8_t *ix;              // coarse index chunk found in the container (null: none): restart points for the walk
-    uint32_t ix_K, ix_blocks, ix_E;
+    uint32_t ix_K, ix_blocks, ix_E, ix_per_chunk, ix_pad;     // ix_pad: bytes of the pad chunk behind every table chunk
     // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
     uint32_t ntiles;
     uint64_t ts_in, ts_img, ts_idx;
     const uint64_t *tile_bits;
 };
 
+
+// entry k of a restart table whose first chunk starts at `base` (layout: qb3_dev.h, IxTable)
+__device__ __forceinline__ const uint8_t *ix_entry_at(const uint8_t *base, uint32_t per_chunk, uint32_t E, uint32_t pad, uint32_t k) {
+    const uint32_t c = k / per_chunk, j = k - c * per_chunk;
+    return base + (uint64_t)c * (IX_HEAD + pad + (uint64_t)per_chunk * E) + IX_HEAD + (uint64_t)j * E;
+}
 
 __device__ __forceinline__ DecArgs dec_for_tile(DecArgs a, uint32_t t) {
     if (a.tile_bits) a.in_bits = a.tile_bits[t];

@@ -66,24 +66,26 @@ class DeviceEncoder:
 
 
 class DeviceDecoder:
-    """Decoder for one device-resident container.  `header` is a host copy of the container up to its "DT" mark: the
-    first 64 bytes, or HEADER_MAX bytes if it may carry the coarse index chunk; a device tensor holding the container
-    is accepted too (the wrapper copies what it needs)."""
+    """Decoder for one device-resident container.  `container` is the device tensor holding it (the wrapper copies
+    the head it needs to the host: qb3x_header_size_bound bytes at most) or a host array holding at least that head."""
 
-    HEADER_MAX = 65536 + 96
-
-    def __init__(self, header, nbytes):
-        if torch.is_tensor(header):
-            header = header[:min(int(nbytes), self.HEADER_MAX)].cpu().numpy()
-        self.hdr = np.ascontiguousarray(header, dtype=np.uint8)
+    def __init__(self, container, nbytes):
+        nbytes = int(nbytes)
+        if torch.is_tensor(container):
+            first = container[:min(nbytes, 64)].cpu().numpy()
+            need = lib.qb3x_header_size_bound(first.ctypes.data_as(_vp), first.size)
+            head = first if need <= first.size else container[:min(nbytes, need)].cpu().numpy()
+        else:
+            head = container
+        self.hdr = np.ascontiguousarray(head, dtype=np.uint8)
         dims = (_sz * 3)()
-        self.p = lib.qb3_read_start(self.hdr.ctypes.data_as(_vp), nbytes, dims)
+        self.p = lib.qb3x_read_start(self.hdr.ctypes.data_as(_vp), min(self.hdr.size, nbytes), nbytes, dims)
         if not self.p:
-            raise ValueError("qb3_read_start rejected the stream")
+            raise ValueError("qb3x_read_start rejected the stream")
         if not lib.qb3_read_info(self.p):
             lib.qb3_destroy_decoder(self.p)
             self.p = None
-            raise ValueError("qb3_read_info failed")
+            raise ValueError("qb3_read_info failed (or the host copy ends before the container's DT mark)")
         self.w, self.h, self.bands = dims[0], dims[1], dims[2]
         self.out_bytes = lib.qb3_decoded_size(self.p)
         self.nbytes = nbytes

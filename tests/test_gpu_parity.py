@@ -107,7 +107,7 @@ def dev_roundtrip(qb3, oracle, torch, w, h, b, dt, gen, seed, mode, cband=None):
     enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cband)
     dst, n, index = enc.encode(img)
     stream = dst[:n].cpu().numpy()
-    dec = qdev.DeviceDecoder(stream[:64], n)
+    dec = qdev.DeviceDecoder(stream[:min(n, 64)], n)
     raw = img.reshape(-1).view(torch.uint8)
     assert torch.equal(dec.decode(dst, index=index), raw), "indexed decode"
     assert torch.equal(dec.decode(dst, index=None), raw), "index-less decode"
@@ -193,7 +193,7 @@ def test_full_size_anchor_on_device(qb3, oracle, a):
         n = len(stream)
         dst = torch.from_numpy(np.concatenate([stream, np.zeros((-n) % 4 + 8, np.uint8)])).cuda()
         index = None
-    dec = qdev.DeviceDecoder(stream[:64], n)
+    dec = qdev.DeviceDecoder(stream[:min(n, 64)], n)
     if not a["roundtrip"]:
         # reference defect B-1: compat flag reproduces the reference's (wrong) output, the default round-trips
         qb3.lib.qb3x_set_decoder_compat(dec.p, qb3.QB3X_REF_CBAND0)
@@ -373,6 +373,89 @@ def test_tiles_api(qb3, oracle, shape):
     L.qb3_destroy_decoder(d)
 
 
+@pytest.mark.parametrize("stored_at", [0, 2, 5])
+def test_tiles_api_with_a_stored_tile(qb3, oracle, stored_at):
+    """a batch in which one tile is incompressible: qb3x_encode_tiles writes it raw (QB3M_STORED, another header layout),
+    the handle's mode survives the call, and qb3x_decode_tiles decodes the whole batch whatever the position of that
+    tile -- also first, where it is the tile the decoder handle was parsed from"""
+    import ctypes as C
+    import torch
+    from qb3_amd import synth
+    L = qb3.lib
+    w, h, b, dt, n = 128, 64, 3, 0, 6
+    imgs = torch.stack([synth.generate(w, h, b, dt, "RANDOM" if t == stored_at else "NOISY3", 2000 + t) for t in range(n)])
+    p = L.qb3_create_encoder(w, h, b, dt)
+    pitch = (L.qb3_max_encoded_size(p) + 3) // 4 * 4
+    isz = L.qb3x_index_size(p)
+    dst = torch.zeros(n * pitch, dtype=torch.uint8, device="cuda")
+    idx = torch.zeros(n * isz, dtype=torch.uint8, device="cuda")
+    sizes = (C.c_size_t * n)()
+    raw = w * h * b
+    for rep in range(2):        # the second call must not inherit QB3M_STORED from the fallback inside the first
+        assert L.qb3x_encode_tiles(p, imgs.data_ptr(), n, raw, dst.data_ptr(), pitch, idx.data_ptr(), sizes, None) == n
+        host = dst.cpu().numpy()
+        for t in range(n):
+            ref = oracle.encode(imgs[t].cpu().numpy(), dt, 8)
+            assert sizes[t] == len(ref) and np.array_equal(host[t * pitch:t * pitch + sizes[t]], ref)
+            assert (host[t * pitch + 10] == 255) == (t == stored_at)
+    L.qb3_destroy_encoder(p)
+    dims = (C.c_size_t * 3)()
+    hdr = host[:64].copy()
+    d = L.qb3_read_start(hdr.ctypes.data, sizes[0], dims)
+    assert L.qb3_read_info(d)
+    for index in (idx.data_ptr(), None):
+        out = torch.zeros_like(imgs)
+        assert L.qb3x_decode_tiles(d, dst.data_ptr(), n, pitch, sizes, out.data_ptr(), raw, index, None) == n
+        assert all(L.qb3x_decode_tile_ok(d, t) == 1 for t in range(n))
+        assert torch.equal(out, imgs)
+    # a damaged tile is reported, the others still decode
+    dst[3 * pitch + 40:3 * pitch + 40 + 64] = 0xff if stored_at != 3 else 0
+    bad_sizes = (C.c_size_t * n)(*sizes)
+    bad_sizes[3] = sizes[3] - 7 if stored_at == 3 else sizes[3] + 9
+    out = torch.zeros_like(imgs)
+    k = L.qb3x_decode_tiles(d, dst.data_ptr(), n, pitch, bad_sizes, out.data_ptr(), raw, None, None)
+    assert k == n - 1 and L.qb3x_decode_tile_ok(d, 3) == 0 and all(L.qb3x_decode_tile_ok(d, t) == 1 for t in range(n) if t != 3)
+    L.qb3_destroy_decoder(d)
+
+
+def test_strided_stored_containers(qb3, oracle):
+    """the line stride is in VALUES on every path (QB3.h:116-120,146-148), also when a 16-bit image falls back to raw
+    storage: strided encode of incompressible data, strided decode of the STORED container, host and device flavour"""
+    import ctypes as C
+    import torch
+    L = qb3.lib
+    w, h, b, dt = 48, 20, 2, 2
+    img = oracle.generate(w, h, b, dt, "RANDOM", 3)
+    stride = w * b + 6
+    wide = np.zeros((h, stride), dtype=np.uint16)
+    wide[:, :w * b] = img.reshape(h, w * b)
+    ref = oracle.encode(img, dt, 8)
+    assert ref[10] == 255
+    got = qb3.encode(img, dt, 8)
+    assert np.array_equal(got, ref)
+    p = L.qb3_create_encoder(w, h, b, dt)
+    L.qb3_set_encoder_stride(p, stride)
+    buf = np.zeros(L.qb3_max_encoded_size(p), dtype=np.uint8)
+    n = L.qb3_encode(p, wide.ctypes.data, buf.ctypes.data)
+    L.qb3_destroy_encoder(p)
+    assert n == len(ref) and np.array_equal(buf[:n], ref)
+    dims = (C.c_size_t * 3)()
+    for device in (False, True):
+        d = L.qb3_read_start(ref.ctypes.data, len(ref), dims)
+        assert L.qb3_read_info(d)
+        L.qb3_set_decoder_stride(d, stride)
+        out = np.zeros((h, stride), dtype=np.uint16)
+        if device:
+            dsrc = torch.from_numpy(np.concatenate([ref, np.zeros((-len(ref)) % 4, np.uint8)])).cuda()
+            dout = torch.zeros(h * stride * 2, dtype=torch.uint8, device="cuda")
+            assert L.qb3x_decode_device(d, dsrc.data_ptr(), dout.data_ptr(), None, None) == w * h * b * 2
+            out = dout.cpu().numpy().view(np.uint16).reshape(h, stride)
+        else:
+            assert L.qb3_read_data(d, out.ctypes.data) == w * h * b * 2
+        L.qb3_destroy_decoder(d)
+        assert np.array_equal(out[:, :w * b], img.reshape(h, w * b)) and not out[:, w * b:].any()
+
+
 @pytest.mark.parametrize("case", [(2048, 2048, 1, 7, "TERRACE", 4, 1), (2048, 2048, 1, 7, "TERRACE", 4, 5), (2048, 1024, 3, 0, "NOISY3", 2, 8),
                                   (1024, 1024, 8, 2, "LANDSAT16", 3, 4), (2048, 2048, 1, 5, "FEW", 4, 7), (1021, 515, 3, 0, "NOISY3", 1, 4)],
                          ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % (c[0], c[1], c[2], c[3], c[4], c[6]))
@@ -530,11 +613,32 @@ IX_CASES = [
 ]
 
 
+def walk_chunks(c, fixed_b7):
+    """Chunk walk of a container the way the reference does it (QB3decode.cpp:193-258): known upper-case chunks by their
+    payload length, unknown lower-case ones by `len` bytes from the chunk START (defect B-7) -- or, fixed_b7, by the
+    4 head bytes plus `len`, what a corrected reader would do.  Returns (offset of "DT", list of (tag, offset, len))."""
+    pos, seen = 11, []
+    while True:
+        tag, ln = bytes(c[pos:pos + 2]), int(c[pos + 2]) | int(c[pos + 3]) << 8
+        if tag == b"DT":
+            return pos, seen
+        seen.append((tag, pos, ln))
+        if tag in (b"CB", b"QV", b"SC"):
+            pos += 4 + ln
+        else:
+            assert tag[0] & 0x20 and ln, "unknown upper-case chunk"
+            pos += ln + (4 if fixed_b7 else 0)
+        assert pos < len(c)
+
+
+IX_CASES.append((8192, 4096, 3, 0, "NOISY3", 6, FTL))      # more entries than one 64 KB chunk holds
+
+
 @pytest.mark.parametrize("case", IX_CASES, ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % (c[0], c[1], c[2], c[3], c[4], c[6]))
 def test_index_chunk(qb3, oracle, case):
-    """qb3x_set_encoder_index_chunk: the container gains one ignorable chunk ("ix") and nothing else changes; the
-    reference's decoder (the oracle restates its skip rule, QB3decode.cpp:251-255) steps over it; this library
-    decodes through it, host and device flavour"""
+    """qb3x_set_encoder_index_chunk: the container gains ignorable chunks ("ix" + "zz" pad pairs) in front of "DT" and
+    nothing else changes; the reference's decoder (the oracle restates its skip rule, QB3decode.cpp:251-255) steps
+    over them, and so would a reader with defect B-7 fixed; this library decodes through them, host and device flavour"""
     import torch
     from qb3_amd import synth, device as qdev
     w, h, b, dt, gen, seed, mode = case
@@ -544,16 +648,26 @@ def test_index_chunk(qb3, oracle, case):
     got = qb3.encode(img, dt, mode, cband=cb, index_chunk=True)
     plain = qb3.encode(img, dt, mode, cband=cb)
     assert np.array_equal(plain, ref)
-    # same container with one chunk inserted in front of "DT"
+    # same container with the table's chunks inserted in front of "DT"
     extra = len(got) - len(ref)
-    assert extra >= 12 + 6 and extra <= 65535
-    dt_at = len(ref) - (len(ref) - bytes(ref).index(b"DT", 11))
-    assert bytes(got[:dt_at]) == bytes(ref[:dt_at]) and bytes(got[dt_at:dt_at + 2]) == b"ix"
-    assert int(got[dt_at + 2]) | int(got[dt_at + 3]) << 8 == extra
-    assert bytes(got[dt_at + extra:]) == bytes(ref[dt_at:])
+    dt_at = bytes(ref).index(b"DT", 11)
+    assert bytes(got[:dt_at]) == bytes(ref[:dt_at]) and bytes(got[dt_at + extra:]) == bytes(ref[dt_at:])
+    for fixed in (False, True):
+        at, seen = walk_chunks(got, fixed)
+        assert at == dt_at + extra
+    _, seen = walk_chunks(got, False)
+    mine = [c for c in seen if c[1] >= dt_at]
+    assert len(mine) % 2 == 0 and len(mine) >= 2
+    entries = 0
+    for ix, zz in zip(mine[0::2], mine[1::2]):
+        assert ix[0] == b"ix" and zz[0] == b"zz" and zz[2] == 4 and zz[1] == ix[1] + ix[2] and got[ix[1] + 4] == 2
+        entries += (ix[2] - 12)
+    assert extra == entries + 16 * (len(mine) // 2)
+    if w * h >= 8192 * 4096:
+        assert len(mine) >= 4, "this case is meant to need more than one chunk"
     raw = img.view(np.uint8).ravel()
     out, _, _, _ = oracle.decode(got, identity=True)
-    assert out is not None and np.array_equal(out, raw), "the reference decoder must step over the chunk"
+    assert out is not None and np.array_equal(out, raw), "the reference decoder must step over the chunks"
     out, dims, dtype, m = qb3.decode(got)
     assert np.array_equal(out, raw)
     # device flavour: container made on the device, decoded with and without the out-of-band index
@@ -565,6 +679,21 @@ def test_index_chunk(qb3, oracle, case):
     draw = dimg.reshape(-1).view(torch.uint8)
     assert torch.equal(dec.decode(dst, index=None), draw)
     assert torch.equal(dec.decode(dst, index=index), draw)
+
+
+def test_index_chunk_version_1_still_decodes(qb3, oracle):
+    """round-1 containers carry ONE "ix" chunk, version 1, no pad chunk: rebuilt here from a version 2 container"""
+    img = oracle.generate(512, 512, 3, 0, "NOISY3", 1)
+    got = qb3.encode(img, 0, FTL, index_chunk=True)
+    at = bytes(got).index(b"ix", 11)
+    ln = int(got[at + 2]) | int(got[at + 3]) << 8
+    assert bytes(got[at + ln:at + ln + 4]) == b"zz\x04\x00" and bytes(got[at + ln + 4:at + ln + 6]) == b"DT"
+    v1 = np.concatenate([got[:at + ln], got[at + ln + 4:]])
+    v1[at + 4] = 1
+    out, _, _, _ = qb3.decode(v1)
+    assert np.array_equal(out, img.ravel())
+    out, _, _, _ = oracle.decode(v1, identity=True)
+    assert np.array_equal(out, img.ravel())
 
 
 def test_index_chunk_not_written_where_it_cannot_be(qb3, oracle):
