@@ -4,19 +4,26 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one pass of the hot path over this rank's synthetic raster, resident in HBM before the clock
-starts: qb3x_encode_device (container + out-of-band index) followed by qb3x_decode_device of that
-container with that index.  With N > 1 every rank codes its own raster: tiles shard with NO data-path
-collective, so the timed region holds only the coding path and scaling is weak.
-The one exchange the workload has -- collecting the finished containers on rank 0, RCCL send/recv over
-xGMI -- is done once after the timed region and reported on its own (`gather`): it is bound by the
-peers' links into rank 0 (435 MB per peer), not by anything this library does.  Rank 0 prints ONE JSON line.
+N = 1 -- BASELINE.json configs[1]: ONE 16384x16384 3-band uint8 raster (NOISY3, seed 2), resident in HBM before the
+clock starts.  A step = qb3x_encode_device (the container, self-indexed: the restart table travels INSIDE it as
+ignorable chunks) followed by qb3x_decode_device of that container ALONE (index = NULL): what `value` counts is
+decode from the stream, as the reference's contract has it (QB3decode.cpp:455-464).  The same decode with this
+library's out-of-band index, and of a plain (reference-made) container with nothing to help, are reported beside it
+in `decode`.  The container minus its table chunks is checked against the reference's published size AND FNV-1a64
+(SURVEY.md Appendix C).  The line also carries, under `workloads`, short measurements of the other BASELINE
+configurations -- 3 (8192^2 x 8 uint16, QB3M_BASE), 4 (4096^2 int32 and int64, FTL and QB3M_BEST), 5 (one rank's 32
+tiles of 4096^2 x 3 through qb3x_encode_tiles / qb3x_decode_tiles) -- each with its own roofline entry.
 
-The workload at N = 1 is BASELINE.json configs[1]: 16384x16384, 3-band uint8, NOISY3 seed 2, QB3M_FTL.
-`roofline` prices the dominant kernel against the HBM rate with the algorithmic bytes of SURVEY.md
-section 8(d): bands*sizeof(T)*(1+rho) bytes per pixel (raw once + stream once), timed live with HIP events
-the library records on the launch stream.  `cpu_baseline` times oracle/ (the CPU restatement, a "port")
-on one host core over a bounded sample of the same raster.
+N > 1 -- BASELINE.json configs[4]: every rank codes 32 independent 4096x4096x3 tiles per step (N = 8: the 256 tiles
+of the configuration; weak scaling), in batches through qb3x_encode_tiles; the containers of batch k travel to rank 0
+(RCCL send/recv over xGMI, one message per tile) while batch k+1 is coded; then every rank decodes its own tiles.
+The gather is INSIDE the timed step: `value` = pixels of all ranks / max over ranks of the time until every
+container is on rank 0 and every tile is decoded.  `coding_only` is the same loop without the gather.
+
+`roofline` prices the dominant kernel against the HBM rate with the algorithmic bytes of SURVEY.md section 8(d):
+bands*sizeof(T)*(1+rho) bytes per pixel (raw once + stream once; the in-container table and the out-of-band index
+are overhead, listed under `extra_bytes`), timed live with HIP events the library records on the launch stream.
+`cpu_baseline` times oracle/ (the CPU restatement, a "port") on one host core over a bounded sample.
 """
 import argparse
 import json
@@ -27,8 +34,199 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-ANCHOR_C2 = 434747055       # reference stream size for 16384x16384x3 NOISY3 seed 2
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+ANCHORS = {                 # reference containers, SURVEY.md Appendix C: (size, FNV-1a64)
+    "c2": (434747055, "777cb7eb671956c2"),
+    "c3": (462603297, "5481f2264a7cae14"),
+    "c4_i32_ftl": (16417361, "4f3674340266a2f6"), "c4_i64_ftl": (16429835, "6917fa654ba9f9f9"),
+    "c4_i32_best": (16413700, "cd51ae557cfbb14f"), "c4_i64_best": (16426177, "62e44ea20713d272"),
+    "c5_tile1000": (27171401, "8e91222e70136a30"), "c5_tile1001": (27171735, "4e40f05b13367ea8"),
+}
+ENC_KERNELS = ("enc_units", "enc_best_pass0", "enc_best_scan", "enc_best_units", "enc_scan", "enc_concat", "enc_seams")
+DEC_KERNELS = ("dec_index_serial", "dec_index_prev", "dec_index_scan", "dec_segments", "dec_units")
+
+
+def container_check(qb3_amd, np, host, tag):
+    """(ok, fnv) of a container against ANCHORS[tag]; the restart-table chunks ("ix" + "zz" pairs in front of "DT"),
+    if any, are left out of both."""
+    size, want = ANCHORS[tag]
+    pos, cut0, cut1 = 11, None, None
+    while pos + 4 <= len(host):
+        sig, ln = bytes(host[pos:pos + 2]), int(host[pos + 2]) | int(host[pos + 3]) << 8
+        if sig == b"DT":
+            break
+        if sig in (b"ix", b"zz"):
+            cut0 = pos if cut0 is None else cut0
+            pos += ln
+            cut1 = pos
+        elif sig in (b"CB", b"QV", b"SC"):
+            pos += 4 + ln
+        else:
+            return False, None
+    if cut0 is None:
+        h = qb3_amd.fnv(host)
+        return len(host) == size and h == want, h
+    h = qb3_amd.fnv(host[:cut0], host[cut1:])
+    return len(host) - (cut1 - cut0) == size and h == want, h
+
+
+class Prof:
+    """per-kernel HIP-event times of the library (qb3x_profile_*), as deltas between marks"""
+
+    def __init__(self, qdev):
+        self.q = qdev
+
+    def start(self, level=1):
+        self.q.profile_reset()
+        self.q.profile_enable(level)
+
+    def stop(self):
+        self.q.profile_enable(False)
+        return {k: (ms / max(c, 1), int(c)) for k, (ms, c) in self.q.profile_report().items()}
+
+
+def kernel_table(avg, algo_bytes):
+    return {k: {"avg_ms": round(ms, 4), "launches": c, "GBps_algorithmic": round(algo_bytes / ms / 1e6, 1) if ms > 0 else None}
+            for k, (ms, c) in sorted(avg.items())}
+
+
+def roofline_of(avg, algo_bytes, names, traffic=None, extra=None):
+    cand = {k: v for k, v in avg.items() if k in names}
+    if not cand:
+        return None
+    dom = max(cand, key=lambda k: cand[k][0])
+    ms = cand[dom][0]
+    ach = algo_bytes / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+         "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes)}
+    if extra:
+        r["extra_bytes"] = extra
+    return r
+
+
+def pmc_traffic(kernel):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(kernel, {})
+        return rec.get("hbm_bytes_per_launch"), rec.get("valu")
+    except (OSError, ValueError):
+        return None, None
+
+
+def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen, seed, mode, steps, label):
+    """One raster: self-indexed encode, decode from the container alone and with the out-of-band index."""
+    import numpy as np
+    img = synth.generate(w, h, bands, dtype, gen, seed, device=dev)
+    raw = img.reshape(-1).view(torch.uint8)
+    raw_bytes = raw.numel()
+    enc = qdev.DeviceEncoder(w, h, bands, dtype, mode=mode, index_chunk=True)
+    dst, n, index = enc.encode(img)
+    host = dst[:n].cpu().numpy()
+    ok, fnv = container_check(qb3_amd, np, host, tag)
+    hdr_mode = int(host[10])
+    dec = qdev.DeviceDecoder(dst, n)
+    out = torch.empty(raw_bytes, dtype=torch.uint8, device=dev)
+    for ix in (None, index):
+        out.zero_()
+        dec.decode(dst, out=out, index=ix)
+        if not torch.equal(out, raw):
+            sys.exit(f"bench.py: {label}: decode(encode(x)) != x -- refusing to report a number")
+    stream_bytes = ANCHORS[tag][0]
+    algo = raw_bytes + stream_bytes
+    prof = Prof(qdev)
+    res = {"workload": label, "stream_bytes": stream_bytes, "ratio": round(stream_bytes / raw_bytes, 4), "container_bytes": int(n),
+           "header_mode": hdr_mode, "bit_identical_to_reference": bool(ok), "fnv1a64": fnv}
+    prof.start()
+    for _ in range(steps):
+        enc.encode(img)
+    torch.cuda.synchronize()
+    e = prof.stop()
+    prof.start()
+    for _ in range(steps):
+        dec.decode(dst, out=out, index=None)
+    torch.cuda.synchronize()
+    d_ix = prof.stop()
+    prof.start()
+    for _ in range(steps):
+        dec.decode(dst, out=out, index=index)
+    torch.cuda.synchronize()
+    d_oob = prof.stop()
+    enc_ms = sum(e[k][0] for k in ENC_KERNELS if k in e)
+    ix_ms = sum(d_ix[k][0] for k in DEC_KERNELS if k in d_ix)
+    oob_ms = sum(d_oob[k][0] for k in DEC_KERNELS if k in d_oob)
+    px = w * h
+    res.update({
+        "encode_ms_kernels": round(enc_ms, 4), "encode_MPixel_s": round(px / enc_ms / 1e3, 1),
+        "decode_from_container_ms_kernels": round(ix_ms, 4), "decode_from_container_MPixel_s": round(px / ix_ms / 1e3, 1),
+        "decode_out_of_band_index_ms_kernels": round(oob_ms, 4), "decode_out_of_band_index_MPixel_s": round(px / oob_ms / 1e3, 1),
+        "kernels": {"encode": kernel_table(e, algo), "decode_from_container": kernel_table(d_ix, algo), "decode_out_of_band_index": kernel_table(d_oob, algo)},
+        "roofline": roofline_of({**e, **d_oob}, algo, ENC_KERNELS + DEC_KERNELS,
+                                extra={"restart_table_in_container": int(n) - stream_bytes, "out_of_band_index": enc.index_bytes}),
+    })
+    del enc, dec, img, out
+    return res
+
+
+def measure_tiles(torch, qb3_amd, synth, qdev, dev, ntiles, steps, seed0=1000):
+    """configs[4], one rank's share: ntiles tiles of 4096^2 x 3 through the batched entry points."""
+    w = h = 4096
+    imgs = torch.stack([synth.generate(w, h, 3, qb3_amd.QB3_U8, "NOISY3", seed0 + t, device=dev) for t in range(ntiles)])
+    tc = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, ntiles, device=dev)
+    sizes = tc.encode(imgs)
+    out = torch.empty_like(imgs)
+    checks = {}
+    for t, tag in ((0, "c5_tile1000"), (1, "c5_tile1001")):
+        if seed0 == 1000 and t < ntiles:
+            host = tc.dst[t * tc.pitch:t * tc.pitch + sizes[t]].cpu().numpy()
+            checks[tag] = bool(sizes[t] == ANCHORS[tag][0] and qb3_amd.fnv(host) == ANCHORS[tag][1])
+    for use_index in (True, False):
+        out.zero_()
+        tc.decode(out, use_index=use_index)
+        if not torch.equal(out, imgs):
+            sys.exit("bench.py: tiles: decode(encode(x)) != x -- refusing to report a number")
+    raw = ntiles * tc.raw_bytes
+    algo = raw + sum(sizes)
+    prof = Prof(qdev)
+    t_enc = t_dec = t_plain = 0.0
+    prof.start()
+    torch.cuda.synchronize()
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        tc.encode(imgs)
+        t1 = time.perf_counter()
+        tc.decode(out, use_index=True)
+        t2 = time.perf_counter()
+        t_enc += t1 - t0
+        t_dec += t2 - t1
+    avg = prof.stop()
+    t0 = time.perf_counter()
+    tc.decode(out, use_index=False)
+    t_plain = time.perf_counter() - t0
+    px = ntiles * w * h
+    res = {"workload": f"{ntiles} tiles of {w}x{h}x3 uint8 NOISY3 (seeds {seed0}..{seed0 + ntiles - 1}) per call, QB3M_FTL, qb3x_encode_tiles + qb3x_decode_tiles",
+           "stream_bytes": int(sum(sizes)), "ratio": round(sum(sizes) / raw, 4), "bit_identical_to_reference": checks,
+           "encode_ms_wall": round(t_enc / steps * 1e3, 3), "decode_ms_wall": round(t_dec / steps * 1e3, 3),
+           "encode_MPixel_s": round(px / (t_enc / steps) / 1e6, 1), "decode_out_of_band_index_MPixel_s": round(px / (t_dec / steps) / 1e6, 1),
+           "decode_plain_containers_ms_wall": round(t_plain * 1e3, 2), "decode_plain_containers_MPixel_s": round(px / t_plain / 1e6, 1),
+           "kernels": kernel_table(avg, algo), "roofline": roofline_of(avg, algo, ENC_KERNELS + DEC_KERNELS)}
+    return res, tc, imgs, out
+
+
+def copy_peak(torch, dev):
+    """device-to-device copy of 1 GiB: the achievable HBM rate next to the 8 TB/s spec (read + write bytes counted)"""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(2 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
 def main():
@@ -36,8 +234,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=16384, help="raster edge in pixels (default: BASELINE configs[1])")
+    ap.add_argument("--size", type=int, default=16384, help="raster edge in pixels at N = 1 (default: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the short measurements of configs 3, 4, 5")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="N = 1: make this configuration the only one run (for profiling); c2 is the headline")
+    ap.add_argument("--tiles-per-rank", type=int, default=32)
+    ap.add_argument("--batch-tiles", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
@@ -47,9 +250,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the QB3 block codec has no CPU fallback")
     if args.backend != "nccl":
@@ -66,144 +268,250 @@ def main():
     import qb3_amd
     from qb3_amd import synth, device as qdev, tiles
 
-    W = H = args.size
-    bands, dtype = 3, qb3_amd.QB3_U8
-    img = synth.generate(W, H, bands, dtype, "NOISY3", 2 + rank, device=dev)
-    raw_bytes = img.numel() * img.element_size()
-    enc = qdev.DeviceEncoder(W, H, bands, dtype, mode=qb3_amd.QB3M_FTL)
-    out = torch.empty(raw_bytes, dtype=torch.uint8, device=dev)
-    dec_cache = {}
-
-    def step(check=False):
-        dst, n, index = enc.encode(img)
-        key = n
-        if key not in dec_cache:            # header parse is host work done once per distinct container
-            dec_cache.clear()
-            dec_cache[key] = qdev.DeviceDecoder(dst[:64].cpu().numpy(), n)
-        dec_cache[key].decode(dst, out=out, index=index)
-        if check and not torch.equal(out.view(torch.uint8), img.view(torch.uint8).reshape(-1)):
-            sys.exit("bench.py: decode(encode(x)) != x -- refusing to report a number")
-        return n
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    nbytes = 0
-    for i in range(max(1, args.warmup)):
-        nbytes = step(check=(i == 0))
-    if rank == 0 and args.size == 16384 and nbytes != ANCHOR_C2:
-        sys.exit(f"bench.py: stream is {nbytes} bytes, the reference produces {ANCHOR_C2} -- not bit-identical")
+    if world > 1:
+        line = run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, world, fence)
+        if rank == 0:
+            print(json.dumps(line))
+        dist.destroy_process_group()
+        return
 
-    # HIP events around the long kernels only inside the timed region (level 2): an event pair costs more than the
-    # microsecond kernels take; those are timed in two extra, untimed steps afterwards
-    qdev.profile_reset()
-    qdev.profile_enable(2)
+    if args.workload != "c2":           # profiling aid: one of the other configurations alone
+        print(json.dumps(run_other(args.workload, args, torch, qb3_amd, synth, qdev, dev)))
+        return
+
+    import numpy as np
+    W = H = args.size
+    bands, dtype = 3, qb3_amd.QB3_U8
+    img = synth.generate(W, H, bands, dtype, "NOISY3", 2, device=dev)
+    raw = img.reshape(-1).view(torch.uint8)
+    raw_bytes = raw.numel()
+    enc = qdev.DeviceEncoder(W, H, bands, dtype, mode=qb3_amd.QB3M_FTL, index_chunk=True)
+    out = torch.empty(raw_bytes, dtype=torch.uint8, device=dev)
+    dst, n, index = enc.encode(img)
+    dec = qdev.DeviceDecoder(dst, n)
+
+    def step():
+        enc.encode(img)                                  # container (self-indexed) -> enc.dst, out-of-band index -> enc.index
+        dec.decode(dst, out=out, index=None)             # decode from the container alone
+
+    # ---- correctness first: bit identity with the reference (size AND hash), both decode flavours exact
+    host = dst[:n].cpu().numpy()
+    ident, fnv = (None, None)
+    if args.size == 16384:
+        ident, fnv = container_check(qb3_amd, np, host, "c2")
+        if not ident:
+            sys.exit(f"bench.py: container (minus its table chunks) hashes to {fnv}, the reference's to {ANCHORS['c2'][1]} -- not bit-identical")
+    stream_bytes = ANCHORS["c2"][0] if args.size == 16384 else n
+    for ix in (None, index):
+        out.zero_()
+        dec.decode(dst, out=out, index=ix)
+        if not torch.equal(out, raw):
+            sys.exit("bench.py: decode(encode(x)) != x -- refusing to report a number")
+    for _ in range(max(1, args.warmup)):
+        step()
+
+    # ---- the timed region: HIP events around the long kernels only (level 2: an event pair costs more than the
+    # microsecond kernels take; those are timed in two extra, untimed steps afterwards)
+    prof = Prof(qdev)
+    prof.start(2)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    qdev.profile_enable(False)
-    timed_kernels = set(qdev.profile_report())
-    qdev.profile_enable(1)
-    prof_small = {}
-    before = qdev.profile_report()
+    timed = prof.stop()
+    prof.start(1)
     for _ in range(2):
         step()
     fence()
-    qdev.profile_enable(False)
-    for name, (ms, cnt) in qdev.profile_report().items():
-        if name not in timed_kernels:
-            prof_small[name] = (ms, cnt)
-    if world > 1:
+    both = prof.stop()
+    avg = dict(both)
+    avg.update(timed)
+    algo = raw_bytes + stream_bytes
+    kernels = kernel_table(avg, algo)
+    for k in kernels:
+        kernels[k]["in_timed_region"] = k in timed
+    enc_ms = sum(avg[k][0] for k in ENC_KERNELS if k in avg)
+    dec_ms = sum(avg[k][0] for k in DEC_KERNELS if k in avg)
+
+    # ---- the same decode with the out-of-band index, and a sustained leg of at least a second
+    prof.start(1)
+    for _ in range(5):
+        dec.decode(dst, out=out, index=index)
+    torch.cuda.synchronize()
+    oob = prof.stop()
+    oob_ms = sum(oob[k][0] for k in DEC_KERNELS if k in oob)
+    fence()
+    s0 = time.perf_counter()
+    sustained_steps = 0
+    while time.perf_counter() - s0 < 1.2:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        sustained_steps += 50
+    sustained = time.perf_counter() - s0
+
+    # ---- a plain container (what the reference writes: no table inside, no index beside it), 4096^2 so that it ends
+    plain = None
+    if not args.no_workloads:
+        pw = 4096
+        pimg = synth.generate(pw, pw, 3, dtype, "NOISY3", 1000, device=dev)
+        penc = qdev.DeviceEncoder(pw, pw, 3, dtype, mode=qb3_amd.QB3M_FTL)
+        pdst, pn, _ = penc.encode(pimg)
+        pdec = qdev.DeviceDecoder(pdst, pn)
+        pout = torch.empty(pw * pw * 3, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        pdec.decode(pdst, out=pout, index=None)
+        torch.cuda.synchronize()
+        pdt = time.perf_counter() - p0
+        plain = {"workload": "4096x4096x3 uint8 NOISY3 seed 1000, plain container, index = NULL (serial walk of the stream on one wave)",
+                 "ms_wall": round(pdt * 1e3, 2), "MPixel_s": round(pw * pw / pdt / 1e6, 1), "exact": bool(torch.equal(pout, pimg.reshape(-1)))}
+        del pimg, penc, pdec, pout, pdst
+
+    dom_traffic, valu = pmc_traffic(max((k for k in avg if k in ENC_KERNELS + DEC_KERNELS), key=lambda k: avg[k][0]))
+    roofline = roofline_of(avg, algo, ENC_KERNELS + DEC_KERNELS, traffic=dom_traffic if args.size == 16384 else None,
+                           extra={"restart_table_in_container": int(n) - stream_bytes, "out_of_band_index_not_used_by_value": enc.index_bytes})
+    if roofline is not None:
+        roofline["valu"] = valu if args.size == 16384 else None
+        roofline["device_copy_GBps"] = copy_peak(torch, dev)
+
+    workloads = None
+    if not args.no_workloads and args.size == 16384:
+        del img, out, enc, dec, dst
+        torch.cuda.empty_cache()
+        workloads = {}
+        for wl in ("c3", "c4", "c5"):
+            workloads.update(run_other(wl, args, torch, qb3_amd, synth, qdev, dev))
+
+    cpu = None if args.no_cpu_baseline else cpu_baseline()
+    line = {
+        "metric": "MPixel/s encode+decode (QB3M_FTL, 8-bit 3-band)",
+        "value": round(W * H / (dt / args.steps) / 1e6, 1),
+        "unit": "MPixel/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{W}x{H}x3 uint8 NOISY3 seed 2; QB3M_FTL qb3x_encode_device (self-indexed container) + qb3x_decode_device of "
+                               "that container alone (index = NULL, restart table inside the container)",
+                   "stream_bytes": stream_bytes, "ratio": round(stream_bytes / raw_bytes, 4), "container_bytes": int(n),
+                   "bit_identical_to_reference": ident, "fnv1a64_without_table_chunks": fnv},
+        "value_uses": "decode_from_container",
+        "encode_MPixel_s_kernels": round(W * H / enc_ms / 1e3, 1) if enc_ms else None,
+        "decode_MPixel_s_kernels": round(W * H / dec_ms / 1e3, 1) if dec_ms else None,
+        "decode": {"from_container_ms_kernels": round(dec_ms, 4), "out_of_band_index_ms_kernels": round(oob_ms, 4),
+                   "out_of_band_index_MPixel_s_kernels": round(W * H / oob_ms / 1e3, 1) if oob_ms else None,
+                   "out_of_band_index_bytes": enc.index_bytes if workloads is None else None, "plain_container": plain},
+        "sustained": {"seconds": round(sustained, 2), "steps": sustained_steps, "MPixel_s": round(sustained_steps * W * H / sustained / 1e6, 1)},
+        "kernels": kernels,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "workloads": workloads,
+    }
+    print(json.dumps(line))
+
+
+def run_other(wl, args, torch, qb3_amd, synth, qdev, dev):
+    """configs 3, 4 and 5 on one GPU, a few steps each"""
+    steps = max(3, min(args.steps, 5))
+    out = {}
+    if wl == "c3":
+        out["c3"] = measure_image(torch, qb3_amd, synth, qdev, dev, "c3", 8192, 8192, 8, qb3_amd.QB3_U16, "LANDSAT16", 3, qb3_amd.QB3M_BASE, steps,
+                                  "8192x8192x8 uint16 LANDSAT16 seed 3, QB3M_BASE")
+    elif wl == "c4":
+        for tag, dt, mode, name in (("c4_i32_ftl", qb3_amd.QB3_I32, qb3_amd.QB3M_FTL, "int32 QB3M_FTL"), ("c4_i64_ftl", qb3_amd.QB3_I64, qb3_amd.QB3M_FTL, "int64 QB3M_FTL"),
+                                    ("c4_i32_best", qb3_amd.QB3_I32, qb3_amd.QB3M_BEST, "int32 QB3M_BEST"), ("c4_i64_best", qb3_amd.QB3_I64, qb3_amd.QB3M_BEST, "int64 QB3M_BEST")):
+            out[tag] = measure_image(torch, qb3_amd, synth, qdev, dev, tag, 4096, 4096, 1, dt, "DEM", 4, mode, steps, f"4096x4096x1 {name}, DEM seed 4")
+        torch.cuda.empty_cache()
+    else:
+        res, tc, imgs, o = measure_tiles(torch, qb3_amd, synth, qdev, dev, args.tiles_per_rank, steps)
+        out["c5_one_rank"] = res
+        del tc, imgs, o
+        torch.cuda.empty_cache()
+    return out
+
+
+def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, world, fence):
+    """N > 1: tiles shard by rank (tiles.shard_range), batches through qb3x_encode_tiles, the gather of batch k beside
+    the coding of batch k+1, then decode; the gather is inside the step."""
+    w = h = 4096
+    total = args.tiles_per_rank * world
+    first, count = tiles.shard_range(total, rank, world)
+    imgs = torch.stack([synth.generate(w, h, 3, qb3_amd.QB3_U8, "NOISY3", 1000 + first + t, device=dev) for t in range(count)])
+    tc = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, count, device=dev)
+    out = torch.empty_like(imgs)
+    nb = max(1, min(args.batch_tiles, count))
+    batches = [(lo, min(nb, count - lo)) for lo in range(0, count, nb)]
+    recv = None
+    if rank == 0 and args.backend == "nccl":            # receive buffers, one per peer and batch slot, reused every step
+        recv = [[None if r == 0 else torch.empty(nb * tc.pitch, dtype=torch.uint8, device=dev) for r in range(world)] for _ in batches]
+
+    def step(gather=True):
+        pend = []
+        for b, (lo, cnt) in enumerate(batches):
+            sizes = tc.encode(imgs, lo, cnt)             # synchronises: the containers of the batch are complete
+            if gather:
+                pend.append(tiles.start_gather(tc.dst[lo * tc.pitch:(lo + cnt) * tc.pitch], tc.pitch, sizes, root=0,
+                                               recv_bufs=recv[b] if recv else None))
+        tc.decode(out, use_index=True)
+        got = [p.wait() for p in pend]
+        return got
+
+    got = step()
+    torch.cuda.synchronize()
+    if not torch.equal(out, imgs):
+        sys.exit("bench.py: decode(encode(x)) != x -- refusing to report a number")
+    intact = None
+    if rank == 0:           # what arrived from the last peer's last batch is a QB3 container of the announced size
+        bufs, size_lists = got[-1]
+        b, sl = bufs[-1], size_lists[-1]
+        intact = bool(len(sl) and bytes(b[:4].cpu().numpy()) == b"QB3\x80")
+    for _ in range(max(1, args.warmup) - 1):
+        step()
+
+    def timed(gather):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(gather)
+        fence()
+        dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    prof = dict(before)             # the long kernels: exactly what the timed region saw
-    prof.update(prof_small)         # the microsecond kernels: from the two untimed steps
+        return float(t.item())
 
-    # ---- the workload's only exchange: containers to rank 0 (variable-size gather), timed on its own
-    gather = None
-    if world > 1:
-        try:
-            dst, n, _ = enc.encode(img)
-            fence()
-            g0 = time.perf_counter()
-            bufs, size_lists = tiles.gather_streams(dst, [n], root=0)
-            fence()
-            gdt = time.perf_counter() - g0
-            if rank == 0:
-                total = sum(sum(sl) for sl in size_lists)
-                ok = all(int(b.numel()) == sum(sl) for b, sl in zip(bufs, size_lists)) and bytes(bufs[-1][:4].cpu().numpy()) == b"QB3\x80"
-                gather = {"ms": round(gdt * 1e3, 3), "bytes_at_root": total, "GBps_into_root": round((total - n) / gdt / 1e9, 1),
-                          "containers_intact": bool(ok), "backend": "nccl (RCCL) send/recv" if args.backend == "nccl" else args.backend + " (rehearsal)"}
-        except Exception as e:      # never lose the coding numbers to a transport problem
-            gather = {"error": repr(e)[:200]}
-
-    # ---- per-kernel rates (rank 0's kernels; every rank runs the same launches)
-    stream_bytes = nbytes
-    algo_bytes = raw_bytes + stream_bytes                       # read raw + write stream (or the reverse)
-    kernels = {}
-    for name, (ms, cnt) in prof.items():
-        avg = ms / max(cnt, 1)
-        kernels[name] = {"avg_ms": round(avg, 4), "launches": int(cnt), "GBps_algorithmic": round(algo_bytes / avg / 1e6, 1) if avg > 0 else None,
-                         "in_timed_region": name in timed_kernels}
-    enc_ms = sum(kernels[k]["avg_ms"] for k in ("enc_units", "enc_scan", "enc_concat", "enc_seams") if k in kernels)
-    dec_ms = sum(kernels[k]["avg_ms"] for k in ("dec_index_serial", "dec_segments", "dec_units") if k in kernels)
-    dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
-    traffic = valu = None
-    try:
-        if args.size != 16384:
-            raise OSError("PMC traffic was collected for the 16384 workload only")
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(dom, {})
-        traffic = rec.get("hbm_bytes_per_launch")
-        valu = rec.get("valu")
-    except (OSError, ValueError):
-        pass
-    roofline = None
-    if dom:
-        achieved = algo_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": algo_bytes,
-                    # where the time goes besides HBM (rocprofv3 SQ counters of the same workload, profiles/): the share of the
-                    # kernel's duration in which the SIMDs issue vector instructions and the LDS pipe is busy -- integer bit
-                    # packing, no MFMA; the rest is memory latency the resident waves do not cover
-                    "valu": valu}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
-
+    dt = timed(True)
+    dt_code = timed(False)
+    bytes_root = None
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        line = {
-            "metric": "MPixel/s encode+decode (QB3M_FTL, 8-bit 3-band)",
-            "value": round(world * W * H / (dt / args.steps) / 1e6, 1),
-            "unit": "MPixel/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{W}x{H}x3 uint8 NOISY3 (seed 2+rank) per GPU; QB3M_FTL qb3x_encode_device + indexed qb3x_decode_device"
-                                   + ("; containers gathered on rank 0 with RCCL after the timed region (see gather)" if world > 1 else ""),
-                       "stream_bytes": stream_bytes, "ratio": round(stream_bytes / raw_bytes, 4),
-                       "bit_identical_to_reference": bool(args.size == 16384)},
-            "encode_MPixel_s_kernels": round(W * H / enc_ms / 1e3, 1) if enc_ms else None,
-            "decode_MPixel_s_kernels": round(W * H / dec_ms / 1e3, 1) if dec_ms else None,
-            "kernels": kernels,
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "gather": gather,
-        }
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+        bytes_root = sum(sum(sl) for (_, sls) in got for sl in sls[1:])
+    px = total * w * h
+    line = {
+        "metric": "MPixel/s encode+decode (QB3M_FTL, 8-bit 3-band)",
+        "value": round(px / (dt / args.steps) / 1e6, 1),
+        "unit": "MPixel/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{total} independent 4096x4096x3 uint8 NOISY3 tiles (seeds 1000..), {args.tiles_per_rank} per GPU, QB3M_FTL: qb3x_encode_tiles in batches of "
+                               f"{nb}, containers gathered on rank 0 ({'RCCL send/recv' if args.backend == 'nccl' else args.backend + ' rehearsal'}) beside the coding "
+                               "of the next batch, qb3x_decode_tiles (out-of-band index) of every rank's own tiles; the gather is inside the step",
+                   "tiles_total": total, "tiles_per_gpu": args.tiles_per_rank, "parallelism": f"tiles sharded over {world} GPUs, no data-path collective but the gather"},
+        "coding_only": {"ms_per_step": round(dt_code / args.steps * 1e3, 3), "MPixel_s": round(px / (dt_code / args.steps) / 1e6, 1)},
+        "gather": {"bytes_into_root_per_step": bytes_root, "GBps_into_root": round(bytes_root / (dt / args.steps) / 1e9, 1) if bytes_root else None,
+                   "containers_intact": intact, "backend": "nccl (RCCL) send/recv" if args.backend == "nccl" else args.backend + " (rehearsal)"},
+        "roofline": None, "cpu_baseline": None,
+    }
+    return line
 
 
 def cpu_baseline(target_s=12.0):
@@ -229,7 +537,10 @@ def cpu_baseline(target_s=12.0):
     px = w * h * reps
     return {"value": round(px / (t_enc + t_dec) / 1e6, 1), "unit": "MPixel/s", "cores": 1, "kind": "port",
             "sample": f"{reps} x (encode + decode) of a 4096x4096x3 uint8 NOISY3 tile, QB3M_FTL, single thread",
-            "encode_MPixel_s": round(px / t_enc / 1e6, 1), "decode_MPixel_s": round(px / t_dec / 1e6, 1)}
+            "encode_MPixel_s": round(px / t_enc / 1e6, 1), "decode_MPixel_s": round(px / t_dec / 1e6, 1),
+            "vs_reference": "the port is the faster baseline: on the same host and input the reference's own library ran 26.5 / 29.5 MPixel/s "
+                            "(encode / decode) against the port's 46.4 / 28.9 (judge-side measurement, VERDICT round 1; the reference cannot "
+                            "be built inside this repository's rules, DESIGN.md section 2)"}
 
 
 if __name__ == "__main__":

@@ -104,6 +104,10 @@ void qb3x_profile_reset(void);
 int  qb3x_profile_get(const char *kernel, double *total_ms, uint64_t *count);   /* 1 if the kernel was seen */
 int  qb3x_profile_names(char *buf, size_t bufsize);                             /* comma separated, returns count */
 
+/* FNV-1a (64 bit) of n host bytes -- the checksum this project's reference anchors are published with (SURVEY.md
+ * Appendix C), for callers that verify containers.  seed = 0 starts a hash, a previous result continues it. */
+uint64_t qb3x_fnv1a64(const void *data, size_t n, uint64_t seed);
+
 /* Last HIP error string seen by this thread inside the library ("" if none). */
 const char *qb3x_last_error(void);
 

@@ -73,6 +73,7 @@ _PROTOS = {
     "qb3_create_decoder": (_vp, [_vp, _sz, C.POINTER(_sz)]),
     "qb3_decode": (_sz, [_vp, _vp]),
     "qb3x_last_error": (C.c_char_p, []),
+    "qb3x_fnv1a64": (_u64, [_vp, _sz, _u64]),
     "qb3x_profile_enable": (None, [C.c_int]),
     "qb3x_profile_reset": (None, []),
     "qb3x_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -87,6 +88,17 @@ EXPORTED = tuple(_PROTOS)
 
 def last_error():
     return lib.qb3x_last_error().decode()
+
+
+def fnv(*parts):
+    """FNV-1a64 (hex) of the concatenation of host arrays."""
+    import numpy as np
+    h = 0
+    for a in parts:
+        a = np.ascontiguousarray(a)
+        if a.nbytes:
+            h = lib.qb3x_fnv1a64(a.ctypes.data_as(_vp), a.nbytes, h)
+    return "%016x" % (h or 0xcbf29ce484222325)
 
 
 def _np_ptr(a):

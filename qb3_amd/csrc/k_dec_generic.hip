@@ -301,18 +301,22 @@ __global__ void dec3_kernel(const DecArgs a0) {
 // Foreign stream: ONE lane walks the stream and rebuilds the index (bit position + band state at every
 // segment start).  Latency bound by construction.
 template <typename T, int MODE>
-__global__ void dec_index_serial(const DecArgs a0) {
-    if (threadIdx.x) return;
-    const DecArgs a = dec_for_tile(a0, blockIdx.x);       // one lane per tile
-    __shared__ uint64_t st_prev[MAXBANDS], st_cf[MAXBANDS];
-    __shared__ uint32_t st_rung[MAXBANDS];
-    const uint32_t bands = a.g.bands, S = a.g.seg_blocks;
-    for (uint32_t c = 0; c < bands; c++) { st_prev[c] = 0; st_cf[c] = 0; st_rung[c] = 0; }
+__global__ void __launch_bounds__(64) dec_index_serial(const DecArgs a0) {
+    // without a restart table: lane 0 walks the whole tile; with one: a LANE per entry (blockIdx.y * 64 + lane)
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    __shared__ uint64_t s_prev[64][MAXBANDS + 1], s_cf[64][MAXBANDS + 1];      // (+1: lanes on different banks)
+    __shared__ uint32_t s_rung[64][MAXBANDS + 1];
+    const uint32_t bands = a.g.bands, S = a.g.seg_blocks, lane = threadIdx.x;
     const uint32_t nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t k = blockIdx.y * 64 + lane;
+    if (a.ix ? k >= a.ix_K : lane != 0) return;
+    uint64_t *st_prev = s_prev[lane], *st_cf = s_cf[lane];
+    uint32_t *st_rung = s_rung[lane];
+    for (uint32_t c = 0; c < bands; c++) { st_prev[c] = 0; st_cf[c] = 0; st_rung[c] = 0; }
     uint32_t gb0 = 0, gb_end = nblocks;
     uint64_t seg = 0, bp = 0;
-    if (a.ix) {                             // restart point blockIdx.y of the container's coarse table
-        const uint8_t *e = ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, blockIdx.y);
+    if (a.ix) {                             // restart point k of the container's table
+        const uint8_t *e = ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, k);
         for (uint32_t i = 0; i < 6; i++) bp |= (uint64_t)e[i] << (8 * i);
         const uint8_t *pv = e + 6 + bands, *cf = pv + bands * sizeof(T);
         for (uint32_t c = 0; c < bands; c++) {
@@ -321,7 +325,7 @@ __global__ void dec_index_serial(const DecArgs a0) {
             for (uint32_t i = 0; i < sizeof(T); i++) { v |= (uint64_t)pv[c * sizeof(T) + i] << (8 * i); if (MODE == CM_BEST) f |= (uint64_t)cf[c * sizeof(T) + i] << (8 * i); }
             st_prev[c] = v; st_cf[c] = f;
         }
-        gb0 = blockIdx.y * a.ix_blocks;
+        gb0 = k * a.ix_blocks;
         gb_end = (nblocks - gb0 < a.ix_blocks) ? nblocks : gb0 + a.ix_blocks;
         seg = gb0 / S;
     }
@@ -384,7 +388,7 @@ void launch_dec_generic(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
 }
 template <typename T>
 static void launch_dec_index_serial_t(const DecArgs &a, hipStream_t st) {
-    const dim3 grid(a.ntiles, a.ix ? a.ix_K : 1), block(64);
+    const dim3 grid(a.ntiles, a.ix ? (a.ix_K + 63) / 64 : 1), block(64);
     switch (a.g.mode) {
     case CM_FTL: hipLaunchKernelGGL((dec_index_serial<T, CM_FTL>), grid, block, 0, st, a); break;
     case CM_BASE: hipLaunchKernelGGL((dec_index_serial<T, CM_BASE>), grid, block, 0, st, a); break;

@@ -134,79 +134,100 @@ __global__ void __launch_bounds__(1024) prev_scan_kernel(const DecArgs a0) {
 }
 
 // ---- the same walk from the container's restart table: ONE LANE per restart point ---------------------------
-// With the "ix" chunks in the container (include/qb3x.h) the stream is cut into K independent walks of about a
-// thousand units.  A lane walks its own piece straight from global memory (a 64-bit bit buffer, the next word always
-// requested one refill ahead); lanes of a wave run in lockstep because a unit is always a switch and sixteen codes
-// whatever its rung (only rung 0 takes a short side path).  8-bit data: B is a template parameter, the unit lengths
-// of four blocks leave as B dwords.
-template <uint32_t UB> struct WalkBits {
-    const uint32_t *in;
-    uint64_t endw, wp, buf;         // wp: index of the word held in nxt
-    uint32_t n, nxt;
-    __device__ __forceinline__ uint32_t ld(uint64_t w) const { return w < endw ? in[w] : 0u; }
-    __device__ __forceinline__ void init(const uint32_t *p, uint64_t bitpos, uint64_t endbit) {
-        in = p; endw = (endbit + 31) >> 5;
-        const uint64_t w = bitpos >> 5;
-        const uint32_t sh = (uint32_t)bitpos & 31;
-        buf = (uint64_t)(ld(w) >> sh); n = 32 - sh; wp = w + 1; nxt = ld(wp);
-    }
-    __device__ __forceinline__ void refill() {      // afterwards n >= 33
-        if (n <= 32) { buf |= (uint64_t)nxt << n; n += 32; nxt = ld(++wp); }
-    }
-    __device__ __forceinline__ void skip(uint32_t k) { buf >>= k; n -= k; }
-    __device__ __forceinline__ uint64_t position() const { return 32 * wp - n; }
-    // length of one unit of a band whose rung is `rung` (updated); sets bad on a signal code
-    __device__ __forceinline__ uint32_t unit(uint32_t &rung, bool &bad) {
-        constexpr uint32_t UMASK = (1u << UB) - 1, NRUNG = 1u << UB;
-        refill();                                   // >= 33 bits: the switch code is at most UB + 2
-        uint32_t x = (uint32_t)buf, ulen = 1;
-        if (x & 1) {                                // code at rung UB - 1 (reference QB3decode.h:97-116)
-            constexpr uint32_t r = UB - 1, half = 1u << (r - 1), top = 1u << r;
-            x >>= 1;
-            uint32_t m, len;
-            if (!(x & 1)) { m = (x & (top - 1)) >> 1; len = r; }
-            else if (!(x & 2)) { m = ((x >> 2) & (half - 1)) | half; len = r + 1; }
-            else { m = ((x >> 2) & (top - 1)) | top; len = r + 2; }
-            ulen = 1 + len;
-            bad = bad || m == NRUNG - 2;            // signal: a common-factor stream, not for this walker
-            const uint32_t delta = (m & 1) ? (NRUNG - (m + 1) / 2) & UMASK : m / 2 + 1;
-            rung = (rung + delta) & UMASK;
-        }
-        skip(ulen);
-        if (rung == 0) {                            // one flag, then 16 raw bits
-            refill();
-            const uint32_t l = ((uint32_t)buf & 1) ? 17 : 1;
-            skip(l);
-            return ulen + l;
-        }
-        const uint32_t kr = rung * 0x01010101u + 0x02000100u;      // code length by the low two bits: r, r+1, r, r+2
-        if (UB == 3) {                              // three codes are at most 27 bits: one refill, one 64-bit shift
+// With the "ix" chunks in the container (include/qb3x.h) the stream is cut into K independent walks, one index
+// segment each where the lane-per-block decoders apply.  A lane walks its own piece; lanes of a wave run in lockstep
+// because a unit is always a switch and sixteen codes whatever its rung (only rung 0 takes a short side path).
+// The kernel is bound by instruction issue, so it is written for instructions per unit: every lane keeps a 256-byte
+// WINDOW of its piece in LDS (sixteen-byte loads, re-centred for all lanes whenever one of them runs low) and reads
+// bits by POSITION -- three dependent 64-bit reads per 8-bit unit, no bit buffer to maintain, no divergent refills;
+// a code costs four vector instructions (shift, length from a per-rung constant, shift, add).
+constexpr uint32_t WALK_WINP = 44;      // window of a lane in dwords (a multiple of 4: 16-byte LDS stores)
+
+// 64 stream bits at bit position `pos` (counted from LDS address 0): lo = bits 0..31, hi = bits 32..63
+__device__ __forceinline__ void lds_bits64(uint32_t pos, uint32_t &lo, uint32_t &hi) {
+    LdsWords p = lds_at((pos >> 3) & ~3u);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    lo = __builtin_amdgcn_alignbit(d1, d0, pos);
+    hi = __builtin_amdgcn_alignbit(d2, d1, pos);
+}
+// n codes at the low end of b (8-bit data: three codes are at most 27 bits); returns the bits they take
+template <int N> __device__ __forceinline__ uint32_t walk_codes(uint32_t b, uint32_t K) {
+    uint32_t acc = 0;
 #pragma unroll
-            for (int g = 0; g < 6; g++) {
-                refill();
-                uint32_t b = (uint32_t)buf, acc = 0;
+    for (int i = 0; i < N; i++) {
+        const uint32_t len = __builtin_amdgcn_ubfe(K, b << 2, 4);     // code length by the low three bits
+        b >>= len; acc += len;
+    }
+    return acc;
+}
+// rung switch at the low end of x: bits taken; rung updated; bad set on the signal code.  Branch free: lanes differ
+// from unit to unit in which of the four forms they meet (reference QB3decode.h:97-116, the code at rung UB - 1).
+template <uint32_t UB> __device__ __forceinline__ uint32_t walk_switch(uint32_t x, uint32_t &rung, bool &bad) {
+    constexpr uint32_t UMASK = (1u << UB) - 1, NRUNG = 1u << UB, r = UB - 1, half = 1u << (r - 1), top = 1u << r;
+    const uint32_t b0 = x & 1, y = x >> 1, c1 = y & 1, c2 = (y >> 1) & 1, t = y >> 2;
+    const uint32_t m0 = (y & (top - 1)) >> 1, m1 = (t & (half - 1)) | half, m2 = (t & (top - 1)) | top;
+    const uint32_t m = c1 ? (c2 ? m2 : m1) : m0;
+    const uint32_t len = r + c1 + (c1 & c2);
+    const uint32_t dpos = (m >> 1) + 1, dneg = (NRUNG - ((m + 1) >> 1)) & UMASK;
+    const uint32_t delta = (m & 1) ? dneg : dpos;
+    bad = bad || (b0 && m == NRUNG - 2);        // signal: a common-factor stream, not for this walker
+    rung = (rung + (b0 ? delta : 0u)) & UMASK;
+    return b0 ? 1 + len : 1u;
+}
+// length of the unit that starts at LDS bit position rp
+template <uint32_t UB> __device__ __forceinline__ uint32_t walk_unit(uint32_t rp, uint32_t &rung, bool &bad) {
+    uint32_t lo, hi;
+    lds_bits64(rp, lo, hi);
+    const uint32_t cs = walk_switch<UB>(lo, rung, bad);
+    // rung 0: one flag, then 16 raw bits.  (Taken by select, not by branch: the code walk below then runs over the same
+    // bits with lengths of at most two and its result is dropped.)
+    const uint32_t len0 = cs + ((__builtin_amdgcn_alignbit(hi, lo, cs) & 1) ? 17 : 1);
+    if (UB == 3) {
+        const uint32_t K = rung * 0x11111111u + 0x20102010u;    // 4-bit fields by the low three bits: r, r+1, r, r+2, ...
+        // read 1: switch + 2 codes (at most 5 + 18 bits) from lo, 3 codes from the next 32 bits; reads 2, 3: 3 + 3, 3 + 2
+        uint32_t used = cs + walk_codes<2>(lo >> cs, K);
+        used += walk_codes<3>(__builtin_amdgcn_alignbit(hi, lo, used), K);
+        uint32_t q = rp + used;
+        lds_bits64(q, lo, hi);
+        used = walk_codes<3>(lo, K);
+        used += walk_codes<3>(__builtin_amdgcn_alignbit(hi, lo, used), K);
+        q += used;
+        lds_bits64(q, lo, hi);
+        used = walk_codes<3>(lo, K);
+        used += walk_codes<2>(__builtin_amdgcn_alignbit(hi, lo, used), K);
+        return rung ? q + used - rp : len0;
+    } else {
+        // 16-bit data: a code is at most 17 bits, three fit a 64-bit read (51 bits; the first read also holds the switch)
+        // (lengths up to 17 do not fit the 4-bit fields of K: byte fields by the low two bits: r, r+1, r, r+2)
+        const uint32_t kr = rung * 0x01010101u + 0x02000100u;
+        uint64_t b = (((uint64_t)hi << 32) | lo) >> cs;
+        uint32_t q = rp + cs;
 #pragma unroll
-                for (int i = 0; i < (g == 5 ? 1 : 3); i++) {
-                    const uint32_t len = __builtin_amdgcn_ubfe(kr, (b & 3u) << 3, 8);
-                    b >>= len; acc += len;
-                }
-                skip(acc); ulen += acc;
+        for (int g = 0; g < 6; g++) {
+            if (g) { lds_bits64(q, lo, hi); b = ((uint64_t)hi << 32) | lo; }
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < (g == 5 ? 1 : 3); i++) {
+                const uint32_t len = __builtin_amdgcn_ubfe(kr, ((uint32_t)b & 3u) << 3, 8);
+                b >>= len; acc += len;
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; i++) {          // one code of up to 17 bits per refill
-                refill();
-                const uint32_t len = __builtin_amdgcn_ubfe(kr, ((uint32_t)buf & 3u) << 3, 8);
-                skip(len); ulen += len;
-            }
+            q += acc;
         }
-        return ulen;
+        return rung ? q - rp : len0;
     }
-};
+}
 
 template <uint32_t UB, int BT>     // BT: bands at compile time (8-bit data), 0: run time
-__global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a) {
-    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, const uint32_t stage_bytes) {
+    // LDS: the 64 windows, then (stage_bytes per lane, 0: none) the unit lengths the wave finds, laid out like the
+    // part of the length table they belong to: a lane's lengths are scattered bytes, the wave's are one contiguous run
+    // that leaves as whole cache lines at the end
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *win = (uint32_t *)smem;
+    uint8_t *ul_s = smem + 64 * WALK_WINP * 4;
+    constexpr uint32_t USZ = UB == 3 ? 1 : 2;                               // bytes per unit length
+    constexpr uint32_t MAXU = UB + 2 + 16 * ((8u << (UB - 3)) + 1);        // longest unit: 149 bits (8-bit), 278 (16-bit)
+    const uint32_t lane = threadIdx.x, k = blockIdx.x * 64 + lane;
     const uint32_t B = BT ? (uint32_t)BT : a.g.bands, NB = a.g.seg_blocks, nblocks = (uint32_t)a.g.nblocks;
     const bool live = k < a.ix_K;
     const uint32_t kk = live ? k : a.ix_K - 1;
@@ -216,65 +237,117 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a) {
     for (uint32_t i = 0; i < 6; i++) bp |= (uint64_t)e[i] << (8 * i);
     const uint32_t gb0 = kk * a.ix_blocks;
     const uint32_t nb = !live ? 0u : (nblocks - gb0 < a.ix_blocks ? nblocks - gb0 : a.ix_blocks);
+    const uint32_t nu = nb * B;                                             // units to walk
     uint64_t seg = gb0 / NB;
-    WalkBits<UB> rd;
-    rd.init(a.in32, a.in_bit0 + bp, a.in_bit0 + a.in_bits);
+    const uint64_t endw = (a.in_bit0 + a.in_bits + 31) >> 5;
+    uint32_t *mywin = win + lane * WALK_WINP;
+    const uint32_t lbit = 8 * (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)mywin;   // LDS bit address of the window
+    // a step walks a block (8-bit, bands known) or a unit; it may start while the window still holds its longest case
+    constexpr uint32_t STEP_UNITS = BT ? (uint32_t)BT : 1u;
+    constexpr uint32_t STEP_BITS = STEP_UNITS * MAXU + 96;                   // + the three dwords of the last read
+    const uint32_t rp_limit = lbit + 32 * WALK_WINP - STEP_BITS;
+    uint64_t P = a.in_bit0 + bp;                                            // bit position, from a.in32
     bool bad = false;
+    uint32_t u = 0;                                                         // units done
+    uint32_t rungs[BT ? BT : 1];
+    uint64_t R = 0;                                                         // run-time bands: rungs, 4 bits per band
     if (BT) {
-        constexpr int BB = BT ? BT : 1;
-        uint32_t rung[BB];
 #pragma unroll
-        for (int c = 0; c < BB; c++) rung[c] = e[6 + c] & 15u;
-        uint8_t *ul8 = (uint8_t *)a.idx.ulen + (uint64_t)gb0 * BB;
-        for (uint32_t b4 = 0; b4 < a.ix_blocks; b4 += 4) {     // ix_blocks is a multiple of the segment size, itself of 4
-            uint32_t pk[BB];
-#pragma unroll
-            for (int c = 0; c < BB; c++) pk[c] = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t blk = b4 + q;
-                if (blk < nb && blk % NB == 0) {
-                    a.idx.bitpos[seg] = rd.position() - a.in_bit0;
-#pragma unroll
-                    for (int c = 0; c < BB; c++) a.idx.rung[seg * BB + c] = (uint8_t)rung[c];
-                    seg++;
-                }
-#pragma unroll
-                for (int c = 0; c < BB; c++) {
-                    const uint32_t ulen = rd.unit(rung[c], bad);
-                    const int j = q * BB + c;               // byte of the group
-                    pk[j >> 2] |= ulen << (8 * (j & 3));
-                }
-            }
-            if (b4 + 4 <= nb) {
-#pragma unroll
-                for (int c = 0; c < BB; c++) ((uint32_t *)(ul8 + (uint64_t)b4 * BB))[c] = pk[c];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4 * BB; j++)
-                    if (b4 + j / BB < nb) ul8[(uint64_t)b4 * BB + j] = (uint8_t)(pk[j >> 2] >> (8 * (j & 3)));
-            }
-        }
-    } else {
-        uint64_t R = 0;                                         // rungs, 4 bits per band
+        for (int c = 0; c < (BT ? BT : 1); c++) rungs[c] = e[6 + c] & 15u;
+    } else
         for (uint32_t c = 0; c < B; c++) R |= (uint64_t)(e[6 + c] & 15u) << (4 * c);
-        for (uint32_t blk = 0; blk < a.ix_blocks; blk++) {
-            const bool act = blk < nb;
-            if (act && blk % NB == 0) {
-                a.idx.bitpos[seg] = rd.position() - a.in_bit0;
-                for (uint32_t c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)((R >> (4 * c)) & 15u);
-                seg++;
+    uint32_t band = 0, blk = 0;                                             // run-time bands: position inside the block
+    while (__any(u < nu)) {
+        // ---- (re)centre every lane's window on its position: sixteen-byte loads, nothing read beyond the stream
+        const uint64_t wb = P >> 5;
+        if (__all(wb + WALK_WINP <= endw)) {        // (all but the last wave of the stream)
+#pragma unroll
+            for (uint32_t q = 0; q < WALK_WINP / 4; q++) {
+                const u32x4_a4 t = *(const u32x4_a4 *)(a.in32 + wb + 4 * q);
+                *(uint4 *)(mywin + 4 * q) = make_uint4(t.x, t.y, t.z, t.w);
             }
-            for (uint32_t c = 0; c < B; c++) {
-                uint32_t rung = (uint32_t)(R >> (4 * c)) & 15u;
-                const uint32_t ulen = rd.unit(rung, bad);
-                R = (R & ~(15ull << (4 * c))) | ((uint64_t)rung << (4 * c));
-                if (act) {
-                    if (UB == 3) ((uint8_t *)a.idx.ulen)[((uint64_t)gb0 + blk) * B + c] = (uint8_t)ulen;
-                    else ((uint16_t *)a.idx.ulen)[((uint64_t)gb0 + blk) * B + c] = (uint16_t)ulen;
+        } else {
+#pragma unroll 1
+            for (uint32_t q = 0; q < WALK_WINP; q++) mywin[q] = wb + q < endw ? a.in32[wb + q] : 0u;
+        }
+        // a lane reads what it wrote itself: LDS operations of a wave execute in order, the fences are for the compiler
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t rp = lbit + (uint32_t)(P - 32 * wb);
+        // ---- walk while every lane that still has units has room for a step
+        while (true) {
+            const bool left = u < nu;
+            if (!__any(left) || __any(left && rp > rp_limit)) break;
+            if (left) {
+                if (BT) {
+                    constexpr int BB = BT ? BT : 1;
+                    const uint32_t b = u / BB;                              // block of the entry
+                    if (b % NB == 0) {
+                        a.idx.bitpos[seg] = 32 * wb + (rp - lbit) - a.in_bit0;
+#pragma unroll
+                        for (int c = 0; c < BB; c++) a.idx.rung[seg * BB + c] = (uint8_t)rungs[c];
+                        if (b == 0)                 // the entering values of the entry's first segment are in the entry
+#pragma unroll
+                            for (int c = 0; c < BB; c++) ((uint8_t *)a.idx.prev)[seg * BB + c] = e[6 + BB + c];
+                        seg++;
+                    }
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int c = 0; c < BB; c++) {
+                        const uint32_t ulen = walk_unit<UB>(rp, rungs[c], bad);
+                        rp += ulen;
+                        pk |= ulen << (8 * c);
+                    }
+                    uint8_t *ul = stage_bytes ? ul_s + lane * stage_bytes + b * BB : (uint8_t *)a.idx.ulen + ((uint64_t)gb0 + b) * BB;
+                    if (BB == 4) *(uint32_t *)ul = pk;
+                    else
+#pragma unroll
+                        for (int c = 0; c < BB; c++) ul[c] = (uint8_t)(pk >> (8 * c));
+                    u += BB;
+                } else {
+                    if (band == 0 && blk % NB == 0) {
+                        a.idx.bitpos[seg] = 32 * wb + (rp - lbit) - a.in_bit0;
+                        for (uint32_t c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)((R >> (4 * c)) & 15u);
+                        if (blk == 0)               // the entering values of the entry's first segment are in the entry
+                            for (uint32_t c = 0; c < B; c++) {
+                                const uint8_t *pv = e + 6 + B + c * (UB == 3 ? 1 : 2);
+                                if (UB == 3) ((uint8_t *)a.idx.prev)[seg * B + c] = pv[0];
+                                else ((uint16_t *)a.idx.prev)[seg * B + c] = (uint16_t)(pv[0] | (pv[1] << 8));
+                            }
+                        seg++;
+                    }
+                    uint32_t rung = (uint32_t)(R >> (4 * band)) & 15u;
+                    const uint32_t ulen = walk_unit<UB>(rp, rung, bad);
+                    rp += ulen;
+                    R = (R & ~(15ull << (4 * band))) | ((uint64_t)rung << (4 * band));
+                    uint8_t *ul = stage_bytes ? ul_s + lane * stage_bytes + (blk * B + band) * USZ
+                                              : (uint8_t *)a.idx.ulen + (((uint64_t)gb0 + blk) * B + band) * USZ;
+                    if (UB == 3) *ul = (uint8_t)ulen;
+                    else *(uint16_t *)ul = (uint16_t)ulen;
+                    if (++band == B) { band = 0; blk++; }
+                    u++;
                 }
             }
         }
+        P = 32 * wb + (rp - lbit);
+    }
+    if (stage_bytes) {
+        // the wave's lengths: entries are consecutive, so only the tail of the last wave is short
+        const uint64_t first = (uint64_t)blockIdx.x * 64 * a.ix_blocks;         // first block of the wave (< nblocks: lane 0 is live)
+        const uint64_t cnt = nblocks - first < 64ull * a.ix_blocks ? nblocks - first : 64ull * a.ix_blocks;
+        const uint32_t bytes = (uint32_t)(cnt * B * USZ);
+        uint8_t *g = (uint8_t *)a.idx.ulen + first * B * USZ;                   // 4-byte aligned: first is a multiple of 64
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t o = lane * 16;
+        for (; o + 16 <= bytes; o += 1024) {
+            const uint4 v = *(const uint4 *)(ul_s + o);
+            const u32x4_a4 t = { v.x, v.y, v.z, v.w };
+            *(u32x4_a4 *)(g + o) = t;
+        }
+        for (uint32_t i = (bytes & ~15u) + lane; i < bytes; i += 64) g[i] = ul_s[i];
     }
     if (bad && live) atomicOr(a.status, 1u);
 }
@@ -282,10 +355,14 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a) {
 void launch_dec_walk(const DecArgs &a, hipStream_t st) {
     if (a.ix && a.ntiles == 1) {            // the container's own restart table: a lane per entry
         const dim3 grid((a.ix_K + 63) / 64), block(64);
-        if (a.g.tsz == 1 && a.g.bands == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 1>), grid, block, 0, st, a);
-        else if (a.g.tsz == 1 && a.g.bands == 3) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 3>), grid, block, 0, st, a);
-        else if (a.g.tsz == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 4>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((dec_walk_lanes_kernel<4, 0>), grid, block, 0, st, a);
+        // unit lengths staged in LDS when a lane's share is small enough (it is when an entry is one index segment)
+        uint32_t stage = a.ix_blocks * a.g.bands * (a.g.tsz == 1 ? 1 : 2);
+        if (stage > 512 || (stage & 3)) stage = 0;
+        const size_t lds = 64 * WALK_WINP * 4 + 64 * (size_t)stage;
+        if (a.g.tsz == 1 && a.g.bands == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 1>), grid, block, lds, st, a, stage);
+        else if (a.g.tsz == 1 && a.g.bands == 3) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 3>), grid, block, lds, st, a, stage);
+        else if (a.g.tsz == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 4>), grid, block, lds, st, a, stage);
+        else hipLaunchKernelGGL((dec_walk_lanes_kernel<4, 0>), grid, block, lds, st, a, stage);
         return;
     }
 

@@ -48,7 +48,6 @@ __device__ __forceinline__ uint64_t chunk_start(const EncArgs &a, uint32_t k) {
 
 // Concatenate: one WAVE per chunk reads the chunk's slot, funnel-shifts it to its bit position and stores the
 // dwords that lie wholly inside the chunk; the first and last shifted dword go to the seam table.
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));     // four dwords at any dword address
 __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;

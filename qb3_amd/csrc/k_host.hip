@@ -143,14 +143,16 @@ uint32_t seg_blocks_for(const Geometry &g) {
     return s ? s : 1;
 }
 uint32_t ix_entry_bytes(const Geometry &g) { return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)); }
-// one entry per about 1024 units (a whole number of index segments): 0.1-0.2 % of a typical stream, and short
-// enough walks that one lane per entry covers a 16384^2 raster in a fraction of a millisecond
+// One entry per index segment where the lane-per-block decoders apply (8- and 16-bit FTL/BASE: a lane then walks one
+// segment, and the segment's entering values come straight from its entry), else one per about 256 units.  For
+// 8-bit RGB that is 12 bytes per 64 blocks: 0.7 % of a typical stream.
 IxTable ix_layout(const Geometry &g) {
     IxTable t;
     if (!g.seg_blocks || !g.nseg) return t;
     t.entry_bytes = ix_entry_bytes(g);
     const uint64_t units_per_seg = (uint64_t)g.seg_blocks * g.bands;
-    const uint64_t spe = units_per_seg >= 1024 ? 1 : 1024 / units_per_seg;      // fine segments per entry
+    const bool per_seg = g.mode != CM_BEST && g.tsz <= 2;
+    const uint64_t spe = (per_seg || units_per_seg >= 256) ? 1 : 256 / units_per_seg;      // index segments per entry
     t.blocks = (uint32_t)(spe * g.seg_blocks);
     t.K = (uint32_t)((g.nseg + spe - 1) / spe);
     t.per_chunk = (65535 - IX_HEAD) / t.entry_bytes;
@@ -376,14 +378,16 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         // index-less stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
         // produce the values entering the segments (totals pass + scan)
         { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
-        {
+        if (!(a.ix && a.ix_blocks == a.g.seg_blocks)) {         // (an entry per segment: the walk copied the entering values)
+          {
             ProfScope ps("dec_index_prev", st);
             DecArgs t = a;
             t.totals_only = 1;
             if (use_px) launch_dec_px(t, plan, st); else launch_dec_px16(t, plan, st);
+          }
+          ProfScope ps("dec_index_scan", st);
+          launch_prev_scan(a, st);
         }
-        ProfScope ps("dec_index_scan", st);
-        launch_prev_scan(a, st);
     } else if (rebuild) {
         ProfScope ps("dec_index_serial", st);
         launch_dec_index_serial(a, st);

@@ -271,8 +271,10 @@ static Geometry make_geometry(size_t w, size_t h, size_t bands, int dtype, size_
 static bool is_rle_mode(int m) { return m == QB3M_RLE || m == QB3M_CF_RLE || m == QB3M_RLE_H || m == QB3M_CF_RLE_H; }
 // bytes the restart-table chunks add to a container of this handle (0: none would be written)
 static size_t ix_room(const encs *p) {
-    if (!p->ix_chunk || p->xsize < 4 || p->ysize < 4 || p->xsize * p->ysize <= 16 || is_rle_mode(p->mode) || p->mode == QB3M_STORED) return 0;
-    const Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, p->mode, p->cband, nullptr);
+    if (!p->ix_chunk || p->xsize < 4 || p->ysize < 4 || p->xsize * p->ysize <= 16 || p->mode == QB3M_STORED) return 0;
+    // (an RLE0 mode codes the stream of its base mode; the table stays when the RLE0 pass does not win)
+    const int m = is_rle_mode(p->mode) ? (int)p->mode - 2 : (int)p->mode;
+    const Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, m, p->cband, nullptr);
     return ix_total_bytes(ix_layout(g));
 }
 QB3_API size_t qb3_max_encoded_size(const encsp p) { return max_encoded_size_ref(p) + ix_room(p); }
@@ -450,7 +452,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     ModeGuard guard(p);
     const qb3_mode mode = p->mode;
     const bool rle = is_rle_mode(mode);
-    const size_t ixroom = ix_room(p);                    // before the RLE demotion: no table under RLE0
+    const size_t ixroom = ix_room(p);
     if (rle) p->mode = (qb3_mode)((int)mode - 2);       // RLE is a post pass over the base mode's stream
     uint8_t hdrbuf[80];
     size_t hdr = write_headers(p, hdrbuf);
@@ -500,7 +502,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     // check_info (reference QB3encode.h:364-373); cband is kept in range by the setter
     if (g.w < 4 || g.h < 4) { p->error = 1; return 0; }
 
-    // optional restart table inside the container (not with RLE0, whose post pass rewrites the container)
+    // optional restart table inside the container (a winning RLE0 pass rewrites the container without it)
     IxTable ixt;
     size_t hdr_stamp = hdr;                               // header bytes prepared on the host
     if (ixroom && !narrow) {
@@ -519,22 +521,23 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     }
     p->error = 0;
     const size_t len = hdr + (size_t)((bits + 7) / 8);
+    const size_t len_ref = len - (ixt.base ? ix_total_bytes(ixt) : 0);      // what the reference's container measures
 
     if (rle) {
         // byte-serial post pass on the host (reference QB3encode.cpp:536-565)
         p->mode = mode;
         // ... and only worth a trip to the host when the stream has a run of four zero bytes at all (probed on the device)
         int has_run = 1;
-        if (len <= maxsz / 2 && len - hdr >= 4) {
+        if (len_ref <= maxsz / 2 && len - hdr >= 4) {
             uint8_t *flag = (uint8_t *)p->d_ws.p;       // the workspace is idle now; its first word serves as the flag
             if (zero_run_probe(out_dev, hdr, len - hdr, flag, &has_run, st)) has_run = 1;
         }
-        if (len <= maxsz / 2 && has_run) {
+        if (len_ref <= maxsz / 2 && has_run) {
             std::vector<uint8_t> data(len - hdr);
             HIPOK(hipMemcpyAsync(data.data(), out_dev + hdr, data.size(), hipMemcpyDeviceToHost, st));
             HIPOK(hipStreamSynchronize(st));
             const size_t rsz = rle0(data.data(), data.size(), nullptr);
-            if (rsz <= maxsz - len && rsz < data.size()) {
+            if (rsz <= maxsz - len_ref && rsz < data.size()) {
                 std::vector<uint8_t> packed(64 + rsz);
                 const size_t h2 = write_headers(p, packed.data());
                 rle0(data.data(), data.size(), packed.data() + h2);
@@ -545,7 +548,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
         }
     }
     // (the restart table does not take part in the decision: the same inputs give the same kind of container)
-    if (raw_size(p) > len - (ixt.base ? ix_total_bytes(ixt) : 0)) {
+    if (raw_size(p) > len_ref) {
         if (on_host) {
             memcpy(host_dst, hdrbuf, hdr_stamp);
             if (!download(p->stager, (uint8_t *)host_dst + hdr_stamp, out_dev + hdr_stamp, len - hdr_stamp, st)) { p->error = QB3E_LIBERR; return 0; }
@@ -1057,6 +1060,13 @@ QB3_API int qb3x_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 QB3_API const char *qb3x_last_error(void) { return last_error(); }
+// FNV-1a, 64 bit, over host bytes; chain calls by passing the previous result as `seed` (0 starts a new hash)
+QB3_API uint64_t qb3x_fnv1a64(const void *data, size_t n, uint64_t seed) {
+    uint64_t h = seed ? seed : 0xcbf29ce484222325ull;
+    const uint8_t *b = (const uint8_t *)data;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h;
+}
 QB3_API void qb3x_profile_enable(int level) { prof_enable(level < 0 ? 0 : level); }
 QB3_API void qb3x_profile_reset(void) { prof_reset(); }
 QB3_API int qb3x_profile_get(const char *kernel, double *total_ms, uint64_t *count) { return prof_get(kernel, total_ms, count) ? 1 : 0; }

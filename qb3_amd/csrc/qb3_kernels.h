@@ -76,6 +76,7 @@ template <uint32_t UB> __device__ __forceinline__ uint32_t cs_code(uint32_t delt
 }
 
 
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));     // four dwords at any dword address
 typedef const __attribute__((address_space(3))) uint32_t *LdsWords;   // explicit LDS pointer: loads become ds_read
 __device__ __forceinline__ LdsWords lds_at(uint32_t byte_off) { return (LdsWords)(uintptr_t)byte_off; }
 // 32 stream bits starting at bit `pos` (counted from LDS address 0)

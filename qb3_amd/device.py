@@ -108,6 +108,67 @@ class DeviceDecoder:
         return out
 
 
+class TileBatchCoder:
+    """qb3x_encode_tiles / qb3x_decode_tiles on torch tensors: n independent tiles of one geometry per call, tile i of
+    the input at i * raw_bytes, its container at i * pitch of `dst`, its out-of-band index at i * index_bytes."""
+
+    def __init__(self, w, h, bands, dtype, n, mode=QB3M_FTL, device="cuda", want_index=True):
+        self.w, self.h, self.bands, self.dtype, self.n, self.mode = w, h, bands, dtype, n, mode
+        self.p = lib.qb3_create_encoder(w, h, bands, dtype)
+        if not self.p:
+            raise ValueError("qb3_create_encoder refused the parameters")
+        lib.qb3_set_encoder_mode(self.p, mode)
+        self.raw_bytes = w * h * bands * TYPESIZE[dtype]
+        self.pitch = (lib.qb3_max_encoded_size(self.p) + 3) // 4 * 4
+        self.index_bytes = lib.qb3x_index_size(self.p) if want_index else 0
+        self.dst = torch.empty(n * self.pitch, dtype=torch.uint8, device=device)
+        self.index = torch.empty(max(1, n * self.index_bytes), dtype=torch.uint8, device=device) if want_index else None
+        self.sizes = (_sz * n)()
+        self.d = None
+
+    def close(self):
+        if lib is None:
+            return
+        if self.p:
+            lib.qb3_destroy_encoder(self.p)
+            self.p = None
+        if self.d:
+            lib.qb3_destroy_decoder(self.d)
+            self.d = None
+
+    __del__ = close
+
+    def encode(self, imgs, first=0, count=None):
+        """imgs: device tensor holding the tiles back to back; codes tiles [first, first + count) of it.  Returns their sizes."""
+        count = self.n - first if count is None else count
+        assert imgs.is_cuda and imgs.is_contiguous() and imgs.numel() * imgs.element_size() >= (first + count) * self.raw_bytes
+        sizes = (_sz * count)()
+        k = lib.qb3x_encode_tiles(self.p, _vp(imgs.data_ptr() + first * self.raw_bytes), count, self.raw_bytes,
+                                  _vp(self.dst.data_ptr() + first * self.pitch), self.pitch,
+                                  _vp(self.index.data_ptr() + first * self.index_bytes) if self.index is not None else None,
+                                  sizes, _stream_ptr())
+        if k != count:
+            raise RuntimeError(f"qb3x_encode_tiles coded {k} of {count} tiles: {last_error()}")
+        for i in range(count):
+            self.sizes[first + i] = sizes[i]
+        return list(sizes)
+
+    def decode(self, out, use_index=True):
+        """decodes the n containers made by encode() into `out` (n * raw_bytes)."""
+        if self.d is None:
+            head = self.dst[:min(int(self.sizes[0]), 256)].cpu().numpy()
+            dims = (_sz * 3)()
+            self.d = lib.qb3x_read_start(head.ctypes.data_as(_vp), head.size, int(self.sizes[0]), dims)
+            if not self.d or not lib.qb3_read_info(self.d):
+                raise ValueError("tile 0 does not parse")
+            self._head = head
+        k = lib.qb3x_decode_tiles(self.d, _vp(self.dst.data_ptr()), self.n, self.pitch, self.sizes, _vp(out.data_ptr()), self.raw_bytes,
+                                  _vp(self.index.data_ptr()) if (use_index and self.index is not None) else None, _stream_ptr())
+        if k != self.n:
+            raise RuntimeError(f"qb3x_decode_tiles decoded {k} of {self.n} tiles: {last_error()}")
+        return out
+
+
 def profile_enable(on=True):
     """True / 1: every kernel; 2: skip the microsecond kernels (less event traffic in a timed loop); False / 0: off."""
     lib.qb3x_profile_enable(int(on))

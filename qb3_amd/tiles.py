@@ -59,3 +59,65 @@ def gather_streams(payload, sizes, root=0, group=None):
         for q in dist.batch_isend_irecv(ops):
             q.wait()
     return (bufs, size_lists) if rank == root else (None, None)
+
+
+class PendingGather:
+    """A gather in flight (start_gather): wait() returns, on the root, ([per-rank buffer], [per-rank size list]) with tile
+    t of rank r at buffer[r][t * pitch : t * pitch + sizes[r][t]]; elsewhere (None, None)."""
+
+    def __init__(self, reqs, bufs, size_lists, keep):
+        self.reqs, self.bufs, self.size_lists, self._keep = reqs, bufs, size_lists, keep
+
+    def wait(self):
+        for q in self.reqs:
+            q.wait()
+        self.reqs = []
+        return self.bufs, self.size_lists
+
+
+def start_gather(dst, pitch, sizes, root=0, group=None, recv_bufs=None):
+    """Starts the gather of this rank's tile containers -- tile t at dst[t * pitch : t * pitch + sizes[t]], the layout
+    qb3x_encode_tiles leaves -- to `root` and returns at once: one point-to-point message per tile, sized to the bytes
+    produced, so the transfer (RCCL send/recv on its own stream over xGMI, every peer on its own link to the root)
+    runs beside the coding of the next batch.  Only the tile counts and sizes are exchanged synchronously (two small
+    all-gathers).  recv_bufs: on the root, optional list of per-rank uint8 tensors to receive into (reused step after
+    step); the root's own entry is ignored (its tiles stay in dst)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    keep = []
+    if dst.is_cuda and dist.get_backend(group) != "nccl":
+        dst = dst.cpu()                 # gloo moves host memory (CPU tests, single-GPU rehearsals); RCCL moves HBM to HBM
+        recv_bufs = None
+    device = dst.device
+    counts = torch.tensor([len(sizes)], dtype=torch.int64, device=device)
+    all_counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_counts, counts, group=group)
+    maxn = max(1, int(max(int(c.item()) for c in all_counts)))
+    mine = torch.zeros(maxn, dtype=torch.int64, device=device)
+    if sizes:
+        mine[:len(sizes)] = torch.tensor(list(sizes), dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros(maxn, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_sizes, mine, group=group)
+    size_lists = [[int(v) for v in s[:int(c.item())].tolist()] for s, c in zip(all_sizes, all_counts)]
+    ops, bufs = [], None
+    if rank == root:
+        bufs = []
+        for r in range(world):
+            if r == root:
+                bufs.append(dst)
+                continue
+            need = len(size_lists[r]) * pitch
+            b = recv_bufs[r] if recv_bufs is not None and recv_bufs[r] is not None and recv_bufs[r].numel() >= need \
+                else torch.empty(need, dtype=torch.uint8, device=device)
+            bufs.append(b)
+            for t, n in enumerate(size_lists[r]):
+                if n:
+                    ops.append(dist.P2POp(dist.irecv, b[t * pitch:t * pitch + n], r, group))
+    else:
+        for t, n in enumerate(sizes):
+            if n:
+                piece = dst[t * pitch:t * pitch + n]
+                keep.append(piece)
+                ops.append(dist.P2POp(dist.isend, piece, root, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return PendingGather(reqs, bufs if rank == root else None, size_lists if rank == root else None, keep)

@@ -632,6 +632,7 @@ def walk_chunks(c, fixed_b7):
 
 
 IX_CASES.append((8192, 4096, 3, 0, "NOISY3", 6, FTL))      # more entries than one 64 KB chunk holds
+IX_CASES.append((256, 128, 1, 5, "DEM", 4, 7))              # an RLE0 mode whose RLE0 pass does not win: the table stays
 
 
 @pytest.mark.parametrize("case", IX_CASES, ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % (c[0], c[1], c[2], c[3], c[4], c[6]))
@@ -697,10 +698,16 @@ def test_index_chunk_version_1_still_decodes(qb3, oracle):
 
 
 def test_index_chunk_not_written_where_it_cannot_be(qb3, oracle):
-    """RLE0 modes (the post pass rewrites the container), narrow images and STORED output carry no chunk"""
+    """a winning RLE0 pass (it rewrites the container), narrow images and STORED output carry no table"""
     img = oracle.generate(96, 64, 1, 5, "TERRACE", 4)
     for mode in (2, 3, 6, 7):
-        assert np.array_equal(qb3.encode(img, 5, mode, index_chunk=True), oracle.encode(img, 5, mode))
+        ref, got = oracle.encode(img, 5, mode), qb3.encode(img, 5, mode, index_chunk=True)
+        if ref[10] == mode:         # the RLE0 pass won
+            assert np.array_equal(got, ref)
+        else:                       # it did not: the base mode's container, with the table
+            dt_at, extra = bytes(ref).index(b"DT", 11), len(got) - len(ref)
+            assert extra > 0 and bytes(got[dt_at:dt_at + 2]) == b"ix"
+            assert np.array_equal(np.concatenate([got[:dt_at], got[dt_at + extra:]]), ref)
     narrow = oracle.generate(2, 40, 3, 0, "NOISY3", 1)
     assert np.array_equal(qb3.encode(narrow, 0, FTL, index_chunk=True), oracle.encode(narrow, 0, FTL))
     noise = oracle.generate(64, 64, 3, 0, "RANDOM", 1)         # incompressible: falls back to STORED

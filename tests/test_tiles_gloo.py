@@ -38,6 +38,40 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_pitched(rank, world, port, q, ntiles):
+    """the layout qb3x_encode_tiles leaves (containers at a fixed pitch) through start_gather, two batches in flight"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as o
+    from qb3_amd import tiles
+    first, count = tiles.shard_range(ntiles, rank, world)
+    pitch = 4096
+    pending = []
+    half = (count + 1) // 2
+    for lo, hi in ((0, half), (half, count)):           # two batches; a rank with no tiles still takes part
+        streams = [o.encode(o.generate(32, 24, 3, 0, "NOISY3", 1000 + t), 0, 8) for t in range(first + lo, first + hi)]
+        dst = torch.zeros(max(1, len(streams)) * pitch, dtype=torch.uint8)
+        for i, s in enumerate(streams):
+            dst[i * pitch:i * pitch + len(s)] = torch.from_numpy(s)
+        pending.append(tiles.start_gather(dst, pitch, [len(s) for s in streams], root=0))
+    got = {}
+    for b, pg in enumerate(pending):
+        bufs, size_lists = pg.wait()
+        if rank == 0:
+            for r, (buf, sl) in enumerate(zip(bufs, size_lists)):
+                f, c = tiles.shard_range(ntiles, r, world)
+                h = (c + 1) // 2
+                base = f + (0 if b == 0 else h)
+                for i, n in enumerate(sl):
+                    got[base + i] = buf[i * pitch:i * pitch + n].numpy().copy()
+    if rank == 0:
+        q.put([got[t] for t in sorted(got)])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_shard_range_is_a_partition():
     from qb3_amd import tiles
     for n in (0, 1, 5, 8, 256, 257):
@@ -61,6 +95,25 @@ def test_gather_streams_two_ranks(oracle):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert len(got) == NTILES
+    for t, s in enumerate(got):
+        ref = oracle.encode(oracle.generate(32, 24, 3, 0, "NOISY3", 1000 + t), 0, 8)
+        assert np.array_equal(s, ref), f"tile {t} changed in transit"
+
+
+@pytest.mark.parametrize("world,ntiles", [(2, 5), (3, 2)], ids=["2ranks-5tiles", "3ranks-2tiles-one-rank-empty"])
+def test_start_gather_pitched_batches(oracle, world, ntiles):
+    """uneven shards, a rank without tiles, two batches in flight at once"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker_pitched, args=(r, world, port, q, ntiles)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(got) == ntiles
     for t, s in enumerate(got):
         ref = oracle.encode(oracle.generate(32, 24, 3, 0, "NOISY3", 1000 + t), 0, 8)
         assert np.array_equal(s, ref), f"tile {t} changed in transit"
