@@ -10,20 +10,46 @@ namespace qb3dev {
 // cf >= 2 and index coding does not beat the "factor differs" size -- a condition that does not involve pcf
 // itself -- so pcf is a LAST-WRITER scan over units: pass 0 records each chunk's last writer per band,
 // best_scan_kernel carries it across chunks, pass 1 codes with the right pcf.
-template <typename T> __device__ __forceinline__ T mdiv_t(T v, T cf) { return (T)((T)((T)(mabs_t<T>(v) / cf) << 1) - (T)(v & 1)); }
+// x mod y and x / y for magnitudes.  8- and 16-bit data: through the float reciprocal (exact after one correction step:
+// both operands are below 2^16); wider data: the integer operations.
+template <typename T> __device__ __forceinline__ T mod_t(T x, T y) {       // y != 0
+    if (sizeof(T) <= 2) {
+        const uint32_t a = (uint32_t)x, b = (uint32_t)y;
+        const uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
+        int32_t r = (int32_t)(a - q * b);
+        r += r < 0 ? (int32_t)b : 0;
+        r -= r >= (int32_t)b ? (int32_t)b : 0;
+        return (T)r;
+    }
+    return (T)(x % y);
+}
+template <typename T> __device__ __forceinline__ T div_exact_t(T x, T y) { // y divides x
+    if (sizeof(T) <= 2) return (T)(uint32_t)((float)(uint32_t)x * __builtin_amdgcn_rcpf((float)(uint32_t)y) + 0.5f);
+    return (T)(x / y);
+}
+template <typename T> __device__ __forceinline__ T mdiv_t(T v, T cf) { return (T)((T)(div_exact_t<T>(mabs_t<T>(v), cf) << 1) - (T)(v & 1)); }
 
-template <typename T> __device__ __forceinline__ T gcf_t(const T (&g)[16]) {      // gcd of the non-zero magnitudes (QB3encode.h:98-126)
-    // a magnitude of 1 settles it; so does an odd value next to an even one... only the first is cheap to see in every
-    // lane at once, and on noisy data it spares most lanes the divergent Euclid loop
+// gcd of the non-zero magnitudes (QB3encode.h:98-126).  What a WAVE pays is its slowest lane, so: a magnitude of 1
+// settles a lane at once (on noisy data nearly all of them); the others start from their smallest magnitude, which
+// the gcd divides, so that one or two values usually bring it down to 1; and the walk over the sixteen values stops
+// as soon as every lane of the wave is settled.
+template <typename T> __device__ __forceinline__ T gcf_t(const T (&g)[16], bool active) {
+    T m[16], mn = (T)~(T)0;
     bool one = false;
 #pragma unroll
-    for (uint32_t i = 0; i < 16; i++) one = one || mabs_t<T>(g[i]) == 1;
-    if (one) return 1;
-    T x = 0;
-#pragma unroll 1
-    for (uint32_t i = 0; i < 16 && x != 1; i++) {
-        T y = mabs_t<T>(g[i]);
-        while (y) { const T t = (T)(x % y); x = y; y = t; }
+    for (uint32_t i = 0; i < 16; i++) {
+        m[i] = mabs_t<T>(g[i]);
+        one = one || m[i] == 1;
+        mn = (m[i] != 0 && m[i] < mn) ? m[i] : mn;
+    }
+    T x = (one || !active) ? (T)1 : mn;         // (an active unit has a non-zero magnitude: its rung is at least 1)
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+        if (!__any(x != 1)) break;
+        if (x != 1) {
+            T y = mod_t<T>(m[i], x);
+            while (y) { const T t = mod_t<T>(x, y); x = y; y = t; }
+        }
     }
     return x;
 }
@@ -88,11 +114,40 @@ template <typename T> struct BestUnit {
     bool writer;            // overwrites pcf with cf-2
 };
 
+// number of distinct values among the sixteen (exact up to 9: all the caller asks is "at most 8?")
+template <typename T> __device__ __forceinline__ uint32_t distinct_t(const T (&g)[16], uint32_t rung, bool need) {
+    uint32_t distinct = 99;
+    // 8-bit data up to rung 5 (values below 64): a bitmap and a population count
+    const bool small = sizeof(T) == 1 && rung <= 5;
+    if (sizeof(T) == 1 && __any(need && small)) {
+        uint64_t bm = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) bm |= 1ull << ((uint32_t)g[i] & 63u);
+        if (small) distinct = (uint32_t)__popcll(bm);
+    }
+    if (__any(need && !small)) {        // plain comparisons, in registers and the same in every lane
+        uint32_t d = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            bool seen = false;
+#pragma unroll
+            for (uint32_t j = 0; j < i; j++) seen = seen || g[j] == g[i];
+            d += !seen;
+        }
+        if (!small) distinct = d;
+    }
+    return distinct;
+}
+
+// cf: the unit's common factor (gcf_t).  writer_only: all the caller wants is u.writer (pass 0).
 template <typename T>
-__device__ __forceinline__ void best_analyse(const T (&g)[16], uint32_t rung, uint32_t oldrung, BestUnit<T> &u) {
+__device__ __forceinline__ void best_analyse(const T (&g)[16], uint32_t rung, uint32_t oldrung, T cf, bool writer_only, BestUnit<T> &u) {
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
-    u.cf = gcf_t<T>(g);
+    u.cf = cf;
     u.szN = u.szBase = u.szCf = 0; u.trung = 0;
+    u.idx = 0xffffffffu;
+    u.writer = false;
+    if (writer_only && cf < 2) return;          // only a unit with a common factor can overwrite the band's factor
     if (u.cf >= 2) {
         T d[16], usedd = 0;
 #pragma unroll
@@ -112,63 +167,79 @@ __device__ __forceinline__ void best_analyse(const T (&g)[16], uint32_t rung, ui
         apply_step<T>(v, rung);
         u.szN = cs_len<UB>((rung - oldrung) & UMASK) + group_len<T>(v, rung);
     }
-    // index coding (QB3encode.h:557-613)
-    u.idx = 0xffffffffu;
-    // (first count the distinct values with plain comparisons, in registers and the same in every lane: more than 8
-    // means no index coding, and the search below -- small arrays indexed at run time, divergent -- is skipped)
-    uint32_t distinct = 0;
-    if (rung > 3 && rung < 63) {
+    // index coding (QB3encode.h:557-613): only tried for rungs 4..62 and when the size so far reaches the threshold
+    // (:702); more than 8 distinct values means no index coding, and the search below -- small arrays indexed at run
+    // time, divergent -- is skipped
+    const uint32_t thr = 36 + 3 * UB + 2 * rung;
+    const uint32_t szDiff = u.szBase + u.szCf, szSame = u.cf >= 2 ? u.szBase : u.szN;
+    const bool try_idx = rung > 3 && rung < 63 && (u.cf >= 2 ? szDiff : szSame) >= thr;
+    const uint32_t distinct = distinct_t<T>(g, rung, try_idx);
+    if (__any(try_idx && distinct <= 8)) {
+        // The size of the index form (QB3encode.h:557-613) without building it.  With the distinct values ranked by
+        // descending count, a value of rank j costs cnt_j index codes of 2 + (j >= 2) + (j >= 4) bits (the plain rung-2
+        // code) plus its own code at `rung`: the sum of the index codes is 64 - S2 - S4 with S2 / S4 the sum of the two /
+        // four largest counts, and the values' own codes do not depend on the order.  Sort the sixteen values (a fixed
+        // network: no run-time indexed arrays, the same instructions in every lane), read the counts off the runs.
+        T v[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) v[i] = g[i];
+#pragma unroll
+        for (uint32_t k = 2; k <= 16; k <<= 1)
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t l = i ^ j;
+                    if (l > i) {
+                        const bool up = (i & k) == 0;
+                        const T lo = v[i] < v[l] ? v[i] : v[l], hi = v[i] < v[l] ? v[l] : v[i];
+                        v[i] = up ? lo : hi; v[l] = up ? hi : lo;
+                    }
+                }
+        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, run = 0, vbits = 0;       // the four largest counts, the run in progress
 #pragma unroll
         for (uint32_t i = 0; i < 16; i++) {
-            bool seen = false;
-#pragma unroll
-            for (uint32_t j = 0; j < i; j++) seen = seen || g[j] == g[i];
-            distinct += !seen;
+            run++;
+            const bool last = i == 15 || v[i + 1] != v[i];
+            if (last) {
+                vbits += vlen_t<T>(v[i], rung);
+                uint32_t r = run;                   // insert into c0 >= c1 >= c2 >= c3
+                uint32_t t = c0 < r ? c0 : r; c0 = c0 < r ? r : c0; r = t;
+                t = c1 < r ? c1 : r; c1 = c1 < r ? r : c1; r = t;
+                t = c2 < r ? c2 : r; c2 = c2 < r ? r : c2; r = t;
+                c3 = c3 < r ? r : c3;
+                run = 0;
+            }
         }
+        const uint32_t bits = (UB + 2) + sw_noflag_len<UB>(UMASK - oldrung) + sw_noflag_len<UB>(rung - oldrung) + 64 - 2 * (c0 + c1) - (c2 + c3) + vbits;
+        if (try_idx && distinct <= 8) u.idx = bits;
     }
-    if (rung > 3 && rung < 63 && distinct <= 8) {
-        T val[8]; uint32_t cnt[8], n = 0;
-        bool fits = true;
-#pragma unroll 1
-        for (uint32_t i = 0; i < 16 && fits; i++) {
-            uint32_t j = 0;
-            while (j < n && val[j] != g[i]) j++;
-            if (j == n) { if (n == 8) fits = false; else { val[n] = g[i]; cnt[n++] = 1; } }
-            else cnt[j]++;
-        }
-        if (fits) {
-            // stable sort by descending count (QB3encode.h:546-554)
-#pragma unroll 1
-            for (uint32_t i = 1; i < n; i++)
-                for (uint32_t j = i; j > 0 && cnt[j] > cnt[j - 1]; j--) {
-                    const T tv = val[j]; val[j] = val[j - 1]; val[j - 1] = tv;
-                    const uint32_t tc = cnt[j]; cnt[j] = cnt[j - 1]; cnt[j - 1] = tc;
-                }
-            uint32_t bits = (UB + 2) + sw_noflag_len<UB>(UMASK - oldrung) + sw_noflag_len<UB>(rung - oldrung);
-#pragma unroll 1
-            for (uint32_t j = 0; j < n; j++) bits += cnt[j] * (2 + (j >= 2) + (j >= 4)) + vlen_t<T>(val[j], rung);   // plain rung-2 index codes
-            u.idx = bits;
-        }
-    }
-    const uint32_t thr = 36 + 3 * UB + 2 * rung;
-    const uint32_t szDiff = u.szBase + u.szCf;
     u.writer = u.cf >= 2 && !(szDiff >= thr && u.idx < szDiff);
 }
 
-// per-band "last writer" inclusive scan over the lanes of the workgroup (lanes are slot-major, band-minor, so the
-// band's units are `bands` lanes apart): key = 0 for "no writer", else anything non-zero; doubling in LDS
-__device__ __forceinline__ void last_writer_scan(uint32_t *key, uint64_t *val, uint32_t n, uint32_t bands, uint32_t mykey, uint64_t myval) {
-    const uint32_t tid = threadIdx.x;
-    if (tid < n) { key[tid] = mykey; val[tid] = myval; }
+// Per-band "last writer" lookup over the lanes of the workgroup.  Lanes are slot-major, band-minor (unit t is band
+// t % bands), so the lanes of one band are `bands` apart.  Every wave publishes the ballot of its writers (one word
+// pair) and every lane its value; after ONE barrier a lane finds the last writer of its band at or before lane
+// `upto` by masking the ballots with its band's lane pattern and counting leading zeros.
+struct WriterBoard { uint64_t *masks; uint64_t *vals; };       // masks: one per wave; vals: one per lane
+__device__ __forceinline__ void writers_publish(const WriterBoard &wb, bool writer, uint64_t val) {
+    const uint64_t m = __ballot(writer);
+    if ((threadIdx.x & 63) == 0) wb.masks[threadIdx.x >> 6] = m;
+    wb.vals[threadIdx.x] = val;
     __syncthreads();
-    for (uint32_t d = bands; d < n; d <<= 1) {
-        uint32_t k = 0; uint64_t v = 0;
-        const bool take = tid < n && tid >= d && key[tid] == 0;
-        if (take) { k = key[tid - d]; v = val[tid - d]; }
-        __syncthreads();
-        if (take && k) { key[tid] = k; val[tid] = v; }
-        __syncthreads();
+}
+// last writer of band `c` among lanes 0..upto (upto < 0: none); false if there is none
+__device__ __forceinline__ bool writers_find(const WriterBoard &wb, uint32_t bands, uint32_t c, int32_t upto, uint64_t *val) {
+    if (upto < 0) return false;
+    uint64_t period = 0;                                        // lanes 0, bands, 2*bands, ...
+    for (uint32_t k = 0; k < 64; k += bands) period |= 1ull << k;
+    for (int32_t w = upto >> 6; w >= 0; w--) {
+        const uint32_t r = (c + bands - (uint32_t)(w * 64) % bands) % bands;    // lanes of wave w that belong to band c: l % bands == r
+        uint64_t m = wb.masks[w] & (period << r);
+        if (w == (upto >> 6)) m &= ~0ull >> (63 - (upto & 63));                 // lanes <= upto
+        if (m) { *val = wb.vals[w * 64 + 63 - __clzll((long long)m)]; return true; }
     }
+    return false;
 }
 
 template <typename T, int PASS>
@@ -185,28 +256,43 @@ __global__ void enc_best_kernel(const EncArgs a0) {
     const uint32_t c = f.c, gblk = f.gblk, rung = f.rung, chunk = f.chunk;
     const bool payload = f.payload;
     const T used = f.used;
-    uint64_t *wval = (uint64_t *)(f.outbuf + ((outdw + 1) & ~1u));
-    uint32_t *wkey = (uint32_t *)(wval + nunits);
+    WriterBoard wb;
+    wb.vals = (uint64_t *)(f.outbuf + ((outdw + 1) & ~1u));     // nthr values, then one mask per wave
+    wb.masks = wb.vals + nthr;
 
+    // pass 0 leaves one byte per unit: does it have a common factor at all?  (Pass 1 then runs the gcd only where a
+    // lane of the wave needs it: on noisy data nowhere.)
+    uint8_t *cfflag = a.cf_flag + (uint64_t)chunk * nthr;
     uint32_t oldrung = 0;
     BestUnit<T> u;
     u.writer = false; u.cf = 1; u.szN = u.szBase = u.szCf = 0; u.idx = 0xffffffffu; u.trung = 0;
-    if (payload) {
-        oldrung = (gblk == 0) ? a0.st.rung[c] : f.rungs[tid - bands];
-        if (used > 1) best_analyse<T>(g, rung, oldrung, u);
+    const bool analyse = payload && used > 1;
+    if (payload) oldrung = (gblk == 0) ? a0.st.rung[c] : f.rungs[tid - bands];
+    {
+        const bool want_gcf = analyse && (PASS == 0 || cfflag[tid] != 0);
+        T cf = 1;
+        if (__any(want_gcf)) cf = gcf_t<T>(g, want_gcf);
+        if (PASS == 0) cfflag[tid] = (uint8_t)(cf >= 2);
+        if (analyse) best_analyse<T>(g, rung, oldrung, cf, PASS == 0, u);
     }
-    // who wrote the band's factor last, up to and including each unit
-    last_writer_scan(wkey, wval, nunits, bands, (payload && u.writer) ? 1u : 0u, (uint64_t)(T)(u.cf - 2));
+    // who wrote the band's factor last
+    (void)nunits;
+    writers_publish(wb, payload && u.writer, (uint64_t)(T)(u.cf - 2));
     if (PASS == 0) {
-        // chunk summary: the entry of the last payload slot of each band
-        const uint32_t last = (slots - 1) * bands + tid;
-        if (tid < bands) { a.cw_has[(uint64_t)chunk * bands + tid] = (uint8_t)(wkey[last] != 0); a.cw_val[(uint64_t)chunk * bands + tid] = wval[last]; }
+        // chunk summary: the last writer of each band among all the chunk's units
+        if (tid < bands) {
+            uint64_t v = 0;
+            const bool has = writers_find(wb, bands, tid, (int32_t)(slots * bands) - 1, &v);
+            a.cw_has[(uint64_t)chunk * bands + tid] = (uint8_t)has; a.cw_val[(uint64_t)chunk * bands + tid] = v;
+        }
         return;
     }
-    // factor state entering this unit: previous unit of the band in the chunk, else the chunk's entry state
+    // factor state entering this unit: the last writer before it in the chunk, else the chunk's entry state
     T pcf = (T)a.centry[(uint64_t)chunk * bands + c];
-    if (payload && tid >= bands && wkey[tid - bands]) pcf = (T)wval[tid - bands];
-    __syncthreads();
+    {
+        uint64_t v = 0;
+        if (payload && writers_find(wb, bands, c, (int32_t)tid - 1, &v)) pcf = (T)v;
+    }
 
     // ---- choose the coding and its length (QB3encode.h:679-713)
     uint32_t len = 0, kind = 0;     // kind: 0 low (used <= 1), 1 plain, 2 common factor, 3 index
@@ -315,37 +401,42 @@ __global__ void enc_best_kernel(const EncArgs a0) {
     if (tid == 0) a.chunk_bits[chunk] = total;
 }
 
-// Carries the last factor writer across chunks: centry[k][c] = factor state on entering chunk k.  One workgroup;
-// "last non-empty" is a max-scan over (chunk index + 1).
-__global__ void best_scan_kernel(const EncArgs a0) {
+// Carries the last factor writer across chunks: centry[k][c] = factor state on entering chunk k.  One workgroup per
+// band (blockIdx.x) and tile; "last non-empty" is a max-scan over (chunk index + 1); a thread owns 8 chunks in a row.
+__global__ void __launch_bounds__(1024) best_scan_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
-    const uint32_t bands = a.g.bands, tid = threadIdx.x;
-    for (uint32_t c = 0; c < bands; c++) {
-        if (tid == 0) carry = 0;
-        __syncthreads();
-        for (uint32_t base = 0; base < a.nchunks; base += blockDim.x) {
-            const uint32_t k = base + tid;
-            uint32_t x = (k < a.nchunks && a.cw_has[(uint64_t)k * bands + c]) ? k + 1 : 0;
-            // inclusive max-scan within the workgroup
-            const uint32_t lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-            uint32_t m = x;
+    constexpr uint32_t PER = 8;
+    const uint32_t bands = a.g.bands, tid = threadIdx.x, c = blockIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < a.nchunks; base += 1024 * PER) {
+        const uint32_t k0 = base + tid * PER;
+        uint32_t has[PER], last = 0;                    // last writer (chunk index + 1) among the thread's chunks
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(m, d, 64); if (lane >= (uint32_t)d) m = max(m, y); }
-            if (lane == 63) wsum[wave] = m;
-            __syncthreads();
-            uint32_t before = carry;
-            for (uint32_t i = 0; i < wave && i < nw; i++) before = max(before, wsum[i]);
-            const uint32_t incl = max(before, m);
-            // exclusive: the last writer strictly before chunk k
-            const uint32_t up = __shfl_up(m, 1, 64);
-            const uint32_t excl = max(before, lane ? up : 0u);
-            if (k < a.nchunks) a.centry[(uint64_t)k * bands + c] = excl ? a.cw_val[(uint64_t)(excl - 1) * bands + c] : a0.st.cf[c];
-            __syncthreads();
-            if (tid == blockDim.x - 1) carry = incl;
-            __syncthreads();
+        for (uint32_t i = 0; i < PER; i++) {
+            has[i] = (k0 + i < a.nchunks && a.cw_has[(uint64_t)(k0 + i) * bands + c]) ? k0 + i + 1 : 0;
+            last = has[i] ? has[i] : last;
         }
+        uint32_t m = last;                              // inclusive max-scan over the threads
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(m, d, 64); if (lane >= (uint32_t)d) m = max(m, y); }
+        if (lane == 63) wsum[wave] = m;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t i = 0; i < wave; i++) before = max(before, wsum[i]);
+        const uint32_t up = __shfl_up(m, 1, 64);
+        uint32_t run = max(before, lane ? up : 0u);     // last writer strictly before the thread's first chunk
+#pragma unroll
+        for (uint32_t i = 0; i < PER; i++) {
+            if (k0 + i < a.nchunks) a.centry[(uint64_t)(k0 + i) * bands + c] = run ? a.cw_val[(uint64_t)(run - 1) * bands + c] : a0.st.cf[c];
+            run = has[i] ? has[i] : run;
+        }
+        __syncthreads();
+        if (tid == 1023) carry = max(before, m);
+        __syncthreads();
     }
 }
 
@@ -358,7 +449,7 @@ static void launch_enc_best_t(const EncArgs &a, const EncPlan &plan, hipStream_t
     }
     {
         ProfScope ps("enc_best_scan", st);
-        hipLaunchKernelGGL(best_scan_kernel, dim3(1, a.ntiles), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(best_scan_kernel, dim3(a.g.bands, a.ntiles), dim3(1024), 0, st, a);
     }
     ProfScope ps("enc_best_units", st);
     hipLaunchKernelGGL((enc_best_kernel<T, 1>), grid, block, plan.lds_bytes, st, a);

@@ -187,8 +187,8 @@ uint32_t max_unit_bits(uint32_t tsz, uint32_t mode) {
 }
 
 // encoder workspace layout (all 8-byte aligned), EncResult last
-struct EncWs { size_t bits, off, gsum, seams, scratch, cwhas, cwval, centry, res, total; uint32_t slot_dw, ngroups; };
-static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
+struct EncWs { size_t bits, off, gsum, seams, scratch, cwhas, cwval, centry, cfflag, res, total; uint32_t slot_dw, ngroups; };
+static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, uint32_t threads) {
     EncWs w;
     // a multiple of 4 dwords: slots are 16-byte aligned (the px kernel copies them out as uint4)
     w.slot_dw = (uint32_t)(((31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1 + 3) & ~(size_t)3);
@@ -204,6 +204,7 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp) {
     w.cwhas = o; o += align8(nb);
     w.cwval = o; o += 8 * nb;
     w.centry = o; o += 8 * nb;
+    w.cfflag = o; o += g.mode == CM_BEST ? align8((size_t)nchunks * threads) : 0;
     w.res = o; o += sizeof(EncResult);
     w.total = o;
     return w;
@@ -251,7 +252,7 @@ EncPlan plan_encode(const Geometry &g) {
     if (p.px) {
         p.threads = 256; p.slots = 256; p.nbp = 255;
         p.nchunks = (uint32_t)((g.nblocks + 254) / 255);
-        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp);
+        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp, p.threads);
         p.lds_bytes = 2048 + 256 + 4 * (size_t)L.slot_dw;
         p.ws_bytes = L.total;
         return p;
@@ -261,7 +262,7 @@ EncPlan plan_encode(const Geometry &g) {
         p.px16 = true; p.px_rgb = rgb16;
         p.threads = 256; p.slots = 256 / p.px16_ng; p.nbp = p.slots - 1;
         p.nchunks = (uint32_t)((g.nblocks + p.nbp - 1) / p.nbp);
-        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp);
+        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp, p.threads);
         p.lds_bytes = 2048 + 256 + 1024 + 4 * (size_t)L.slot_dw;
         p.ws_bytes = L.total;
         return p;
@@ -273,8 +274,8 @@ EncPlan plan_encode(const Geometry &g) {
     p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
     const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1;
     p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * ((outdw + 1) & ~(size_t)1);
-    if (g.mode == CM_BEST) p.lds_bytes += 12 * (size_t)p.slots * g.bands + 8;
-    p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp).total;
+    if (g.mode == CM_BEST) p.lds_bytes += 8 * (size_t)p.threads + 8 * 16 + 8;     // the writer board: a value per lane, a ballot per wave
+    p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp, p.threads).total;
     return p;
 }
 
@@ -302,13 +303,13 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
     a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
     uint8_t *w = (uint8_t *)ws;
-    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp);
+    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp, plan.threads);
     a.chunk_bits = (uint32_t *)(w + L.bits);
     a.chunk_off = (uint64_t *)(w + L.off);
     a.group_sum = (uint64_t *)(w + L.gsum);
     a.seams = (uint32_t *)(w + L.seams);
     a.scratch = (uint32_t *)(w + L.scratch);
-    a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry);
+    a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry); a.cf_flag = w + L.cfflag;
     a.slot_dw = L.slot_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.src_pitch & 3);
