@@ -3,32 +3,12 @@
 
 namespace qb3dev {
 
-template <int B, bool RGB, uint64_t ORDER, bool STEP>
-__global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
-    const EncArgs a = enc_for_tile(a0, blockIdx.y);
-    constexpr uint32_t UMASK = 7;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
+// The block of lane `tid` of a chunk (4 rows x B dwords) and the dword holding the previous block's last visited pixel.
+template <int B, uint64_t ORDER>
+__device__ __forceinline__ void px_load_block(const EncArgs &a, bool valid, uint32_t gblk, uint32_t (&w)[4][B], uint32_t &pd) {
+    const uint32_t nbx = a.g.nbx;
     const uint64_t stride = a.g.stride;
-
-    uint32_t *etab = (uint32_t *)smem;                      // 512 entries
-    uint32_t *wsum = etab + 512;                            // 64 dwords: scan scratch, [32..35] rungs of each wave's last lane
-    uint32_t *outbuf = wsum + 64;                           // slot_dw dwords (a multiple of 4)
-    // the code table is asked for now and written to LDS only before the first barrier: its round trip runs beside the
-    // pixel loads instead of in front of them
-    const uint4 tabv = ((const uint4 *)px_enc_tab.e)[tid & 127];
-    for (uint32_t i = tid; i < a.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
-    const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
-
-    const uint32_t chunk = blockIdx.x;
-    const int64_t gs = (int64_t)chunk * 255 - 1 + tid;     // lane 0 is the halo block
-    const bool valid = gs >= 0 && gs < (int64_t)nblocks, payload = valid && tid >= 1;
-    const uint32_t gblk = valid ? (uint32_t)gs : 0u;
-
-    // ---- load the block (4 rows x B dwords) and the dword holding the previous block's last visited pixel
-    uint32_t w[4][B];
-    uint32_t pd = 0;
+    pd = 0;
     constexpr uint32_t n15 = order_nib(ORDER, 15);
     // Rows need not be dword aligned (odd widths and strides, the shifted last column, any pointer): a row is read as the
     // aligned dwords that cover it -- one more than it has when it is not aligned -- and funnel-shifted into place.
@@ -79,6 +59,19 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
             for (int k = 0; k < B; k++) w[r][k] = 0;
     }
 
+}
+
+// Codes the chunk whose blocks the lanes hold (lane 0: the halo block) into the LDS bit buffer, from bit 0; the
+// buffer must be zero.  total: bits of the chunk; pos: where the lane's block starts.  DEFER_POS: the caller writes
+// the index position of a segment that starts at this lane (seg_out, else ~0) once it knows the chunk's offset.
+template <int B, bool RGB, uint64_t ORDER, bool STEP, bool DEFER_POS>
+__device__ __forceinline__ void px_code_chunk(const EncArgs &a, const EncArgs &a0, uint32_t chunk, bool valid, bool payload, uint32_t gblk,
+                                              const uint32_t (&w)[4][B], uint32_t pd, uint32_t *etab, uint32_t *wsum, uint32_t *outbuf,
+                                              uint32_t etab_off, bool put_tab, const uint4 &tabv, uint32_t &total, uint32_t &pos, uint32_t &seg_out) {
+    constexpr uint32_t UMASK = 7;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nblocks = (uint32_t)a.g.nblocks;
+    seg_out = ~0u;
     // ---- per band: bytes in curve order, band difference, running delta, mag-sign -- four values per register
     uint32_t cur[B][4];
 #pragma unroll
@@ -114,7 +107,7 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
     // rungs of the previous block: neighbouring lane, or the last lane of the previous wave through LDS
     uint32_t prp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rp_packed, 0x138, 0xf, 0xf, false);      // wave_shr:1
     if (lane == 63) wsum[32 + wave] = rp_packed;
-    if (tid < 128) ((uint4 *)etab)[tid] = tabv;
+    if (put_tab && tid < 128) ((uint4 *)etab)[tid] = tabv;
     __syncthreads();
     if (lane == 0 && wave) prp = wsum[32 + wave - 1];
     if (gblk == 0) { prp = 0;
@@ -175,7 +168,7 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
     }
     const uint32_t mybits = blen[0];
     block_exscan_dpp<1>(blen, wsum);
-    const uint32_t pos = blen[0], total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    pos = blen[0]; total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     (void)mybits;
 
     if (payload) {
@@ -201,10 +194,36 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
                     ((uint8_t *)a.idx.prev)[(uint64_t)seg * B + c] = (uint8_t)pvv[c];
                     a.idx.rung[(uint64_t)seg * B + c] = (uint8_t)((prp >> (4 * c)) & 15u);
                 }
-                a.idx.bitpos[seg] = ((uint64_t)chunk << 32) | pos;
+                if (DEFER_POS) seg_out = seg; else a.idx.bitpos[seg] = ((uint64_t)chunk << 32) | pos;
             }
         }
     }
+}
+
+template <int B, bool RGB, uint64_t ORDER, bool STEP>
+__global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nblocks = (uint32_t)a.g.nblocks;
+
+    uint32_t *etab = (uint32_t *)smem;                      // 512 entries
+    uint32_t *wsum = etab + 512;                            // 64 dwords: scan scratch, [32..35] rungs of each wave's last lane
+    uint32_t *outbuf = wsum + 64;                           // slot_dw dwords (a multiple of 4)
+    // the code table is asked for now and written to LDS only before the first barrier: its round trip runs beside the
+    // pixel loads instead of in front of them
+    const uint4 tabv = ((const uint4 *)px_enc_tab.e)[tid & 127];
+    for (uint32_t i = tid; i < a.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
+    const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
+
+    const uint32_t chunk = blockIdx.x;
+    const int64_t gs = (int64_t)chunk * 255 - 1 + tid;     // lane 0 is the halo block
+    const bool valid = gs >= 0 && gs < (int64_t)nblocks, payload = valid && tid >= 1;
+    const uint32_t gblk = valid ? (uint32_t)gs : 0u;
+    uint32_t w[4][B], pd, total, pos, seg;
+    px_load_block<B, ORDER>(a, valid, gblk, w, pd);
+    px_code_chunk<B, RGB, ORDER, STEP, false>(a, a0, chunk, valid, payload, gblk, w, pd, etab, wsum, outbuf, etab_off, true, tabv, total, pos, seg);
+    // the chunk's bits go to its slot; enc_concat_kernel moves them into place once every chunk is counted
     __syncthreads();
     const uint32_t nd4 = (total + 127) >> 7;
     uint4 *slot = (uint4 *)(a.scratch + (uint64_t)chunk * a.slot_dw);
@@ -212,10 +231,225 @@ __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
     if (tid == 0) a.chunk_bits[chunk] = total;
 }
 
+// ---- single pass: persistent workgroups, decoupled look-back ------------------------------------------------
+// The same coding, but a chunk's bits go from LDS straight to their place in the stream: no slot, no concatenate
+// pass, half the HBM traffic.  What a chunk needs for that is the sum of the bit counts of all chunks before it.
+// Workgroup g of G (all resident: G is sized from the occupancy query, and every wait is bounded) codes chunks g,
+// g + G, ...  After coding a chunk it publishes its count in lookback[chunk] as ONE 8-byte word {state, value} --
+// state 1: the chunk's own count, 2: the count of everything up to and including the chunk -- with an agent-scope
+// store, and wave 0 reads the words of its predecessors 64 at a time (agent-scope loads: the XCDs' L2s are not coherent
+// with each other) until it meets a state-2 word behind only state-1 words; their sum is the chunk's offset.  The
+// next chunk's pixel loads are issued before that wait, so their round trip runs beside it.  Dwords a chunk shares
+// with its neighbours go to the seam table as in the slot path (enc_seam_kernel assembles them).
+// A wait that exceeds its bound (a predecessor that is not resident: never seen, by construction) publishes state 3,
+// which every later chunk passes on; the host then codes the image again through the slots.
+constexpr uint64_t LB_VAL = (1ull << 62) - 1;
+__device__ __forceinline__ uint64_t lb_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lb_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int B, bool RGB, uint64_t ORDER, bool STEP, bool LOOKBACK>
+__global__ void __launch_bounds__(256, 4) enc_px_sp_kernel(const EncArgs a0) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *etab = (uint32_t *)smem;                      // 512 entries
+    uint32_t *wsum = etab + 512;                            // 64 dwords: scan scratch; [40..43]: the chunk's offset (lo, hi), abort flag
+    uint32_t *outbuf = wsum + 64;                           // slot_dw dwords (a multiple of 4)
+    const uint4 tabv = ((const uint4 *)px_enc_tab.e)[tid & 127];
+    for (uint32_t i = tid; i < a0.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
+    const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
+    const uint32_t nchunks = a0.nchunks, G = gridDim.x;
+    const uint64_t nq = (uint64_t)nchunks * a0.ntiles;     // chunks of all tiles, tile-major
+
+    auto chunk_lanes = [&](uint64_t q, uint32_t &tile, uint32_t &chunk, bool &valid, bool &payload, uint32_t &gblk) {
+        tile = (uint32_t)(q / nchunks); chunk = (uint32_t)(q - (uint64_t)tile * nchunks);
+        const int64_t gs = (int64_t)chunk * 255 - 1 + tid;  // lane 0 is the halo block
+        valid = gs >= 0 && gs < (int64_t)a0.g.nblocks; payload = valid && tid >= 1;
+        gblk = valid ? (uint32_t)gs : 0u;
+    };
+    uint64_t q = blockIdx.x;
+    uint32_t w[4][B], pd = 0;
+    uint32_t tile = 0, chunk = 0, gblk = 0;
+    bool valid = false, payload = false, first = true;
+    if (q < nq) {
+        chunk_lanes(q, tile, chunk, valid, payload, gblk);
+        px_load_block<B, ORDER>(enc_for_tile(a0, tile), valid, gblk, w, pd);
+    }
+    while (q < nq) {
+        const EncArgs a = enc_for_tile(a0, tile);
+        uint32_t total, pos, seg;
+        px_code_chunk<B, RGB, ORDER, STEP, LOOKBACK>(a, a0, chunk, valid, payload, gblk, w, pd, etab, wsum, outbuf, etab_off, first, tabv, total, pos, seg);
+        first = false;
+        uint64_t *lb = a.lookback;
+        if (LOOKBACK && tid == 0) lb_store(&lb[chunk], ((chunk == 0 ? 2ull : 1ull) << 62) | total);
+        // the next chunk's pixels: requested now, used after the wait and the write-out
+        const uint64_t qn = q + G;
+        uint32_t ntile = 0, nchunk = 0, ngblk = 0;
+        bool nvalid = false, npayload = false;
+        if (qn < nq) {
+            chunk_lanes(qn, ntile, nchunk, nvalid, npayload, ngblk);
+            px_load_block<B, ORDER>(enc_for_tile(a0, ntile), nvalid, ngblk, w, pd);
+        }
+        if (!LOOKBACK) {
+            // persistent workgroups, slots: the chunk's bits go to its slot (enc_concat_kernel moves them into place); what the
+            // persistence buys is the next chunk's pixels arriving while these bits leave
+            __syncthreads();
+            const uint32_t nd4 = (total + 127) >> 7;
+            uint4 *slot = (uint4 *)(a.scratch + (uint64_t)chunk * a.slot_dw);
+            for (uint32_t d = tid; d < nd4; d += 256) slot[d] = ((const uint4 *)outbuf)[d];
+            if (tid == 0) a.chunk_bits[chunk] = total;
+            __syncthreads();
+            for (uint32_t d = tid; d < nd4; d += 256) ((uint4 *)outbuf)[d] = make_uint4(0, 0, 0, 0);
+            q = qn; tile = ntile; chunk = nchunk; valid = nvalid; payload = npayload; gblk = ngblk;
+            continue;
+        }
+        // ---- the chunk's offset: look back over the predecessors' words
+        if (wave == 0) {
+            // a lane reads LBW words a round -- the window is 64 * LBW chunks: the running total moves down the chunks by one
+            // window per memory round trip, and that, not the coding, would set the pace with a narrow one
+            constexpr int LBW = 8;
+            uint64_t excl = 0;
+            uint32_t state = chunk == 0 ? 2u : 0u;          // 2: done, 3: abort
+            int64_t base = (int64_t)chunk - 1;
+            uint32_t spins = 0;
+            while (state == 0) {
+                // wait for the nearest word with ONE load per try (a whole window polled by every waiting workgroup costs
+                // the memory system more than the coding), then read the window behind it once
+                {
+                    uint32_t st = 0;
+                    while (true) {
+                        st = (uint32_t)(lb_load(&lb[base]) >> 62);          // (every lane: the same word, one request)
+                        if (st != 0) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 22)) { st = 3; break; }
+                    }
+                    if (st == 3) { state = 3; break; }
+                }
+                uint64_t v[LBW];
+#pragma unroll
+                for (int j = 0; j < LBW; j++) {             // word p = 64 * j + lane of the window is chunk base - p (a load: 512 bytes in a row)
+                    const int64_t idx = base - (int64_t)(64 * j + lane);
+                    v[j] = idx >= 0 ? lb_load(&lb[idx]) : (2ull << 62);          // in front of chunk 0: a total of zero
+                }
+                uint32_t nr = 64 * LBW, ni = 64 * LBW, nd = 64 * LBW;         // first word not there yet / with a running total / dead
+#pragma unroll
+                for (int j = 0; j < LBW; j++) {
+                    const uint32_t st = (uint32_t)(v[j] >> 62);
+                    const uint64_t notready = __ballot(st == 0), incl = __ballot(st >= 2), dead = __ballot(st == 3);
+                    if (notready) nr = min(nr, (uint32_t)(64 * j + __builtin_ctzll(notready)));
+                    if (incl) ni = min(ni, (uint32_t)(64 * j + __builtin_ctzll(incl)));
+                    if (dead) nd = min(nd, (uint32_t)(64 * j + __builtin_ctzll(dead)));
+                }
+                const uint32_t take = ni < nr ? ni + 1 : nr;                   // words that can be added now
+                if (nd < take) { state = 3; break; }
+                uint32_t part = 0;                                             // the counts: each below 2^17
+#pragma unroll
+                for (int j = 0; j < LBW; j++) {
+                    const uint32_t p = 64 * j + lane;
+                    part += (p < take && p != ni) ? (uint32_t)(v[j] & LB_VAL) : 0u;
+                }
+                part = wave_iscan32(part);
+                excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
+                if (ni < nr) {
+                    uint64_t t = 0;
+#pragma unroll
+                    for (int j = 0; j < LBW; j++) t = (64 * j + lane == ni) ? v[j] : t;
+                    const int src = __builtin_amdgcn_readfirstlane((int)(ni & 63));
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, src);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), src);
+                    excl += (((uint64_t)hi << 32) | lo) & LB_VAL;
+                    state = 2;
+                } else {
+                    base -= take;             // (take >= 1: the nearest word was there)
+                }
+            }
+            if (lane == 0) {
+                lb_store(&lb[chunk], (state == 3 ? 3ull << 62 : 2ull << 62) | ((excl + total) & LB_VAL));
+                wsum[40] = (uint32_t)excl; wsum[41] = (uint32_t)(excl >> 32); wsum[42] = state;
+            }
+        }
+        __syncthreads();
+        const uint64_t excl = ((uint64_t)wsum[41] << 32) | wsum[40];
+        if (wsum[42] == 3 && tid == 0) lb[nchunks] = 1;          // abort flag: enc_seam_kernel hands it to the host
+        // ---- what waited for the offset: index positions, the offset table of the seam pass, the stream itself
+        if (seg != ~0u) a.idx.bitpos[seg] = excl + pos;
+        if (tid == 0) {
+            a.chunk_off[chunk] = excl;
+            if (chunk == nchunks - 1) a.group_sum[(nchunks + SCAN_GROUP - 1) / SCAN_GROUP] = excl + total;
+        }
+        {
+            const uint64_t G0 = (uint64_t)a.out_bit0 + excl;
+            const uint32_t phase = (uint32_t)G0 & 31, sh = (32 - phase) & 31;
+            const uint32_t nd = (phase + total + 31) >> 5, tailbits = (phase + total) & 31;
+            uint32_t *gout = a.out32 + (G0 >> 5);
+            // four output dwords a lane (one 16-byte store); dwords shared with a neighbouring chunk go to the seam table
+            for (uint32_t d0 = 4 * tid; d0 < nd; d0 += 1024) {
+                const uint4 c4 = *(const uint4 *)(outbuf + d0);            // (the buffer is zero behind the chunk's last dword)
+                const uint32_t prv = d0 ? outbuf[d0 - 1] : 0u;
+                uint32_t v[4] = { c4.x, c4.y, c4.z, c4.w };
+                if (phase) {
+                    v[3] = __builtin_amdgcn_alignbit(c4.w, c4.z, sh); v[2] = __builtin_amdgcn_alignbit(c4.z, c4.y, sh);
+                    v[1] = __builtin_amdgcn_alignbit(c4.y, c4.x, sh); v[0] = __builtin_amdgcn_alignbit(c4.x, prv, sh);
+                }
+                if (d0 > 0 && d0 + 4 < nd) {
+                    const u32x4_a4 t = { v[0], v[1], v[2], v[3] };
+                    *(u32x4_a4 *)(gout + d0) = t;
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t d = d0 + k;
+                        if (d < nd) {
+                            const bool shared = (d == 0 && phase) || (d == nd - 1 && tailbits);
+                            if (!shared) gout[d] = v[k];
+                            if (d == 0) a.seams[2 * chunk] = v[k];
+                            if (d == nd - 1) a.seams[2 * chunk + 1] = v[k];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // the buffer of the next chunk (its first bits are written two barriers from here)
+            for (uint32_t d = tid; d < (nd + 4) / 4 && d < a0.slot_dw / 4; d += 256) ((uint4 *)outbuf)[d] = make_uint4(0, 0, 0, 0);
+        }
+        q = qn; tile = ntile; chunk = nchunk; valid = nvalid; payload = npayload; gblk = ngblk;
+    }
+}
+
 // dispatch over the compile-time parameters
 template <int B, bool RGB>
 static void launch_enc_px_b(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
+    if (a.single_pass || plan.persistent) {
+        // persistent grid: every workgroup must be resident (look-back waits on lower chunks only, and those belong to
+        // workgroups of the same grid): what the occupancy query admits per CU, at most 8, times the CUs
+        auto launch = [&](auto kernel) {
+            static int per_cu = 0, cus = 0;
+            if (!per_cu) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { cus = 256; per_cu = 4; }
+                else {
+                    cus = prop.multiProcessorCount;
+                    int n = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, plan.lds_bytes) != hipSuccess || n < 1) n = 4;
+                    per_cu = n > 8 ? 8 : n;
+                }
+            }
+            const uint64_t nq = (uint64_t)plan.nchunks * a.ntiles, cap = (uint64_t)per_cu * cus;
+            hipLaunchKernelGGL(kernel, dim3((uint32_t)(nq < cap ? nq : cap)), dim3(256), plan.lds_bytes, st, a);
+        };
+        if (a.single_pass) {
+            if (!z && !step) launch(enc_px_sp_kernel<B, RGB, HILBERT, false, true>);
+            else if (!z && step) launch(enc_px_sp_kernel<B, RGB, HILBERT, true, true>);
+            else if (z && !step) launch(enc_px_sp_kernel<B, RGB, ZCURVE, false, true>);
+            else launch(enc_px_sp_kernel<B, RGB, ZCURVE, true, true>);
+        } else {
+            if (!z && !step) launch(enc_px_sp_kernel<B, RGB, HILBERT, false, false>);
+            else if (!z && step) launch(enc_px_sp_kernel<B, RGB, HILBERT, true, false>);
+            else if (z && !step) launch(enc_px_sp_kernel<B, RGB, ZCURVE, false, false>);
+            else launch(enc_px_sp_kernel<B, RGB, ZCURVE, true, false>);
+        }
+        return;
+    }
     dim3 grid(plan.nchunks, a.ntiles), block(256);
     if (!z && !step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, HILBERT, false>), grid, block, plan.lds_bytes, st, a);
     else if (!z && step) hipLaunchKernelGGL((enc_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_bytes, st, a);

@@ -38,7 +38,8 @@ const Tuning &tuning() {
         Tuning v;
         v.no_px = on("QB3_NO_PX");                   // generic kernels also where a lane-per-block kernel applies
         v.slow_index = on("QB3_SLOW_INDEX");         // index-less streams: the one-lane index rebuild instead of the walkers
-        v.no_single_pass = on("QB3_NO_SINGLE_PASS"); // 8-bit lane-per-block encoder: slots + concatenate instead of look-back
+        v.single_pass = on("QB3_SINGLE_PASS");       // 8-bit lane-per-block encoder: look-back and in-place writes instead of slots + concatenate (measured slower)
+        v.persistent = on("QB3_PERSISTENT");         // 8-bit lane-per-block encoder: persistent workgroups instead of a workgroup per chunk (measured slower)
         return v;
     }();
     return t;
@@ -187,8 +188,8 @@ uint32_t max_unit_bits(uint32_t tsz, uint32_t mode) {
 }
 
 // encoder workspace layout (all 8-byte aligned), EncResult last
-struct EncWs { size_t bits, off, gsum, seams, scratch, cwhas, cwval, centry, cfflag, res, total; uint32_t slot_dw, ngroups; };
-static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, uint32_t threads) {
+struct EncWs { size_t bits, off, gsum, lookback, seams, scratch, cwhas, cwval, centry, cfflag, res, total; uint32_t slot_dw, ngroups; };
+static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, uint32_t threads, bool with_slots = true) {
     EncWs w;
     // a multiple of 4 dwords: slots are 16-byte aligned (the px kernel copies them out as uint4)
     w.slot_dw = (uint32_t)(((31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1 + 3) & ~(size_t)3);
@@ -197,9 +198,10 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, ui
     w.bits = o; o += align8(4 * (size_t)nchunks);
     w.off = o; o += 8 * (size_t)nchunks;
     w.gsum = o; o += 8 * ((size_t)w.ngroups + 1);
+    w.lookback = o; o += 8 * ((size_t)nchunks + 1);        // (right behind gsum: the single-pass encoder zeroes both with one memset)
     w.seams = o; o += 8 * (size_t)nchunks;
     o = (o + 15) & ~(size_t)15;
-    w.scratch = o; o += align8(4 * (size_t)nchunks * w.slot_dw);
+    w.scratch = o; o += with_slots ? align8(4 * (size_t)nchunks * w.slot_dw) : 0;      // (the single-pass encoder has no slots)
     const size_t nb = g.mode == CM_BEST ? (size_t)nchunks * g.bands : 0;
     w.cwhas = o; o += align8(nb);
     w.cwval = o; o += 8 * nb;
@@ -244,16 +246,19 @@ static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *
     return ident || def;
 }
 
-EncPlan plan_encode(const Geometry &g) {
+EncPlan plan_encode(const Geometry &g, bool allow_single_pass) {
     EncPlan p;
     const uint32_t dpr = g.bands * g.tsz;
     p.px = px_eligible(g, &p.px_rgb);
     p.px16 = false; p.px16_bg = p.px16_ng = 0;
+    p.single_pass = p.persistent = false;
     if (p.px) {
+        p.single_pass = allow_single_pass && tuning().single_pass;
+        p.persistent = tuning().persistent;
         p.threads = 256; p.slots = 256; p.nbp = 255;
         p.nchunks = (uint32_t)((g.nblocks + 254) / 255);
-        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp, p.threads);
-        p.lds_bytes = 2048 + 256 + 4 * (size_t)L.slot_dw;
+        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp, p.threads, !p.single_pass);
+        p.lds_bytes = 2048 + 256 + 4 * (size_t)L.slot_dw + 16;      // (+16: the single-pass write-out reads whole 16-byte groups)
         p.ws_bytes = L.total;
         return p;
     }
@@ -281,7 +286,15 @@ EncPlan plan_encode(const Geometry &g) {
 
 static int launch_encode_all(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     if (a.g.mode == CM_BEST) launch_enc_best(a, plan, st);
-    else if (plan.px && a.g.tsz == 1) { ProfScope ps("enc_units", st); launch_enc_px(a, plan, st); }
+    else if (plan.px && a.g.tsz == 1) {
+        if (a.single_pass) {        // the look-back words, the abort flag behind them, the (unused) group sums in front: zero per launch
+            const size_t bytes = 8 * ((size_t)(plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP + 1) + 8 * ((size_t)plan.nchunks + 1);
+            if (a.ntiles > 1) HIPCHK(hipMemset2DAsync(a.group_sum, a.ts_ws, 0, bytes, a.ntiles, st));
+            else HIPCHK(hipMemsetAsync(a.group_sum, 0, bytes, st));
+        }
+        ProfScope ps("enc_units", st);
+        launch_enc_px(a, plan, st);
+    }
     else if (plan.px16 && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0) { ProfScope ps("enc_units", st); launch_enc_px16(a, plan, st); }
     else { ProfScope ps("enc_units", st); launch_enc_generic(a, plan, st); }
     launch_enc_post(a, plan, st);
@@ -303,12 +316,14 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
     a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
     uint8_t *w = (uint8_t *)ws;
-    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp, plan.threads);
+    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp, plan.threads, !(plan.px && plan.single_pass));
     a.chunk_bits = (uint32_t *)(w + L.bits);
     a.chunk_off = (uint64_t *)(w + L.off);
     a.group_sum = (uint64_t *)(w + L.gsum);
     a.seams = (uint32_t *)(w + L.seams);
     a.scratch = (uint32_t *)(w + L.scratch);
+    a.lookback = (uint64_t *)(w + L.lookback);
+    a.single_pass = plan.px && plan.single_pass && g.tsz == 1 && g.mode != CM_BEST;
     a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry); a.cf_flag = w + L.cfflag;
     a.slot_dw = L.slot_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);

@@ -151,6 +151,7 @@ struct encs {
     qb3_dtype type;
     bool away;
     bool ix_chunk;          // qb3x_set_encoder_index_chunk: embed the restart table ("ix" chunks)
+    bool no_single_pass;    // the single-pass encoder gave up once on this handle: slots + concatenation from then on
     DevBuf d_img, d_out, d_ws, d_q, d_idx;
     Stager stager;
 };
@@ -217,7 +218,8 @@ QB3_API encsp qb3_create_encoder(size_t w, size_t h, size_t b, qb3_dtype dt) {
     encs *p = new encs();
     p->xsize = w; p->ysize = h; p->nbands = b; p->type = dt;
     p->stride = 0; p->order = 0; p->quanta = 1; p->away = false; p->mode = QB3M_DEFAULT; p->error = 0;
-    { const char *e = getenv("QB3X_INDEX_CHUNK"); p->ix_chunk = e && atoi(e) != 0; }     // for callers that only know the reference API
+    { const char *e = getenv("QB3X_INDEX_CHUNK"); p->ix_chunk = e && atoi(e) != 0; }
+    p->no_single_pass = false;     // for callers that only know the reference API
     for (size_t c = 0; c < QB3_MAXBANDS; c++) p->cband[c] = c < b ? c : 0;
     if (b == 3 || b == 4) p->cband[0] = p->cband[2] = 1;
     qb3_reset_encoder(p);
@@ -399,7 +401,7 @@ static size_t stored_encode_host(encsp p, const void *source, void *destination)
 static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, uint8_t *d_out, size_t hdr,
                                  void *d_index, hipStream_t st, bool carry, uint64_t *bits, const uint8_t *hdrbytes,
                                  size_t hdr_stamp, const IxTable &ix) {
-    EncPlan plan = plan_encode(g);
+    EncPlan plan = plan_encode(g, !p->no_single_pass);
     if (!p->d_ws.ensure(plan.ws_bytes)) return false;
     BandState bs;
     memset(&bs, 0, sizeof(bs));
@@ -414,6 +416,13 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
     prof_collect();
+    if (res.error && plan.single_pass) {
+        // the single-pass encoder gave up on a look-back wait (a workgroup of its grid was not resident: the occupancy
+        // query promised more than the device admitted).  Nothing is lost: code again through slots + concatenation,
+        // and keep doing so on this handle.
+        p->no_single_pass = true;
+        return encode_blocks_device(p, g, d_img, d_out, hdr, d_index, st, carry, bits, hdrbytes, hdr_stamp, ix);
+    }
     *bits = res.total_bits;
     if (carry)
         for (size_t c = 0; c < p->nbands; c++) {
@@ -618,8 +627,8 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
     uint8_t hdrbuf[64];
     const size_t hdr = write_headers(p, hdrbuf);
     Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, p->mode, p->cband, nullptr);
-    const EncPlan plan = plan_encode(g);
-    const size_t wsp = (plan.ws_bytes + 255) & ~(size_t)255;
+    EncPlan plan = plan_encode(g, !p->no_single_pass);
+    size_t wsp = (plan.ws_bytes + 255) & ~(size_t)255;
     size_t batch = (size_t)8 << 30 >= wsp ? ((size_t)8 << 30) / wsp : 1;     // keep the workspace under 8 GiB
     if (batch > n) batch = n;
     if (batch > 65535) batch = 65535;
@@ -640,6 +649,13 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("encode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
         prof_collect();
+        bool gave_up = false;
+        for (size_t i = 0; i < cnt; i++) gave_up = gave_up || (res[i].error && plan.single_pass);
+        if (gave_up) {          // see encode_blocks_device: the whole call again, through the slots
+            p->no_single_pass = true;
+            p->mode = mode;
+            return qb3x_encode_tiles(p, d_src, n, src_pitch, d_dst, dst_pitch, d_index, sizes, stream);
+        }
         const size_t raw = p->xsize * p->ysize * p->nbands * tsz;
         for (size_t i = 0; i < cnt; i++) {
             const size_t len = hdr + (size_t)((res[i].total_bits + 7) / 8);

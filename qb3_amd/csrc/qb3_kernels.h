@@ -203,6 +203,8 @@ struct EncArgs {
     uint64_t *cw_val;       //   ... and with what (cf - 2)
     uint64_t *centry;       //   ... factor state on entering the chunk (after best_scan_kernel)
     uint8_t *cf_flag;       //   ... per chunk and lane: the unit has a common factor (pass 0 -> pass 1)
+    uint64_t *lookback;     // single-pass encoder: per chunk {state, bit count} words, then the abort flag (zeroed per launch)
+    uint32_t single_pass;   // the chunks were written in place: no scan, no concatenation, index positions are final
     uint32_t ntiles;
     uint64_t ts_img, ts_out, ts_ws, ts_idx;     // batched tiles: byte strides from tile to tile (blockIdx.y = tile)
     uint32_t hdr_len;       // container header bytes to put in front of the stream (write_header_kernel)
@@ -229,7 +231,7 @@ __device__ __forceinline__ EncArgs enc_for_tile(EncArgs a, uint32_t t) {
         const uint64_t w = t * a.ts_ws, x = t * a.ts_idx;
         a.chunk_bits = shift_ptr(a.chunk_bits, w); a.chunk_off = shift_ptr(a.chunk_off, w); a.group_sum = shift_ptr(a.group_sum, w);
         a.scratch = shift_ptr(a.scratch, w); a.seams = shift_ptr(a.seams, w); a.res = shift_ptr(a.res, w);
-        a.cw_has = shift_ptr(a.cw_has, w); a.cw_val = shift_ptr(a.cw_val, w); a.centry = shift_ptr(a.centry, w); a.cf_flag = shift_ptr(a.cf_flag, w);
+        a.cw_has = shift_ptr(a.cw_has, w); a.cw_val = shift_ptr(a.cw_val, w); a.centry = shift_ptr(a.centry, w); a.cf_flag = shift_ptr(a.cf_flag, w); a.lookback = shift_ptr(a.lookback, w);
         a.idx.bitpos = shift_ptr(a.idx.bitpos, x); a.idx.prev = shift_ptr(a.idx.prev, x); a.idx.cf = shift_ptr(a.idx.cf, x);
         a.idx.rung = shift_ptr(a.idx.rung, x); a.idx.ulen = shift_ptr(a.idx.ulen, x);
     }
@@ -519,7 +521,7 @@ struct ProfScope {
 };
 
 // process-wide debugging switches, read once from the environment (k_host.hip)
-struct Tuning { bool no_px; bool slow_index; bool no_single_pass; };
+struct Tuning { bool no_px; bool slow_index; bool single_pass; bool persistent; };
 const Tuning &tuning();
 
 uint32_t magic_div(uint32_t d);

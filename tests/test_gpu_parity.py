@@ -790,3 +790,50 @@ def test_handles_are_independent_across_threads(qb3, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("switch", ["QB3_SINGLE_PASS", "QB3_PERSISTENT", "QB3_NO_PX", "QB3_SLOW_INDEX"])
+def test_alternative_kernel_paths(qb3, oracle, switch, tmp_path):
+    """the paths that are not the default -- the single-pass (look-back) and the persistent 8-bit encoders, the generic
+    kernels on rasters the lane-per-block kernels would take, the one-lane index rebuild -- give the same bytes and pixels.
+    (The switches are read once per process: a child process each.)"""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import qb3_amd
+from qb3_amd import synth, device as qdev
+from oracle import pyoracle as o
+for (w, h, b, dt, gen, seed, mode) in [(1024, 1024, 3, 0, "NOISY3", 2, 8), (509, 259, 3, 0, "NOISY3", 1, 4), (768, 512, 1, 0, "GRAD", 0, 8),
+                                       (640, 384, 4, 0, "RANDOM", 5, 8), (512, 256, 8, 2, "LANDSAT16", 3, 4)]:
+    img = synth.generate(w, h, b, dt, gen, seed)
+    ref = o.encode(o.generate(w, h, b, dt, gen, seed), dt, mode)
+    enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode)
+    for rep in range(3):
+        dst, n, index = enc.encode(img)
+        assert n == len(ref) and np.array_equal(dst[:n].cpu().numpy(), ref), (w, h, b, rep)
+    dec = qdev.DeviceDecoder(dst, n)
+    raw = img.reshape(-1).view(torch.uint8)
+    if ref[10] != 255:
+        assert torch.equal(dec.decode(dst, index=index), raw) and torch.equal(dec.decode(dst, index=None), raw)
+# a batch of tiles through the same paths
+import ctypes as C
+L = qb3_amd.lib
+w, h, b, n = 256, 192, 3, 5
+imgs = torch.stack([synth.generate(w, h, b, 0, "NOISY3", 3000 + t) for t in range(n)])
+p = L.qb3_create_encoder(w, h, b, 0)
+pitch = (L.qb3_max_encoded_size(p) + 3) // 4 * 4
+dst = torch.zeros(n * pitch, dtype=torch.uint8, device="cuda")
+sizes = (C.c_size_t * n)()
+assert L.qb3x_encode_tiles(p, imgs.data_ptr(), n, w * h * b, dst.data_ptr(), pitch, None, sizes, None) == n
+host = dst.cpu().numpy()
+for t in range(n):
+    ref = o.encode(imgs[t].cpu().numpy(), 0, 8)
+    assert sizes[t] == len(ref) and np.array_equal(host[t * pitch:t * pitch + sizes[t]], ref), t
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env[switch] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
