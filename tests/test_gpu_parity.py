@@ -837,3 +837,112 @@ print("ok")
     env[switch] = "1"
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("case", [(1100, 700, 3, 0, 256, []), (1024, 512, 1, 0, 512, ["-b"]), (600, 300, 3, 2, 128, ["-f"])],
+                         ids=lambda c: "%dx%dx%d-t%d-tile%d%s" % (c[0], c[1], c[2], c[3], c[4], "".join(c[5])))
+def test_tile_batcher_tool(qb3, oracle, tmp_path, case):
+    """tools/qb3tiles.cpp, the GDAL-MRF-style caller of qb3x_encode_tiles / qb3x_decode_tiles: a raster cut into tiles,
+    every tile the container qb3_encode writes for it (the reference's per-tile calling pattern: README.md:30-31,
+    cqb3.cpp:614-641), edge tiles padded by replication, the raster back exactly"""
+    import subprocess
+    w, h, b, dt, T, flags = case
+    tool = os.path.join(os.path.dirname(qb3.LIB_PATH), "qb3tiles")
+    gen = "NOISY3" if dt == 0 else "LANDSAT16"
+    img = oracle.generate(w, h, b, dt, gen, 7)
+    pnm = tmp_path / "in.pnm"
+    body = img.astype(">u2").tobytes() if dt == 2 else img.tobytes()
+    pnm.write_bytes(b"P%c\n%d %d\n%d\n" % (b"56"[b == 3], w, h, 255 if dt == 0 else 65535) + body)
+    r = subprocess.run([tool, "-e", "-v", "-t", str(T), *flags, str(pnm), str(tmp_path / "out.qts")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = np.fromfile(tmp_path / "out.qts", dtype=np.uint8)
+    assert bytes(f[:4]) == b"QTS1"
+    hw = f[4:32].view(np.uint32)
+    assert list(hw[:5]) == [w, h, b, dt, T]
+    tx, ty = int(hw[5]), int(hw[6])
+    assert (tx, ty) == ((w + T - 1) // T, (h + T - 1) // T)
+    tab = f[32:32 + 16 * tx * ty].view(np.uint64).reshape(-1, 2)
+    mode = 7 if "-b" in flags else 8
+    for k in (0, tx - 1, tx * ty - 1):          # an inner tile, the last column (padded), the last tile (padded both ways)
+        j, i = divmod(k, tx)
+        ys = np.minimum(np.arange(j * T, j * T + T), h - 1)
+        xs = np.minimum(np.arange(i * T, i * T + T), w - 1)
+        tile = np.ascontiguousarray(img[ys][:, xs])
+        want = oracle.encode(tile, dt, mode)
+        off, size = int(tab[k, 0]), int(tab[k, 1])
+        assert size == len(want) and np.array_equal(f[off:off + size], want), "tile %d" % k
+        r = subprocess.run([tool, "-x", str(tmp_path / "out.qts"), str(k), str(tmp_path / "t.qb3")], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "t.qb3", dtype=np.uint8), want)
+    r = subprocess.run([tool, "-d", "-v", str(tmp_path / "out.qts"), str(tmp_path / "back.pnm")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    back = (tmp_path / "back.pnm").read_bytes()
+    hdr = b"P%c\n%d %d\n%d\n" % (b"56"[b == 3], w, h, 255 if dt == 0 else 65535)
+    assert back.startswith(hdr)
+    px = np.frombuffer(back[len(hdr):], dtype=np.uint8)
+    if dt == 2:
+        px = px.view(">u2").astype("<u2").view(np.uint8)
+    assert np.array_equal(px, img.view(np.uint8).ravel())
+
+
+def test_config5_one_rank_batch(qb3, oracle):
+    """BASELINE.json configs[4], one rank's share: 32 tiles of 4096 x 4096 x 3 (NOISY3, seeds 1000..1031) through ONE
+    qb3x_encode_tiles call and ONE qb3x_decode_tiles call; tiles 1000 and 1001 are the reference's containers byte for
+    byte (size and FNV-1a64 of SURVEY.md Appendix C), every tile comes back exactly, with the index and without"""
+    import torch
+    from qb3_amd import synth, device as qdev
+    rows = {a["seed"]: a for a in anchors() if a["cfg"] == "5"}
+    n, w = 32, 4096
+    imgs = torch.stack([synth.generate(w, w, 3, 0, "NOISY3", 1000 + t) for t in range(n)])
+    tc = qdev.TileBatchCoder(w, w, 3, 0, n)
+    sizes = tc.encode(imgs)
+    for t in (0, 1):
+        a = rows[1000 + t]
+        host = tc.dst[t * tc.pitch:t * tc.pitch + sizes[t]].cpu().numpy()
+        assert sizes[t] == a["size"] and qb3.fnv(host) == a["fnv_stream"]
+    assert len(set(sizes)) > 8                  # thirty-two different streams, not one stream thirty-two times
+    out = torch.empty_like(imgs)
+    for use_index in (True, False):
+        out.zero_()
+        tc.decode(out, use_index=use_index)
+        assert torch.equal(out, imgs)
+
+
+@pytest.mark.parametrize("mode", [4, 7], ids=["BASE", "BEST"])
+@pytest.mark.parametrize("away", [False, True])
+@pytest.mark.parametrize("q", [2, 3, 4, 10])
+def test_quanta_all_modes(qb3, oracle, q, away, mode):
+    """the reference's own matrix: quanta 2/3/4/10 x away x BASE/BEST on 8-bit data (test_qb3.cpp:643-660): same
+    container as the CPU path, decode within q/2 of the input"""
+    img = oracle.generate(253, 131, 3, 0, "NOISY3", 11)
+    want = oracle.encode(img, 0, mode, quanta=q, away=away)
+    got = qb3.encode(img, 0, mode, quanta=q, away=away)
+    assert np.array_equal(got, want)
+    out, dims, _, _ = qb3.decode(got)
+    ref, _, _, _ = oracle.decode(want, identity=True)
+    assert np.array_equal(out, ref)
+    err = np.abs(out.astype(np.int32) - img.ravel().astype(np.int32))
+    assert err.max() <= q // 2 + (q % 2 == 0 and not away) * 0 + 1 and (np.abs(out.astype(np.int32) - np.clip(img.ravel().astype(np.int32), 0, (255 // q) * q + q)) <= q).all()
+
+
+@pytest.mark.parametrize("case", [(2, 5), (2, 1 << 8), (5, 5), (5, 1 << 8), (5, 1 << 24), (7, 5), (7, 1 << 24), (7, 1 << 56), (6, 1 << 56)],
+                         ids=lambda c: "t%d-x%d" % c)
+def test_common_factor_data_in_best_mode(qb3, oracle, case):
+    """the reference's "common factor" inputs (test_qb3.cpp:675-686): values multiplied by 5, 2^8, 2^24, 2^56 on 16-,
+    32- and 64-bit types, QB3M_BEST -- same container as the CPU path, exact round trip, device and host flavour"""
+    import torch
+    from qb3_amd import device as qdev
+    dt, mul = case
+    base = oracle.generate(192, 160, 1, 0, "NOISY3", 21).astype(np.int64)       # small values: the product fits the type
+    img = (base * mul).astype(oracle.NPTYPE[dt])
+    for mode in (7, 5):
+        want = oracle.encode(img, dt, mode)
+        got = qb3.encode(img, dt, mode)
+        assert np.array_equal(got, want)
+        out, _, _, _ = qb3.decode(got)
+        assert np.array_equal(out, img.view(np.uint8).ravel())
+    dimg = torch.from_numpy(img.view(np.uint8)).cuda()
+    enc = qdev.DeviceEncoder(192, 160, 1, dt, mode=7)
+    dst, n, index = enc.encode(dimg)
+    assert n == len(want if False else oracle.encode(img, dt, 7)) and np.array_equal(dst[:n].cpu().numpy(), oracle.encode(img, dt, 7))
+    dec = qdev.DeviceDecoder(dst, n)
+    assert torch.equal(dec.decode(dst, index=index), dimg.reshape(-1)) and torch.equal(dec.decode(dst, index=None), dimg.reshape(-1))
