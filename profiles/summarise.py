@@ -26,9 +26,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # library profile names (qb3x_profile_names) by a substring of the kernel symbol
-KEYS = [("enc_px_kernel", "enc_units"), ("enc_kernel", "enc_units"), ("enc_best_kernel", "enc_best"), ("best_scan", "enc_best_scan"),
+KEYS = [("enc_px_sp_kernel", "enc_units"), ("enc_px_kernel", "enc_units"), ("enc_px16_kernel", "enc_units"), ("enc_kernel", "enc_units"),
+        ("enc_best_kernel<unsigned char, 0>", "enc_best_pass0"), ("enc_best_kernel<unsigned short, 0>", "enc_best_pass0"),
+        ("enc_best_kernel<unsigned int, 0>", "enc_best_pass0"), ("enc_best_kernel<unsigned long, 0>", "enc_best_pass0"),
+        ("enc_best_kernel", "enc_best_units"), ("best_scan", "enc_best_scan"),
         ("enc_scan2", "enc_scan2"), ("enc_scan", "enc_scan"), ("enc_concat", "enc_concat"), ("enc_seam", "enc_seams"),
-        ("write_header", "write_header"), ("dec_px_kernel", "dec_units"), ("dec3_kernel", "dec_units"),
+        ("write_header", "write_header"), ("ix_fill", "ix_fill"), ("dec_px_kernel", "dec_units"), ("dec_px16_kernel", "dec_units"), ("dec3_kernel", "dec_units"),
+        ("dec_walk_lanes", "dec_index_serial"), ("dec_walk_kernel", "dec_index_serial"), ("prev_scan", "dec_index_scan"),
         ("dec_index_serial", "dec_index_serial"), ("dec_kernel", "dec_segments")]
 
 
@@ -73,7 +77,10 @@ def pmc(d, counter):
 
 
 def main():
-    tag, trace_dir, fetch_dir, write_dir = sys.argv[1:5]
+    stats_only = sys.argv[1] == "--stats-only"
+    if stats_only:
+        sys.argv.pop(1)
+    tag, trace_dir = sys.argv[1:3]
     cmd = os.environ.get("PROFILE_CMD", "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline")
     stats = kernel_stats(trace_dir)
     with open(os.path.join(HERE, tag + "_kernel_stats.csv"), "w") as f:
@@ -81,6 +88,11 @@ def main():
         f.write("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs\n")
         for name, n, tot, avg, lo, hi in stats:
             f.write('"%s",%d,%d,%.1f,%d,%d\n' % (name, n, tot, avg, lo, hi))
+    if stats_only:
+        for name, n, tot, avg, lo, hi in stats:
+            print("%-28s calls %3d avg %9.1f us" % (key_of(name), n, avg / 1e3))
+        return
+    fetch_dir, write_dir = sys.argv[3:5]
     fetch, nf = pmc(fetch_dir, "FETCH_SIZE")
     write, _ = pmc(write_dir, "WRITE_SIZE")
     traffic = {}
