@@ -79,7 +79,21 @@ template <typename T> __device__ __forceinline__ uint32_t group_len(const T (&v)
     }
     return n;
 }
-template <typename T> __device__ __forceinline__ void put_group(LdsWriter &w, const T (&v)[16], uint32_t rung) {
+// etab: the LDS code table of rungs 1..7 (fill_enc_tab: length << 12 | code, middle swap applied), or null
+template <typename T> __device__ __forceinline__ void put_group(LdsWriter &w, const T (&v)[16], uint32_t rung, const uint16_t *etab = nullptr) {
+    if (etab && rung < 8) {
+        // below rung 8 every value is under 256: one table read per value, and three codes (at most 27 bits) to a write
+        // into the bit buffer instead of one each
+        const uint16_t *tab = etab + enc_tab_off(rung);
+        uint32_t acc = 0, al = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t e = tab[(uint32_t)v[i]];
+            acc |= (e & 0xfffu) << al; al += e >> 12;
+            if (i % 3 == 2 || i == 15) { w.put(acc, al); acc = 0; al = 0; }
+        }
+        return;
+    }
     const T top = (T)((T)1 << rung);
 #pragma unroll
     for (uint32_t i = 0; i < 16; i++) {
@@ -174,7 +188,13 @@ __device__ __forceinline__ void best_analyse(const T (&g)[16], uint32_t rung, ui
     const uint32_t szDiff = u.szBase + u.szCf, szSame = u.cf >= 2 ? u.szBase : u.szN;
     const bool try_idx = rung > 3 && rung < 63 && (u.cf >= 2 ? szDiff : szSame) >= thr;
     const uint32_t distinct = distinct_t<T>(g, rung, try_idx);
-    if (__any(try_idx && distinct <= 8)) {
+    // Can the index form win at all?  With n distinct values the index codes take at least 32 + max(n-2, 0) + max(n-4, 0)
+    // bits (every count beyond the first value's is 1) and the values at least n * rung: where that bound already
+    // reaches the size to beat, the exact size is not needed.  On noisy data this spares nearly every wave the sort.
+    const uint32_t idx_head = (UB + 2) + sw_noflag_len<UB>(UMASK - oldrung) + sw_noflag_len<UB>(rung - oldrung);
+    const uint32_t idx_floor = idx_head + 32 + (distinct > 2 ? distinct - 2 : 0) + (distinct > 4 ? distinct - 4 : 0) + distinct * rung;
+    const bool idx_may_win = try_idx && distinct <= 8 && idx_floor < (u.cf >= 2 ? szDiff : szSame);
+    if (__any(idx_may_win)) {
         // The size of the index form (QB3encode.h:557-613) without building it.  With the distinct values ranked by
         // descending count, a value of rank j costs cnt_j index codes of 2 + (j >= 2) + (j >= 4) bits (the plain rung-2
         // code) plus its own code at `rung`: the sum of the index codes is 64 - S2 - S4 with S2 / S4 the sum of the two /
@@ -211,8 +231,8 @@ __device__ __forceinline__ void best_analyse(const T (&g)[16], uint32_t rung, ui
                 run = 0;
             }
         }
-        const uint32_t bits = (UB + 2) + sw_noflag_len<UB>(UMASK - oldrung) + sw_noflag_len<UB>(rung - oldrung) + 64 - 2 * (c0 + c1) - (c2 + c3) + vbits;
-        if (try_idx && distinct <= 8) u.idx = bits;
+        const uint32_t bits = idx_head + 64 - 2 * (c0 + c1) - (c2 + c3) + vbits;
+        if (idx_may_win) u.idx = bits;
     }
     u.writer = u.cf >= 2 && !(szDiff >= thr && u.idx < szDiff);
 }
@@ -326,7 +346,7 @@ __global__ void enc_best_kernel(const EncArgs a0) {
         } else if (kind == 1) {
             w.put(cs_code<UB>((rung - oldrung) & UMASK), cs_len<UB>((rung - oldrung) & UMASK));
             apply_step<T>(g, rung);
-            put_group<T>(w, g, rung);
+            put_group<T>(w, g, rung, f.etab);
         } else if (kind == 2) {     // cfgenc, QB3encode.h:283-361
             T d[16];
 #pragma unroll
@@ -349,7 +369,7 @@ __global__ void enc_best_kernel(const EncArgs a0) {
 #pragma unroll
                 for (uint32_t i = 0; i < 16; i++) bits |= (uint32_t)(d[i] & 1) << i;
                 w.put(bits, 16);
-            } else { apply_step<T>(d, trung); put_group<T>(w, d, trung); }
+            } else { apply_step<T>(d, trung); put_group<T>(w, d, trung, f.etab); }
         } else {                    // ienc, QB3encode.h:557-613
             T val[8]; uint32_t cnt[8], n = 0;
 #pragma unroll 1
@@ -401,23 +421,44 @@ __global__ void enc_best_kernel(const EncArgs a0) {
     if (tid == 0) a.chunk_bits[chunk] = total;
 }
 
-// Carries the last factor writer across chunks: centry[k][c] = factor state on entering chunk k.  One workgroup per
-// band (blockIdx.x) and tile; "last non-empty" is a max-scan over (chunk index + 1); a thread owns 8 chunks in a row.
-__global__ void __launch_bounds__(1024) best_scan_kernel(const EncArgs a0) {
-    const EncArgs a = enc_for_tile(a0, blockIdx.y);
-    __shared__ uint32_t wsum[16];
+// Carries the last factor writer across chunks: centry[k][c] = factor state on entering chunk k.  "Last non-empty" is
+// a max-scan over (chunk index + 1).  The chunks are cut into BS_PARTS parts; PHASE 0: the last writer inside every
+// part (a max-reduction) -> part_last; PHASE 1: a part starts from the last writer of the parts before it and scans
+// its own chunks, a thread 8 chunks in a row.  grid = (parts, bands, tiles).
+constexpr uint32_t BS_PARTS = 32;
+template <int PHASE>
+__global__ void __launch_bounds__(256) best_scan_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.z);
+    __shared__ uint32_t wsum[4];
     __shared__ uint32_t carry;
     constexpr uint32_t PER = 8;
-    const uint32_t bands = a.g.bands, tid = threadIdx.x, c = blockIdx.x;
+    const uint32_t bands = a.g.bands, tid = threadIdx.x, c = blockIdx.y, part = blockIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
+    const uint32_t per_part = ((a.nchunks + BS_PARTS - 1) / BS_PARTS + 256 * PER - 1) / (256 * PER) * (256 * PER);
+    const uint32_t k_begin = min(a.nchunks, part * per_part), k_end = min(a.nchunks, k_begin + per_part);
+    uint32_t *part_last = a.centry_parts + (uint64_t)c * BS_PARTS;       // per band: BS_PARTS words
+    if (PHASE == 0) {
+        uint32_t m = 0;
+        for (uint32_t k = k_begin + tid; k < k_end; k += 256) m = a.cw_has[(uint64_t)k * bands + c] ? k + 1 : m;      // k ascends: the last one stays
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if (lane == 0) wsum[wave] = m;
+        __syncthreads();
+        if (tid == 0) part_last[part] = max(max(wsum[0], wsum[1]), max(wsum[2], wsum[3]));
+        return;
+    }
+    if (tid == 0) {
+        uint32_t m = 0;
+        for (uint32_t p = 0; p < part; p++) m = max(m, part_last[p]);
+        carry = m;
+    }
     __syncthreads();
-    for (uint32_t base = 0; base < a.nchunks; base += 1024 * PER) {
+    for (uint32_t base = k_begin; base < k_end; base += 256 * PER) {
         const uint32_t k0 = base + tid * PER;
         uint32_t has[PER], last = 0;                    // last writer (chunk index + 1) among the thread's chunks
 #pragma unroll
         for (uint32_t i = 0; i < PER; i++) {
-            has[i] = (k0 + i < a.nchunks && a.cw_has[(uint64_t)(k0 + i) * bands + c]) ? k0 + i + 1 : 0;
+            has[i] = (k0 + i < k_end && a.cw_has[(uint64_t)(k0 + i) * bands + c]) ? k0 + i + 1 : 0;
             last = has[i] ? has[i] : last;
         }
         uint32_t m = last;                              // inclusive max-scan over the threads
@@ -431,11 +472,11 @@ __global__ void __launch_bounds__(1024) best_scan_kernel(const EncArgs a0) {
         uint32_t run = max(before, lane ? up : 0u);     // last writer strictly before the thread's first chunk
 #pragma unroll
         for (uint32_t i = 0; i < PER; i++) {
-            if (k0 + i < a.nchunks) a.centry[(uint64_t)(k0 + i) * bands + c] = run ? a.cw_val[(uint64_t)(run - 1) * bands + c] : a0.st.cf[c];
+            if (k0 + i < k_end) a.centry[(uint64_t)(k0 + i) * bands + c] = run ? a.cw_val[(uint64_t)(run - 1) * bands + c] : a0.st.cf[c];
             run = has[i] ? has[i] : run;
         }
         __syncthreads();
-        if (tid == 1023) carry = max(before, m);
+        if (tid == 255) carry = max(before, m);
         __syncthreads();
     }
 }
@@ -449,7 +490,8 @@ static void launch_enc_best_t(const EncArgs &a, const EncPlan &plan, hipStream_t
     }
     {
         ProfScope ps("enc_best_scan", st);
-        hipLaunchKernelGGL(best_scan_kernel, dim3(a.g.bands, a.ntiles), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(best_scan_kernel<0>, dim3(BS_PARTS, a.g.bands, a.ntiles), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(best_scan_kernel<1>, dim3(BS_PARTS, a.g.bands, a.ntiles), dim3(256), 0, st, a);
     }
     ProfScope ps("enc_best_units", st);
     hipLaunchKernelGGL((enc_best_kernel<T, 1>), grid, block, plan.lds_bytes, st, a);

@@ -188,7 +188,7 @@ uint32_t max_unit_bits(uint32_t tsz, uint32_t mode) {
 }
 
 // encoder workspace layout (all 8-byte aligned), EncResult last
-struct EncWs { size_t bits, off, gsum, lookback, seams, scratch, cwhas, cwval, centry, cfflag, res, total; uint32_t slot_dw, ngroups; };
+struct EncWs { size_t bits, off, gsum, lookback, seams, scratch, cwhas, cwval, centry, cparts, cfflag, res, total; uint32_t slot_dw, ngroups; };
 static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, uint32_t threads, bool with_slots = true) {
     EncWs w;
     // a multiple of 4 dwords: slots are 16-byte aligned (the px kernel copies them out as uint4)
@@ -206,6 +206,7 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, ui
     w.cwhas = o; o += align8(nb);
     w.cwval = o; o += 8 * nb;
     w.centry = o; o += 8 * nb;
+    w.cparts = o; o += g.mode == CM_BEST ? 4 * 32 * (size_t)MAXBANDS : 0;
     w.cfflag = o; o += g.mode == CM_BEST ? align8((size_t)nchunks * threads) : 0;
     w.res = o; o += sizeof(EncResult);
     w.total = o;
@@ -324,7 +325,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.scratch = (uint32_t *)(w + L.scratch);
     a.lookback = (uint64_t *)(w + L.lookback);
     a.single_pass = plan.px && plan.single_pass && g.tsz == 1 && g.mode != CM_BEST;
-    a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry); a.cf_flag = w + L.cfflag;
+    a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry); a.cf_flag = w + L.cfflag; a.centry_parts = (uint32_t *)(w + L.cparts);
     a.slot_dw = L.slot_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.src_pitch & 3);
