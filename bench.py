@@ -42,7 +42,7 @@ ANCHORS = {                 # reference containers, SURVEY.md Appendix C: (size,
     "c4_i32_best": (16413700, "cd51ae557cfbb14f"), "c4_i64_best": (16426177, "62e44ea20713d272"),
     "c5_tile1000": (27171401, "8e91222e70136a30"), "c5_tile1001": (27171735, "4e40f05b13367ea8"),
 }
-ENC_KERNELS = ("enc_units", "enc_best_pass0", "enc_best_scan", "enc_best_units", "enc_scan", "enc_concat", "enc_seams")
+ENC_KERNELS = ("enc_units", "enc_best_units", "enc_best_scan", "enc_best_recode", "enc_scan", "enc_concat", "enc_seams")
 DEC_KERNELS = ("dec_index_serial", "dec_index_prev", "dec_index_scan", "dec_segments", "dec_units")
 
 

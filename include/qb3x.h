@@ -95,7 +95,7 @@ size_t qb3_decode(decsp p, void *destination);                                  
 
 /* Per-kernel timing for benchmarks: when enabled, every kernel the library launches is bracketed by HIP
  * events on the launch stream; totals are resolved at the library's own synchronisation points.
- * Kernel names: enc_units, enc_scan, enc_concat, enc_seams, enc_best_pass0, enc_best_scan, enc_best_units,
+ * Kernel names: enc_units, enc_scan, enc_concat, enc_seams, enc_best_units, enc_best_scan, enc_best_recode,
  * dec_index_serial, dec_index_prev, dec_index_scan, dec_units, dec_segments.
  * level: 0 off, 1 every kernel, 2 all but the microsecond kernels (enc_scan, enc_seams, enc_best_scan), whose two
  * events cost more than they take. */

@@ -27,8 +27,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 # library profile names (qb3x_profile_names) by a substring of the kernel symbol
 KEYS = [("enc_px_sp_kernel", "enc_units"), ("enc_px_kernel", "enc_units"), ("enc_px16_kernel", "enc_units"), ("enc_kernel", "enc_units"),
-        ("enc_best_kernel<unsigned char, 0>", "enc_best_pass0"), ("enc_best_kernel<unsigned short, 0>", "enc_best_pass0"),
-        ("enc_best_kernel<unsigned int, 0>", "enc_best_pass0"), ("enc_best_kernel<unsigned long, 0>", "enc_best_pass0"),
+        ("enc_best_kernel<unsigned char, false>", "enc_best_recode"), ("enc_best_kernel<unsigned short, false>", "enc_best_recode"),
+        ("enc_best_kernel<unsigned int, false>", "enc_best_recode"), ("enc_best_kernel<unsigned long, false>", "enc_best_recode"),
         ("enc_best_kernel", "enc_best_units"), ("best_scan", "enc_best_scan"),
         ("enc_scan2", "enc_scan2"), ("enc_scan", "enc_scan"), ("enc_concat", "enc_concat"), ("enc_seam", "enc_seams"),
         ("write_header", "write_header"), ("ix_fill", "ix_fill"), ("dec_px_kernel", "dec_units"), ("dec_px16_kernel", "dec_units"), ("dec3_kernel", "dec_units"),

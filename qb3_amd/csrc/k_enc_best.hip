@@ -8,8 +8,9 @@ namespace qb3dev {
 // plainly, as common factor times a smaller group, or as up to eight distinct values plus indices.  The only
 // state besides the rung is pcf, the previous factor of the band.  A unit overwrites pcf with cf-2 exactly when
 // cf >= 2 and index coding does not beat the "factor differs" size -- a condition that does not involve pcf
-// itself -- so pcf is a LAST-WRITER scan over units: pass 0 records each chunk's last writer per band,
-// best_scan_kernel carries it across chunks, pass 1 codes with the right pcf.
+// itself -- so pcf is a LAST-WRITER scan over units.  The chunks are coded ONCE assuming the starting state on entry,
+// each leaving its last writer per band; best_scan_kernel carries the writers across chunks and lists the chunks whose
+// assumption was wrong and mattered; those are coded again (on data without common factors: none).
 // x mod y and x / y for magnitudes.  8- and 16-bit data: through the float reciprocal (exact after one correction step:
 // both operands are below 2^16); wider data: the integer operations.
 template <typename T> __device__ __forceinline__ T mod_t(T x, T y) {       // y != 0
@@ -262,56 +263,57 @@ __device__ __forceinline__ bool writers_find(const WriterBoard &wb, uint32_t ban
     return false;
 }
 
-template <typename T, int PASS>
-__global__ void enc_best_kernel(const EncArgs a0) {
-    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+// One chunk.  FIRST: the pass over all chunks, each assuming that the band's factor on entering the chunk is the state
+// the image starts with; it also leaves the chunk's summary (its last factor writer per band, and whether anything in
+// it depended on the entering factor).  !FIRST: a chunk coded again with its true entering factor (best_scan_kernel
+// lists the chunks whose assumption was wrong AND mattered: on data without common factors, none).
+template <typename T, bool FIRST>
+__device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, uint8_t *smem, uint32_t chunk, bool summary_only) {
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-    const uint32_t bands = a.g.bands, nblocks = (uint32_t)a.g.nblocks, slots = a.slots, nunits = slots * bands;
+    const uint32_t bands = a.g.bands, nblocks = (uint32_t)a.g.nblocks, slots = a.slots;
     T g[16];
     EncFront<T> f;
     const uint32_t outdw = a.slot_dw;
-    enc_front<T>(a, a0, smem, PASS ? outdw : 0, f, g);
-    const uint32_t c = f.c, gblk = f.gblk, rung = f.rung, chunk = f.chunk;
+    enc_front<T>(a, a0, smem, outdw, f, g, chunk);
+    const uint32_t c = f.c, gblk = f.gblk, rung = f.rung;
     const bool payload = f.payload;
     const T used = f.used;
     WriterBoard wb;
-    wb.vals = (uint64_t *)(f.outbuf + ((outdw + 1) & ~1u));     // nthr values, then one mask per wave
+    wb.vals = (uint64_t *)(f.outbuf + ((outdw + 1) & ~1u));     // nthr values, then one mask per wave, then a "used the entry state" word per band
     wb.masks = wb.vals + nthr;
+    uint32_t *used_entry = (uint32_t *)(wb.masks + 16);
+    if (FIRST && tid < bands) used_entry[tid] = 0;
 
-    // pass 0 leaves one byte per unit: does it have a common factor at all?  (Pass 1 then runs the gcd only where a
-    // lane of the wave needs it: on noisy data nowhere.)
-    uint8_t *cfflag = a.cf_flag + (uint64_t)chunk * nthr;
     uint32_t oldrung = 0;
     BestUnit<T> u;
     u.writer = false; u.cf = 1; u.szN = u.szBase = u.szCf = 0; u.idx = 0xffffffffu; u.trung = 0;
     const bool analyse = payload && used > 1;
     if (payload) oldrung = (gblk == 0) ? a0.st.rung[c] : f.rungs[tid - bands];
     {
-        const bool want_gcf = analyse && (PASS == 0 || cfflag[tid] != 0);
         T cf = 1;
-        if (__any(want_gcf)) cf = gcf_t<T>(g, want_gcf);
-        if (PASS == 0) cfflag[tid] = (uint8_t)(cf >= 2);
-        if (analyse) best_analyse<T>(g, rung, oldrung, cf, PASS == 0, u);
+        if (__any(analyse)) cf = gcf_t<T>(g, analyse);
+        if (analyse) best_analyse<T>(g, rung, oldrung, cf, summary_only, u);
     }
     // who wrote the band's factor last
-    (void)nunits;
     writers_publish(wb, payload && u.writer, (uint64_t)(T)(u.cf - 2));
-    if (PASS == 0) {
-        // chunk summary: the last writer of each band among all the chunk's units
-        if (tid < bands) {
-            uint64_t v = 0;
-            const bool has = writers_find(wb, bands, tid, (int32_t)(slots * bands) - 1, &v);
-            a.cw_has[(uint64_t)chunk * bands + tid] = (uint8_t)has; a.cw_val[(uint64_t)chunk * bands + tid] = v;
-        }
-        return;
+    if (FIRST && tid < bands) {         // chunk summary: the last writer of each band among all the chunk's units
+        uint64_t v = 0;
+        const bool has = writers_find(wb, bands, tid, (int32_t)(slots * bands) - 1, &v);
+        a.cw_has[(uint64_t)chunk * bands + tid] = (uint8_t)has; a.cw_val[(uint64_t)chunk * bands + tid] = v;
     }
+    if (FIRST && summary_only) return;   // (workgroup uniform)
     // factor state entering this unit: the last writer before it in the chunk, else the chunk's entry state
-    T pcf = (T)a.centry[(uint64_t)chunk * bands + c];
+    T pcf = FIRST ? (T)a0.st.cf[c] : (T)a.centry[(uint64_t)chunk * bands + c];
     {
         uint64_t v = 0;
-        if (payload && writers_find(wb, bands, c, (int32_t)tid - 1, &v)) pcf = (T)v;
+        const bool mine = payload && writers_find(wb, bands, c, (int32_t)tid - 1, &v);
+        if (mine) pcf = (T)v;
+        // what depends on the entering factor: the coding of a unit with a common factor (the image's final state is
+        // best_scan_kernel's business)
+        if (FIRST && payload && !mine && u.cf >= 2) atomicOr(&used_entry[c], 1u);
+        // ... and index entries that hold it are marked, best_idx_fix_kernel gives them the true value
+        if (FIRST && payload && a.have_idx && gblk % a.g.seg_blocks == 0) a.seg_from_entry[(uint64_t)(gblk / a.g.seg_blocks) * bands + c] = (uint8_t)!mine;
     }
 
     // ---- choose the coding and its length (QB3encode.h:679-713)
@@ -402,7 +404,7 @@ __global__ void enc_best_kernel(const EncArgs a0) {
         // coder state on leaving the image (reference QB3encode.h:718-722)
         if (gblk == nblocks - 1) {
             a.res->prev[c] = (uint64_t)f.lastv; a.res->rung[c] = rung;
-            a.res->cf[c] = (uint64_t)(kind == 2 ? (T)(u.cf - 2) : pcf);     // only a kept common-factor coding moves pcf
+            // (the band's final factor: best_scan_kernel, from the chunk summaries)
         }
         if (a.have_idx) {
             const uint32_t seg = gblk / a.g.seg_blocks;
@@ -419,6 +421,45 @@ __global__ void enc_best_kernel(const EncArgs a0) {
     uint32_t *slot = a.scratch + (uint64_t)chunk * a.slot_dw;
     for (uint32_t d = tid; d < nd; d += nthr) slot[d] = f.outbuf[d];
     if (tid == 0) a.chunk_bits[chunk] = total;
+    if (FIRST) {
+        if (tid < bands) a.cw_used[(uint64_t)chunk * bands + tid] = (uint8_t)used_entry[tid];
+        if (tid == 0) a.recode_need[chunk] = 0;
+    }
+}
+
+// The image is coded in one pass when it has no common factors to speak of, in two when it has: a SAMPLE of the chunks
+// (one in every nchunks/1024) is analysed first; if factor writers that change the state are common in it (recode_n[1]
+// counts them), the first pass only collects the chunk summaries (cheap) while the last pass codes every chunk with its
+// true entering factor;
+// otherwise the first pass codes every chunk assuming the starting state and the last pass repairs the listed few.
+template <typename T>
+__global__ void enc_best_sample_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t step = (a.nchunks + gridDim.x - 1) / gridDim.x, chunk = blockIdx.x * step;
+    if (chunk >= a.nchunks) return;
+    best_chunk<T, true>(a, a0, smem, chunk, true);
+    // what counts is a writer that moves the factor AWAY from the state the one-pass coding assumes
+    if (threadIdx.x < a.g.bands && a.cw_has[(uint64_t)chunk * a.g.bands + threadIdx.x] &&
+        a.cw_val[(uint64_t)chunk * a.g.bands + threadIdx.x] != a0.st.cf[threadIdx.x]) atomicAdd(&a.recode_n[1], 1u);
+}
+// two passes when more than one in sixteen of the sampled (chunk, band) pairs had such a writer
+__device__ __forceinline__ bool best_two_pass(const EncArgs &a) {
+    const uint32_t sampled = a.nchunks < 1024 ? a.nchunks : 1024;
+    return a.recode_n[1] > ((sampled * a.g.bands) >> 4);
+}
+
+template <typename T, bool FIRST>
+__global__ void enc_best_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const bool two_pass = best_two_pass(a);
+    if (FIRST) { best_chunk<T, true>(a, a0, smem, blockIdx.x, two_pass); return; }
+    const uint32_t n = two_pass ? a.nchunks : a.recode_n[0];
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        best_chunk<T, false>(a, a0, smem, two_pass ? i : a.recode_list[i], false);
+        __syncthreads();
+    }
 }
 
 // Carries the last factor writer across chunks: centry[k][c] = factor state on entering chunk k.  "Last non-empty" is
@@ -438,6 +479,7 @@ __global__ void __launch_bounds__(256) best_scan_kernel(const EncArgs a0) {
     const uint32_t k_begin = min(a.nchunks, part * per_part), k_end = min(a.nchunks, k_begin + per_part);
     uint32_t *part_last = a.centry_parts + (uint64_t)c * BS_PARTS;       // per band: BS_PARTS words
     if (PHASE == 0) {
+        if (part == 0 && c == 0 && tid == 0) a.recode_n[0] = 0;
         uint32_t m = 0;
         for (uint32_t k = k_begin + tid; k < k_end; k += 256) m = a.cw_has[(uint64_t)k * bands + c] ? k + 1 : m;      // k ascends: the last one stays
 #pragma unroll
@@ -472,8 +514,16 @@ __global__ void __launch_bounds__(256) best_scan_kernel(const EncArgs a0) {
         uint32_t run = max(before, lane ? up : 0u);     // last writer strictly before the thread's first chunk
 #pragma unroll
         for (uint32_t i = 0; i < PER; i++) {
-            if (k0 + i < k_end) a.centry[(uint64_t)(k0 + i) * bands + c] = run ? a.cw_val[(uint64_t)(run - 1) * bands + c] : a0.st.cf[c];
+            const uint32_t k = k0 + i;
+            if (k < k_end) {
+                const uint64_t entry = run ? a.cw_val[(uint64_t)(run - 1) * bands + c] : a0.st.cf[c];
+                a.centry[(uint64_t)k * bands + c] = entry;
+                // the first pass assumed the image's starting state: where that was wrong and the chunk looked at it, code it again
+                if (!best_two_pass(a) && entry != a0.st.cf[c] && a.cw_used[(uint64_t)k * bands + c] && atomicExch(&a.recode_need[k], 1u) == 0)
+                    a.recode_list[atomicAdd(a.recode_n, 1u)] = k;
+            }
             run = has[i] ? has[i] : run;
+            if (k == a.nchunks - 1) a.res->cf[c] = run ? a.cw_val[(uint64_t)(run - 1) * bands + c] : a0.st.cf[c];   // the band's factor on leaving the image
         }
         __syncthreads();
         if (tid == 255) carry = max(before, m);
@@ -481,20 +531,37 @@ __global__ void __launch_bounds__(256) best_scan_kernel(const EncArgs a0) {
     }
 }
 
+// One-pass coding: index entries that recorded the assumed entering factor get the true one.
+template <typename T>
+__global__ void best_idx_fix_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    if (best_two_pass(a)) return;
+    const uint32_t bands = a.g.bands, nbp = a.slots - 1;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.g.nseg * bands || !a.seg_from_entry[i]) return;
+    const uint64_t seg = i / bands;
+    const uint32_t c = (uint32_t)(i - seg * bands), chunk = (uint32_t)(seg * a.g.seg_blocks / nbp);
+    ((T *)a.idx.cf)[i] = (T)a.centry[(uint64_t)chunk * bands + c];
+}
+
 template <typename T>
 static void launch_enc_best_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     dim3 grid(plan.nchunks, a.ntiles), block(plan.threads);
     {
-        ProfScope ps("enc_best_pass0", st);
-        hipLaunchKernelGGL((enc_best_kernel<T, 0>), grid, block, plan.lds_bytes, st, a);
+        ProfScope ps("enc_best_units", st);
+        if (a.ntiles > 1) (void)hipMemset2DAsync(a.recode_n, a.ts_ws, 0, 8, a.ntiles, st);
+        else (void)hipMemsetAsync(a.recode_n, 0, 8, st);
+        hipLaunchKernelGGL((enc_best_sample_kernel<T>), dim3(plan.nchunks < 1024 ? plan.nchunks : 1024, a.ntiles), block, plan.lds_bytes, st, a);
+        hipLaunchKernelGGL((enc_best_kernel<T, true>), grid, block, plan.lds_bytes, st, a);
     }
     {
         ProfScope ps("enc_best_scan", st);
         hipLaunchKernelGGL(best_scan_kernel<0>, dim3(BS_PARTS, a.g.bands, a.ntiles), dim3(256), 0, st, a);
         hipLaunchKernelGGL(best_scan_kernel<1>, dim3(BS_PARTS, a.g.bands, a.ntiles), dim3(256), 0, st, a);
     }
-    ProfScope ps("enc_best_units", st);
-    hipLaunchKernelGGL((enc_best_kernel<T, 1>), grid, block, plan.lds_bytes, st, a);
+    ProfScope ps("enc_best_recode", st);
+    if (a.have_idx) hipLaunchKernelGGL((best_idx_fix_kernel<T>), dim3((uint32_t)((a.g.nseg * a.g.bands + 255) / 256), a.ntiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((enc_best_kernel<T, false>), dim3(plan.nchunks < 4096 ? plan.nchunks : 4096, a.ntiles), block, plan.lds_bytes, st, a);
 }
 void launch_enc_best(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     switch (a.g.tsz) {

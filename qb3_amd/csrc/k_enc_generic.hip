@@ -12,7 +12,7 @@ __global__ void enc_kernel(const EncArgs a0) {
     const uint32_t bands = a.g.bands, nblocks = (uint32_t)a.g.nblocks;
     T g[16];
     EncFront<T> f;
-    enc_front<T>(a, a0, smem, (31 + (a.slots - 1) * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1, f, g);
+    enc_front<T>(a, a0, smem, (31 + (a.slots - 1) * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1, f, g, blockIdx.x);
     const uint32_t c = f.c, gblk = f.gblk, rung = f.rung, chunk = f.chunk;
     const bool payload = f.payload;
     const T used = f.used, pv = f.pv, lastv = f.lastv;

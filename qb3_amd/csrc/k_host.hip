@@ -60,7 +60,7 @@ static std::vector<hipEvent_t> g_prof_pool;
 static std::map<std::string, std::pair<double, uint64_t>> g_prof_acc;
 void prof_enable(int level) { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_level = level; }
 // level 2 skips the microsecond kernels: two events per kernel cost more than those kernels take
-static bool prof_minor(const char *n) { const std::string s(n); return s == "enc_scan" || s == "enc_seams" || s == "enc_best_scan"; }
+static bool prof_minor(const char *n) { const std::string s(n); return s == "enc_scan" || s == "enc_seams" || s == "enc_best_scan" || s == "enc_best_recode"; }
 void prof_reset() { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_acc.clear(); }
 static hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -188,7 +188,7 @@ uint32_t max_unit_bits(uint32_t tsz, uint32_t mode) {
 }
 
 // encoder workspace layout (all 8-byte aligned), EncResult last
-struct EncWs { size_t bits, off, gsum, lookback, seams, scratch, cwhas, cwval, centry, cparts, cfflag, res, total; uint32_t slot_dw, ngroups; };
+struct EncWs { size_t bits, off, gsum, lookback, seams, scratch, cwhas, cwval, centry, cparts, cwused, segfe, rneed, rlist, res, total; uint32_t slot_dw, ngroups; };
 static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, uint32_t threads, bool with_slots = true) {
     EncWs w;
     // a multiple of 4 dwords: slots are 16-byte aligned (the px kernel copies them out as uint4)
@@ -206,8 +206,11 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, ui
     w.cwhas = o; o += align8(nb);
     w.cwval = o; o += 8 * nb;
     w.centry = o; o += 8 * nb;
-    w.cparts = o; o += g.mode == CM_BEST ? 4 * 32 * (size_t)MAXBANDS : 0;
-    w.cfflag = o; o += g.mode == CM_BEST ? align8((size_t)nchunks * threads) : 0;
+    w.cparts = o; o += g.mode == CM_BEST ? 4 * (32 * (size_t)MAXBANDS + 2) : 0;       // (+ the recode counter)
+    w.cwused = o; o += align8(nb);
+    w.segfe = o; o += g.mode == CM_BEST ? align8((size_t)g.nseg * g.bands) : 0;
+    w.rneed = o; o += g.mode == CM_BEST ? align8(4 * (size_t)nchunks) : 0;
+    w.rlist = o; o += g.mode == CM_BEST ? align8(4 * (size_t)nchunks) : 0;
     w.res = o; o += sizeof(EncResult);
     w.total = o;
     return w;
@@ -280,7 +283,7 @@ EncPlan plan_encode(const Geometry &g, bool allow_single_pass) {
     p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
     const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1;
     p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * ((outdw + 1) & ~(size_t)1);
-    if (g.mode == CM_BEST) p.lds_bytes += 8 * (size_t)p.threads + 8 * 16 + 8;     // the writer board: a value per lane, a ballot per wave
+    if (g.mode == CM_BEST) p.lds_bytes += 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8;     // the writer board: a value per lane, a ballot per wave, a word per band
     p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp, p.threads).total;
     return p;
 }
@@ -325,7 +328,8 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.scratch = (uint32_t *)(w + L.scratch);
     a.lookback = (uint64_t *)(w + L.lookback);
     a.single_pass = plan.px && plan.single_pass && g.tsz == 1 && g.mode != CM_BEST;
-    a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry); a.cf_flag = w + L.cfflag; a.centry_parts = (uint32_t *)(w + L.cparts);
+    a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry); a.centry_parts = (uint32_t *)(w + L.cparts); a.recode_n = a.centry_parts + 32 * MAXBANDS;
+    a.cw_used = w + L.cwused; a.seg_from_entry = w + L.segfe; a.recode_need = (uint32_t *)(w + L.rneed); a.recode_list = (uint32_t *)(w + L.rlist);
     a.slot_dw = L.slot_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.src_pitch & 3);

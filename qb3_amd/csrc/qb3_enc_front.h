@@ -13,7 +13,7 @@ template <typename T> struct EncFront {
 };
 
 template <typename T>
-__device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, uint8_t *smem, uint32_t outdw, EncFront<T> &f, T (&g)[16]) {
+__device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, uint8_t *smem, uint32_t outdw, EncFront<T> &f, T (&g)[16], uint32_t chunk) {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t bands = a.g.bands, slots = a.slots, dpr = a.dpr, nbp = slots - 1;
     const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
@@ -30,7 +30,6 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, u
     fill_enc_tab(f.etab);
     uint64_t *slot_base = f.slot_base; uint32_t *tile = f.tile;
 
-    const uint32_t chunk = blockIdx.x;
     const uint32_t g0 = chunk * nbp;                      // first payload block of this chunk
     f.nbp = nbp; f.chunk = chunk;
 

@@ -203,7 +203,9 @@ struct EncArgs {
     uint64_t *cw_val;       //   ... and with what (cf - 2)
     uint64_t *centry;       //   ... factor state on entering the chunk (after best_scan_kernel)
     uint32_t *centry_parts; //   ... best_scan_kernel: the last writer of every part of the chunk range, per band
-    uint8_t *cf_flag;       //   ... per chunk and lane: the unit has a common factor (pass 0 -> pass 1)
+    uint8_t *cw_used;       //   ... per chunk and band: something in the chunk depended on the factor on entry
+    uint8_t *seg_from_entry;    //   ... per index segment and band: its factor entry is the chunk's entering factor
+    uint32_t *recode_need, *recode_list, *recode_n;    //   ... chunks to code again: flag per chunk, list, count
     uint64_t *lookback;     // single-pass encoder: per chunk {state, bit count} words, then the abort flag (zeroed per launch)
     uint32_t single_pass;   // the chunks were written in place: no scan, no concatenation, index positions are final
     uint32_t ntiles;
@@ -232,7 +234,7 @@ __device__ __forceinline__ EncArgs enc_for_tile(EncArgs a, uint32_t t) {
         const uint64_t w = t * a.ts_ws, x = t * a.ts_idx;
         a.chunk_bits = shift_ptr(a.chunk_bits, w); a.chunk_off = shift_ptr(a.chunk_off, w); a.group_sum = shift_ptr(a.group_sum, w);
         a.scratch = shift_ptr(a.scratch, w); a.seams = shift_ptr(a.seams, w); a.res = shift_ptr(a.res, w);
-        a.cw_has = shift_ptr(a.cw_has, w); a.cw_val = shift_ptr(a.cw_val, w); a.centry = shift_ptr(a.centry, w); a.cf_flag = shift_ptr(a.cf_flag, w); a.centry_parts = shift_ptr(a.centry_parts, w); a.lookback = shift_ptr(a.lookback, w);
+        a.cw_has = shift_ptr(a.cw_has, w); a.cw_val = shift_ptr(a.cw_val, w); a.centry = shift_ptr(a.centry, w); a.cw_used = shift_ptr(a.cw_used, w); a.seg_from_entry = shift_ptr(a.seg_from_entry, w); a.recode_need = shift_ptr(a.recode_need, w); a.recode_list = shift_ptr(a.recode_list, w); a.recode_n = shift_ptr(a.recode_n, w); a.centry_parts = shift_ptr(a.centry_parts, w); a.lookback = shift_ptr(a.lookback, w);
         a.idx.bitpos = shift_ptr(a.idx.bitpos, x); a.idx.prev = shift_ptr(a.idx.prev, x); a.idx.cf = shift_ptr(a.idx.cf, x);
         a.idx.rung = shift_ptr(a.idx.rung, x); a.idx.ulen = shift_ptr(a.idx.ulen, x);
     }
