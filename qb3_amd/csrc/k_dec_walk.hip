@@ -196,6 +196,15 @@ template <uint32_t UB> __device__ __forceinline__ uint32_t walk_unit(uint32_t rp
         used = walk_codes<3>(lo, K);
         used += walk_codes<2>(__builtin_amdgcn_alignbit(hi, lo, used), K);
         return rung ? q + used - rp : len0;
+    } else if (UB >= 5) {
+        // 32- and 64-bit data: a code is up to 65 bits long but its length is still in its two low bits: one read a code
+        uint32_t q = rp + cs;
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const uint32_t b = lds_bits(q);
+            q += rung + (b & 1) + ((b & 3) == 3);
+        }
+        return rung ? q - rp : len0;
     } else {
         // 16-bit data: a code is at most 17 bits, three fit a 64-bit read (51 bits; the first read also holds the switch)
         // (lengths up to 17 do not fit the 4-bit fields of K: byte fields by the low two bits: r, r+1, r, r+2)
@@ -226,7 +235,7 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
     uint32_t *win = (uint32_t *)smem;
     uint8_t *ul_s = smem + 64 * WALK_WINP * 4;
     constexpr uint32_t USZ = UB == 3 ? 1 : 2;                               // bytes per unit length
-    constexpr uint32_t MAXU = UB + 2 + 16 * ((8u << (UB - 3)) + 1);        // longest unit: 149 bits (8-bit), 278 (16-bit)
+    constexpr uint32_t MAXU = UB + 2 + 16 * ((8u << (UB - 3)) + 1);        // longest unit: 149 bits (8-bit), 278 (16-bit), 535, 1048
     const uint32_t lane = threadIdx.x, k = blockIdx.x * 64 + lane;
     const uint32_t B = BT ? (uint32_t)BT : a.g.bands, NB = a.g.seg_blocks, nblocks = (uint32_t)a.g.nblocks;
     const bool live = k < a.ix_K;
@@ -251,11 +260,14 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
     uint32_t u = 0;                                                         // units done
     uint32_t rungs[BT ? BT : 1];
     uint64_t R = 0;                                                         // run-time bands: rungs, 4 bits per band
+    uint8_t *wide_rung = ul_s + 64 * stage_bytes + lane * MAXBANDS;         // ... 32/64-bit data (rungs up to 63): a byte per band, in LDS
     if (BT) {
 #pragma unroll
         for (int c = 0; c < (BT ? BT : 1); c++) rungs[c] = e[6 + c] & 15u;
-    } else
+    } else if (UB <= 4) {
         for (uint32_t c = 0; c < B; c++) R |= (uint64_t)(e[6 + c] & 15u) << (4 * c);
+    } else
+        for (uint32_t c = 0; c < B; c++) wide_rung[c] = e[6 + c];
     uint32_t band = 0, blk = 0;                                             // run-time bands: position inside the block
     while (__any(u < nu)) {
         // ---- (re)centre every lane's window on its position: sixteen-byte loads, nothing read beyond the stream
@@ -308,19 +320,22 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
                 } else {
                     if (band == 0 && blk % NB == 0) {
                         a.idx.bitpos[seg] = 32 * wb + (rp - lbit) - a.in_bit0;
-                        for (uint32_t c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)((R >> (4 * c)) & 15u);
-                        if (blk == 0)               // the entering values of the entry's first segment are in the entry
-                            for (uint32_t c = 0; c < B; c++) {
-                                const uint8_t *pv = e + 6 + B + c * (UB == 3 ? 1 : 2);
-                                if (UB == 3) ((uint8_t *)a.idx.prev)[seg * B + c] = pv[0];
-                                else ((uint16_t *)a.idx.prev)[seg * B + c] = (uint16_t)(pv[0] | (pv[1] << 8));
-                            }
+                        for (uint32_t c = 0; c < B; c++) a.idx.rung[seg * B + c] = UB <= 4 ? (uint8_t)((R >> (4 * c)) & 15u) : wide_rung[c];
+                        if (blk == 0) {             // the entering values of the entry's first segment are in the entry
+                            constexpr uint32_t TSZ = 1u << (UB - 3);
+                            const uint8_t *pv = e + 6 + B;
+                            uint8_t *dst = (uint8_t *)a.idx.prev + seg * B * TSZ;
+                            for (uint32_t i = 0; i < B * TSZ; i++) dst[i] = pv[i];
+                        }
                         seg++;
                     }
-                    uint32_t rung = (uint32_t)(R >> (4 * band)) & 15u;
+                    uint32_t rung;
+                    if (UB <= 4) rung = (uint32_t)(R >> (4 * band)) & 15u;
+                    else rung = wide_rung[band];
                     const uint32_t ulen = walk_unit<UB>(rp, rung, bad);
                     rp += ulen;
-                    R = (R & ~(15ull << (4 * band))) | ((uint64_t)rung << (4 * band));
+                    if (UB <= 4) R = (R & ~(15ull << (4 * band))) | ((uint64_t)rung << (4 * band));
+                    else wide_rung[band] = (uint8_t)rung;
                     uint8_t *ul = stage_bytes ? ul_s + lane * stage_bytes + (blk * B + band) * USZ
                                               : (uint8_t *)a.idx.ulen + (((uint64_t)gb0 + blk) * B + band) * USZ;
                     if (UB == 3) *ul = (uint8_t)ulen;
@@ -358,11 +373,13 @@ void launch_dec_walk(const DecArgs &a, hipStream_t st) {
         // unit lengths staged in LDS when a lane's share is small enough (it is when an entry is one index segment)
         uint32_t stage = a.ix_blocks * a.g.bands * (a.g.tsz == 1 ? 1 : 2);
         if (stage > 512 || (stage & 3)) stage = 0;
-        const size_t lds = 64 * WALK_WINP * 4 + 64 * (size_t)stage;
+        const size_t lds = 64 * WALK_WINP * 4 + 64 * (size_t)stage + (a.g.tsz >= 4 ? 64 * MAXBANDS : 0);
         if (a.g.tsz == 1 && a.g.bands == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 1>), grid, block, lds, st, a, stage);
         else if (a.g.tsz == 1 && a.g.bands == 3) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 3>), grid, block, lds, st, a, stage);
         else if (a.g.tsz == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 4>), grid, block, lds, st, a, stage);
-        else hipLaunchKernelGGL((dec_walk_lanes_kernel<4, 0>), grid, block, lds, st, a, stage);
+        else if (a.g.tsz == 2) hipLaunchKernelGGL((dec_walk_lanes_kernel<4, 0>), grid, block, lds, st, a, stage);
+        else if (a.g.tsz == 4) hipLaunchKernelGGL((dec_walk_lanes_kernel<5, 0>), grid, block, lds, st, a, stage);
+        else hipLaunchKernelGGL((dec_walk_lanes_kernel<6, 0>), grid, block, lds, st, a, stage);
         return;
     }
 

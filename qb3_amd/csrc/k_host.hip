@@ -144,15 +144,15 @@ uint32_t seg_blocks_for(const Geometry &g) {
     return s ? s : 1;
 }
 uint32_t ix_entry_bytes(const Geometry &g) { return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)); }
-// One entry per index segment where the lane-per-block decoders apply (8- and 16-bit FTL/BASE: a lane then walks one
-// segment, and the segment's entering values come straight from its entry), else one per about 256 units.  For
-// 8-bit RGB that is 12 bytes per 64 blocks: 0.7 % of a typical stream.
+// One entry per index segment for FTL/BASE streams (a lane then walks one segment, lengths only, and the segment's
+// entering values come straight from its entry), one per about 256 units for the common-factor modes.  For 8-bit RGB
+// that is 12 bytes per 64 blocks: 0.7 % of a typical stream.
 IxTable ix_layout(const Geometry &g) {
     IxTable t;
     if (!g.seg_blocks || !g.nseg) return t;
     t.entry_bytes = ix_entry_bytes(g);
     const uint64_t units_per_seg = (uint64_t)g.seg_blocks * g.bands;
-    const bool per_seg = g.mode != CM_BEST && g.tsz <= 2;
+    const bool per_seg = g.mode != CM_BEST;
     const uint64_t spe = (per_seg || units_per_seg >= 256) ? 1 : 256 / units_per_seg;      // index segments per entry
     t.blocks = (uint32_t)(spe * g.seg_blocks);
     t.K = (uint32_t)((g.nseg + spe - 1) / spe);
@@ -395,11 +395,13 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     const bool best = a.g.mode == CM_BEST;
     const bool use_px = plan.px && !best && a.g.tsz == 1;
     const bool use_px16 = plan.px16 && !best && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0;
-    if (rebuild && (use_px || use_px16) && !tuning().slow_index) {
+    // 32/64-bit FTL/BASE streams that bring a restart table with an entry per index segment: the lengths-only walk too
+    const bool wide_walk = rebuild && a.ix && a.ntiles == 1 && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
+    if (rebuild && (use_px || use_px16 || wide_walk) && !tuning().slow_index) {
         // index-less stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
         // produce the values entering the segments (totals pass + scan)
         { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
-        if (!(a.ix && a.ix_blocks == a.g.seg_blocks)) {         // (an entry per segment: the walk copied the entering values)
+        if (!(a.ix && a.ix_blocks == a.g.seg_blocks) && !wide_walk) {         // (an entry per segment: the walk copied the entering values)
           {
             ProfScope ps("dec_index_prev", st);
             DecArgs t = a;

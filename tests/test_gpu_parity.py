@@ -633,6 +633,9 @@ def walk_chunks(c, fixed_b7):
 
 IX_CASES.append((8192, 4096, 3, 0, "NOISY3", 6, FTL))      # more entries than one 64 KB chunk holds
 IX_CASES.append((256, 128, 1, 5, "DEM", 4, 7))              # an RLE0 mode whose RLE0 pass does not win: the table stays
+IX_CASES.append((520, 300, 1, 7, "DEM", 4, BASE))           # 64-bit: the lengths-only walk, one read a code
+IX_CASES.append((256, 256, 1, 6, "RUNG63", 4, FTL))         # ... with 65-bit codes
+IX_CASES.append((160, 120, 5, 4, "DEM", 4, FTL))            # ... 32-bit, five bands, a band map
 
 
 @pytest.mark.parametrize("case", IX_CASES, ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % (c[0], c[1], c[2], c[3], c[4], c[6]))
@@ -673,7 +676,7 @@ def test_index_chunk(qb3, oracle, case):
     assert np.array_equal(out, raw)
     # device flavour: container made on the device, decoded with and without the out-of-band index
     enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cb, index_chunk=True)
-    dimg = synth.generate(w, h, b, dt, gen, seed)
+    dimg = torch.from_numpy(img.view(np.uint8).copy()).cuda()
     dst, n, index = enc.encode(dimg)
     assert n == len(got) and np.array_equal(dst[:n].cpu().numpy(), got)
     dec = qdev.DeviceDecoder(dst, n)
