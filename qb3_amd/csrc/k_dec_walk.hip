@@ -1,5 +1,6 @@
 // qb3_amd/csrc/k_dec_walk.hip -- index-less 8/16-bit FTL/BASE streams: find the unit lengths by walking
 #include "qb3_kernels.h"
+#include <type_traits>
 
 namespace qb3dev {
 
@@ -366,6 +367,222 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
     }
     if (bad && live) atomicOr(a.status, 1u);
 }
+
+// ---- plain 8-bit streams (no index, no restart table): walk through a TABLE of unit lengths by position -----------
+// Where a unit starts depends on every unit before it, but how long a unit WOULD be if it started at bit p with rung r
+// depends on the bits alone.  walk_table_kernel computes that for every bit position of a slab of the stream and every
+// rung, the whole chip at once (a code's length is its rung plus what its two low bits say, so the sixteen codes of a
+// unit are four rounds of pointer doubling over "length of the next code"); walk_chain_kernel then follows the one
+// chain that is real, at one LDS look-up a unit instead of a switch and sixteen codes.
+// Table rows: utab[p][r_in] = bits of the unit at p entered with rung r_in; dtab[p] = the switch's rung step | signal<<7.
+constexpr uint32_t WT_W = 2048, WT_MARG = 160, WT_NP = WT_W + WT_MARG;    // positions a workgroup tabulates; the bits it looks ahead
+struct WalkState { uint64_t P; uint32_t gb, rungs, bad, pad; };           // a tile's walk between two slabs
+
+__global__ void __launch_bounds__(256) walk_table_kernel(const DecArgs a0, uint8_t *utab, uint8_t *dtab, uint64_t slab0, uint64_t slab_bits, uint64_t tab_pitch) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    const uint64_t p0 = slab0 + (uint64_t)blockIdx.x * WT_W;
+    if (p0 >= a.in_bits + 2 * WT_W) return;                                 // (uniform) far beyond the stream: no walk comes here
+    __shared__ uint32_t words[WT_NP / 32 + 3];
+    __shared__ uint8_t nA[7][WT_NP], nB[7][WT_NP];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t q0 = a.in_bit0 + p0, w0 = q0 >> 5, endw = (a.in_bit0 + a.in_bits + 31) >> 5;
+    const uint32_t sh = (uint32_t)q0 & 31;
+    for (uint32_t i = tid; i < WT_NP / 32 + 3; i += 256) words[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
+    __syncthreads();
+    auto bits = [&](uint32_t i) { const uint32_t b = sh + i, k = b >> 5; return __builtin_amdgcn_alignbit(words[k + 1], words[k], b & 31); };
+    for (uint32_t i = tid; i < WT_NP; i += 256) {                           // one code (reference QB3decode.h:119-129: r, r + 1 or r + 2 bits)
+        const uint32_t x = bits(i), e = (x & 1) + ((x & 3) == 3);
+#pragma unroll
+        for (uint32_t r = 1; r < 8; r++) nA[r - 1][i] = (uint8_t)(r + e);
+    }
+    __syncthreads();
+    uint8_t (*src)[WT_NP] = nA, (*dst)[WT_NP] = nB;
+    uint32_t valid = WT_NP;
+#pragma unroll 1
+    for (uint32_t lvl = 0; lvl < 4; lvl++) {                                // 2, 4, 8, 16 codes
+        valid -= 9u << lvl;                                                 // (a code is at most nine bits)
+        for (uint32_t r = 0; r < 7; r++)
+            for (uint32_t i = tid; i < valid; i += 256) { const uint32_t n = src[r][i]; dst[r][i] = (uint8_t)(n + src[r][i + n]); }
+        __syncthreads();
+        uint8_t (*t)[WT_NP] = src; src = dst; dst = t;
+    }
+    // valid = WT_NP - 135 >= WT_W + 5: sixteen codes from every position a switch in this window can end on
+    uint8_t *ut = utab + ((uint64_t)blockIdx.y * tab_pitch + (p0 - slab0)) * 8, *dt = dtab + (uint64_t)blockIdx.y * tab_pitch + (p0 - slab0);
+    for (uint32_t p = tid; p < WT_W; p += 256) {
+        const uint32_t x = bits(p);
+        uint32_t delta = 0; bool sig = false;
+        const uint32_t cs = walk_switch<3>(x, delta, sig);                  // from rung 0: the step itself
+        const uint32_t len0 = cs + (((x >> cs) & 1) ? 17 : 1);              // rung 0: one flag, then 16 raw bits
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (uint32_t rin = 0; rin < 8; rin++) {
+            const uint32_t r = (rin + delta) & 7u;
+            const uint32_t u = r ? cs + src[r ? r - 1 : 0][p + cs] : len0;
+            if (rin < 4) lo |= u << (8 * rin); else hi |= u << (8 * (rin - 4));
+        }
+        *(uint2 *)(ut + 8 * p) = make_uint2(lo, hi);
+        dt[p] = (uint8_t)(delta | (sig ? 0x80u : 0u));
+    }
+}
+
+// The chain: ONE LANE follows the units, a look-up (and a step of the band's rung) per unit -- the walk is a pointer
+// chase through LDS, so what counts is the latency of a look-up and the instructions that depend on it: the lane
+// carries the LDS ADDRESS of the next look-up (window base + 8 * position + rung), and one shift-and-add on the
+// length just read makes the next one.  The other three waves of the workgroup bring the next window of the table
+// into LDS and write the unit lengths of the last one out.
+namespace chain {
+// a window holds the table rows of WIN positions plus those a block that STARTS in them can reach (its later units)
+constexpr uint32_t WIN = 2048, MARG = 448, WROWS = WIN + MARG, STG = WIN / 2 + 8;      // (a unit is at least two bits)
+static_assert(MARG >= 3 * 149 && MARG <= WT_W && WIN % WT_W == 0, "look-ahead of a block");
+// dynamic LDS, from address 0: [unit rows x 2 windows][switch bytes x 2][staged unit lengths x 2, four bytes a block][words]
+constexpr uint32_t UB = 0, DB = 2 * WROWS * 8, SG = DB + 2 * WROWS, MISC = SG + 2 * STG * 4, LDS_BYTES = MISC + 32;
+static_assert(SG % 16 == 0 && MISC % 8 == 0 && LDS_BYTES <= 65536, "LDS layout");
+typedef const __attribute__((address_space(3))) uint8_t *LdsBytes;
+typedef __attribute__((address_space(3))) uint32_t *LdsWordsW;
+__device__ __forceinline__ uint32_t ldsb(uint32_t addr) { return ((LdsBytes)(uintptr_t)addr)[0]; }
+
+// Walk the blocks that start in window BUF from position o; returns the position reached.  n: blocks staged.
+template <int B, uint32_t BUF, typename SEG>
+__device__ __forceinline__ uint32_t walk_window(uint32_t o, uint32_t olim, uint32_t &left, uint32_t &inseg, uint32_t NB, uint32_t (&rung)[B], uint32_t &bad, uint32_t &n, SEG &&on_segment) {
+    constexpr uint32_t U0 = UB + BUF * WROWS * 8, D0 = DB + BUF * WROWS, S0 = SG + BUF * STG * 4;
+    uint32_t A = U0 + o * 8 + rung[0];
+    while (true) {
+        o = (A - U0) >> 3;
+        if (o >= olim || !left) break;                  // a block per turn; its first unit starts in this window
+        if (inseg == 0) on_segment(o);
+        if (++inseg == NB) inseg = 0;
+        uint32_t pk = 0;
+#pragma unroll
+        for (int c = 0; c < B; c++) {                   // positions < WIN + 447
+            const uint32_t u = ldsb(A), d = ldsb(D0 + ((A - U0) >> 3));
+            const uint32_t rold = rung[c];
+            rung[c] = (rold + d) & 7u;
+            bad |= d;
+            A = (u << 3) + (A - rold + rung[(c + 1) % B]);          // (the next band's rung: this block has not stepped it yet; band 0's it has)
+            pk |= u << (8 * c);
+        }
+        ((LdsWordsW)(uintptr_t)(S0 + 4 * n))[0] = pk;
+        n++; left--;
+    }
+    return o;
+}
+}  // namespace chain
+
+template <int B>
+__global__ void __launch_bounds__(256) walk_chain_kernel(const DecArgs a0, const uint8_t *utab, const uint8_t *dtab, uint64_t slab0, uint64_t slab_bits, uint64_t tab_pitch,
+                                                         WalkState *states, uint32_t first_round) {
+    using namespace chain;
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *stg_gb = (uint32_t *)(smem + MISC), *stg_n = stg_gb + 2;      // first block and number of blocks staged in a window
+    uint64_t *sP = (uint64_t *)(smem + MISC + 16);
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t NB = a.g.seg_blocks, nblocks = (uint32_t)a.g.nblocks;
+    WalkState *S = states + blockIdx.x;
+    uint64_t P = first_round ? 0 : S->P;                                    // in stream bits
+    uint32_t gb = first_round ? 0 : S->gb;
+    const uint32_t R = first_round ? 0 : S->rungs;
+    uint32_t bad = first_round ? 0 : S->bad;
+    // blocks that start before slab_end are walked here; table rows exist up to tab_end
+    const uint64_t slab_end = slab0 + slab_bits, tab_end = slab_end + WT_W;
+    const uint8_t *ut = utab + (uint64_t)blockIdx.x * tab_pitch * 8, *dt = dtab + (uint64_t)blockIdx.x * tab_pitch;
+    // (all loads of a thread in flight before the first LDS store: the loaders are bound by the latency of HBM)
+    auto load_window = [&](uint64_t ws, uint32_t buf, uint32_t t, auto nt_c) {          // sixteen bytes a load
+        constexpr uint32_t NT = decltype(nt_c)::value, NU = (WROWS * 8 / 16 + NT - 1) / NT;
+        static_assert(WROWS / 16 <= NT, "switch bytes: one load a thread");
+        const uint64_t off = ws - slab0;
+        uint4 v[NU], d = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t q = 0; q < NU; q++) {
+            const uint32_t i = t + q * NT;
+            v[q] = (i < WROWS * 8 / 16 && ws + 2 * i + 2 <= tab_end) ? ((const uint4 *)(ut + off * 8))[i] : make_uint4(0, 0, 0, 0);
+        }
+        if (t < WROWS / 16 && ws + 16 * t + 16 <= tab_end) d = ((const uint4 *)(dt + off))[t];
+#pragma unroll
+        for (uint32_t q = 0; q < NU; q++) { const uint32_t i = t + q * NT; if (i < WROWS * 8 / 16) ((uint4 *)(smem + UB + buf * WROWS * 8))[i] = v[q]; }
+        if (t < WROWS / 16) ((uint4 *)(smem + DB + buf * WROWS))[t] = d;
+    };
+    auto flush = [&](uint32_t buf, uint32_t t, uint32_t nt) {                           // staged unit lengths to the index
+        const uint32_t g0 = stg_gb[buf], n = stg_n[buf] * B;
+        uint8_t *ul = (uint8_t *)a.idx.ulen + (uint64_t)g0 * B;
+        const uint8_t *sg = smem + SG + buf * STG * 4;
+        for (uint32_t j = t; j < n; j += nt) ul[j] = sg[(j / B) * 4 + j % B];
+    };
+    if (P < slab0 || P >= slab_end || P >= a.in_bits || gb >= nblocks) return;         // (uniform) nothing of this tile in this slab
+    uint64_t wstart = slab0 + ((P - slab0) / WIN) * WIN;
+    load_window(wstart, 0, tid, std::integral_constant<uint32_t, 256>());
+    uint32_t buf = 0, turn = 0;
+    uint32_t rung[B];
+#pragma unroll
+    for (int c = 0; c < B; c++) rung[c] = (R >> (4 * c)) & 15u;
+    __syncthreads();
+    while (true) {
+        const uint64_t wend = wstart + WIN;
+        if (wave) {
+            if (wend < slab_end) load_window(wend, buf ^ 1, tid - 64, std::integral_constant<uint32_t, 192>());    // the next window, beside the walk
+            if (turn) flush(buf ^ 1, tid - 64, 192);                                    // what the last turn staged
+        } else if (tid == 0) {
+            const uint32_t olim = slab_end - wstart < WIN ? (uint32_t)(slab_end - wstart) : WIN;
+            uint32_t left = nblocks - gb, inseg = gb % NB, n = 0;
+            auto on_segment = [&](uint32_t o) {
+                const uint64_t seg = (nblocks - left) / NB;
+                a.idx.bitpos[seg] = wstart + o;
+#pragma unroll
+                for (int c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)rung[c];
+            };
+            stg_gb[buf] = gb;
+            const uint32_t o0 = (uint32_t)(P - wstart);
+            const uint32_t o = buf ? walk_window<B, 1>(o0, olim, left, inseg, NB, rung, bad, n, on_segment)
+                                   : walk_window<B, 0>(o0, olim, left, inseg, NB, rung, bad, n, on_segment);
+            stg_n[buf] = n;
+            *sP = wstart + o;
+        }
+        __syncthreads();
+        P = *sP; gb = stg_gb[buf] + stg_n[buf];
+        // the walk is over when it has run out of slab, of stream or of blocks (uniform: from shared values)
+        if (P >= slab_end || P >= a.in_bits || gb >= nblocks) break;
+        wstart = wend; buf ^= 1; turn++;
+        // (sP and stg_*[buf] are next written after the lane has walked a window; the readers above are long past)
+    }
+    flush(buf, tid, 256);
+    if (tid == 0) {
+        uint32_t Rn = 0;
+#pragma unroll
+        for (int c = 0; c < B; c++) Rn |= rung[c] << (4 * c);
+        S->P = P; S->gb = gb; S->rungs = Rn; S->bad = bad & 0x80u;
+        if (bad & 0x80u) atomicOr(a.status, 1u);
+    }
+}
+
+// Slabs of the streams are tabulated by the whole chip, then walked by a workgroup per tile, slab after slab.
+// tab: [WalkState per tile][unit-length rows, 8 bytes a position][switch bytes]; max_bits: the longest stream of the call.
+void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+    const uint32_t nt = a.ntiles;
+    const size_t state_bytes = ((size_t)nt * sizeof(WalkState) + 255) & ~(size_t)255;
+    uint8_t *base = (uint8_t *)tab;
+    // positions per tile and round: what the table holds, in whole windows, one window kept for the look-ahead
+    uint64_t rows = (tab_bytes - state_bytes) / (9 * (uint64_t)nt);
+    rows = rows / WT_W * WT_W;
+    uint64_t slab = rows - WT_W;
+    const uint64_t need = (max_bits + WT_W - 1) / WT_W * WT_W;
+    if (slab > need) slab = need;
+    const uint64_t pitch = slab + WT_W;
+    uint8_t *utab = base + state_bytes, *dtab = utab + (uint64_t)nt * pitch * 8;
+    WalkState *states = (WalkState *)base;
+    uint32_t first = 1;
+    for (uint64_t s0 = 0; s0 < max_bits; s0 += slab, first = 0) {
+        { ProfScope ps("dec_index_table", st); hipLaunchKernelGGL(walk_table_kernel, dim3((uint32_t)(pitch / WT_W), nt), dim3(256), 0, st, a, utab, dtab, s0, slab, pitch); }
+        ProfScope ps("dec_index_serial", st);
+        if (a.g.bands == 1) hipLaunchKernelGGL(walk_chain_kernel<1>, dim3(nt), dim3(256), chain::LDS_BYTES, st, a, utab, dtab, s0, slab, pitch, states, first);
+        else if (a.g.bands == 3) hipLaunchKernelGGL(walk_chain_kernel<3>, dim3(nt), dim3(256), chain::LDS_BYTES, st, a, utab, dtab, s0, slab, pitch, states, first);
+        else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(256), chain::LDS_BYTES, st, a, utab, dtab, s0, slab, pitch, states, first);
+    }
+}
+size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits) {
+    const uint64_t need = (max_bits + WT_W - 1) / WT_W * WT_W + WT_W;
+    return (((size_t)ntiles * sizeof(WalkState) + 255) & ~(size_t)255) + 9 * (size_t)ntiles * need + 4096;
+}
+size_t walk_table_min_bytes(uint32_t ntiles) { return walk_table_bytes(ntiles, 8 * WT_W); }
 
 void launch_dec_walk(const DecArgs &a, hipStream_t st) {
     if (a.ix && a.ntiles == 1) {            // the container's own restart table: a lane per entry

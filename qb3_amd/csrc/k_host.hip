@@ -37,6 +37,7 @@ const Tuning &tuning() {
         auto on = [](const char *name) { const char *e = getenv(name); return e && e[0] && e[0] != '0'; };
         Tuning v;
         v.no_px = on("QB3_NO_PX");                   // generic kernels also where a lane-per-block kernel applies
+        v.slow_walk = on("QB3_SLOW_WALK");           // plain 8-bit streams: the one-wave walk instead of the table walk
         v.slow_index = on("QB3_SLOW_INDEX");         // index-less streams: the one-lane index rebuild instead of the walkers
         v.single_pass = on("QB3_SINGLE_PASS");       // 8-bit lane-per-block encoder: look-back and in-place writes instead of slots + concatenate (measured slower)
         v.persistent = on("QB3_PERSISTENT");         // 8-bit lane-per-block encoder: persistent workgroups instead of a workgroup per chunk (measured slower)
@@ -391,7 +392,11 @@ DecPlan plan_decode(const Geometry &g) {
     return p;
 }
 
-static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st) {
+bool walk_table_applies(const Geometry &g, const DecPlan &plan) {
+    return plan.px && g.mode != CM_BEST && g.tsz == 1 && !tuning().slow_walk && !tuning().slow_index;
+}
+
+static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st, void *walk_tab, size_t walk_tab_bytes, uint64_t max_bits) {
     const bool best = a.g.mode == CM_BEST;
     const bool use_px = plan.px && !best && a.g.tsz == 1;
     const bool use_px16 = plan.px16 && !best && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0;
@@ -400,7 +405,10 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     if (rebuild && (use_px || use_px16 || wide_walk) && !tuning().slow_index) {
         // index-less stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
         // produce the values entering the segments (totals pass + scan)
-        { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
+        // plain 8-bit stream: through the table of unit lengths by position when the caller brought memory for it
+        const bool has_ix = a.ix && a.ntiles == 1;
+        if (use_px && !has_ix && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles) && !tuning().slow_walk) launch_dec_walk_table(a, st, walk_tab, walk_tab_bytes, max_bits);
+        else { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
         if (!(a.ix && a.ix_blocks == a.g.seg_blocks) && !wide_walk) {         // (an entry per segment: the walk copied the entering values)
           {
             ProfScope ps("dec_index_prev", st);
@@ -439,7 +447,7 @@ int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, i
 
 int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
                   void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb,
-                  const uint64_t *tile_bits, const IxTable &ix) {
+                  const uint64_t *tile_bits, const IxTable &ix, void *walk_tab, size_t walk_tab_bytes) {
     hipStream_t st = (hipStream_t)stream;
     DecArgs a;
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
@@ -468,7 +476,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
     a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;
     if (g.tsz != 1 && g.tsz != 2 && g.tsz != 4 && g.tsz != 8) { set_error("decode: bad value size", 0); return -1; }
-    return launch_decode_all(a, plan, rebuild, st);
+    return launch_decode_all(a, plan, rebuild, st, walk_tab, walk_tab_bytes, tb.n ? tb.max_bits : in_bits);
 }
 
 }  // namespace qb3dev

@@ -173,7 +173,7 @@ struct decs {
     uint32_t ix_K, ix_blocks, ix_E, ix_per_chunk;
     bool ix_pads, ix_bad;   // pad chunks behind the table chunks (version 2); the chunks seen do not form one table
     std::vector<uint8_t> tile_ok;   // qb3x_decode_tiles: per tile outcome of the last call
-    DevBuf d_in, d_img, d_ws, d_ix;
+    DevBuf d_in, d_img, d_ws, d_ix, d_tab;      // d_tab: the unit-length table a plain 8-bit stream is walked through
     Stager stager;
 };
 
@@ -675,7 +675,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
 // ---------------------------------------------------------------- decoder handle
 QB3_API void qb3_destroy_decoder(decsp p) {
     if (!p) return;
-    p->d_in.release(); p->d_img.release(); p->d_ws.release(); p->d_ix.release(); p->stager.release();
+    p->d_in.release(); p->d_img.release(); p->d_ws.release(); p->d_ix.release(); p->d_tab.release(); p->stager.release();
     delete p;
 }
 QB3_API size_t qb3_decoded_size(const decsp p) { return p->xsize * p->ysize * p->nbands * szof(p->type); }
@@ -833,6 +833,17 @@ QB3_API size_t qb3x_decoder_index_size(const decsp p) {
 #undef HIPOK
 #define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(#x, (int)e_); p->error = QB3E_LIBERR; return 0; } } while (0)
 
+// A plain 8-bit stream (no index, no restart table) is walked through a table in device memory (qb3_dev.h): make sure
+// the decoder holds one -- the whole call in one round, or WALK_TAB_CAP and several rounds.  False: out of memory.
+static const size_t WALK_TAB_CAP = (size_t)1 << 30;
+static bool walk_table_ready(decsp p, const Geometry &g, const DecPlan &plan, uint32_t ntiles, uint64_t max_bits) {
+    if (!walk_table_applies(g, plan)) return true;
+    size_t want = walk_table_bytes(ntiles, max_bits);
+    const size_t least = walk_table_min_bytes(ntiles);
+    if (want > WALK_TAB_CAP) want = WALK_TAB_CAP > least ? WALK_TAB_CAP : least;
+    return p->d_tab.cap >= want || p->d_tab.ensure(want);
+}
+
 // Decode the block stream at d_stream (+ byte offset off inside a 4-byte aligned device buffer) into d_img.
 static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_buf, size_t off, size_t nbytes,
                                  void *d_img, const void *d_index, hipStream_t st, const IxTable &ix = IxTable()) {
@@ -840,7 +851,9 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
     if (!p->d_ws.ensure(plan.ws_bytes)) return false;
     uint32_t *d_status = nullptr;
     const uint32_t *in32 = (const uint32_t *)(d_buf + (off & ~(size_t)3));
-    if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st, TileBatch(), nullptr, ix))
+    if (!d_index && !ix.base && !walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
+    if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st, TileBatch(), nullptr, ix,
+                      p->d_tab.p, p->d_tab.cap))
         return false;
     uint32_t status = 0;
     hipError_t e = hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st);
@@ -1049,10 +1062,13 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
             if (e != hipSuccess) { set_error("decode tiles: upload of stream lengths", (int)e); p->error = QB3E_LIBERR; return done; }
             TileBatch tb;
             tb.n = (uint32_t)cnt; tb.src_pitch = src_pitch; tb.dst_pitch = dst_pitch; tb.idx_pitch = isz;
+            for (size_t i = 0; i < cnt; i++) if (bits[i] > tb.max_bits) tb.max_bits = bits[i];
+            if (!d_index && !walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
             const uint8_t *src0 = (const uint8_t *)d_src + first * src_pitch;
             uint32_t *d_status = nullptr;
             if (launch_decode(g, plan, (const uint32_t *)(src0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), 0, (uint8_t *)d_dst + first * dst_pitch,
-                              d_index ? (const uint8_t *)d_index + first * isz : nullptr, p->d_ws.p, &d_status, st, tb, (const uint64_t *)p->d_in.p)) { p->error = QB3E_LIBERR; return done; }
+                              d_index ? (const uint8_t *)d_index + first * isz : nullptr, p->d_ws.p, &d_status, st, tb, (const uint64_t *)p->d_in.p,
+                              IxTable(), p->d_tab.p, p->d_tab.cap)) { p->error = QB3E_LIBERR; return done; }
             e = hipMemcpyAsync(status.data(), d_status, 4 * cnt, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }

@@ -97,7 +97,13 @@ inline size_t ix_total_bytes(const IxTable &t) { return ix_chunks(t) * (IX_HEAD 
 
 // Batched tiles: n images/streams laid out at fixed byte pitches, processed by one set of launches (blockIdx.y).
 // n == 0 means a single image.  ws_pitch = plan.ws_bytes of one tile; idx_pitch = index_bytes of one tile.
-struct TileBatch { uint32_t n = 0; uint64_t src_pitch = 0, dst_pitch = 0, ws_pitch = 0, idx_pitch = 0; };
+struct TileBatch { uint32_t n = 0; uint64_t src_pitch = 0, dst_pitch = 0, ws_pitch = 0, idx_pitch = 0; uint64_t max_bits = 0; /* decode: the longest stream */ };
+// Plain 8-bit streams (no index, no restart table) are walked through a table of unit lengths by position (k_dec_walk.hip).
+// walk_table_bytes: memory that takes the whole call in one round; less means more rounds, down to walk_table_min_bytes.
+size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits);
+size_t walk_table_min_bytes(uint32_t ntiles);
+struct DecPlan;
+bool walk_table_applies(const Geometry &g, const DecPlan &plan);
 
 // Encode the block stream of one image.  All pointers are device pointers.
 //   img        image, g.tsz-byte values
@@ -138,7 +144,8 @@ DecPlan plan_decode(const Geometry &g);
 int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
                   void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb = TileBatch(),
                   const uint64_t *tile_bits = nullptr,     // tile_bits: device array, stream length of each tile in bits
-                  const IxTable &ix = IxTable());
+                  const IxTable &ix = IxTable(),
+                  void *walk_tab = nullptr, size_t walk_tab_bytes = 0);    // table memory for plain 8-bit streams (null: the one-wave walk)
 
 // RLE0 can only win on a stream with a run of four zero bytes: *has_run says whether bytes [off, off+nbytes) of d_buf have one
 int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, int *has_run, void *stream);
