@@ -43,7 +43,7 @@ ANCHORS = {                 # reference containers, SURVEY.md Appendix C: (size,
     "c5_tile1000": (27171401, "8e91222e70136a30"), "c5_tile1001": (27171735, "4e40f05b13367ea8"),
 }
 ENC_KERNELS = ("enc_units", "enc_best_units", "enc_best_scan", "enc_best_recode", "enc_scan", "enc_concat", "enc_seams")
-DEC_KERNELS = ("dec_index_serial", "dec_index_prev", "dec_index_scan", "dec_segments", "dec_units")
+DEC_KERNELS = ("dec_index_table", "dec_index_serial", "dec_index_prev", "dec_index_scan", "dec_segments", "dec_units")
 
 
 def container_check(qb3_amd, np, host, tag):
@@ -373,23 +373,30 @@ def main():
         sustained_steps += 50
     sustained = time.perf_counter() - s0
 
-    # ---- a plain container (what the reference writes: no table inside, no index beside it), 4096^2 so that it ends
+    # ---- plain containers (what the reference writes: no table inside, no index beside them): the stream is walked
+    # serially (a table of unit lengths by bit position, built by the whole chip, then one look-up per unit on one lane)
     plain = None
     if not args.no_workloads:
-        pw = 4096
-        pimg = synth.generate(pw, pw, 3, dtype, "NOISY3", 1000, device=dev)
-        penc = qdev.DeviceEncoder(pw, pw, 3, dtype, mode=qb3_amd.QB3M_FTL)
-        pdst, pn, _ = penc.encode(pimg)
-        pdec = qdev.DeviceDecoder(pdst, pn)
-        pout = torch.empty(pw * pw * 3, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        p0 = time.perf_counter()
-        pdec.decode(pdst, out=pout, index=None)
-        torch.cuda.synchronize()
-        pdt = time.perf_counter() - p0
-        plain = {"workload": "4096x4096x3 uint8 NOISY3 seed 1000, plain container, index = NULL (serial walk of the stream on one wave)",
-                 "ms_wall": round(pdt * 1e3, 2), "MPixel_s": round(pw * pw / pdt / 1e6, 1), "exact": bool(torch.equal(pout, pimg.reshape(-1)))}
-        del pimg, penc, pdec, pout, pdst
+        def plain_decode(pimg, pw):
+            penc = qdev.DeviceEncoder(pw, pw, 3, dtype, mode=qb3_amd.QB3M_FTL)
+            pdst, pn, _ = penc.encode(pimg)
+            pdec = qdev.DeviceDecoder(pdst, pn)
+            pout = torch.empty(pw * pw * 3, dtype=torch.uint8, device=dev)
+            pdec.decode(pdst, out=pout, index=None)          # (first call: allocates the table)
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            pdec.decode(pdst, out=pout, index=None)
+            torch.cuda.synchronize()
+            pdt = time.perf_counter() - p0
+            return {"ms_wall": round(pdt * 1e3, 2), "MPixel_s": round(pw * pw / pdt / 1e6, 1), "exact": bool(torch.equal(pout, pimg.reshape(-1)))}
+        pimg = synth.generate(4096, 4096, 3, dtype, "NOISY3", 1000, device=dev)
+        plain = {"workload": "4096x4096x3 uint8 NOISY3 seed 1000, plain container, index = NULL"}
+        plain.update(plain_decode(pimg, 4096))
+        del pimg
+        if args.size == 16384:
+            plain["config2"] = {"workload": "the 16384x16384x3 raster of the headline, plain container, index = NULL"}
+            plain["config2"].update(plain_decode(img, 16384))
+        torch.cuda.empty_cache()
 
     dom_traffic, valu = pmc_traffic(max((k for k in avg if k in ENC_KERNELS + DEC_KERNELS), key=lambda k: avg[k][0]))
     roofline = roofline_of(avg, algo, ENC_KERNELS + DEC_KERNELS, traffic=dom_traffic if args.size == 16384 else None,

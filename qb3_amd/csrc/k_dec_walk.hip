@@ -373,216 +373,311 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
 // depends on the bits alone.  walk_table_kernel computes that for every bit position of a slab of the stream and every
 // rung, the whole chip at once (a code's length is its rung plus what its two low bits say, so the sixteen codes of a
 // unit are four rounds of pointer doubling over "length of the next code"); walk_chain_kernel then follows the one
-// chain that is real, at one LDS look-up a unit instead of a switch and sixteen codes.
-// Table rows: utab[p][r_in] = bits of the unit at p entered with rung r_in; dtab[p] = the switch's rung step | signal<<7.
-constexpr uint32_t WT_W = 2048, WT_MARG = 160, WT_NP = WT_W + WT_MARG;    // positions a workgroup tabulates; the bits it looks ahead
+// chain that is real.  That walk is a pointer chase (measured on this chip: 48 cycles for a dependent LDS read, and
+// about 8 more for every instruction between the value read and the next address), so the table is written in the
+// form that makes the value read BE the next address: in windows of CW positions, a row of eight 16-bit entries per
+// position, entry[o][r_in] = 16 * (o + unit length) | 2 * (rung after the unit's switch) | signal, o counted from
+// the window's start.  16 * o' is the LDS offset of row o' in the window's buffer: one AND-OR with the buffer's base
+// and the rung of the band that comes next gives the address of the next look-up.
+namespace chain {
+constexpr uint32_t CW = 3072;                           // positions at which the blocks of a window start
+constexpr uint32_t ROWS = CW + 576;                     // ... and those their later units can start at (3 x 149 bits), in 3 x 64 rows for the loaders
+constexpr uint32_t WIN_BYTES = ROWS * 16, SLOT = 65536; // a window in LDS: its rows, in a slot whose base has no bit below 2^16
+constexpr uint32_t NSLOT = 2;                           // windows in LDS: one walked, one on its way
+constexpr uint32_t TR_ENTRIES = CW / 2 + 16, TR_BYTES = TR_ENTRIES * 2;     // trail of a window: a unit is at least two bits
+constexpr uint32_t TR0 = NSLOT * SLOT, META = TR0 + NSLOT * TR_BYTES, LDS_BYTES = META + 128;
+static_assert(ROWS + 149 <= 4096 && WIN_BYTES <= SLOT && ROWS % 192 == 0 && ROWS >= CW + 448 && TR_BYTES % 16 == 0 && CW == 0xc00, "window layout (the walk tests position >= CW by its two top bits)");
+constexpr uint32_t NP = ROWS + 160;                     // positions a table workgroup looks at: sixteen codes beyond the last switch
+static_assert(NP % 32 == 0, "whole words");
+}  // namespace chain
 struct WalkState { uint64_t P; uint32_t gb, rungs, bad, pad; };           // a tile's walk between two slabs
 
-__global__ void __launch_bounds__(256) walk_table_kernel(const DecArgs a0, uint8_t *utab, uint8_t *dtab, uint64_t slab0, uint64_t slab_bits, uint64_t tab_pitch) {
+__global__ void __launch_bounds__(256) walk_table_kernel(const DecArgs a0, uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch) {
+    using namespace chain;
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
-    const uint64_t p0 = slab0 + (uint64_t)blockIdx.x * WT_W;
-    if (p0 >= a.in_bits + 2 * WT_W) return;                                 // (uniform) far beyond the stream: no walk comes here
-    __shared__ uint32_t words[WT_NP / 32 + 3];
-    __shared__ uint8_t nA[7][WT_NP], nB[7][WT_NP];
+    const uint64_t p0 = slab0 + (uint64_t)blockIdx.x * CW;
+    if (p0 >= a.in_bits + 2 * CW) return;                                   // (uniform) far beyond the stream: no walk comes here
+    __shared__ uint32_t words[NP / 32 + 3];
+    __shared__ uint8_t nA[7][NP], nB[7][NP];
     const uint32_t tid = threadIdx.x;
     const uint64_t q0 = a.in_bit0 + p0, w0 = q0 >> 5, endw = (a.in_bit0 + a.in_bits + 31) >> 5;
     const uint32_t sh = (uint32_t)q0 & 31;
-    for (uint32_t i = tid; i < WT_NP / 32 + 3; i += 256) words[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
+    for (uint32_t i = tid; i < NP / 32 + 3; i += 256) words[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
     __syncthreads();
     auto bits = [&](uint32_t i) { const uint32_t b = sh + i, k = b >> 5; return __builtin_amdgcn_alignbit(words[k + 1], words[k], b & 31); };
-    for (uint32_t i = tid; i < WT_NP; i += 256) {                           // one code (reference QB3decode.h:119-129: r, r + 1 or r + 2 bits)
+    for (uint32_t i = tid; i < NP; i += 256) {                              // one code (reference QB3decode.h:119-129: r, r + 1 or r + 2 bits)
         const uint32_t x = bits(i), e = (x & 1) + ((x & 3) == 3);
 #pragma unroll
         for (uint32_t r = 1; r < 8; r++) nA[r - 1][i] = (uint8_t)(r + e);
     }
     __syncthreads();
-    uint8_t (*src)[WT_NP] = nA, (*dst)[WT_NP] = nB;
-    uint32_t valid = WT_NP;
+    uint8_t (*src)[NP] = nA, (*dst)[NP] = nB;
+    uint32_t valid = NP;
 #pragma unroll 1
     for (uint32_t lvl = 0; lvl < 4; lvl++) {                                // 2, 4, 8, 16 codes
         valid -= 9u << lvl;                                                 // (a code is at most nine bits)
         for (uint32_t r = 0; r < 7; r++)
             for (uint32_t i = tid; i < valid; i += 256) { const uint32_t n = src[r][i]; dst[r][i] = (uint8_t)(n + src[r][i + n]); }
         __syncthreads();
-        uint8_t (*t)[WT_NP] = src; src = dst; dst = t;
+        uint8_t (*t)[NP] = src; src = dst; dst = t;
     }
-    // valid = WT_NP - 135 >= WT_W + 5: sixteen codes from every position a switch in this window can end on
-    uint8_t *ut = utab + ((uint64_t)blockIdx.y * tab_pitch + (p0 - slab0)) * 8, *dt = dtab + (uint64_t)blockIdx.y * tab_pitch + (p0 - slab0);
-    for (uint32_t p = tid; p < WT_W; p += 256) {
-        const uint32_t x = bits(p);
+    // valid = NP - 135 >= ROWS + 5: sixteen codes from every position a switch in this window can end on
+    uint4 *out = tab + ((uint64_t)blockIdx.y * tab_pitch + (uint64_t)blockIdx.x * ROWS);
+    for (uint32_t o = tid; o < ROWS; o += 256) {
+        const uint32_t x = bits(o);
         uint32_t delta = 0; bool sig = false;
         const uint32_t cs = walk_switch<3>(x, delta, sig);                  // from rung 0: the step itself
         const uint32_t len0 = cs + (((x >> cs) & 1) ? 17 : 1);              // rung 0: one flag, then 16 raw bits
-        uint32_t lo = 0, hi = 0;
+        uint32_t e[8];
 #pragma unroll
         for (uint32_t rin = 0; rin < 8; rin++) {
             const uint32_t r = (rin + delta) & 7u;
-            const uint32_t u = r ? cs + src[r ? r - 1 : 0][p + cs] : len0;
-            if (rin < 4) lo |= u << (8 * rin); else hi |= u << (8 * (rin - 4));
+            const uint32_t u = r ? cs + src[r ? r - 1 : 0][o + cs] : len0;
+            e[rin] = ((o + u) << 4) | (r << 1) | (sig ? 1u : 0u);
         }
-        *(uint2 *)(ut + 8 * p) = make_uint2(lo, hi);
-        dt[p] = (uint8_t)(delta | (sig ? 0x80u : 0u));
+        out[o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
     }
 }
 
-// The chain: ONE LANE follows the units, a look-up (and a step of the band's rung) per unit -- the walk is a pointer
-// chase through LDS, so what counts is the latency of a look-up and the instructions that depend on it: the lane
-// carries the LDS ADDRESS of the next look-up (window base + 8 * position + rung), and one shift-and-add on the
-// length just read makes the next one.  The other three waves of the workgroup bring the next window of the table
-// into LDS and write the unit lengths of the last one out.
 namespace chain {
-// a window holds the table rows of WIN positions plus those a block that STARTS in them can reach (its later units)
-constexpr uint32_t WIN = 2048, MARG = 448, WROWS = WIN + MARG, STG = WIN / 2 + 8;      // (a unit is at least two bits)
-static_assert(MARG >= 3 * 149 && MARG <= WT_W && WIN % WT_W == 0, "look-ahead of a block");
-// dynamic LDS, from address 0: [unit rows x 2 windows][switch bytes x 2][staged unit lengths x 2, four bytes a block][words]
-constexpr uint32_t UB = 0, DB = 2 * WROWS * 8, SG = DB + 2 * WROWS, MISC = SG + 2 * STG * 4, LDS_BYTES = MISC + 32;
-static_assert(SG % 16 == 0 && MISC % 8 == 0 && LDS_BYTES <= 65536, "LDS layout");
-typedef const __attribute__((address_space(3))) uint8_t *LdsBytes;
-typedef __attribute__((address_space(3))) uint32_t *LdsWordsW;
-__device__ __forceinline__ uint32_t ldsb(uint32_t addr) { return ((LdsBytes)(uintptr_t)addr)[0]; }
+typedef volatile __attribute__((address_space(3))) uint32_t *LdsFlag;
+__device__ __forceinline__ uint32_t flag_get(uint32_t addr) { return *(LdsFlag)(uintptr_t)addr; }
+__device__ __forceinline__ void flag_set(uint32_t addr, uint32_t v) { *(LdsFlag)(uintptr_t)addr = v; }
+// words at META: what the waves of a workgroup tell each other (all counts of windows)
+constexpr uint32_t F_LOADED = META /* [NSLOT][4] */, F_TRAILED = META + 32, F_GB0 = META + 40, F_NUNITS = META + 48,
+                   F_WALKED = META + 56, F_WRITTEN = META + 60, F_STOP = META + 64;
+constexpr uint32_t SPIN_MAX = 1u << 22;                                     // (a wait that long is a defect: give up, flag the tile)
 
-// Walk the blocks that start in window BUF from position o; returns the position reached.  n: blocks staged.
-template <int B, uint32_t BUF, typename SEG>
-__device__ __forceinline__ uint32_t walk_window(uint32_t o, uint32_t olim, uint32_t &left, uint32_t &inseg, uint32_t NB, uint32_t (&rung)[B], uint32_t &bad, uint32_t &n, SEG &&on_segment) {
-    constexpr uint32_t U0 = UB + BUF * WROWS * 8, D0 = DB + BUF * WROWS, S0 = SG + BUF * STG * 4;
-    uint32_t A = U0 + o * 8 + rung[0];
-    while (true) {
-        o = (A - U0) >> 3;
-        if (o >= olim || !left) break;                  // a block per turn; its first unit starts in this window
-        if (inseg == 0) on_segment(o);
-        if (++inseg == NB) inseg = 0;
-        uint32_t pk = 0;
-#pragma unroll
-        for (int c = 0; c < B; c++) {                   // positions < WIN + 447
-            const uint32_t u = ldsb(A), d = ldsb(D0 + ((A - U0) >> 3));
-            const uint32_t rold = rung[c];
-            rung[c] = (rold + d) & 7u;
-            bad |= d;
-            A = (u << 3) + (A - rold + rung[(c + 1) % B]);          // (the next band's rung: this block has not stepped it yet; band 0's it has)
-            pk |= u << (8 * c);
-        }
-        ((LdsWordsW)(uintptr_t)(S0 + 4 * n))[0] = pk;
-        n++; left--;
+// One window: follow the chain from address A (slot base | 16 * position | 2 * rung of band 0) until a block starts
+// beyond the window or the blocks run out.  T: LDS address of the trail (the address of every unit).  R[c]: slot
+// base | 2 * rung of band c.  The loop is written out because the ORDER is the point -- every instruction between a
+// read's value and the next read's issue costs its full latency (measured: 48 cycles the read, 8-10 each other), so
+// between them stands only the AND-OR that makes the address; the trail write, the bookkeeping of the unit BEFORE
+// (its band's new rung, the signal bit) and the loop's own tests all issue while a read is in flight.
+#define CH_READ(E) "ds_read_u16 %[" #E "], %[A]\n"
+#define CH_BOOK(E, Rc) "v_and_or_b32 %[" #Rc "], %[" #E "], 14, %[base]\n v_or_b32 %[bad], %[bad], %[" #E "]\n"
+#define CH_STEP(E, Rn, off) "ds_write_b16 %[T], %[A] offset:" #off "\n s_waitcnt lgkmcnt(1)\n v_and_or_b32 %[A], %[" #E "], %[M], %[" #Rn "]\n"
+#define CH_TOP "v_and_b32 %[t], 0xc000, %[A]\n v_cmp_eq_u32 vcc, 0xc000, %[t]\n"
+#define CH_EXIT "s_cbranch_vccnz 2f\n s_cmp_eq_u32 %[left], 0\n s_cbranch_scc1 2f\n"
+template <int B>
+__device__ __forceinline__ void walk_asm(uint32_t &A, uint32_t &T, uint32_t (&R)[B], uint32_t &bad, uint32_t &left, uint32_t base) {
+    uint32_t t;
+    const uint32_t M = 0xfff0u;
+    if constexpr (B == 3) {
+        uint32_t e0, e1, e2 = R[2] & 14u;           // (the first turn books "the unit before": nothing changes)
+        asm volatile(
+            CH_READ(e0)
+            "1:\n" CH_TOP CH_BOOK(e2, R2) CH_EXIT
+            CH_STEP(e0, R1, 0)
+            CH_READ(e1) CH_BOOK(e0, R0) CH_STEP(e1, R2, 2)
+            CH_READ(e2) CH_BOOK(e1, R1) CH_STEP(e2, R0, 4)
+            CH_READ(e0)
+            "v_add_u32 %[T], 6, %[T]\n s_sub_u32 %[left], %[left], 1\n s_branch 1b\n"
+            "2:\n s_waitcnt lgkmcnt(0)\n"
+            : [A] "+v"(A), [T] "+v"(T), [R0] "+v"(R[0]), [R1] "+v"(R[1]), [R2] "+v"(R[2]), [bad] "+v"(bad), [left] "+s"(left),
+              [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "+v"(e2), [t] "=&v"(t)
+            : [M] "s"(M), [base] "v"(base)
+            : "vcc", "scc", "memory");
+    } else if constexpr (B == 4) {
+        uint32_t e0, e1, e2, e3 = R[3] & 14u;
+        asm volatile(
+            CH_READ(e0)
+            "1:\n" CH_TOP CH_BOOK(e3, R3) CH_EXIT
+            CH_STEP(e0, R1, 0)
+            CH_READ(e1) CH_BOOK(e0, R0) CH_STEP(e1, R2, 2)
+            CH_READ(e2) CH_BOOK(e1, R1) CH_STEP(e2, R3, 4)
+            CH_READ(e3) CH_BOOK(e2, R2) CH_STEP(e3, R0, 6)
+            CH_READ(e0)
+            "v_add_u32 %[T], 8, %[T]\n s_sub_u32 %[left], %[left], 1\n s_branch 1b\n"
+            "2:\n s_waitcnt lgkmcnt(0)\n"
+            : [A] "+v"(A), [T] "+v"(T), [R0] "+v"(R[0]), [R1] "+v"(R[1]), [R2] "+v"(R[2]), [R3] "+v"(R[3]), [bad] "+v"(bad), [left] "+s"(left),
+              [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2), [e3] "+v"(e3), [t] "=&v"(t)
+            : [M] "s"(M), [base] "v"(base)
+            : "vcc", "scc", "memory");
+    } else {
+        // one band: the rung that comes next is the one just read: the next address is the entry without its signal bit
+        uint32_t e0;
+        const uint32_t M1 = 0xfffeu;
+        asm volatile(
+            CH_READ(e0)
+            "1:\n" CH_TOP CH_EXIT
+            "ds_write_b16 %[T], %[A]\n s_waitcnt lgkmcnt(1)\n v_or_b32 %[bad], %[bad], %[e0]\n v_and_or_b32 %[A], %[e0], %[M], %[base]\n"
+            CH_READ(e0)
+            "v_add_u32 %[T], 2, %[T]\n s_sub_u32 %[left], %[left], 1\n s_branch 1b\n"
+            "2:\n s_waitcnt lgkmcnt(0)\n"
+            : [A] "+v"(A), [T] "+v"(T), [bad] "+v"(bad), [left] "+s"(left), [e0] "=&v"(e0), [t] "=&v"(t)
+            : [M] "s"(M1), [base] "v"(base)
+            : "vcc", "scc", "memory");
+        R[0] = base | (A & 14u);
     }
-    return o;
 }
+#undef CH_READ
+#undef CH_BOOK
+#undef CH_STEP
+#undef CH_TOP
+#undef CH_EXIT
 }  // namespace chain
 
+// A workgroup per tile, eight waves: wave 0 (one lane) walks; waves 1-6 bring windows of the table into LDS -- three
+// waves a window, one group the even windows and one the odd, so that a group's loads from HBM are in flight while the
+// window before theirs is walked; wave 7 turns the trail of a walked window into unit lengths and segment entries.
 template <int B>
-__global__ void __launch_bounds__(256) walk_chain_kernel(const DecArgs a0, const uint8_t *utab, const uint8_t *dtab, uint64_t slab0, uint64_t slab_bits, uint64_t tab_pitch,
+__global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch,
                                                          WalkState *states, uint32_t first_round) {
     using namespace chain;
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *stg_gb = (uint32_t *)(smem + MISC), *stg_n = stg_gb + 2;      // first block and number of blocks staged in a window
-    uint64_t *sP = (uint64_t *)(smem + MISC + 16);
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t NB = a.g.seg_blocks, nblocks = (uint32_t)a.g.nblocks;
     WalkState *S = states + blockIdx.x;
-    uint64_t P = first_round ? 0 : S->P;                                    // in stream bits
-    uint32_t gb = first_round ? 0 : S->gb;
-    const uint32_t R = first_round ? 0 : S->rungs;
-    uint32_t bad = first_round ? 0 : S->bad;
-    // blocks that start before slab_end are walked here; table rows exist up to tab_end
-    const uint64_t slab_end = slab0 + slab_bits, tab_end = slab_end + WT_W;
-    const uint8_t *ut = utab + (uint64_t)blockIdx.x * tab_pitch * 8, *dt = dtab + (uint64_t)blockIdx.x * tab_pitch;
-    // (all loads of a thread in flight before the first LDS store: the loaders are bound by the latency of HBM)
-    auto load_window = [&](uint64_t ws, uint32_t buf, uint32_t t, auto nt_c) {          // sixteen bytes a load
-        constexpr uint32_t NT = decltype(nt_c)::value, NU = (WROWS * 8 / 16 + NT - 1) / NT;
-        static_assert(WROWS / 16 <= NT, "switch bytes: one load a thread");
-        const uint64_t off = ws - slab0;
-        uint4 v[NU], d = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (uint32_t q = 0; q < NU; q++) {
-            const uint32_t i = t + q * NT;
-            v[q] = (i < WROWS * 8 / 16 && ws + 2 * i + 2 <= tab_end) ? ((const uint4 *)(ut + off * 8))[i] : make_uint4(0, 0, 0, 0);
-        }
-        if (t < WROWS / 16 && ws + 16 * t + 16 <= tab_end) d = ((const uint4 *)(dt + off))[t];
-#pragma unroll
-        for (uint32_t q = 0; q < NU; q++) { const uint32_t i = t + q * NT; if (i < WROWS * 8 / 16) ((uint4 *)(smem + UB + buf * WROWS * 8))[i] = v[q]; }
-        if (t < WROWS / 16) ((uint4 *)(smem + DB + buf * WROWS))[t] = d;
-    };
-    auto flush = [&](uint32_t buf, uint32_t t, uint32_t nt) {                           // staged unit lengths to the index
-        const uint32_t g0 = stg_gb[buf], n = stg_n[buf] * B;
-        uint8_t *ul = (uint8_t *)a.idx.ulen + (uint64_t)g0 * B;
-        const uint8_t *sg = smem + SG + buf * STG * 4;
-        for (uint32_t j = t; j < n; j += nt) ul[j] = sg[(j / B) * 4 + j % B];
-    };
-    if (P < slab0 || P >= slab_end || P >= a.in_bits || gb >= nblocks) return;         // (uniform) nothing of this tile in this slab
-    uint64_t wstart = slab0 + ((P - slab0) / WIN) * WIN;
-    load_window(wstart, 0, tid, std::integral_constant<uint32_t, 256>());
-    uint32_t buf = 0, turn = 0;
-    uint32_t rung[B];
-#pragma unroll
-    for (int c = 0; c < B; c++) rung[c] = (R >> (4 * c)) & 15u;
+    const uint64_t P0 = first_round ? 0 : S->P;                             // in stream bits
+    const uint32_t gb_in = first_round ? 0 : S->gb;
+    const uint32_t R_in = first_round ? 0 : S->rungs;
+    const uint64_t slab_end = slab0 + (uint64_t)nwin * CW;
+    if (P0 < slab0 || P0 >= slab_end || P0 >= a.in_bits || gb_in >= nblocks) return;       // (uniform) nothing of this tile in this slab
+    const uint32_t k0 = (uint32_t)((P0 - slab0) / CW);                      // the window the walk starts in
+    if (tid < 32) ((uint32_t *)(smem + META))[tid] = tid == (F_STOP - META) / 4 ? 0xffffffffu : 0u;
     __syncthreads();
-    while (true) {
-        const uint64_t wend = wstart + WIN;
-        if (wave) {
-            if (wend < slab_end) load_window(wend, buf ^ 1, tid - 64, std::integral_constant<uint32_t, 192>());    // the next window, beside the walk
-            if (turn) flush(buf ^ 1, tid - 64, 192);                                    // what the last turn staged
-        } else if (tid == 0) {
-            const uint32_t olim = slab_end - wstart < WIN ? (uint32_t)(slab_end - wstart) : WIN;
-            uint32_t left = nblocks - gb, inseg = gb % NB, n = 0;
-            auto on_segment = [&](uint32_t o) {
-                const uint64_t seg = (nblocks - left) / NB;
-                a.idx.bitpos[seg] = wstart + o;
-#pragma unroll
-                for (int c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)rung[c];
-            };
-            stg_gb[buf] = gb;
-            const uint32_t o0 = (uint32_t)(P - wstart);
-            const uint32_t o = buf ? walk_window<B, 1>(o0, olim, left, inseg, NB, rung, bad, n, on_segment)
-                                   : walk_window<B, 0>(o0, olim, left, inseg, NB, rung, bad, n, on_segment);
-            stg_n[buf] = n;
-            *sP = wstart + o;
+    const uint4 *wt = tab + (uint64_t)blockIdx.x * tab_pitch;
+
+    if (wave == 0) {
+        if (lane) return;
+        uint32_t R[B], bad = first_round ? 0 : S->bad;
+        uint32_t left = nblocks - gb_in, k = k0, o = (uint32_t)((P0 - slab0) % CW);
+        for (int c = 0; c < B; c++) R[c] = ((R_in >> (4 * c)) & 7u) << 1;
+        bool stuck = false;
+        uint64_t Pn = P0;                                                   // where the next block starts
+        while (true) {
+            const uint32_t s = k % NSLOT, base = s * SLOT;
+            uint32_t spin = 0;                                              // the window in LDS (three parts), and this trail slot written out
+            while ((flag_get(F_LOADED + 16 * s) != k + 1 || flag_get(F_LOADED + 16 * s + 4) != k + 1 || flag_get(F_LOADED + 16 * s + 8) != k + 1 ||
+                    flag_get(F_WRITTEN) + NSLOT <= k - k0) && ++spin < SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+            if (spin >= SPIN_MAX) { stuck = true; break; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (int c = 0; c < B; c++) R[c] = (R[c] & 14u) | base;
+            uint32_t A = base | (o << 4) | (R[0] & 14u), T = TR0 + s * TR_BYTES;
+            const uint32_t T0 = T, left0 = left;
+            walk_asm<B>(A, T, R, bad, left, base);
+            *(volatile __attribute__((address_space(3))) uint16_t *)(uintptr_t)T = (uint16_t)A;        // where the next block starts: the last unit's end
+            flag_set(F_GB0 + 4 * s, nblocks - left0);
+            flag_set(F_NUNITS + 4 * s, (T - T0) >> 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            flag_set(F_TRAILED + 4 * s, k + 1);
+            const uint32_t oe = (A & 0xfff0u) >> 4;
+            Pn = slab0 + (uint64_t)k * CW + oe;
+            k++;
+            flag_set(F_WALKED, k - k0);
+            if (!left) break;                                               // the blocks ran out
+            o = oe - CW;                                                    // (the walk left the window: oe >= CW)
+            if (k >= nwin || Pn >= a.in_bits) break;                        // the slab ends here, or the stream does (a damaged one)
         }
-        __syncthreads();
-        P = *sP; gb = stg_gb[buf] + stg_n[buf];
-        // the walk is over when it has run out of slab, of stream or of blocks (uniform: from shared values)
-        if (P >= slab_end || P >= a.in_bits || gb >= nblocks) break;
-        wstart = wend; buf ^= 1; turn++;
-        // (sP and stg_*[buf] are next written after the lane has walked a window; the readers above are long past)
-    }
-    flush(buf, tid, 256);
-    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        flag_set(F_STOP, k);                                                // k windows were walked
         uint32_t Rn = 0;
+        for (int c = 0; c < B; c++) Rn |= ((R[c] >> 1) & 7u) << (4 * c);
+        S->P = stuck ? ~0ull : Pn; S->gb = nblocks - left; S->rungs = Rn; S->bad = (bad & 1u) | (stuck ? 1u : 0u);
+        if ((bad & 1u) || stuck) atomicOr(a.status, 1u);
+        return;
+    }
+    if (wave <= 6) {
+        // loaders: group g (three waves, a third of the rows each) takes the windows of parity g, into slot g
+        const uint32_t g = (wave - 1) / 3, part = (wave - 1) % 3;
+        constexpr uint32_t NV = ROWS / 192;                                 // sixty-four rows a load: loads of a wave per window
+        for (uint32_t k = k0 + ((k0 ^ g) & 1u); k < nwin; k += 2) {
+            const uint4 *src = wt + (uint64_t)k * ROWS;
+            // (named values, not an array: the array went to scratch memory)
+#define CH_REP19(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18)
+            static_assert(NV == 19, "CH_REP19");
+#define CH_LD(i) const uint4 v##i = src[lane + 64 * (part + 3 * i)];
+            CH_REP19(CH_LD)
+            uint32_t spin = 0;
+            bool stop = false;
+            while (true) {                                                  // the slot is free when the window two back has been walked
+                if (flag_get(F_STOP) != 0xffffffffu) { stop = true; break; }
+                if (flag_get(F_WALKED) + NSLOT > k - k0) break;
+                if (++spin >= SPIN_MAX) { stop = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (stop) break;
+            uint4 *slot = (uint4 *)(smem + g * SLOT);
+#define CH_ST(i) slot[lane + 64 * (part + 3 * i)] = v##i;
+            CH_REP19(CH_ST)
+#undef CH_ST
+#undef CH_LD
+#undef CH_REP19
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) flag_set(F_LOADED + 16 * g + 4 * part, k + 1);
+        }
+        return;
+    }
+    // writer: the trail of a walked window gives the position and rung of every unit: lengths by difference
+    for (uint32_t k = k0;; k++) {
+        const uint32_t s = k % NSLOT;
+        uint32_t spin = 0;
+        bool stop = false;
+        while (flag_get(F_TRAILED + 4 * s) != k + 1) {
+            const uint32_t st = flag_get(F_STOP);
+            if ((st != 0xffffffffu && k >= st) || ++spin >= SPIN_MAX) { stop = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (stop) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t gb0 = flag_get(F_GB0 + 4 * s), n = flag_get(F_NUNITS + 4 * s);
+        const uint16_t *tr = (const uint16_t *)(smem + TR0 + s * TR_BYTES);
+        const uint64_t wpos = slab0 + (uint64_t)k * CW;
+        uint8_t *ul = (uint8_t *)a.idx.ulen + (uint64_t)gb0 * B;
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint32_t o0 = tr[j] >> 4, o1 = tr[j + 1] >> 4;
+            ul[j] = (uint8_t)(o1 - o0);
+            if (j % B == 0 && (gb0 + j / B) % NB == 0) {
+                const uint64_t seg = (gb0 + j / B) / NB;
+                a.idx.bitpos[seg] = wpos + o0;
 #pragma unroll
-        for (int c = 0; c < B; c++) Rn |= rung[c] << (4 * c);
-        S->P = P; S->gb = gb; S->rungs = Rn; S->bad = bad & 0x80u;
-        if (bad & 0x80u) atomicOr(a.status, 1u);
+                for (int c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)((tr[j + c] >> 1) & 7u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) flag_set(F_WRITTEN, k - k0 + 1);
     }
 }
 
 // Slabs of the streams are tabulated by the whole chip, then walked by a workgroup per tile, slab after slab.
-// tab: [WalkState per tile][unit-length rows, 8 bytes a position][switch bytes]; max_bits: the longest stream of the call.
+// tab: [WalkState per tile][windows of table rows per tile]; max_bits: the longest stream of the call.
 void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+    using namespace chain;
+    static const bool lds_ok = [] {
+        bool ok = true;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        return ok;
+    }();
+    (void)lds_ok;
     const uint32_t nt = a.ntiles;
     const size_t state_bytes = ((size_t)nt * sizeof(WalkState) + 255) & ~(size_t)255;
     uint8_t *base = (uint8_t *)tab;
-    // positions per tile and round: what the table holds, in whole windows, one window kept for the look-ahead
-    uint64_t rows = (tab_bytes - state_bytes) / (9 * (uint64_t)nt);
-    rows = rows / WT_W * WT_W;
-    uint64_t slab = rows - WT_W;
-    const uint64_t need = (max_bits + WT_W - 1) / WT_W * WT_W;
-    if (slab > need) slab = need;
-    const uint64_t pitch = slab + WT_W;
-    uint8_t *utab = base + state_bytes, *dtab = utab + (uint64_t)nt * pitch * 8;
+    // windows per tile and round: what the table holds
+    uint64_t nwin = (tab_bytes - state_bytes) / ((uint64_t)WIN_BYTES * nt);
+    const uint64_t need = (max_bits + CW - 1) / CW;
+    if (nwin > need) nwin = need;
+    if (nwin > 0x7fffffffu / ROWS) nwin = 0x7fffffffu / ROWS;
+    const uint64_t pitch = nwin * ROWS;                                     // in rows of sixteen bytes
+    uint4 *rows = (uint4 *)(base + state_bytes);
     WalkState *states = (WalkState *)base;
     uint32_t first = 1;
-    for (uint64_t s0 = 0; s0 < max_bits; s0 += slab, first = 0) {
-        { ProfScope ps("dec_index_table", st); hipLaunchKernelGGL(walk_table_kernel, dim3((uint32_t)(pitch / WT_W), nt), dim3(256), 0, st, a, utab, dtab, s0, slab, pitch); }
+    for (uint64_t s0 = 0; s0 < max_bits; s0 += nwin * CW, first = 0) {
+        { ProfScope ps("dec_index_table", st); hipLaunchKernelGGL(walk_table_kernel, dim3((uint32_t)nwin, nt), dim3(256), 0, st, a, rows, s0, (uint32_t)nwin, pitch); }
         ProfScope ps("dec_index_serial", st);
-        if (a.g.bands == 1) hipLaunchKernelGGL(walk_chain_kernel<1>, dim3(nt), dim3(256), chain::LDS_BYTES, st, a, utab, dtab, s0, slab, pitch, states, first);
-        else if (a.g.bands == 3) hipLaunchKernelGGL(walk_chain_kernel<3>, dim3(nt), dim3(256), chain::LDS_BYTES, st, a, utab, dtab, s0, slab, pitch, states, first);
-        else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(256), chain::LDS_BYTES, st, a, utab, dtab, s0, slab, pitch, states, first);
+        if (a.g.bands == 1) hipLaunchKernelGGL(walk_chain_kernel<1>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, (uint32_t)nwin, pitch, states, first);
+        else if (a.g.bands == 3) hipLaunchKernelGGL(walk_chain_kernel<3>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, (uint32_t)nwin, pitch, states, first);
+        else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, (uint32_t)nwin, pitch, states, first);
     }
 }
 size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits) {
-    const uint64_t need = (max_bits + WT_W - 1) / WT_W * WT_W + WT_W;
-    return (((size_t)ntiles * sizeof(WalkState) + 255) & ~(size_t)255) + 9 * (size_t)ntiles * need + 4096;
+    const uint64_t need = (max_bits + chain::CW - 1) / chain::CW;
+    return (((size_t)ntiles * sizeof(WalkState) + 255) & ~(size_t)255) + (size_t)chain::WIN_BYTES * ntiles * need + 4096;
 }
-size_t walk_table_min_bytes(uint32_t ntiles) { return walk_table_bytes(ntiles, 8 * WT_W); }
+size_t walk_table_min_bytes(uint32_t ntiles) { return walk_table_bytes(ntiles, 16 * chain::CW); }
 
 void launch_dec_walk(const DecArgs &a, hipStream_t st) {
     if (a.ix && a.ntiles == 1) {            // the container's own restart table: a lane per entry

@@ -38,6 +38,8 @@ const Tuning &tuning() {
         Tuning v;
         v.no_px = on("QB3_NO_PX");                   // generic kernels also where a lane-per-block kernel applies
         v.slow_walk = on("QB3_SLOW_WALK");           // plain 8-bit streams: the one-wave walk instead of the table walk
+        const char *cap = getenv("QB3_WALK_TAB_KB"); // plain 8-bit streams: bytes of table memory (a small one means many rounds)
+        v.walk_tab_kb = cap ? (size_t)strtoull(cap, nullptr, 10) : 0;
         v.slow_index = on("QB3_SLOW_INDEX");         // index-less streams: the one-lane index rebuild instead of the walkers
         v.single_pass = on("QB3_SINGLE_PASS");       // 8-bit lane-per-block encoder: look-back and in-place writes instead of slots + concatenate (measured slower)
         v.persistent = on("QB3_PERSISTENT");         // 8-bit lane-per-block encoder: persistent workgroups instead of a workgroup per chunk (measured slower)
@@ -392,6 +394,7 @@ DecPlan plan_decode(const Geometry &g) {
     return p;
 }
 
+size_t walk_table_cap() { return tuning().walk_tab_kb ? tuning().walk_tab_kb << 10 : (size_t)1 << 30; }
 bool walk_table_applies(const Geometry &g, const DecPlan &plan) {
     return plan.px && g.mode != CM_BEST && g.tsz == 1 && !tuning().slow_walk && !tuning().slow_index;
 }

@@ -834,13 +834,13 @@ QB3_API size_t qb3x_decoder_index_size(const decsp p) {
 #define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(#x, (int)e_); p->error = QB3E_LIBERR; return 0; } } while (0)
 
 // A plain 8-bit stream (no index, no restart table) is walked through a table in device memory (qb3_dev.h): make sure
-// the decoder holds one -- the whole call in one round, or WALK_TAB_CAP and several rounds.  False: out of memory.
-static const size_t WALK_TAB_CAP = (size_t)1 << 30;
+// the decoder holds one -- the whole call in one round, or walk_table_cap() and several rounds.  False: out of memory.
 static bool walk_table_ready(decsp p, const Geometry &g, const DecPlan &plan, uint32_t ntiles, uint64_t max_bits) {
     if (!walk_table_applies(g, plan)) return true;
     size_t want = walk_table_bytes(ntiles, max_bits);
     const size_t least = walk_table_min_bytes(ntiles);
-    if (want > WALK_TAB_CAP) want = WALK_TAB_CAP > least ? WALK_TAB_CAP : least;
+    const size_t cap = walk_table_cap();
+    if (want > cap) want = cap > least ? cap : least;
     return p->d_tab.cap >= want || p->d_tab.ensure(want);
 }
 

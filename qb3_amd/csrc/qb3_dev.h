@@ -102,6 +102,7 @@ struct TileBatch { uint32_t n = 0; uint64_t src_pitch = 0, dst_pitch = 0, ws_pit
 // walk_table_bytes: memory that takes the whole call in one round; less means more rounds, down to walk_table_min_bytes.
 size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits);
 size_t walk_table_min_bytes(uint32_t ntiles);
+size_t walk_table_cap();                // what a decoder allocates at most (1 GiB; QB3_WALK_TAB_KB overrides)
 struct DecPlan;
 bool walk_table_applies(const Geometry &g, const DecPlan &plan);
 

@@ -524,7 +524,7 @@ struct ProfScope {
 };
 
 // process-wide debugging switches, read once from the environment (k_host.hip)
-struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool single_pass; bool persistent; };
+struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool single_pass; bool persistent; size_t walk_tab_kb; };
 const Tuning &tuning();
 
 uint32_t magic_div(uint32_t d);

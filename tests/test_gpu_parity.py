@@ -795,10 +795,11 @@ def test_handles_are_independent_across_threads(qb3, oracle):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("switch", ["QB3_SINGLE_PASS", "QB3_PERSISTENT", "QB3_NO_PX", "QB3_SLOW_INDEX"])
+@pytest.mark.parametrize("switch", ["QB3_SINGLE_PASS", "QB3_PERSISTENT", "QB3_NO_PX", "QB3_SLOW_INDEX", "QB3_SLOW_WALK", "QB3_WALK_TAB_KB=2048"])
 def test_alternative_kernel_paths(qb3, oracle, switch, tmp_path):
     """the paths that are not the default -- the single-pass (look-back) and the persistent 8-bit encoders, the generic
-    kernels on rasters the lane-per-block kernels would take, the one-lane index rebuild -- give the same bytes and pixels.
+    kernels on rasters the lane-per-block kernels would take, the one-lane index rebuild, the one-wave walk of a plain
+    stream, the table walk in many rounds (a table of 2 MiB) -- give the same bytes and pixels.
     (The switches are read once per process: a child process each.)"""
     import subprocess
     import sys
@@ -834,10 +835,18 @@ host = dst.cpu().numpy()
 for t in range(n):
     ref = o.encode(imgs[t].cpu().numpy(), 0, 8)
     assert sizes[t] == len(ref) and np.array_equal(host[t * pitch:t * pitch + sizes[t]], ref), t
+dims = (C.c_size_t * 3)()
+hdr = host[:64].copy()
+d = L.qb3_read_start(hdr.ctypes.data, sizes[0], dims)
+assert L.qb3_read_info(d)
+out = torch.zeros_like(imgs)
+assert L.qb3x_decode_tiles(d, dst.data_ptr(), n, pitch, sizes, out.data_ptr(), w * h * b, None, None) == n     # the streams alone
+assert torch.equal(out, imgs)
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env[switch] = "1"
+    name, _, value = switch.partition("=")
+    env[name] = value or "1"
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
