@@ -444,8 +444,14 @@ typedef volatile __attribute__((address_space(3))) uint32_t *LdsFlag;
 __device__ __forceinline__ uint32_t flag_get(uint32_t addr) { return *(LdsFlag)(uintptr_t)addr; }
 __device__ __forceinline__ void flag_set(uint32_t addr, uint32_t v) { *(LdsFlag)(uintptr_t)addr = v; }
 // words at META: what the waves of a workgroup tell each other (all counts of windows)
-constexpr uint32_t F_LOADED = META /* [NSLOT][4] */, F_TRAILED = META + 32, F_GB0 = META + 40, F_NUNITS = META + 48,
-                   F_WALKED = META + 56, F_WRITTEN = META + 60, F_STOP = META + 64;
+// F_READY[slot]: four words the walk reads at once: a window's three parts in LDS, and its trail slot written out
+constexpr uint32_t F_READY = META /* [NSLOT][4] */, F_TRAILED = META + 32, F_GB0 = META + 40, F_NUNITS = META + 48,
+                   F_WALKED = META + 56, F_STOP = META + 64;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool ready(uint32_t slot, uint32_t want) {
+    const u32x4_t f = *(volatile __attribute__((address_space(3))) u32x4_t *)(uintptr_t)(F_READY + 16 * slot);
+    return f.x == want && f.y == want && f.z == want && f.w == want;
+}
 constexpr uint32_t SPIN_MAX = 1u << 22;                                     // (a wait that long is a defect: give up, flag the tile)
 
 // One window: follow the chain from address A (slot base | 16 * position | 2 * rung of band 0) until a block starts
@@ -536,7 +542,12 @@ __global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const
     const uint64_t slab_end = slab0 + (uint64_t)nwin * CW;
     if (P0 < slab0 || P0 >= slab_end || P0 >= a.in_bits || gb_in >= nblocks) return;       // (uniform) nothing of this tile in this slab
     const uint32_t k0 = (uint32_t)((P0 - slab0) / CW);                      // the window the walk starts in
-    if (tid < 32) ((uint32_t *)(smem + META))[tid] = tid == (F_STOP - META) / 4 ? 0xffffffffu : 0u;
+    if (tid < 32) {     // (the first two windows find their trail slots free)
+        uint32_t v = tid == (F_STOP - META) / 4 ? 0xffffffffu : 0u;
+        if (tid == (k0 % NSLOT) * 4 + 3) v = k0 + 1;
+        if (tid == ((k0 + 1) % NSLOT) * 4 + 3) v = k0 + 2;
+        ((uint32_t *)(smem + META))[tid] = v;
+    }
     __syncthreads();
     const uint4 *wt = tab + (uint64_t)blockIdx.x * tab_pitch;
 
@@ -550,8 +561,7 @@ __global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const
         while (true) {
             const uint32_t s = k % NSLOT, base = s * SLOT;
             uint32_t spin = 0;                                              // the window in LDS (three parts), and this trail slot written out
-            while ((flag_get(F_LOADED + 16 * s) != k + 1 || flag_get(F_LOADED + 16 * s + 4) != k + 1 || flag_get(F_LOADED + 16 * s + 8) != k + 1 ||
-                    flag_get(F_WRITTEN) + NSLOT <= k - k0) && ++spin < SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+            while (!ready(s, k + 1) && ++spin < SPIN_MAX) __builtin_amdgcn_s_sleep(1);
             if (spin >= SPIN_MAX) { stuck = true; break; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             for (int c = 0; c < B; c++) R[c] = (R[c] & 14u) | base;
@@ -606,7 +616,7 @@ __global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const
 #undef CH_LD
 #undef CH_REP19
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) flag_set(F_LOADED + 16 * g + 4 * part, k + 1);
+            if (lane == 0) flag_set(F_READY + 16 * g + 4 * part, k + 1);
         }
         return;
     }
@@ -637,12 +647,20 @@ __global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) flag_set(F_WRITTEN, k - k0 + 1);
+        if (lane == 0) flag_set(F_READY + 16 * s + 12, k + NSLOT + 1);      // the slot is free for the window that takes it next
     }
 }
 
-// Slabs of the streams are tabulated by the whole chip, then walked by a workgroup per tile, slab after slab.
-// tab: [WalkState per tile][windows of table rows per tile]; max_bits: the longest stream of the call.
+// Slabs of the streams are tabulated by the whole chip, then walked by a workgroup per tile, slab after slab; the
+// table of the next slab is built (on a stream of its own, in the other half of the memory) while this one is walked.
+// tab: [WalkState per tile][windows of table rows per tile] x 2; max_bits: the longest stream of the call.
+static void launch_chain(const DecArgs &a, hipStream_t st, const uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch, WalkState *states, uint32_t first) {
+    using namespace chain;
+    const uint32_t nt = a.ntiles;
+    if (a.g.bands == 1) hipLaunchKernelGGL(walk_chain_kernel<1>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, nwin, pitch, states, first);
+    else if (a.g.bands == 3) hipLaunchKernelGGL(walk_chain_kernel<3>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, nwin, pitch, states, first);
+    else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, nwin, pitch, states, first);
+}
 void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
     using namespace chain;
     static const bool lds_ok = [] {
@@ -656,28 +674,52 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
     const uint32_t nt = a.ntiles;
     const size_t state_bytes = ((size_t)nt * sizeof(WalkState) + 255) & ~(size_t)255;
     uint8_t *base = (uint8_t *)tab;
-    // windows per tile and round: what the table holds
-    uint64_t nwin = (tab_bytes - state_bytes) / ((uint64_t)WIN_BYTES * nt);
-    const uint64_t need = (max_bits + CW - 1) / CW;
-    if (nwin > need) nwin = need;
+    WalkState *states = (WalkState *)base;
+    const uint64_t need = (max_bits + CW - 1) / CW;                         // windows of the longest stream
+    const uint64_t cap = (tab_bytes - state_bytes) / ((uint64_t)WIN_BYTES * nt);    // windows per tile the memory holds
+    // one round when the streams are short (nothing to overlap, and a stream costs more to create than it saves)
+    if (need <= cap && need * CW <= (8u << 20)) {
+        const uint64_t pitch = need * ROWS;
+        uint4 *rows = (uint4 *)(base + state_bytes);
+        { ProfScope ps("dec_index_table", st); hipLaunchKernelGGL(walk_table_kernel, dim3((uint32_t)need, nt), dim3(256), 0, st, a, rows, 0, (uint32_t)need, pitch); }
+        ProfScope ps("dec_index_serial", st);
+        launch_chain(a, st, rows, 0, (uint32_t)need, pitch, states, 1);
+        return;
+    }
+    // rounds of at most half the memory, and at least four of them
+    uint64_t nwin = cap / 2;
+    if (nwin > (need + 3) / 4) nwin = (need + 3) / 4;
+    if (nwin < 16) nwin = 16;                                               // (walk_table_min_bytes holds 2 x 16)
     if (nwin > 0x7fffffffu / ROWS) nwin = 0x7fffffffu / ROWS;
     const uint64_t pitch = nwin * ROWS;                                     // in rows of sixteen bytes
-    uint4 *rows = (uint4 *)(base + state_bytes);
-    WalkState *states = (WalkState *)base;
-    uint32_t first = 1;
-    for (uint64_t s0 = 0; s0 < max_bits; s0 += nwin * CW, first = 0) {
-        { ProfScope ps("dec_index_table", st); hipLaunchKernelGGL(walk_table_kernel, dim3((uint32_t)nwin, nt), dim3(256), 0, st, a, rows, s0, (uint32_t)nwin, pitch); }
-        ProfScope ps("dec_index_serial", st);
-        if (a.g.bands == 1) hipLaunchKernelGGL(walk_chain_kernel<1>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, (uint32_t)nwin, pitch, states, first);
-        else if (a.g.bands == 3) hipLaunchKernelGGL(walk_chain_kernel<3>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, (uint32_t)nwin, pitch, states, first);
-        else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, (uint32_t)nwin, pitch, states, first);
+    uint4 *rows[2] = {(uint4 *)(base + state_bytes), (uint4 *)(base + state_bytes) + pitch * nt};
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_tab[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_start = nullptr;
+    bool ok = hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++)
+        ok = hipEventCreateWithFlags(&ev_tab[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ev_start, hipEventDisableTiming) == hipSuccess;
+    if (ok) { (void)hipEventRecord(ev_start, st); (void)hipStreamWaitEvent(aux, ev_start, 0); }
+    hipStream_t tst = ok ? aux : st;                                        // (no second stream: everything in order on the caller's)
+    uint32_t first = 1, j = 0;
+    for (uint64_t s0 = 0; s0 < max_bits; s0 += nwin * CW, first = 0, j++) {
+        const int h = j & 1;
+        if (ok && j >= 2) (void)hipStreamWaitEvent(aux, ev_done[h], 0);     // the walk of two rounds ago has left this half
+        { ProfScope ps("dec_index_table", tst); hipLaunchKernelGGL(walk_table_kernel, dim3((uint32_t)nwin, nt), dim3(256), 0, tst, a, rows[h], s0, (uint32_t)nwin, pitch); }
+        if (ok) { (void)hipEventRecord(ev_tab[h], aux); (void)hipStreamWaitEvent(st, ev_tab[h], 0); }
+        { ProfScope ps("dec_index_serial", st); launch_chain(a, st, rows[h], s0, (uint32_t)nwin, pitch, states, first); }
+        if (ok) (void)hipEventRecord(ev_done[h], st);
     }
+    // (destroying a stream or an event with work pending is deferred by the runtime until that work is done)
+    for (int i = 0; i < 2; i++) { if (ev_tab[i]) (void)hipEventDestroy(ev_tab[i]); if (ev_done[i]) (void)hipEventDestroy(ev_done[i]); }
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    if (aux) (void)hipStreamDestroy(aux);
 }
 size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits) {
     const uint64_t need = (max_bits + chain::CW - 1) / chain::CW;
     return (((size_t)ntiles * sizeof(WalkState) + 255) & ~(size_t)255) + (size_t)chain::WIN_BYTES * ntiles * need + 4096;
 }
-size_t walk_table_min_bytes(uint32_t ntiles) { return walk_table_bytes(ntiles, 16 * chain::CW); }
+size_t walk_table_min_bytes(uint32_t ntiles) { return walk_table_bytes(ntiles, 2 * 16 * chain::CW); }
 
 void launch_dec_walk(const DecArgs &a, hipStream_t st) {
     if (a.ix && a.ntiles == 1) {            // the container's own restart table: a lane per entry
