@@ -148,7 +148,7 @@ uint32_t seg_blocks_for(const Geometry &g) {
 }
 uint32_t ix_entry_bytes(const Geometry &g) { return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)); }
 // One entry per index segment for FTL/BASE streams (a lane then walks one segment, lengths only, and the segment's
-// entering values come straight from its entry), one per about 256 units for the common-factor modes.  For 8-bit RGB
+// entering values come straight from its entry), one per about 64 units for the common-factor modes.  For 8-bit RGB
 // that is 12 bytes per 64 blocks: 0.7 % of a typical stream.
 IxTable ix_layout(const Geometry &g) {
     IxTable t;
@@ -156,7 +156,9 @@ IxTable ix_layout(const Geometry &g) {
     t.entry_bytes = ix_entry_bytes(g);
     const uint64_t units_per_seg = (uint64_t)g.seg_blocks * g.bands;
     const bool per_seg = g.mode != CM_BEST;
-    const uint64_t spe = (per_seg || units_per_seg >= 256) ? 1 : 256 / units_per_seg;      // index segments per entry
+    // (common-factor streams: the lane that starts at an entry parses whole units from global memory, bound by latency --
+    // 64 units an entry keeps four times the lanes in flight that 256 did, for 1.5-3 % of the stream)
+    const uint64_t spe = (per_seg || units_per_seg >= 64) ? 1 : 64 / units_per_seg;        // index segments per entry
     t.blocks = (uint32_t)(spe * g.seg_blocks);
     t.K = (uint32_t)((g.nseg + spe - 1) / spe);
     t.per_chunk = (65535 - IX_HEAD) / t.entry_bytes;
