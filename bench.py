@@ -252,7 +252,7 @@ def main():
     ap.add_argument("--size", type=int, default=16384, help="raster edge in pixels at N = 1 (default: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the short measurements of configs 3, 4, 5")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2best", "c3", "c4", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2best", "c3", "c4", "c5", "plain"],
                     help="N = 1: make this configuration the only one run (for profiling); c2 is the headline")
     ap.add_argument("--tiles-per-rank", type=int, default=32)
     ap.add_argument("--batch-tiles", type=int, default=8)
@@ -445,7 +445,28 @@ def run_other(wl, args, torch, qb3_amd, synth, qdev, dev):
     """configs 3, 4 and 5 on one GPU, a few steps each"""
     steps = max(3, min(args.steps, 5))
     out = {}
-    if wl == "c2best":      # not a BASELINE configuration: the raster of configs[1] in QB3M_BEST (common factor + index coding)
+    if wl == "plain":       # a plain container (what the reference writes) decoded from the stream alone: the serial walk
+        w = 4096
+        img = synth.generate(w, w, 3, qb3_amd.QB3_U8, "NOISY3", 1000, device=dev)
+        enc = qdev.DeviceEncoder(w, w, 3, qb3_amd.QB3_U8, mode=qb3_amd.QB3M_FTL)
+        dst, n, _ = enc.encode(img)
+        dec = qdev.DeviceDecoder(dst, n)
+        res = torch.empty(w * w * 3, dtype=torch.uint8, device=dev)
+        dec.decode(dst, out=res, index=None)
+        prof = Prof(qdev)
+        prof.start()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            dec.decode(dst, out=res, index=None)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        avg = prof.stop()
+        # (the table and the chain run once per slab of the stream: launches > steps; ms per decode = avg_ms * launches / steps)
+        out["plain"] = {"workload": "4096x4096x3 uint8 NOISY3 seed 1000, QB3M_FTL, plain container, qb3x_decode_device with index = NULL",
+                        "stream_bytes": int(n), "ms_wall": round(dt * 1e3, 2), "MPixel_s": round(w * w / dt / 1e6, 1), "exact": bool(torch.equal(res, img.reshape(-1))),
+                        "kernels": {k: {"avg_ms": round(v[0], 4), "launches": v[1], "ms_per_decode": round(v[0] * v[1] / steps, 3)} for k, v in sorted(avg.items())}}
+    elif wl == "c2best":    # not a BASELINE configuration: the raster of configs[1] in QB3M_BEST (common factor + index coding)
         out["c2_best"] = measure_image(torch, qb3_amd, synth, qdev, dev, "c2_best", 16384, 16384, 3, qb3_amd.QB3_U8, "NOISY3", 2, qb3_amd.QB3M_BEST, steps,
                                        "16384x16384x3 uint8 NOISY3 seed 2, QB3M_BEST")
     elif wl == "c3":

@@ -2,7 +2,7 @@
 # profiles/collect.sh TAG -- the rocprofv3 runs behind profiles/TAG_* (run on the GPU box from the repo root).
 # Counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa tracing next to --pmc).
 # TAG_*: BASELINE configs[1] alone (bench.py --no-workloads): kernel trace, FETCH_SIZE, WRITE_SIZE and SQ passes.
-# TAG_c3 / TAG_c4 / TAG_c5 / TAG_best_*: kernel traces of the other configurations (bench.py --workload ...).
+# TAG_c2best / TAG_c3 / TAG_c4 / TAG_c5 / TAG_plain: kernel traces of the other configurations (bench.py --workload ...).
 set -e
 TAG=${1:-rXX}
 OUT=gpurun_out/prof_$TAG
@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 PROFILE_CMD="python3 $CMD" python3 profiles/summarise.py $TAG $OUT/trace $OUT/fetch $OUT/write $OUT/sq
 cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc_hbm.csv profiles/${TAG}_sq.csv profiles/pmc_traffic.json $OUT/
 grep '^{' $OUT/bench_under_rocprof.json > $OUT/${TAG}_bench_under_rocprof.json || true
-for WL in c2best c3 c4 c5; do
+for WL in c2best c3 c4 c5 plain; do
     W="bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $WL"
     rocprofv3 --kernel-trace --stats -d $OUT/trace_$WL -o t --output-format csv -- python3 $W > $OUT/${TAG}_${WL}_bench_under_rocprof.json 2> $OUT/trace_$WL.log
     PROFILE_CMD="python3 $W" python3 profiles/summarise.py --stats-only ${TAG}_$WL $OUT/trace_$WL

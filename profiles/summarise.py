@@ -33,6 +33,7 @@ KEYS = [("enc_px_sp_kernel", "enc_units"), ("enc_px_kernel", "enc_units"), ("enc
         ("enc_scan2", "enc_scan2"), ("enc_scan", "enc_scan"), ("enc_concat", "enc_concat"), ("enc_seam", "enc_seams"),
         ("write_header", "write_header"), ("ix_fill", "ix_fill"), ("dec_px_kernel", "dec_units"), ("dec_px16_kernel", "dec_units"), ("dec3_kernel", "dec_units"),
         ("dec_walk_lanes", "dec_index_serial"), ("dec_walk_kernel", "dec_index_serial"), ("prev_scan", "dec_index_scan"),
+        ("walk_table_kernel", "dec_index_table"), ("walk_chain_kernel", "dec_index_serial"),
         ("dec_index_serial", "dec_index_serial"), ("dec_kernel", "dec_segments")]
 
 
