@@ -610,7 +610,8 @@ __global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const
             }
             if (stop) break;
             uint4 *slot = (uint4 *)(smem + g * SLOT);
-#define CH_ST(i) slot[lane + 64 * (part + 3 * i)] = v##i;
+            // (a pause after every store: nineteen 1 KB stores back to back hold the LDS long enough to stall the walk's reads)
+#define CH_ST(i) slot[lane + 64 * (part + 3 * i)] = v##i; __builtin_amdgcn_s_sleep(3);
             CH_REP19(CH_ST)
 #undef CH_ST
 #undef CH_LD
