@@ -23,44 +23,59 @@ __device__ __forceinline__ uint32_t px16_switch(uint32_t pos, uint32_t *cslen, b
     return (m & 1) ? (16 - (m + 1) / 2) & 15 : m / 2 + 1;
 }
 
-// 16 values of a 16-bit unit at bit `gpos`: rp[k] = running sums of values 2k, 2k+1 (16-bit lanes); returns the total
-template <bool STEP>
-__device__ __forceinline__ uint32_t px16_group(uint32_t gpos, uint32_t rung, uint32_t (&rp)[8]) {
-    if (rung < 8) return px_group<STEP>(gpos, rung, rp);     // values below 256: the table path of the 8-bit kernel
-    const uint32_t top = 1u << rung, half = top >> 1;
-    uint32_t pos = gpos, acc = 0, fl = 0;
-    uint64_t buf = 0;
+// The units of a lane's BG bands whose rung is 8 or more, by the code rule (values do not fit the 8-bit tables): 16
+// values each from bit gpos[c]; rp[c][k] = running sums of values 2k, 2k+1 (16-bit halves); tot[c] = the unit's total.
+// The BG walks are independent chains of data-dependent LDS reads and shifts, so they advance in LOCKSTEP, code by
+// code: several reads in flight instead of one (the kernel is bound by that latency, not by issue: SQ_INSTS_VALU x 2 /
+// SIMD = 28 % of its duration when the bands were walked one after the other).  A band whose rung is below 8 walks
+// along with a harmless result (its reads stay inside the staged words and their zero margin); the caller overwrites it.
+template <bool STEP, int N>         // N bands at a time: two is what the registers hold without spilling
+__device__ __forceinline__ void px16_groups_hi(const uint32_t *gpos, const uint32_t *rung, uint32_t (*rp)[8], uint32_t *tot) {
+    constexpr int BG = N;
+    uint32_t pos[BG], acc[BG], fl[BG], top[BG], half[BG];
+    uint64_t buf[BG];
+#pragma unroll
+    for (int c = 0; c < BG; c++) { pos[c] = gpos[c]; acc[c] = 0; fl[c] = 0; top[c] = 1u << rung[c]; half[c] = top[c] >> 1; buf[c] = 0; }
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         if (i % 3 == 0) {                               // three codes are at most 51 bits
-            LdsWords p = lds_at((pos >> 3) & ~3u);
-            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-            buf = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, pos) << 32) | __builtin_amdgcn_alignbit(d1, d0, pos);
-        }
-        const uint32_t x = (uint32_t)buf;
-        const bool c1 = x & 1, c2 = (x & 3) == 3;
-        const uint32_t len = rung + c1 + c2;
-        const uint32_t v = c2 ? (((x >> 2) & (top - 1)) | top) : c1 ? (((x >> 2) & (half - 1)) | half) : ((x & (top - 1)) >> 1);
-        buf >>= len; pos += len;
-        acc += (v >> 1) ^ (0u - (v & 1u));              // undo mag-sign, accumulate (mod 2^16 in the packed lanes)
-        if (STEP) fl |= ((uint32_t)c2 | ((v & 1u) << 1)) << (2 * i);
-        if (i & 1) rp[i >> 1] |= acc << 16; else rp[i >> 1] = acc & 0xffffu;
-    }
-    if (STEP) {                                         // undo the step (reference QB3decode.h:285-289), as in px_group
-        const uint32_t tb = fl & 0x55555555u, u = tb | (tb << 1);
-        const uint32_t m = __popc(tb);
-        if ((u & (u + 1)) == 0 && m < 16) {
-            const uint32_t c16 = ((fl >> (2 * m + 1)) & 1u) ? (0u - half) & 0xffffu : half;
-            const uint32_t ge = 0xffff0000u >> (16 - m);
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t pair = (ge >> (2 * k)) & 3u;
-                rp[k] = pk_add16(rp[k], ((pair | (pair << 15)) & 0x00010001u) * c16);
+            for (int c = 0; c < BG; c++) {
+                LdsWords p = lds_at((pos[c] >> 3) & ~3u);
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+                buf[c] = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, pos[c]) << 32) | __builtin_amdgcn_alignbit(d1, d0, pos[c]);
             }
-            acc += c16;
+        }
+#pragma unroll
+        for (int c = 0; c < BG; c++) {
+            const uint32_t x = (uint32_t)buf[c];
+            const bool c1 = x & 1, c2 = (x & 3) == 3;
+            const uint32_t len = rung[c] + c1 + c2;
+            const uint32_t v = c2 ? (((x >> 2) & (top[c] - 1)) | top[c]) : c1 ? (((x >> 2) & (half[c] - 1)) | half[c]) : ((x & (top[c] - 1)) >> 1);
+            buf[c] >>= len; pos[c] += len;
+            acc[c] += (v >> 1) ^ (0u - (v & 1u));       // undo mag-sign, accumulate (mod 2^16 in the packed halves)
+            if (STEP) fl[c] |= ((uint32_t)c2 | ((v & 1u) << 1)) << (2 * i);
+            if (i & 1) rp[c][i >> 1] |= acc[c] << 16; else rp[c][i >> 1] = acc[c] & 0xffffu;
         }
     }
-    return acc;
+#pragma unroll
+    for (int c = 0; c < BG; c++) {
+        if (STEP) {                                     // undo the step (reference QB3decode.h:285-289), as in px_group
+            const uint32_t tb = fl[c] & 0x55555555u, u = tb | (tb << 1);
+            const uint32_t m = __popc(tb);
+            if ((u & (u + 1)) == 0 && m < 16) {
+                const uint32_t c16 = ((fl[c] >> (2 * m + 1)) & 1u) ? (0u - half[c]) & 0xffffu : half[c];
+                const uint32_t ge = 0xffff0000u >> (16 - m);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t pair = (ge >> (2 * k)) & 3u;
+                    rp[c][k] = pk_add16(rp[c][k], ((pair | (pair << 15)) & 0x00010001u) * c16);
+                }
+                acc[c] += c16;
+            }
+        }
+        tot[c] = acc[c];
+    }
 }
 
 // inclusive scan over the lanes of the same band group (stride NG), NW words per lane
@@ -82,7 +97,7 @@ __device__ __forceinline__ void group_iscan(uint32_t (&v)[NW], uint32_t NG) {
 }
 
 template <int BG, bool RGB, uint64_t ORDER, bool STEP>
-__global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
+__global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NW = (BG + 1) / 2;                    // 32-bit words of a scan packed 16 bits per band
@@ -106,34 +121,54 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
     const uint64_t P0 = a.idx.bitpos[segc];
     const uint64_t P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
     uint32_t ul_[BG], rg0[BG], pv0[BG], blen = 0;
-    {
+    {   // a lane's BG lengths, rungs and entering values are contiguous: one load each where the address allows
         const uint16_t *ul = (const uint16_t *)a.idx.ulen + ((uint64_t)g0 + slot) * B + band0;
+        const uint16_t *pvp = (const uint16_t *)a.idx.prev + segc * B + band0;
+        const uint8_t *rgp = a.idx.rung + segc * B + band0;
+        if (BG == 4 && !(((uintptr_t)ul | (uintptr_t)pvp) & 7) && !((uintptr_t)rgp & 3)) {
+            const uint2 u = act ? *(const uint2 *)ul : make_uint2(0, 0), v = *(const uint2 *)pvp;
+            const uint32_t r = *(const uint32_t *)rgp;
+            ul_[0] = u.x & 0xffffu; ul_[1 % BG] = u.x >> 16; ul_[2 % BG] = u.y & 0xffffu; ul_[3 % BG] = u.y >> 16;
+            pv0[0] = v.x & 0xffffu; pv0[1 % BG] = v.x >> 16; pv0[2 % BG] = v.y & 0xffffu; pv0[3 % BG] = v.y >> 16;
 #pragma unroll
-        for (int c = 0; c < BG; c++) {
-            ul_[c] = act ? ul[c] : 0u;
-            rg0[c] = a.idx.rung[segc * B + band0 + c];
-            pv0[c] = ((const uint16_t *)a.idx.prev)[segc * B + band0 + c];
+            for (int c = 0; c < BG; c++) rg0[c] = (r >> (8 * c)) & 0xffu;
+        } else {
+#pragma unroll
+            for (int c = 0; c < BG; c++) {
+                ul_[c] = act ? ul[c] : 0u;
+                rg0[c] = rgp[c];
+                pv0[c] = pvp[c];
+            }
         }
     }
     for (uint32_t i = tid; i < 256; i += blockDim.x) ((uint4 *)tab)[i] = ((const uint4 *)px_dec_tab.e)[i];
     __syncthreads();                                    // the only workgroup barrier
     if (!live) return;
-    const uint64_t w0 = (a.in_bit0 + P0) >> 5;
+    // the segment's words, from the 16-byte aligned word at or before its first: sixteen bytes a load, four loads in
+    // flight per lane (1024 words: a typical segment in ONE round trip), then the LDS stores; 16 zero words follow
+    const uint64_t w0 = ((a.in_bit0 + P0) >> 5) & ~(uint64_t)3;
     const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
     const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0;
     const bool fits = ndw64 <= a.in_cap_dw && lds0 == 0;
     const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
-    for (uint32_t base = 0; base < ndw + 16; base += 512) {         // eight loads in flight per lane, then eight LDS stores; 16 zero words follow
-        uint32_t sw[8];
+    const bool in16 = !((uintptr_t)a.in32 & 15);         // (the stream's base decides whether whole 16-byte loads are aligned)
+    for (uint32_t base = 0; base < ndw + 16; base += 1024) {
+        uint4 sw[4];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const uint32_t i = base + lane + 64 * q;
-            sw[q] = (i < ndw && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u;
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i = base + 4 * (lane + 64 * q);
+            if (in16 && i + 4 <= ndw && w0 + i + 4 <= endw_abs) sw[q] = *(const uint4 *)(a.in32 + w0 + i);
+            else {
+                sw[q].x = (i + 0 < ndw && w0 + i + 0 < endw_abs) ? a.in32[w0 + i + 0] : 0u;
+                sw[q].y = (i + 1 < ndw && w0 + i + 1 < endw_abs) ? a.in32[w0 + i + 1] : 0u;
+                sw[q].z = (i + 2 < ndw && w0 + i + 2 < endw_abs) ? a.in32[w0 + i + 2] : 0u;
+                sw[q].w = (i + 3 < ndw && w0 + i + 3 < endw_abs) ? a.in32[w0 + i + 3] : 0u;
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const uint32_t i = base + lane + 64 * q;
-            if (i < ndw + 16) stage[i] = sw[q];
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i = base + 4 * (lane + 64 * q);
+            if (i < ndw + 16) *(uint4 *)(stage + i) = sw[q];
         }
     }
 #pragma unroll
@@ -163,11 +198,26 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
     uint32_t rp[BG][8], spk[NW], sinc[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) spk[k] = 0;
+    {
+        uint32_t rungs[BG], tots[BG];
+        bool lane_hi = false, lane_lo = false;
 #pragma unroll
-    for (int c = 0; c < BG; c++) {
-        const uint32_t rung = (rg0[c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 15u;
-        const uint32_t tot = px16_group<STEP>(gpos[c], rung, rp[c]) & 0xffffu;
-        spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
+        for (int c = 0; c < BG; c++) {
+            rungs[c] = (rg0[c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 15u;
+            lane_hi = lane_hi || rungs[c] >= 8; lane_lo = lane_lo || rungs[c] < 8;
+            tots[c] = 0;
+        }
+        if (__any(lane_hi)) {                           // the lane's bands in lockstep, two at a time
+            if (BG >= 2) px16_groups_hi<STEP, 2>(&gpos[0], &rungs[0], &rp[0], &tots[0]);
+            if (BG == 4) px16_groups_hi<STEP, 2>(&gpos[2], &rungs[2], &rp[2], &tots[2]);
+            if (BG & 1) px16_groups_hi<STEP, 1>(&gpos[BG - 1], &rungs[BG - 1], &rp[BG - 1], &tots[BG - 1]);
+        }
+        if (__any(lane_lo)) {                           // values below 256: the table path of the 8-bit kernel
+#pragma unroll
+            for (int c = 0; c < BG; c++) if (rungs[c] < 8) tots[c] = px_group<STEP>(gpos[c], rungs[c], rp[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < BG; c++) spk[c >> 1] |= (act ? tots[c] & 0xffffu : 0u) << (16 * (c & 1));
     }
     {   // per-band scan of the unit totals modulo 2^16: the two halves of a word must not carry into each other
         uint32_t lo[NW], hi[NW];
@@ -182,7 +232,7 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
         if (lane >= 64 - NG)
 #pragma unroll
             for (int c = 0; c < BG; c++) ((uint16_t *)a.idx.prev)[seg * B + band0 + c] = (uint16_t)(sinc[c >> 1] >> (16 * (c & 1)));
-        if (bad) atomicOr(a.status, fits ? 1u : 8u);
+        if (bad) atomicOr(a.status, fits ? 1u : (lds0 == 0 && ndw64 <= a.in_cap_full ? 16u : 8u));     // 16: staging sized for this stream's average was too small -- the host runs the call again with the worst case
         return;
     }
     if (act) {
@@ -219,6 +269,8 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
                 p[2 * N - 1] = (uint16_t)(src[N - 1] >> 16);
             }
         };
+        // (wave uniform) eight bands, pixels on 16-byte addresses
+        const bool pair16 = BG == 4 && NG == 2 && !((uintptr_t)a.img & 15) && !((stride * 2) & 15);
 #pragma unroll
         for (int y = 0; y < 4; y++) {
             uint16_t *rowp = p0 + (uint64_t)y * stride;
@@ -231,14 +283,25 @@ __global__ void __launch_bounds__(256) dec_px16_kernel(const DecArgs a0) {
                                      (uint32_t)(4 + 2 * (i1 & 1)) << 16 | (uint32_t)(4 + 2 * (i1 & 1) + 1) << 24;
                 ow[j] = __builtin_amdgcn_perm(rp[h1 % BG][i1 >> 1], rp[h0 % BG][i0 >> 1], sel);
             }
-            if (BG % 2 == 0) {
+            if (BG == 4 && pair16) {
+                // eight bands: the two lanes of a block hold half a pixel each (8 bytes at a 16-byte stride: every store would
+                // touch 32 lines for 16 bytes each).  They swap halves -- the even lane takes pixels 0 and 1 whole, the odd
+                // lane pixels 2 and 3 -- and store 32 contiguous bytes each.
+                uint32_t rcv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) rcv[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(grp ? ow[j] : ow[4 + j]), 0xb1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                const uint4 pa = grp ? make_uint4(rcv[0], rcv[1], ow[4], ow[5]) : make_uint4(ow[0], ow[1], rcv[0], rcv[1]);
+                const uint4 pb = grp ? make_uint4(rcv[2], rcv[3], ow[6], ow[7]) : make_uint4(ow[2], ow[3], rcv[2], rcv[3]);
+                uint4 *dst = (uint4 *)(rowp - band0 + (grp ? 2 * B : 0));
+                dst[0] = pa; dst[1] = pb;
+            } else if (BG % 2 == 0) {
 #pragma unroll
                 for (int x = 0; x < 4; x++) store_dw(rowp + (uint64_t)x * B, &ow[x * (BG / 2)], std::integral_constant<int, (BG / 2 ? BG / 2 : 1)>());
             } else
                 store_dw(rowp, &ow[0], std::integral_constant<int, 2 * BG>());
         }
     }
-    if (bad) atomicOr(a.status, fits ? 1u : 8u);
+    if (bad) atomicOr(a.status, fits ? 1u : (lds0 == 0 && ndw64 <= a.in_cap_full ? 16u : 8u));     // 16: staging sized for this stream's average was too small -- the host runs the call again with the worst case
     if (lane == 63 && seg == a.g.nseg - 1 && fits) {
         const uint64_t used = (uint64_t)(cpos + binc - stage_bit0) + 32 * w0 - a.in_bit0;
         if (used > a.in_bits) atomicOr(a.status, 4u);

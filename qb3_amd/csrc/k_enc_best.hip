@@ -433,7 +433,7 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
 // true entering factor;
 // otherwise the first pass codes every chunk assuming the starting state and the last pass repairs the listed few.
 template <typename T>
-__global__ void enc_best_sample_kernel(const EncArgs a0) {
+__global__ void __launch_bounds__(256) enc_best_sample_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t step = (a.nchunks + gridDim.x - 1) / gridDim.x, chunk = blockIdx.x * step;
@@ -450,7 +450,7 @@ __device__ __forceinline__ bool best_two_pass(const EncArgs &a) {
 }
 
 template <typename T, bool FIRST>
-__global__ void enc_best_kernel(const EncArgs a0) {
+__global__ void __launch_bounds__(256) enc_best_kernel(const EncArgs a0) {      // (256 = the plan's largest block: without the bound the compiler budgets for 1024 threads and the recode loop spills)
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const bool two_pass = best_two_pass(a);

@@ -248,7 +248,7 @@ __device__ __forceinline__ uint64_t lb_load(const uint64_t *p) { return __hip_at
 __device__ __forceinline__ void lb_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int B, bool RGB, uint64_t ORDER, bool STEP, bool LOOKBACK>
-__global__ void __launch_bounds__(256, 4) enc_px_sp_kernel(const EncArgs a0) {
+__global__ void __launch_bounds__(256, 3) enc_px_sp_kernel(const EncArgs a0) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *etab = (uint32_t *)smem;                      // 512 entries

@@ -391,6 +391,7 @@ DecPlan plan_decode(const Geometry &g) {
     bool rgb16 = false;
     if (!p.px && p.fast && px16_eligible(g, &rgb16, &p.px16_bg, &p.px16_ng) && NB * p.px16_ng <= 64) {
         p.px16 = true; p.px_rgb = rgb16;
+        p.px_cap_dw = (p.px_cap_dw + 4 + 3) & ~3u;             // staged from a 16-byte aligned word, in 16-byte pieces
         p.lds_px = 4096 + 4 * 4 * ((size_t)p.px_cap_dw + 16);
     }
     return p;
@@ -450,11 +451,22 @@ int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, i
     return 0;
 }
 
-int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
+int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
                   void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb,
-                  const uint64_t *tile_bits, const IxTable &ix, void *walk_tab, size_t walk_tab_bytes) {
+                  const uint64_t *tile_bits, const IxTable &ix, void *walk_tab, size_t walk_tab_bytes, bool full_staging) {
     hipStream_t st = (hipStream_t)stream;
     DecArgs a;
+    // 16-bit lane-per-block decoder: a wave stages its segment in LDS, and four worst-case segments (278 bits a unit) keep
+    // the CU at 4 workgroups.  Size the staging for a third above THIS stream's average segment instead; a segment that
+    // does not fit raises status bit 4 and the caller runs the call again with full_staging.
+    DecPlan plan = plan_in;
+    if (plan.px16 && !full_staging && g.nseg) {
+        const uint64_t bits = tb.n ? tb.max_bits : in_bits;
+        uint64_t cap = bits / 32 / g.nseg;
+        cap = (cap + cap / 3 + 64 + 3) & ~(uint64_t)3;
+        if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_px = 4096 + 4 * 4 * ((size_t)cap + 16); }
+    }
+    a.in_cap_full = plan_in.px_cap_dw;
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
     a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = a.ix_per_chunk = a.ix_pad = 0;
     if (ix.base && !tb.n && ix.blocks && ix.per_chunk && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&

@@ -852,18 +852,21 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
     uint32_t *d_status = nullptr;
     const uint32_t *in32 = (const uint32_t *)(d_buf + (off & ~(size_t)3));
     if (!d_index && !ix.base && !walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
-    if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st, TileBatch(), nullptr, ix,
-                      p->d_tab.p, p->d_tab.cap))
-        return false;
     uint32_t status = 0;
-    hipError_t e = hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { set_error("decode kernels", (int)e); return false; }
+    for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the stream's average)
+        if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st, TileBatch(), nullptr, ix,
+                          p->d_tab.p, p->d_tab.cap, full != 0))
+            return false;
+        hipError_t e = hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("decode kernels", (int)e); return false; }
+        if (!(status & 16)) break;
+    }
     prof_collect();
     // bit 0: corrupt unit, bit 1: more than 7 unused bits at the end (reference QB3decode.h:411,569,740).
     // bit 2 (ran past the end) is not an error in the reference, whose reader clamps (bitstream.h:36).
     // bit 3: the index handed in does not describe this stream (a segment longer than any valid one).
-    if (status & 11) { set_error("decode: corrupt or over-long stream", 0); p->error = QB3E_ERR; return false; }
+    if (status & 27) { set_error("decode: corrupt or over-long stream", 0); p->error = QB3E_ERR; return false; }
     return true;
 }
 
@@ -1066,14 +1069,19 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
             if (!d_index && !walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
             const uint8_t *src0 = (const uint8_t *)d_src + first * src_pitch;
             uint32_t *d_status = nullptr;
-            if (launch_decode(g, plan, (const uint32_t *)(src0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), 0, (uint8_t *)d_dst + first * dst_pitch,
-                              d_index ? (const uint8_t *)d_index + first * isz : nullptr, p->d_ws.p, &d_status, st, tb, (const uint64_t *)p->d_in.p,
-                              IxTable(), p->d_tab.p, p->d_tab.cap)) { p->error = QB3E_LIBERR; return done; }
-            e = hipMemcpyAsync(status.data(), d_status, 4 * cnt, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
+            for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the streams' average)
+                if (launch_decode(g, plan, (const uint32_t *)(src0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), 0, (uint8_t *)d_dst + first * dst_pitch,
+                                  d_index ? (const uint8_t *)d_index + first * isz : nullptr, p->d_ws.p, &d_status, st, tb, (const uint64_t *)p->d_in.p,
+                                  IxTable(), p->d_tab.p, p->d_tab.cap, full != 0)) { p->error = QB3E_LIBERR; return done; }
+                e = hipMemcpyAsync(status.data(), d_status, 4 * cnt, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
+                bool again = false;
+                for (size_t i = 0; i < cnt; i++) again = again || (status[i] & 16);
+                if (!again) break;
+            }
             prof_collect();
-            for (size_t i = 0; i < cnt; i++) if (bits[i] && !(status[i] & 11)) { p->tile_ok[first + i] = 1; done++; }
+            for (size_t i = 0; i < cnt; i++) if (bits[i] && !(status[i] & 27)) { p->tile_ok[first + i] = 1; done++; }
         }
     }
     for (size_t i = 0; i < n; i++) {

@@ -146,7 +146,8 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
                   void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb = TileBatch(),
                   const uint64_t *tile_bits = nullptr,     // tile_bits: device array, stream length of each tile in bits
                   const IxTable &ix = IxTable(),
-                  void *walk_tab = nullptr, size_t walk_tab_bytes = 0);    // table memory for plain 8-bit streams (null: the one-wave walk)
+                  void *walk_tab = nullptr, size_t walk_tab_bytes = 0,     // table memory for plain 8-bit streams (null: the one-wave walk)
+                  bool full_staging = false);   // 16-bit data: worst-case LDS staging (after a call that ended with status bit 4)
 
 // RLE0 can only win on a stream with a run of four zero bytes: *has_run says whether bytes [off, off+nbytes) of d_buf have one
 int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, int *has_run, void *stream);
