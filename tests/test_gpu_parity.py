@@ -278,6 +278,32 @@ def test_stride(qb3, oracle):
     assert np.array_equal(out[:, :w * b], img.reshape(h, w * b)) and not out[:, w * b:].any()
 
 
+@pytest.mark.parametrize("bands,mode", [(8, FTL), (8, BASE), (4, FTL), (2, BASE)])
+def test_16bit_segments_far_longer_than_the_average(qb3, oracle, bands, mode):
+    """the 16-bit lane-per-block decoder sizes its LDS staging for a third above the stream's AVERAGE segment; a flat image
+    with a patch of noise has segments many times the average: the first launch reports them (status bit 4), the call is
+    run again with the worst-case staging, and the pixels are exact -- with the index, from the stream alone, in a batch"""
+    import ctypes as C
+    import torch
+    from qb3_amd import device as qdev
+    w, h = 512, 256
+    rng = np.random.default_rng(5)
+    img = np.full((h, w, bands), 1000, dtype=np.uint16)
+    img[64:160, 128:320, :] = rng.integers(0, 65536, size=(96, 192, bands), dtype=np.uint16)
+    cb = [1, 1, 1] + list(range(3, bands)) if bands == 8 else None
+    stream = oracle.encode(img, 2, mode, cband=cb)
+    assert stream[10] != 255                                            # coded, not stored raw
+    out, dims, dtype, _ = qb3.decode(stream)                            # host API: from the stream alone
+    assert dims == (w, h, bands) and np.array_equal(out, img.view(np.uint8).ravel())
+    enc = qdev.DeviceEncoder(w, h, bands, 2, mode=mode, cband=cb)
+    dimg = torch.from_numpy(img.view(np.uint8).ravel().copy()).cuda()
+    dst, n, index = enc.encode(dimg)
+    assert n == len(stream) and np.array_equal(dst[:n].cpu().numpy(), stream)
+    dec = qdev.DeviceDecoder(dst, n)
+    assert torch.equal(dec.decode(dst, index=index).view(torch.uint8), dimg)
+    assert torch.equal(dec.decode(dst, index=None).view(torch.uint8), dimg)
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 3), (40, 3, 1), (1, 17, 2), (300, 1, 3), (3, 3, 1)])
 def test_narrow_images(qb3, oracle, shape):
     w, h, b = shape
