@@ -3,16 +3,14 @@
 
 namespace qb3dev {
 
-// Lane per index segment.
-template <typename T, int MODE>
-__global__ void dec_kernel(const DecArgs a0) {
-    const DecArgs a = dec_for_tile(a0, blockIdx.y);
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// Lane per index segment.  The stream words of the workgroup's segments (they are consecutive) are staged in LDS with
+// coalesced 16-byte loads when they fit -- a lane refilling its bit buffer from global memory waits a memory round
+// trip per word, 64 lanes on 64 different lines: the kernel spent 70 % of its wave cycles waiting -- and the lanes
+// read LDS; a span that does not fit (seg_cap_dw is sized for half as much again as the stream's average) is read
+// from global memory as before.
+template <typename T, int MODE, typename RD>
+__device__ __forceinline__ void dec_segment(const DecArgs &a, const DecArgs &a0, RD &rd, uint32_t *lane_mem, uint64_t seg, uint64_t pos_bias) {
     const uint32_t bands = a.g.bands, S = a.g.seg_blocks, nbx = a.g.nbx;
-    const uint64_t seg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= a.g.nseg) return;
-    // per-lane LDS: scratch block [y][x][band] then band state
-    uint32_t *lane_mem = (uint32_t *)smem + (size_t)threadIdx.x * a.lane_dw;
     T *blk = (T *)lane_mem;
     T *prev = blk + 16 * bands;
     T *pcf = prev + bands;
@@ -22,8 +20,6 @@ __global__ void dec_kernel(const DecArgs a0) {
         pcf[c] = (MODE == CM_BEST) ? ((const T *)a.idx.cf)[seg * bands + c] : (T)0;
         rungs[c] = a.idx.rung[seg * bands + c];
     }
-    Reader rd;
-    rd.init(a.in32, a.in_bit0 + a.idx.bitpos[seg], a.in_bit0 + a.in_bits);
     const uint64_t order = a.g.order;
     const uint32_t gend = (uint32_t)(((seg + 1) * S < a.g.nblocks) ? (seg + 1) * S : a.g.nblocks);
     bool ok = true;
@@ -32,7 +28,7 @@ __global__ void dec_kernel(const DecArgs a0) {
         for (uint32_t c = 0; c < bands; c++) {
             uint32_t rung = rungs[c];
             T cf = pcf[c];
-            ok = parse_unit<T, MODE, Reader>(rd, rung, cf, g) && ok;
+            ok = parse_unit<T, MODE, RD>(rd, rung, cf, g) && ok;
             rungs[c] = (uint8_t)rung;
             pcf[c] = cf;
             T prv = prev[c];
@@ -65,9 +61,57 @@ __global__ void dec_kernel(const DecArgs a0) {
     if (!ok) atomicOr(a.status, 1u);
     if (seg == a.g.nseg - 1) {
         // reference: fails when more than 7 bits are left (QB3decode.h:411,569,740); also flag overruns
-        const uint64_t used = rd.position() - a.in_bit0;
+        const uint64_t used = rd.position() + pos_bias - a.in_bit0;
         if (used > a.in_bits) atomicOr(a.status, 4u);
         else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
+    }
+}
+
+template <typename T, int MODE>
+__global__ void dec_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * nthr, seg = seg0 + tid;
+    // per-lane LDS: scratch block [y][x][band] then band state; the staged stream words follow the lanes' areas
+    uint32_t *lane_mem = (uint32_t *)smem + (size_t)tid * a.lane_dw;
+    uint32_t *stage = (uint32_t *)smem + (((size_t)nthr * a.lane_dw + 3) & ~(size_t)3);
+    const uint64_t segl = seg0 + nthr < a.g.nseg ? seg0 + nthr : a.g.nseg;           // (workgroup uniform) one past the last segment
+    const uint64_t P0 = a.idx.bitpos[seg0], P1 = segl < a.g.nseg ? a.idx.bitpos[segl] : a.in_bits;
+    const uint64_t w0 = ((a.in_bit0 + P0) >> 5) & ~(uint64_t)3;
+    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
+    const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0 + 2;                      // (+2: a refill may look one word ahead)
+    const bool staged = a.seg_cap_dw && P1 >= P0 && ndw64 <= a.seg_cap_dw;
+    if (staged) {
+        const uint32_t ndw = (uint32_t)ndw64;
+        const bool in16 = !((uintptr_t)a.in32 & 15);
+        for (uint32_t base = 0; base < ndw; base += 16 * nthr) {            // four 16-byte loads in flight per lane
+            uint4 sw[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t i = base + 4 * (tid + q * nthr);
+                if (in16 && i + 4 <= ndw && w0 + i + 4 <= endw_abs) sw[q] = *(const uint4 *)(a.in32 + w0 + i);
+                else {
+                    sw[q].x = (i + 0 < ndw && w0 + i + 0 < endw_abs) ? a.in32[w0 + i + 0] : 0u;
+                    sw[q].y = (i + 1 < ndw && w0 + i + 1 < endw_abs) ? a.in32[w0 + i + 1] : 0u;
+                    sw[q].z = (i + 2 < ndw && w0 + i + 2 < endw_abs) ? a.in32[w0 + i + 2] : 0u;
+                    sw[q].w = (i + 3 < ndw && w0 + i + 3 < endw_abs) ? a.in32[w0 + i + 3] : 0u;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t i = base + 4 * (tid + q * nthr); if (i < ndw) *(uint4 *)(stage + i) = sw[q]; }
+        }
+        __syncthreads();
+    }
+    if (seg >= a.g.nseg) return;
+    if (staged) {
+        ReaderT<LdsWords> rd;
+        rd.init((LdsWords)stage, a.in_bit0 + a.idx.bitpos[seg] - 32 * w0, 32 * (uint64_t)(((uint32_t)ndw64 + 3) & ~3u));
+        dec_segment<T, MODE, ReaderT<LdsWords>>(a, a0, rd, lane_mem, seg, 32 * w0);
+    } else {
+        Reader rd;
+        rd.init(a.in32, a.in_bit0 + a.idx.bitpos[seg], a.in_bit0 + a.in_bits);
+        dec_segment<T, MODE, Reader>(a, a0, rd, lane_mem, seg, 0);
     }
 }
 
@@ -372,10 +416,11 @@ static void launch_dec_generic_t(const DecArgs &a, const DecPlan &plan, hipStrea
         return;
     }
     const dim3 grid(plan.nwg, a.ntiles), block(plan.threads);
+    const size_t lds = a.seg_cap_dw ? (((size_t)plan.threads * a.lane_dw + 3) & ~(size_t)3) * 4 + 4 * (size_t)a.seg_cap_dw : plan.lds_bytes;
     switch (a.g.mode) {
-    case CM_FTL: hipLaunchKernelGGL((dec_kernel<T, CM_FTL>), grid, block, plan.lds_bytes, st, a); break;
-    case CM_BASE: hipLaunchKernelGGL((dec_kernel<T, CM_BASE>), grid, block, plan.lds_bytes, st, a); break;
-    default: hipLaunchKernelGGL((dec_kernel<T, CM_BEST>), grid, block, plan.lds_bytes, st, a); break;
+    case CM_FTL: hipLaunchKernelGGL((dec_kernel<T, CM_FTL>), grid, block, lds, st, a); break;
+    case CM_BASE: hipLaunchKernelGGL((dec_kernel<T, CM_BASE>), grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL((dec_kernel<T, CM_BEST>), grid, block, lds, st, a); break;
     }
 }
 void launch_dec_generic(const DecArgs &a, const DecPlan &plan, hipStream_t st) {

@@ -467,6 +467,18 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
         if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_px = 4096 + 4 * 4 * ((size_t)cap + 16); }
     }
     a.in_cap_full = plan_in.px_cap_dw;
+    // lane-per-segment decoder: LDS for the stream words of a workgroup's segments, half as much again as the average
+    // (the lanes' own areas + the staging stay under 48 KB; a longer span is read from global memory)
+    a.seg_cap_dw = 0;
+    if (g.nseg && !(plan.fast && g.mode != CM_BEST)) {
+        const uint64_t bits = tb.n ? tb.max_bits : in_bits;
+        const uint64_t lanes_bytes = (size_t)plan.threads * dec_lane_dwords(g) * 4;
+        uint64_t cap = bits / 32 * plan.threads / g.nseg;
+        cap = (cap + cap / 2 + 64 + 3) & ~(uint64_t)3;
+        const uint64_t room = lanes_bytes < 48 * 1024 ? (48 * 1024 - lanes_bytes) / 4 : 0;
+        if (cap > room) cap = room & ~(uint64_t)3;
+        if (bits && cap >= 64) a.seg_cap_dw = (uint32_t)cap;
+    }
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
     a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = a.ix_per_chunk = a.ix_pad = 0;
     if (ix.base && !tb.n && ix.blocks && ix.per_chunk && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&
