@@ -10,16 +10,27 @@ namespace qb3dev {
 // from global memory as before.
 template <typename T, int MODE, typename RD>
 __device__ __forceinline__ void dec_segment(const DecArgs &a, const DecArgs &a0, RD &rd, uint32_t *lane_mem, uint64_t seg, uint64_t pos_bias) {
-    const uint32_t bands = a.g.bands, S = a.g.seg_blocks, nbx = a.g.nbx;
+    const uint32_t bands = a.g.bands, S = a.from_ix ? a.ix_blocks : a.g.seg_blocks, nbx = a.g.nbx;
+    const uint64_t nseg = a.from_ix ? a.ix_K : a.g.nseg;
     T *blk = (T *)lane_mem;
     T *prev = blk + 16 * bands;
     T *pcf = prev + bands;
     uint8_t *rungs = (uint8_t *)(pcf + bands);
-    for (uint32_t c = 0; c < bands; c++) {
-        prev[c] = ((const T *)a.idx.prev)[seg * bands + c];
-        pcf[c] = (MODE == CM_BEST) ? ((const T *)a.idx.cf)[seg * bands + c] : (T)0;
-        rungs[c] = a.idx.rung[seg * bands + c];
-    }
+    if (a.from_ix) {            // the state entering the piece comes from the container's own table (layout: include/qb3x.h)
+        const uint8_t *e = ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, (uint32_t)seg);
+        const uint8_t *pv = e + 6 + bands, *cf = pv + bands * sizeof(T);
+        for (uint32_t c = 0; c < bands; c++) {
+            rungs[c] = e[6 + c];
+            uint64_t v = 0, f = 0;
+            for (uint32_t i = 0; i < sizeof(T); i++) { v |= (uint64_t)pv[c * sizeof(T) + i] << (8 * i); if (MODE == CM_BEST) f |= (uint64_t)cf[c * sizeof(T) + i] << (8 * i); }
+            prev[c] = (T)v; pcf[c] = (T)f;
+        }
+    } else
+        for (uint32_t c = 0; c < bands; c++) {
+            prev[c] = ((const T *)a.idx.prev)[seg * bands + c];
+            pcf[c] = (MODE == CM_BEST) ? ((const T *)a.idx.cf)[seg * bands + c] : (T)0;
+            rungs[c] = a.idx.rung[seg * bands + c];
+        }
     const uint64_t order = a.g.order;
     const uint32_t gend = (uint32_t)(((seg + 1) * S < a.g.nblocks) ? (seg + 1) * S : a.g.nblocks);
     bool ok = true;
@@ -59,7 +70,7 @@ __device__ __forceinline__ void dec_segment(const DecArgs &a, const DecArgs &a0,
         }
     }
     if (!ok) atomicOr(a.status, 1u);
-    if (seg == a.g.nseg - 1) {
+    if (seg == nseg - 1) {
         // reference: fails when more than 7 bits are left (QB3decode.h:411,569,740); also flag overruns
         const uint64_t used = rd.position() + pos_bias - a.in_bit0;
         if (used > a.in_bits) atomicOr(a.status, 4u);
@@ -76,8 +87,18 @@ __global__ void dec_kernel(const DecArgs a0) {
     // per-lane LDS: scratch block [y][x][band] then band state; the staged stream words follow the lanes' areas
     uint32_t *lane_mem = (uint32_t *)smem + (size_t)tid * a.lane_dw;
     uint32_t *stage = (uint32_t *)smem + (((size_t)nthr * a.lane_dw + 3) & ~(size_t)3);
-    const uint64_t segl = seg0 + nthr < a.g.nseg ? seg0 + nthr : a.g.nseg;           // (workgroup uniform) one past the last segment
-    const uint64_t P0 = a.idx.bitpos[seg0], P1 = segl < a.g.nseg ? a.idx.bitpos[segl] : a.in_bits;
+    // a "segment" is an index segment -- or, decoding straight from the container's restart table (from_ix), the piece
+    // between two of its entries: no index is rebuilt, the lane decodes its piece from the entry's state
+    const uint64_t nseg = a.from_ix ? a.ix_K : a.g.nseg;
+    auto seg_pos = [&](uint64_t sidx) -> uint64_t {
+        if (!a.from_ix) return a.idx.bitpos[sidx];
+        const uint8_t *e = ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, (uint32_t)sidx);
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < 6; i++) v |= (uint64_t)e[i] << (8 * i);
+        return v;
+    };
+    const uint64_t segl = seg0 + nthr < nseg ? seg0 + nthr : nseg;                    // (workgroup uniform) one past the last segment
+    const uint64_t P0 = seg_pos(seg0), P1 = segl < nseg ? seg_pos(segl) : a.in_bits;
     const uint64_t w0 = ((a.in_bit0 + P0) >> 5) & ~(uint64_t)3;
     const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
     const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0 + 2;                      // (+2: a refill may look one word ahead)
@@ -103,14 +124,14 @@ __global__ void dec_kernel(const DecArgs a0) {
         }
         __syncthreads();
     }
-    if (seg >= a.g.nseg) return;
+    if (seg >= nseg) return;
     if (staged) {
         ReaderT<LdsWords> rd;
-        rd.init((LdsWords)stage, a.in_bit0 + a.idx.bitpos[seg] - 32 * w0, 32 * (uint64_t)(((uint32_t)ndw64 + 3) & ~3u));
+        rd.init((LdsWords)stage, a.in_bit0 + seg_pos(seg) - 32 * w0, 32 * (uint64_t)(((uint32_t)ndw64 + 3) & ~3u));
         dec_segment<T, MODE, ReaderT<LdsWords>>(a, a0, rd, lane_mem, seg, 32 * w0);
     } else {
         Reader rd;
-        rd.init(a.in32, a.in_bit0 + a.idx.bitpos[seg], a.in_bit0 + a.in_bits);
+        rd.init(a.in32, a.in_bit0 + seg_pos(seg), a.in_bit0 + a.in_bits);
         dec_segment<T, MODE, Reader>(a, a0, rd, lane_mem, seg, 0);
     }
 }
@@ -415,7 +436,7 @@ static void launch_dec_generic_t(const DecArgs &a, const DecPlan &plan, hipStrea
         else hipLaunchKernelGGL((dec3_kernel<T, false>), grid, block, plan.lds2_bytes, st, a);
         return;
     }
-    const dim3 grid(plan.nwg, a.ntiles), block(plan.threads);
+    const dim3 grid(a.from_ix ? (a.ix_K + plan.threads - 1) / plan.threads : plan.nwg, a.ntiles), block(plan.threads);
     const size_t lds = a.seg_cap_dw ? (((size_t)plan.threads * a.lane_dw + 3) & ~(size_t)3) * 4 + 4 * (size_t)a.seg_cap_dw : plan.lds_bytes;
     switch (a.g.mode) {
     case CM_FTL: hipLaunchKernelGGL((dec_kernel<T, CM_FTL>), grid, block, lds, st, a); break;

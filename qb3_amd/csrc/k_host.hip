@@ -425,7 +425,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
           ProfScope ps("dec_index_scan", st);
           launch_prev_scan(a, st);
         }
-    } else if (rebuild) {
+    } else if (rebuild && !a.from_ix) {
         ProfScope ps("dec_index_serial", st);
         launch_dec_index_serial(a, st);
     }
@@ -467,24 +467,25 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
         if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_px = 4096 + 4 * 4 * ((size_t)cap + 16); }
     }
     a.in_cap_full = plan_in.px_cap_dw;
-    // lane-per-segment decoder: LDS for the stream words of a workgroup's segments, half as much again as the average
-    // (the lanes' own areas + the staging stay under 48 KB; a longer span is read from global memory)
-    a.seg_cap_dw = 0;
-    if (g.nseg && !(plan.fast && g.mode != CM_BEST)) {
-        const uint64_t bits = tb.n ? tb.max_bits : in_bits;
-        const uint64_t lanes_bytes = (size_t)plan.threads * dec_lane_dwords(g) * 4;
-        uint64_t cap = bits / 32 * plan.threads / g.nseg;
-        cap = (cap + cap / 2 + 64 + 3) & ~(uint64_t)3;
-        const uint64_t room = lanes_bytes < 48 * 1024 ? (48 * 1024 - lanes_bytes) / 4 : 0;
-        if (cap > room) cap = room & ~(uint64_t)3;
-        if (bits && cap >= 64) a.seg_cap_dw = (uint32_t)cap;
-    }
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
     a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = a.ix_per_chunk = a.ix_pad = 0;
     if (ix.base && !tb.n && ix.blocks && ix.per_chunk && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&
         ix.K == (g.nblocks + ix.blocks - 1) / ix.blocks) {
         a.ix = ix.base; a.ix_K = ix.K; a.ix_blocks = ix.blocks; a.ix_E = ix.entry_bytes; a.ix_per_chunk = ix.per_chunk;
         a.ix_pad = ix.pads ? IX_PAD : 0;
+    }
+    // lane-per-segment decoder: LDS for the stream words of a workgroup's segments, half as much again as the average,
+    // when that is at most 24 KB (more would cost more in resident workgroups than the staging saves; a longer span is
+    // read from global memory).  With a restart table in the container and no index, the lanes decode straight from the
+    // table's entries (from_ix: no index is rebuilt at all; their pieces are long, so usually not staged).
+    a.seg_cap_dw = 0;
+    const bool lane_per_segment = !(plan.fast && g.mode != CM_BEST);
+    a.from_ix = (lane_per_segment && index == nullptr && a.ix && !tuning().slow_index) ? 1u : 0u;
+    if (g.nseg && lane_per_segment) {
+        const uint64_t bits = tb.n ? tb.max_bits : in_bits;
+        uint64_t cap = bits / 32 * plan.threads / (a.from_ix ? a.ix_K : g.nseg);
+        cap = (cap + cap / 2 + 64 + 3) & ~(uint64_t)3;
+        if (bits && cap <= 24 * 1024 / 4) a.seg_cap_dw = (uint32_t)cap;
     }
     a.g = g; a.in32 = in32; a.in_bit0 = in_bit0; a.in_bits = in_bits; a.img = img;
     a.ntiles = tb.n ? tb.n : 1; a.ts_in = tb.src_pitch; a.ts_img = tb.dst_pitch; a.tile_bits = tile_bits;

@@ -306,6 +306,7 @@ struct DecArgs {
     uint32_t dpr;
     // unit-parallel kernel (dec3_kernel)
     uint32_t bpp, passes, in_cap_dw, magic_bpp, magic_dpr;
+    uint32_t from_ix;        // lane-per-segment decoder: the segments are the pieces between the entries of the container's restart table
     uint32_t seg_cap_dw;     // lane-per-segment decoder: stream words a workgroup may stage in LDS (0: lanes read global memory)
     uint32_t in_cap_full;    // 16-bit lane-per-block decoder: the worst-case staging (in_cap_dw may be sized for this stream's average)
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups (lanes) per block
