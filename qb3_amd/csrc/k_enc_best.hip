@@ -131,16 +131,27 @@ template <typename T> struct BestUnit {
 
 // number of distinct values among the sixteen (exact up to 9: all the caller asks is "at most 8?")
 template <typename T> __device__ __forceinline__ uint32_t distinct_t(const T (&g)[16], uint32_t rung, bool need) {
+    // All the caller asks is "at most 8 distinct values, and then how many" (index coding holds no more).
     uint32_t distinct = 99;
-    // 8-bit data up to rung 5 (values below 64): a bitmap and a population count
-    const bool small = sizeof(T) == 1 && rung <= 5;
-    if (sizeof(T) == 1 && __any(need && small)) {
-        uint64_t bm = 0;
+    bool open = need;                   // lanes that still need the exact count
+    if (sizeof(T) == 1) {
+        // 8-bit data: the values' low five bits in a 32-bit bitmap: exact up to rung 4 (values below 32), else a LOWER
+        // bound -- more than 8 there settles the lane (on noisy data nearly every lane, with 32-bit operations)
+        if (__any(need)) {
+            uint32_t bm = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < 16; i++) bm |= 1ull << ((uint32_t)g[i] & 63u);
-        if (small) distinct = (uint32_t)__popcll(bm);
+            for (uint32_t i = 0; i < 16; i++) bm |= 1u << ((uint32_t)g[i] & 31u);
+            const uint32_t lb = (uint32_t)__popc(bm);
+            if (rung <= 4 || lb > 8) { distinct = lb; open = false; }
+        }
+        if (__any(open && rung <= 5)) {     // values below 64: a 64-bit bitmap
+            uint64_t bm = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) bm |= 1ull << ((uint32_t)g[i] & 63u);
+            if (open && rung <= 5) { distinct = (uint32_t)__popcll(bm); open = false; }
+        }
     }
-    if (__any(need && !small)) {        // plain comparisons, in registers and the same in every lane
+    if (__any(open)) {                  // plain comparisons, in registers and the same in every lane
         uint32_t d = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 16; i++) {
@@ -149,7 +160,7 @@ template <typename T> __device__ __forceinline__ uint32_t distinct_t(const T (&g
             for (uint32_t j = 0; j < i; j++) seen = seen || g[j] == g[i];
             d += !seen;
         }
-        if (!small) distinct = d;
+        if (open) distinct = d;
     }
     return distinct;
 }
