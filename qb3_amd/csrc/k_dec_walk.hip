@@ -647,52 +647,290 @@ __global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const
                 for (int c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)((tr[j + c] >> 1) & 7u);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // (no release fence: the trail has been READ -- LDS operations of a wave are in order -- and the index stores may still be
+        // on their way; a fence would hold the slot for a memory round trip per window)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) flag_set(F_READY + 16 * s + 12, k + NSLOT + 1);      // the slot is free for the window that takes it next
+    }
+}
+
+// ---- the same for plain 16-bit streams ---------------------------------------------------------------------------
+// Sixteen rungs, codes of up to 17 bits, units of up to 278: a row is sixteen 16-bit entries (32 bytes), a window 1536
+// positions (48 KB, two of them side by side in LDS: slot 1 is reached through the read's immediate offset, so the
+// addresses the walk carries stay window-relative).  A block has up to 16 bands here and can be longer than a window,
+// so the walk changes windows between any two UNITS (every look-up position is inside the window: no margin rows,
+// 32 table bytes per stream bit); the rungs of the bands live in a small LDS array, and the trail holds the entries
+// read (next position | rung out), from which a writer wave derives unit lengths and segment entries.  The walk loop is
+// plain C++ here (about 1.5 x the cycles per unit of the hand-ordered 8-bit loop).
+namespace chain16 {
+constexpr uint32_t NR = 16, ROWB = 32, CW = 1536, WIN_BYTES = CW * ROWB, WIN_U4 = WIN_BYTES / 16;      // 49152 bytes, 3072 sixteen-byte pieces
+constexpr uint32_t MAXC = 17, NP = CW + 288;            // longest code; positions a table workgroup looks at
+static_assert(NP % 32 == 0 && NP >= CW + 6 + 15 * MAXC + 2 && WIN_BYTES == 0xc000 && (CW + 278) * ROWB < 65536 && WIN_U4 % 192 == 0, "16-bit window layout");
+constexpr uint32_t TR_BYTES = ((CW / 2 + 8) * 2 + 15) & ~15u;              // trail of a window: a unit is at least two bits
+constexpr uint32_t TR0 = 2 * WIN_BYTES, RS0 = TR0 + 2 * TR_BYTES, WR0 = RS0 + 64, META = WR0 + 64, LDS_BYTES = META + 128;
+constexpr uint32_t F_READY = META /* [2][4] */, F_TRAILED = META + 32, F_NUNITS = META + 40, F_O0 = META + 48,
+                   F_WALKED = META + 56, F_STOP = META + 60, F_U0 = META + 64 /* u64[2] */;
+}  // namespace chain16
+struct WalkState16 { uint64_t P, unit, rungs; uint32_t bad, pad; };        // a tile's walk between two slabs (rungs: 4 bits a band)
+
+__global__ void __launch_bounds__(256) walk_table16_kernel(const DecArgs a0, uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch) {
+    using namespace chain16;
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    const uint64_t p0 = slab0 + (uint64_t)blockIdx.x * CW;
+    if (p0 >= a.in_bits + 2 * CW) return;                                   // (uniform) far beyond the stream: no walk comes here
+    __shared__ uint32_t words[NP / 32 + 3];
+    __shared__ uint8_t nA[NR - 1][NP], nB[NR - 1][NP];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t q0 = a.in_bit0 + p0, w0 = q0 >> 5, endw = (a.in_bit0 + a.in_bits + 31) >> 5;
+    const uint32_t sh = (uint32_t)q0 & 31;
+    for (uint32_t i = tid; i < NP / 32 + 3; i += 256) words[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
+    __syncthreads();
+    auto bits = [&](uint32_t i) { const uint32_t b = sh + i, k = b >> 5; return __builtin_amdgcn_alignbit(words[k + 1], words[k], b & 31); };
+    for (uint32_t i = tid; i < NP; i += 256) {                              // one code: r, r + 1 or r + 2 bits
+        const uint32_t x = bits(i), e = (x & 1) + ((x & 3) == 3);
+#pragma unroll
+        for (uint32_t r = 1; r < NR; r++) nA[r - 1][i] = (uint8_t)(r + e);
+    }
+    __syncthreads();
+    uint8_t (*src)[NP] = nA, (*dst)[NP] = nB;
+    uint32_t valid = NP;
+#pragma unroll 1
+    for (uint32_t lvl = 0; lvl < 3; lvl++) {                                // 2, 4, 8 codes (eight codes are at most 136 bits: a byte)
+        valid -= MAXC << lvl;
+        for (uint32_t r = 0; r < NR - 1; r++)
+            for (uint32_t i = tid; i < valid; i += 256) { const uint32_t n = src[r][i]; dst[r][i] = (uint8_t)(n + src[r][i + n]); }
+        __syncthreads();
+        uint8_t (*t)[NP] = src; src = dst; dst = t;
+    }
+    // src = eight codes, valid for i < NP - 7 * 17; sixteen = eight + eight, formed here (up to 272: not a byte)
+    uint4 *out = tab + ((uint64_t)blockIdx.y * tab_pitch + (uint64_t)blockIdx.x * WIN_U4);
+    for (uint32_t o = tid; o < CW; o += 256) {
+        const uint32_t x = bits(o);
+        uint32_t delta = 0; bool sig = false;
+        const uint32_t cs = walk_switch<4>(x, delta, sig);                  // from rung 0: the step itself
+        const uint32_t len0 = cs + (((x >> cs) & 1) ? 17 : 1);              // rung 0: one flag, then 16 raw bits
+        uint32_t e[NR];
+#pragma unroll
+        for (uint32_t rin = 0; rin < NR; rin++) {
+            const uint32_t r = (rin + delta) & (NR - 1);
+            uint32_t u = len0;
+            if (r) { const uint32_t n8 = src[r - 1][o + cs]; u = cs + n8 + src[r - 1][o + cs + n8]; }
+            e[rin] = ((o + u) * ROWB) | (r << 1) | (sig ? 1u : 0u);
+        }
+        out[2 * o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+        out[2 * o + 1] = make_uint4(e[8] | e[9] << 16, e[10] | e[11] << 16, e[12] | e[13] << 16, e[14] | e[15] << 16);
+    }
+}
+
+// A workgroup per tile, eight waves: wave 0 (one lane) walks; waves 1-6 load windows (two groups of three, as in the
+// 8-bit kernel); wave 7 writes unit lengths and segment entries from the trail.
+__global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, const uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch,
+                                                           WalkState16 *states, uint32_t first_round) {
+    using namespace chain16;
+    using chain::flag_get; using chain::flag_set; using chain::SPIN_MAX;
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t B = a.g.bands, NB = a.g.seg_blocks;
+    const uint64_t nunits = a.g.nblocks * B;
+    WalkState16 *S = states + blockIdx.x;
+    const uint64_t P0 = first_round ? 0 : S->P, U_in = first_round ? 0 : S->unit, R_in = first_round ? 0 : S->rungs;
+    const uint64_t slab_end = slab0 + (uint64_t)nwin * CW;
+    if (P0 < slab0 || P0 >= slab_end || P0 >= a.in_bits || U_in >= nunits) return;         // (uniform) nothing of this tile in this slab
+    const uint32_t k0 = (uint32_t)((P0 - slab0) / CW);                      // the window the walk starts in
+    volatile uint32_t *rs = (volatile uint32_t *)(smem + RS0), *wr = (volatile uint32_t *)(smem + WR0);     // rung * 2 per band: the walk's, the writer's
+    if (tid < 32) {     // (the first two windows find their trail slots free)
+        uint32_t v = tid == (F_STOP - META) / 4 ? 0xffffffffu : 0u;
+        if (tid == (k0 & 1) * 4 + 3) v = k0 + 1;
+        if (tid == ((k0 + 1) & 1) * 4 + 3) v = k0 + 2;
+        ((uint32_t *)(smem + META))[tid] = v;
+    }
+    if (tid < 16) { const uint32_t r2 = (uint32_t)((R_in >> (4 * tid)) & 15u) << 1; rs[tid] = r2; wr[tid] = r2; }
+    __syncthreads();
+    const uint4 *wt = tab + (uint64_t)blockIdx.x * tab_pitch;
+    auto ready = [&](uint32_t slot, uint32_t want) {
+        const chain::u32x4_t f = *(volatile __attribute__((address_space(3))) chain::u32x4_t *)(uintptr_t)(F_READY + 16 * slot);
+        return f.x == want && f.y == want && f.z == want && f.w == want;
+    };
+
+    if (wave == 0) {
+        if (lane) return;
+        uint32_t bad = first_round ? 0 : S->bad, k = k0, o = (uint32_t)((P0 - slab0) % CW);
+        uint64_t U = U_in, Pn = P0;
+        uint32_t c = (uint32_t)(U % B);
+        bool stuck = false;
+        while (true) {
+            const uint32_t s = k & 1;
+            uint32_t spin = 0;
+            while (!ready(s, k + 1) && ++spin < SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+            if (spin >= SPIN_MAX) { stuck = true; break; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint8_t *win = smem + s * WIN_BYTES;
+            volatile uint16_t *tr = (volatile uint16_t *)(smem + TR0 + s * TR_BYTES);
+            uint32_t A = o * ROWB + rs[c], n = 0;
+            const uint64_t left64 = nunits - U;
+            uint32_t left = left64 > 0xffffffffull ? 0xffffffffu : (uint32_t)left64;
+            typedef const __attribute__((address_space(3))) uint16_t *LdsHalf;
+            typedef __attribute__((address_space(3))) uint16_t *LdsHalfW;
+            typedef __attribute__((address_space(3))) uint32_t *LdsWordW;
+            const uint32_t wbase = s * WIN_BYTES;
+            LdsHalfW trw = (LdsHalfW)(uintptr_t)(TR0 + s * TR_BYTES);
+            LdsWordW rsw = (LdsWordW)(uintptr_t)RS0;
+            constexpr uint32_t M = 0xffe0u, RM = (NR - 1) << 1;
+            // a unit per turn, until one starts beyond the window: ONE dependent LDS read a unit -- the rung of the band
+            // that comes next is fetched a unit ahead (from registers for one or two bands, else from the LDS array)
+            if (B == 1) {
+                while (A < CW * ROWB && left) {
+                    const uint32_t e = *(LdsHalf)(uintptr_t)(wbase + A);
+                    trw[n++] = (uint16_t)e; bad |= e;
+                    A = e & (M | RM);
+                    left--;
+                }
+                rsw[0] = A & RM;
+            } else if (B == 2) {
+                uint32_t rn = rsw[c ^ 1];
+                while (A < CW * ROWB && left) {
+                    const uint32_t e = *(LdsHalf)(uintptr_t)(wbase + A);
+                    trw[n++] = (uint16_t)e; bad |= e;
+                    A = (e & M) | rn;
+                    rn = e & RM;                // this band comes again after the next unit
+                    c ^= 1; left--;
+                }
+                rsw[c] = A & RM; rsw[c ^ 1] = rn;
+            } else {
+                uint32_t cn = c + 1 == B ? 0 : c + 1;
+                uint32_t rn = rsw[cn];
+                while (A < CW * ROWB && left) {
+                    const uint32_t cn2 = cn + 1 == B ? 0 : cn + 1;
+                    const uint32_t e = *(LdsHalf)(uintptr_t)(wbase + A);
+                    const uint32_t r2 = rsw[cn2];                           // (three bands or more: not the band being written below)
+                    trw[n++] = (uint16_t)e; bad |= e;
+                    rsw[c] = e & RM;
+                    A = (e & M) | rn;
+                    c = cn; cn = cn2; rn = r2; left--;
+                }
+            }
+            *(volatile uint64_t *)(smem + F_U0 + 8 * s) = U;
+            flag_set(F_NUNITS + 4 * s, n);
+            flag_set(F_O0 + 4 * s, o);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            flag_set(F_TRAILED + 4 * s, k + 1);
+            U += n;
+            const uint32_t oe = A / ROWB;
+            Pn = slab0 + (uint64_t)k * CW + oe;
+            k++;
+            flag_set(F_WALKED, k - k0);
+            if (U >= nunits) break;                                         // the units ran out
+            o = oe - CW;                                                    // (the walk left the window: oe >= CW)
+            if (k >= nwin || Pn >= a.in_bits) break;                        // the slab ends here, or the stream does (a damaged one)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        flag_set(F_STOP, k);
+        uint64_t Rn = 0;
+        for (uint32_t i = 0; i < B; i++) Rn |= (uint64_t)((rs[i] >> 1) & 15u) << (4 * i);
+        S->P = stuck ? ~0ull : Pn; S->unit = U; S->rungs = Rn; S->bad = (bad & 1u) | (stuck ? 1u : 0u);
+        if ((bad & 1u) || stuck) atomicOr(a.status, 1u);
+        return;
+    }
+    if (wave <= 6) {
+        const uint32_t g = (wave - 1) / 3, part = (wave - 1) % 3;
+        constexpr uint32_t NV = WIN_U4 / 192;
+        static_assert(NV == 16, "CH16_REP");
+        for (uint32_t k = k0 + ((k0 ^ g) & 1u); k < nwin; k += 2) {
+            const uint4 *src = wt + (uint64_t)k * WIN_U4;
+#define CH16_REP(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define CH16_LD(i) const uint4 v##i = src[lane + 64 * (part + 3 * i)];
+            CH16_REP(CH16_LD)
+            uint32_t spin = 0;
+            bool stop = false;
+            while (true) {                                                  // the slot is free when the window two back has been walked
+                if (flag_get(F_STOP) != 0xffffffffu) { stop = true; break; }
+                if (flag_get(F_WALKED) + 2 > k - k0) break;
+                if (++spin >= SPIN_MAX) { stop = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (stop) break;
+            uint4 *slot = (uint4 *)(smem + g * WIN_BYTES);
+#define CH16_ST(i) slot[lane + 64 * (part + 3 * i)] = v##i;
+            CH16_REP(CH16_ST)
+#undef CH16_ST
+#undef CH16_LD
+#undef CH16_REP
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) flag_set(F_READY + 16 * g + 4 * part, k + 1);
+        }
+        return;
+    }
+    // writer: entry j of the trail = (16 * position the unit ENDS at | rung of its band after it): lengths by difference
+    for (uint32_t k = k0;; k++) {
+        const uint32_t s = k & 1;
+        uint32_t spin = 0;
+        bool stop = false;
+        while (flag_get(F_TRAILED + 4 * s) != k + 1) {
+            const uint32_t st = flag_get(F_STOP);
+            if ((st != 0xffffffffu && k >= st) || ++spin >= SPIN_MAX) { stop = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (stop) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint64_t U0 = *(volatile uint64_t *)(smem + F_U0 + 8 * s);
+        const uint32_t n = flag_get(F_NUNITS + 4 * s), o_first = flag_get(F_O0 + 4 * s);
+        const uint16_t *tr = (const uint16_t *)(smem + TR0 + s * TR_BYTES);
+        const uint64_t wpos = slab0 + (uint64_t)k * CW;
+        uint16_t *ul = (uint16_t *)a.idx.ulen + U0;
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint32_t o0 = j ? tr[j - 1] / ROWB : o_first, o1 = tr[j] / ROWB;
+            ul[j] = (uint16_t)(o1 - o0);
+            const uint64_t Uj = U0 + j;
+            if (Uj % B == 0 && (Uj / B) % NB == 0) {        // a segment starts here: position, and every band's rung as the block finds it
+                const uint64_t seg = Uj / B / NB;
+                a.idx.bitpos[seg] = wpos + o0;
+                for (uint32_t cc = 0; cc < B; cc++) {       // band cc's unit before this one: B - cc units back
+                    const int32_t jj = (int32_t)j - (int32_t)(B - cc);
+                    a.idx.rung[seg * B + cc] = (uint8_t)(((jj >= 0 ? (uint32_t)tr[jj] : wr[cc]) >> 1) & 15u);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the rung every band has after this window: the last unit of each band in it
+        if (lane < B) {
+            const uint32_t cl = (uint32_t)((U0 + n - 1) % B);               // band of the window's last unit
+            const uint32_t back = (cl + B - lane) % B;                      // band `lane` last came `back` units before it
+            if (n > back) wr[lane] = tr[n - 1 - back] & ((NR - 1) << 1);
+        }
+        // (no release fence: the trail has been READ -- LDS operations of a wave are in order -- and the index stores may still be
+        // on their way; a fence would hold the slot for a memory round trip per window)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) flag_set(F_READY + 16 * s + 12, k + 3);              // the trail slot is free for the window that takes it next
     }
 }
 
 // Slabs of the streams are tabulated by the whole chip, then walked by a workgroup per tile, slab after slab; the
 // table of the next slab is built (on a stream of its own, in the other half of the memory) while this one is walked.
-// tab: [WalkState per tile][windows of table rows per tile] x 2; max_bits: the longest stream of the call.
-static void launch_chain(const DecArgs &a, hipStream_t st, const uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch, WalkState *states, uint32_t first) {
-    using namespace chain;
+// tab: [walk state per tile][windows of table rows per tile] x 2; max_bits: the longest stream of the call.
+template <typename TABLE, typename CHAIN>
+static void walk_in_slabs(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits, uint32_t cw, uint32_t win_u4, size_t state_size,
+                          TABLE &&launch_table, CHAIN &&launch_chain) {
     const uint32_t nt = a.ntiles;
-    if (a.g.bands == 1) hipLaunchKernelGGL(walk_chain_kernel<1>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, nwin, pitch, states, first);
-    else if (a.g.bands == 3) hipLaunchKernelGGL(walk_chain_kernel<3>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, nwin, pitch, states, first);
-    else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(512), LDS_BYTES, st, a, rows, s0, nwin, pitch, states, first);
-}
-void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
-    using namespace chain;
-    static const bool lds_ok = [] {
-        bool ok = true;
-        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-        return ok;
-    }();
-    (void)lds_ok;
-    const uint32_t nt = a.ntiles;
-    const size_t state_bytes = ((size_t)nt * sizeof(WalkState) + 255) & ~(size_t)255;
+    const size_t state_bytes = ((size_t)nt * state_size + 255) & ~(size_t)255;
     uint8_t *base = (uint8_t *)tab;
-    WalkState *states = (WalkState *)base;
-    const uint64_t need = (max_bits + CW - 1) / CW;                         // windows of the longest stream
-    const uint64_t cap = (tab_bytes - state_bytes) / ((uint64_t)WIN_BYTES * nt);    // windows per tile the memory holds
+    const uint64_t need = (max_bits + cw - 1) / cw;                         // windows of the longest stream
+    const uint64_t cap = (tab_bytes - state_bytes) / ((uint64_t)win_u4 * 16 * nt);  // windows per tile the memory holds
     // one round when the streams are short (nothing to overlap, and a stream costs more to create than it saves)
-    if (need <= cap && need * CW <= (8u << 20)) {
-        const uint64_t pitch = need * ROWS;
+    if (need <= cap && need * cw <= (8u << 20)) {
+        const uint64_t pitch = need * win_u4;
         uint4 *rows = (uint4 *)(base + state_bytes);
-        { ProfScope ps("dec_index_table", st); hipLaunchKernelGGL(walk_table_kernel, dim3((uint32_t)need, nt), dim3(256), 0, st, a, rows, 0, (uint32_t)need, pitch); }
+        { ProfScope ps("dec_index_table", st); launch_table(st, rows, (uint64_t)0, (uint32_t)need, pitch); }
         ProfScope ps("dec_index_serial", st);
-        launch_chain(a, st, rows, 0, (uint32_t)need, pitch, states, 1);
+        launch_chain(st, rows, (uint64_t)0, (uint32_t)need, pitch, base, 1u);
         return;
     }
     // rounds of at most half the memory, and at least four of them
     uint64_t nwin = cap / 2;
     if (nwin > (need + 3) / 4) nwin = (need + 3) / 4;
     if (nwin < 16) nwin = 16;                                               // (walk_table_min_bytes holds 2 x 16)
-    if (nwin > 0x7fffffffu / ROWS) nwin = 0x7fffffffu / ROWS;
-    const uint64_t pitch = nwin * ROWS;                                     // in rows of sixteen bytes
+    if (nwin > 0x7fffffffu / win_u4) nwin = 0x7fffffffu / win_u4;
+    const uint64_t pitch = nwin * win_u4;                                   // in rows of sixteen bytes
     uint4 *rows[2] = {(uint4 *)(base + state_bytes), (uint4 *)(base + state_bytes) + pitch * nt};
     hipStream_t aux = nullptr;
     hipEvent_t ev_tab[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_start = nullptr;
@@ -703,12 +941,12 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
     if (ok) { (void)hipEventRecord(ev_start, st); (void)hipStreamWaitEvent(aux, ev_start, 0); }
     hipStream_t tst = ok ? aux : st;                                        // (no second stream: everything in order on the caller's)
     uint32_t first = 1, j = 0;
-    for (uint64_t s0 = 0; s0 < max_bits; s0 += nwin * CW, first = 0, j++) {
+    for (uint64_t s0 = 0; s0 < max_bits; s0 += nwin * cw, first = 0, j++) {
         const int h = j & 1;
         if (ok && j >= 2) (void)hipStreamWaitEvent(aux, ev_done[h], 0);     // the walk of two rounds ago has left this half
-        { ProfScope ps("dec_index_table", tst); hipLaunchKernelGGL(walk_table_kernel, dim3((uint32_t)nwin, nt), dim3(256), 0, tst, a, rows[h], s0, (uint32_t)nwin, pitch); }
+        { ProfScope ps("dec_index_table", tst); launch_table(tst, rows[h], s0, (uint32_t)nwin, pitch); }
         if (ok) { (void)hipEventRecord(ev_tab[h], aux); (void)hipStreamWaitEvent(st, ev_tab[h], 0); }
-        { ProfScope ps("dec_index_serial", st); launch_chain(a, st, rows[h], s0, (uint32_t)nwin, pitch, states, first); }
+        { ProfScope ps("dec_index_serial", st); launch_chain(st, rows[h], s0, (uint32_t)nwin, pitch, base, first); }
         if (ok) (void)hipEventRecord(ev_done[h], st);
     }
     // (destroying a stream or an event with work pending is deferred by the runtime until that work is done)
@@ -716,11 +954,42 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (aux) (void)hipStreamDestroy(aux);
 }
-size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits) {
-    const uint64_t need = (max_bits + chain::CW - 1) / chain::CW;
-    return (((size_t)ntiles * sizeof(WalkState) + 255) & ~(size_t)255) + (size_t)chain::WIN_BYTES * ntiles * need + 4096;
+void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+    static const bool lds_ok = [] {
+        bool ok = true;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chain16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, chain16::LDS_BYTES) == hipSuccess;
+        return ok;
+    }();
+    (void)lds_ok;
+    const uint32_t nt = a.ntiles;
+    if (a.g.tsz == 2) {
+        walk_in_slabs(a, st, tab, tab_bytes, max_bits, chain16::CW, chain16::WIN_U4, sizeof(WalkState16),
+            [&](hipStream_t s, uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch) {
+                hipLaunchKernelGGL(walk_table16_kernel, dim3(nwin, nt), dim3(256), 0, s, a, rows, s0, nwin, pitch); },
+            [&](hipStream_t s, const uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch, uint8_t *states, uint32_t first) {
+                hipLaunchKernelGGL(walk_chain16_kernel, dim3(nt), dim3(512), chain16::LDS_BYTES, s, a, rows, s0, nwin, pitch, (WalkState16 *)states, first); });
+        return;
+    }
+    walk_in_slabs(a, st, tab, tab_bytes, max_bits, chain::CW, chain::ROWS, sizeof(WalkState),
+        [&](hipStream_t s, uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch) {
+            hipLaunchKernelGGL(walk_table_kernel, dim3(nwin, nt), dim3(256), 0, s, a, rows, s0, nwin, pitch); },
+        [&](hipStream_t s, const uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch, uint8_t *states, uint32_t first) {
+            using namespace chain;
+            WalkState *ws = (WalkState *)states;
+            if (a.g.bands == 1) hipLaunchKernelGGL(walk_chain_kernel<1>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first);
+            else if (a.g.bands == 3) hipLaunchKernelGGL(walk_chain_kernel<3>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first);
+            else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first); });
 }
-size_t walk_table_min_bytes(uint32_t ntiles) { return walk_table_bytes(ntiles, 2 * 16 * chain::CW); }
+// bytes of table memory that take `max_bits` of every stream in one round (16-bit data: 32 bytes a stream bit)
+size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits, uint32_t tsz) {
+    const uint32_t cw = tsz == 2 ? chain16::CW : chain::CW, win_bytes = tsz == 2 ? chain16::WIN_BYTES : chain::WIN_BYTES;
+    const uint64_t need = (max_bits + cw - 1) / cw;
+    return (((size_t)ntiles * sizeof(WalkState16) + 255) & ~(size_t)255) + (size_t)win_bytes * ntiles * need + 4096;
+}
+size_t walk_table_min_bytes(uint32_t ntiles, uint32_t tsz) { return walk_table_bytes(ntiles, 2 * 16 * (tsz == 2 ? chain16::CW : chain::CW), tsz); }
 
 void launch_dec_walk(const DecArgs &a, hipStream_t st) {
     if (a.ix && a.ntiles == 1) {            // the container's own restart table: a lane per entry

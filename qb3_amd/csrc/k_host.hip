@@ -399,7 +399,7 @@ DecPlan plan_decode(const Geometry &g) {
 
 size_t walk_table_cap() { return tuning().walk_tab_kb ? tuning().walk_tab_kb << 10 : (size_t)1 << 30; }
 bool walk_table_applies(const Geometry &g, const DecPlan &plan) {
-    return plan.px && g.mode != CM_BEST && g.tsz == 1 && !tuning().slow_walk && !tuning().slow_index;
+    return ((plan.px && g.tsz == 1) || (plan.px16 && g.tsz == 2)) && g.mode != CM_BEST && !tuning().slow_walk && !tuning().slow_index;
 }
 
 static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st, void *walk_tab, size_t walk_tab_bytes, uint64_t max_bits) {
@@ -413,7 +413,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         // produce the values entering the segments (totals pass + scan)
         // plain 8-bit stream: through the table of unit lengths by position when the caller brought memory for it
         const bool has_ix = a.ix && a.ntiles == 1;
-        if (use_px && !has_ix && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles) && !tuning().slow_walk) launch_dec_walk_table(a, st, walk_tab, walk_tab_bytes, max_bits);
+        if ((use_px || use_px16) && !has_ix && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk) launch_dec_walk_table(a, st, walk_tab, walk_tab_bytes, max_bits);
         else { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
         if (!(a.ix && a.ix_blocks == a.g.seg_blocks) && !wide_walk) {         // (an entry per segment: the walk copied the entering values)
           {

@@ -98,10 +98,10 @@ inline size_t ix_total_bytes(const IxTable &t) { return ix_chunks(t) * (IX_HEAD 
 // Batched tiles: n images/streams laid out at fixed byte pitches, processed by one set of launches (blockIdx.y).
 // n == 0 means a single image.  ws_pitch = plan.ws_bytes of one tile; idx_pitch = index_bytes of one tile.
 struct TileBatch { uint32_t n = 0; uint64_t src_pitch = 0, dst_pitch = 0, ws_pitch = 0, idx_pitch = 0; uint64_t max_bits = 0; /* decode: the longest stream */ };
-// Plain 8-bit streams (no index, no restart table) are walked through a table of unit lengths by position (k_dec_walk.hip).
+// Plain 8- and 16-bit streams (no index, no restart table) are walked through a table of unit lengths by position (k_dec_walk.hip).
 // walk_table_bytes: memory that takes the whole call in one round; less means more rounds, down to walk_table_min_bytes.
-size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits);
-size_t walk_table_min_bytes(uint32_t ntiles);
+size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits, uint32_t tsz);
+size_t walk_table_min_bytes(uint32_t ntiles, uint32_t tsz);
 size_t walk_table_cap();                // what a decoder allocates at most (1 GiB; QB3_WALK_TAB_KB overrides)
 struct DecPlan;
 bool walk_table_applies(const Geometry &g, const DecPlan &plan);

@@ -836,7 +836,8 @@ import qb3_amd
 from qb3_amd import synth, device as qdev
 from oracle import pyoracle as o
 for (w, h, b, dt, gen, seed, mode) in [(1024, 1024, 3, 0, "NOISY3", 2, 8), (509, 259, 3, 0, "NOISY3", 1, 4), (768, 512, 1, 0, "GRAD", 0, 8),
-                                       (640, 384, 4, 0, "RANDOM", 5, 8), (512, 256, 8, 2, "LANDSAT16", 3, 4)]:
+                                       (640, 384, 4, 0, "RANDOM", 5, 8), (512, 256, 8, 2, "LANDSAT16", 3, 4), (1024, 768, 8, 2, "LANDSAT16", 4, 8),
+                                       (700, 300, 1, 2, "LANDSAT16", 5, 8), (600, 400, 2, 2, "LANDSAT16", 6, 4), (512, 512, 6, 2, "LANDSAT16", 7, 8)]:
     img = synth.generate(w, h, b, dt, gen, seed)
     ref = o.encode(o.generate(w, h, b, dt, gen, seed), dt, mode)
     enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode)
