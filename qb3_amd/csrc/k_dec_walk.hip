@@ -312,11 +312,29 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
                         rp += ulen;
                         pk |= ulen << (8 * c);
                     }
-                    uint8_t *ul = stage_bytes ? ul_s + lane * stage_bytes + b * BB : (uint8_t *)a.idx.ulen + ((uint64_t)gb0 + b) * BB;
-                    if (BB == 4) *(uint32_t *)ul = pk;
-                    else
+                    if (stage_bytes) {
+                        // sixteen blocks of lengths collect in the lane's 16 * BB bytes of LDS, then leave as BB sixteen-byte
+                        // stores to the lane's place in the length table (a whole segment staged per lane cost 12 KB a wave
+                        // and with it half the resident waves)
+                        uint8_t *ul = ul_s + lane * (16 * BB) + (b & 15u) * BB;
+                        if (BB == 4) *(uint32_t *)ul = pk;
+                        else
+#pragma unroll
+                            for (int c = 0; c < BB; c++) ul[c] = (uint8_t)(pk >> (8 * c));
+                        if ((b & 15u) == 15u) {
+                            uint8_t *g = (uint8_t *)a.idx.ulen + ((uint64_t)gb0 + (b & ~15u)) * BB;
+#pragma unroll
+                            for (int q = 0; q < BB; q++) {
+                                const uint4 v = *(const uint4 *)(ul_s + lane * (16 * BB) + 16 * q);
+                                const u32x4_a4 t = { v.x, v.y, v.z, v.w };
+                                *(u32x4_a4 *)(g + 16 * q) = t;
+                            }
+                        }
+                    } else {
+                        uint8_t *ul = (uint8_t *)a.idx.ulen + ((uint64_t)gb0 + b) * BB;
 #pragma unroll
                         for (int c = 0; c < BB; c++) ul[c] = (uint8_t)(pk >> (8 * c));
+                    }
                     u += BB;
                 } else {
                     if (band == 0 && blk % NB == 0) {
@@ -348,7 +366,12 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
         }
         P = 32 * wb + (rp - lbit);
     }
-    if (stage_bytes) {
+    if (stage_bytes && BT) {            // a lane's last blocks when their count is not a multiple of sixteen
+        constexpr int BB = BT ? BT : 1;
+        const uint32_t done = nb & ~15u;
+        for (uint32_t b = done; b < nb; b++)
+            for (int c = 0; c < BB; c++) ((uint8_t *)a.idx.ulen)[((uint64_t)gb0 + b) * BB + c] = ul_s[lane * (16 * BB) + (b & 15u) * BB + c];
+    } else if (stage_bytes) {
         // the wave's lengths: entries are consecutive, so only the tail of the last wave is short
         const uint64_t first = (uint64_t)blockIdx.x * 64 * a.ix_blocks;         // first block of the wave (< nblocks: lane 0 is live)
         const uint64_t cnt = nblocks - first < 64ull * a.ix_blocks ? nblocks - first : 64ull * a.ix_blocks;
@@ -997,7 +1020,8 @@ void launch_dec_walk(const DecArgs &a, hipStream_t st) {
         // unit lengths staged in LDS when a lane's share is small enough (it is when an entry is one index segment)
         uint32_t stage = a.ix_blocks * a.g.bands * (a.g.tsz == 1 ? 1 : 2);
         if (stage > 512 || (stage & 3)) stage = 0;
-        const size_t lds = 64 * WALK_WINP * 4 + 64 * (size_t)stage + (a.g.tsz >= 4 ? 64 * MAXBANDS : 0);
+        const bool bt = a.g.tsz == 1;                                       // bands at compile time: a ring of sixteen blocks per lane instead of the whole piece
+        const size_t lds = 64 * WALK_WINP * 4 + (bt && stage ? 64 * 16 * (size_t)a.g.bands : 64 * (size_t)stage) + (a.g.tsz >= 4 ? 64 * MAXBANDS : 0);
         if (a.g.tsz == 1 && a.g.bands == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 1>), grid, block, lds, st, a, stage);
         else if (a.g.tsz == 1 && a.g.bands == 3) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 3>), grid, block, lds, st, a, stage);
         else if (a.g.tsz == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 4>), grid, block, lds, st, a, stage);
