@@ -142,7 +142,10 @@ __global__ void __launch_bounds__(1024) prev_scan_kernel(const DecArgs a0) {
 // WINDOW of its piece in LDS (sixteen-byte loads, re-centred for all lanes whenever one of them runs low) and reads
 // bits by POSITION -- three dependent 64-bit reads per 8-bit unit, no bit buffer to maintain, no divergent refills;
 // a code costs four vector instructions (shift, length from a per-rung constant, shift, add).
-constexpr uint32_t WALK_WINP = 44;      // window of a lane in dwords (a multiple of 4: 16-byte LDS stores)
+// window of a lane in dwords (a multiple of 4: 16-byte LDS stores): 144 bytes for 8- and 16-bit data (measured: 176 bytes
+// 0.336 ms on config 2, 144 bytes 0.326, 128 bytes 0.68 -- the window must leave room to walk after the longest step),
+// 176 for 32- and 64-bit data, whose longest unit alone is 131 bytes
+__host__ __device__ constexpr uint32_t walk_winp(uint32_t ub) { return ub <= 4 ? 36 : 44; }
 
 // 64 stream bits at bit position `pos` (counted from LDS address 0): lo = bits 0..31, hi = bits 32..63
 __device__ __forceinline__ void lds_bits64(uint32_t pos, uint32_t &lo, uint32_t &hi) {
@@ -233,6 +236,7 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
     // part of the length table they belong to: a lane's lengths are scattered bytes, the wave's are one contiguous run
     // that leaves as whole cache lines at the end
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t WALK_WINP = walk_winp(UB);
     uint32_t *win = (uint32_t *)smem;
     uint8_t *ul_s = smem + 64 * WALK_WINP * 4;
     constexpr uint32_t USZ = UB == 3 ? 1 : 2;                               // bytes per unit length
@@ -1021,7 +1025,7 @@ void launch_dec_walk(const DecArgs &a, hipStream_t st) {
         uint32_t stage = a.ix_blocks * a.g.bands * (a.g.tsz == 1 ? 1 : 2);
         if (stage > 512 || (stage & 3)) stage = 0;
         const bool bt = a.g.tsz == 1;                                       // bands at compile time: a ring of sixteen blocks per lane instead of the whole piece
-        const size_t lds = 64 * WALK_WINP * 4 + (bt && stage ? 64 * 16 * (size_t)a.g.bands : 64 * (size_t)stage) + (a.g.tsz >= 4 ? 64 * MAXBANDS : 0);
+        const size_t lds = 64 * walk_winp(a.g.tsz == 1 ? 3 : a.g.tsz == 2 ? 4 : 5) * 4 + (bt && stage ? 64 * 16 * (size_t)a.g.bands : 64 * (size_t)stage) + (a.g.tsz >= 4 ? 64 * MAXBANDS : 0);
         if (a.g.tsz == 1 && a.g.bands == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 1>), grid, block, lds, st, a, stage);
         else if (a.g.tsz == 1 && a.g.bands == 3) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 3>), grid, block, lds, st, a, stage);
         else if (a.g.tsz == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 4>), grid, block, lds, st, a, stage);
