@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
     uint32_t u = 0;                                                         // units done
     uint32_t rungs[BT ? BT : 1];
     uint64_t R = 0;                                                         // run-time bands: rungs, 4 bits per band
-    uint8_t *wide_rung = ul_s + 64 * stage_bytes + lane * MAXBANDS;         // ... 32/64-bit data (rungs up to 63): a byte per band, in LDS
+    uint8_t *wide_rung = ul_s + (stage_bytes ? 64 * 64 : 0) + lane * MAXBANDS;         // ... 32/64-bit data (rungs up to 63): a byte per band, in LDS
     if (BT) {
 #pragma unroll
         for (int c = 0; c < (BT ? BT : 1); c++) rungs[c] = e[6 + c] & 15u;
@@ -359,10 +359,25 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
                     rp += ulen;
                     if (UB <= 4) R = (R & ~(15ull << (4 * band))) | ((uint64_t)rung << (4 * band));
                     else wide_rung[band] = (uint8_t)rung;
-                    uint8_t *ul = stage_bytes ? ul_s + lane * stage_bytes + (blk * B + band) * USZ
-                                              : (uint8_t *)a.idx.ulen + (((uint64_t)gb0 + blk) * B + band) * USZ;
-                    if (UB == 3) *ul = (uint8_t)ulen;
-                    else *(uint16_t *)ul = (uint16_t)ulen;
+                    if (stage_bytes) {          // a ring of 64 bytes of lengths per lane; a full ring leaves as four 16-byte stores
+                        const uint32_t off = u * USZ;
+                        uint8_t *ul = ul_s + lane * 64 + (off & 63u);
+                        if (UB == 3) *ul = (uint8_t)ulen;
+                        else *(uint16_t *)ul = (uint16_t)ulen;
+                        if (((off + USZ) & 63u) == 0) {
+                            uint8_t *g = (uint8_t *)a.idx.ulen + (uint64_t)gb0 * B * USZ + (off & ~63u);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const uint4 v = *(const uint4 *)(ul_s + lane * 64 + 16 * q);
+                                const u32x4_a4 t = { v.x, v.y, v.z, v.w };
+                                *(u32x4_a4 *)(g + 16 * q) = t;
+                            }
+                        }
+                    } else {
+                        uint8_t *ul = (uint8_t *)a.idx.ulen + (((uint64_t)gb0 + blk) * B + band) * USZ;
+                        if (UB == 3) *ul = (uint8_t)ulen;
+                        else *(uint16_t *)ul = (uint16_t)ulen;
+                    }
                     if (++band == B) { band = 0; blk++; }
                     u++;
                 }
@@ -375,22 +390,9 @@ __global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, con
         const uint32_t done = nb & ~15u;
         for (uint32_t b = done; b < nb; b++)
             for (int c = 0; c < BB; c++) ((uint8_t *)a.idx.ulen)[((uint64_t)gb0 + b) * BB + c] = ul_s[lane * (16 * BB) + (b & 15u) * BB + c];
-    } else if (stage_bytes) {
-        // the wave's lengths: entries are consecutive, so only the tail of the last wave is short
-        const uint64_t first = (uint64_t)blockIdx.x * 64 * a.ix_blocks;         // first block of the wave (< nblocks: lane 0 is live)
-        const uint64_t cnt = nblocks - first < 64ull * a.ix_blocks ? nblocks - first : 64ull * a.ix_blocks;
-        const uint32_t bytes = (uint32_t)(cnt * B * USZ);
-        uint8_t *g = (uint8_t *)a.idx.ulen + first * B * USZ;                   // 4-byte aligned: first is a multiple of 64
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t o = lane * 16;
-        for (; o + 16 <= bytes; o += 1024) {
-            const uint4 v = *(const uint4 *)(ul_s + o);
-            const u32x4_a4 t = { v.x, v.y, v.z, v.w };
-            *(u32x4_a4 *)(g + o) = t;
-        }
-        for (uint32_t i = (bytes & ~15u) + lane; i < bytes; i += 64) g[i] = ul_s[i];
+    } else if (stage_bytes) {           // what is left in the lane's ring
+        const uint32_t total = nu * USZ, done = total & ~63u;
+        for (uint32_t i = done; i < total; i++) ((uint8_t *)a.idx.ulen)[(uint64_t)gb0 * B * USZ + i] = ul_s[lane * 64 + (i & 63u)];
     }
     if (bad && live) atomicOr(a.status, 1u);
 }
@@ -792,8 +794,6 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
             while (!ready(s, k + 1) && ++spin < SPIN_MAX) __builtin_amdgcn_s_sleep(1);
             if (spin >= SPIN_MAX) { stuck = true; break; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint8_t *win = smem + s * WIN_BYTES;
-            volatile uint16_t *tr = (volatile uint16_t *)(smem + TR0 + s * TR_BYTES);
             uint32_t A = o * ROWB + rs[c], n = 0;
             const uint64_t left64 = nunits - U;
             uint32_t left = left64 > 0xffffffffull ? 0xffffffffu : (uint32_t)left64;
@@ -1022,10 +1022,10 @@ void launch_dec_walk(const DecArgs &a, hipStream_t st) {
     if (a.ix && a.ntiles == 1) {            // the container's own restart table: a lane per entry
         const dim3 grid((a.ix_K + 63) / 64), block(64);
         // unit lengths staged in LDS when a lane's share is small enough (it is when an entry is one index segment)
-        uint32_t stage = a.ix_blocks * a.g.bands * (a.g.tsz == 1 ? 1 : 2);
-        if (stage > 512 || (stage & 3)) stage = 0;
+        // unit lengths leave through a small per-lane ring in LDS (sixteen blocks for 8-bit data, 64 bytes otherwise)
+        const uint32_t stage = 1;
         const bool bt = a.g.tsz == 1;                                       // bands at compile time: a ring of sixteen blocks per lane instead of the whole piece
-        const size_t lds = 64 * walk_winp(a.g.tsz == 1 ? 3 : a.g.tsz == 2 ? 4 : 5) * 4 + (bt && stage ? 64 * 16 * (size_t)a.g.bands : 64 * (size_t)stage) + (a.g.tsz >= 4 ? 64 * MAXBANDS : 0);
+        const size_t lds = 64 * walk_winp(a.g.tsz == 1 ? 3 : a.g.tsz == 2 ? 4 : 5) * 4 + (bt && stage ? 64 * 16 * (size_t)a.g.bands : stage ? 64 * 64 : 0) + (a.g.tsz >= 4 ? 64 * MAXBANDS : 0);
         if (a.g.tsz == 1 && a.g.bands == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 1>), grid, block, lds, st, a, stage);
         else if (a.g.tsz == 1 && a.g.bands == 3) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 3>), grid, block, lds, st, a, stage);
         else if (a.g.tsz == 1) hipLaunchKernelGGL((dec_walk_lanes_kernel<3, 4>), grid, block, lds, st, a, stage);
