@@ -108,6 +108,12 @@ int  qb3x_profile_names(char *buf, size_t bufsize);                             
  * Appendix C), for callers that verify containers.  seed = 0 starts a hash, a previous result continues it. */
 uint64_t qb3x_fnv1a64(const void *data, size_t n, uint64_t seed);
 
+/* The RLE0 byte pass of the *_RLE modes (reference QB3encode.cpp:271-332, QB3decode.cpp:267-307) on DEVICE buffers: the
+ * coded (decode = 0) or expanded (decode != 0) form of the n bytes at d_src, bit for bit what the reference's serial
+ * loops produce.  d_dst == NULL asks for the size only.  Returns the size; 0 on failure or when it exceeds dst_cap.
+ * The library uses it for QB3M_RLE / QB3M_CF_RLE (and the legacy _H modes) so that such streams stay on the device. */
+size_t qb3x_rle0_device(const void *d_src, size_t n, void *d_dst, size_t dst_cap, int decode, void *stream);
+
 /* Last HIP error string seen by this thread inside the library ("" if none). */
 const char *qb3x_last_error(void);
 

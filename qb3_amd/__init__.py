@@ -74,6 +74,7 @@ _PROTOS = {
     "qb3_decode": (_sz, [_vp, _vp]),
     "qb3x_last_error": (C.c_char_p, []),
     "qb3x_fnv1a64": (_u64, [_vp, _sz, _u64]),
+    "qb3x_rle0_device": (_sz, [_vp, _sz, _vp, _sz, C.c_int, _vp]),
     "qb3x_profile_enable": (None, [C.c_int]),
     "qb3x_profile_reset": (None, []),
     "qb3x_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -1,8 +1,8 @@
 // qb3_amd/csrc/qb3_api.cpp -- the C ABI (include/QB3.h, include/qb3x.h) of the MI355X-native QB3 codec.
 //
-// Host side only: handle bookkeeping, container headers, the byte-serial RLE0 post pass, STORED fallback
+// Host side only: handle bookkeeping, container headers, STORED fallback (the RLE0 byte pass is a device pass: k_rle0.hip)
 // and the HIP plumbing (buffers, copies, one synchronisation per call).  The block coding itself -- the hot
-// path -- is in qb3_kernels.hip and always runs on the GPU; there is no CPU fallback for it.
+// path -- is in the k_*.hip files and always runs on the GPU; there is no CPU fallback for it.
 //
 // Behaviour mirrors the reference C API (reference QB3lib/QB3encode.cpp, QB3decode.cpp), including the
 // quirks a drop-in has to keep: band state carried across qb3_encode calls until qb3_reset_encoder
@@ -152,7 +152,7 @@ struct encs {
     bool away;
     bool ix_chunk;          // qb3x_set_encoder_index_chunk: embed the restart table ("ix" chunks)
     bool no_single_pass;    // the single-pass encoder gave up once on this handle: slots + concatenation from then on
-    DevBuf d_img, d_out, d_ws, d_q, d_idx;
+    DevBuf d_img, d_out, d_ws, d_q, d_idx, d_rle;      // d_rle: workspace of the RLE0 passes (k_rle0.hip)
     Stager stager;
 };
 
@@ -173,7 +173,7 @@ struct decs {
     uint32_t ix_K, ix_blocks, ix_E, ix_per_chunk;
     bool ix_pads, ix_bad;   // pad chunks behind the table chunks (version 2); the chunks seen do not form one table
     std::vector<uint8_t> tile_ok;   // qb3x_decode_tiles: per tile outcome of the last call
-    DevBuf d_in, d_img, d_ws, d_ix, d_tab;      // d_tab: the unit-length table a plain 8-bit stream is walked through
+    DevBuf d_in, d_img, d_ws, d_ix, d_rle, d_tab;      // d_rle: RLE0 workspace (+ the packed bytes of a host call); d_tab: the unit-length table a plain 8-bit stream is walked through
     Stager stager;
 };
 
@@ -233,7 +233,7 @@ QB3_API void qb3_reset_encoder(encsp p) {
 
 QB3_API void qb3_destroy_encoder(encsp p) {
     if (!p) return;
-    p->d_img.release(); p->d_out.release(); p->d_ws.release(); p->d_q.release(); p->d_idx.release(); p->stager.release();
+    p->d_img.release(); p->d_out.release(); p->d_ws.release(); p->d_q.release(); p->d_idx.release(); p->d_rle.release(); p->stager.release();
     delete p;
 }
 
@@ -331,55 +331,7 @@ static std::vector<uint8_t> remap_small(const uint8_t *src, size_t w, size_t h, 
     return t;
 }
 
-// ---------------------------------------------------------------- RLE0 (reference QB3encode.cpp:271-332)
-static size_t rle0(const uint8_t *src, size_t len, uint8_t *dst) {      // dst == nullptr: size only
-    size_t i = 0, o = 0;
-    uint8_t last = 0;
-    while (i + 2 < len) {
-        uint8_t c = src[i++];
-        const size_t rem = len - i;
-        bool run = (c == 0 || c == 0xff) && c == src[i];
-        if (run && c == 0 && (last == 0xff || rem < 3 || src[i + 1] || src[i + 2])) run = false;
-        if (!run) { if (dst) dst[o] = c; o++; last = c; continue; }
-        i++;
-        if (c == 0) {
-            i += 2;
-            size_t r = 0, lim = len - i > 0xfe ? 0xfe : len - i;
-            while (r < lim && !src[i + r]) r++;
-            i += r; c = (uint8_t)r;
-        }
-        last = 0;
-        if (dst) { dst[o] = 0xff; dst[o + 1] = 0xff; dst[o + 2] = c; }
-        o += 3;
-    }
-    for (; i < len; i++, o++) if (dst) dst[o] = src[i];
-    return o;
-}
-
-// reference QB3decode.cpp:267-307
-static size_t derle0_size(const uint8_t *src, size_t len) {
-    size_t i = 0, n = 0;
-    while (i + 2 < len) {
-        if (src[i] != 0xff || src[i + 1] != 0xff) { n++; i++; continue; }
-        n += (src[i + 2] == 0xff) ? 2 : 4 + (size_t)src[i + 2];
-        i += 3;
-    }
-    return n + (len - i);
-}
-static int64_t derle0(const uint8_t *src, size_t slen, uint8_t *d, size_t dlen) {
-    size_t i = 0, o = 0;
-    while (o < dlen && i + 2 < slen) {
-        uint8_t c = src[i++];
-        if (c != 0xff || src[i] != 0xff) { d[o++] = c; continue; }
-        size_t count = 2;
-        if (src[i + 1] != 0xff) { c = 0; count = 4 + (size_t)src[i + 1]; }
-        if (dlen - o < count) return (int64_t)o - (int64_t)dlen;
-        i += 2;
-        while (count--) d[o++] = c;
-    }
-    while (i < slen && o < dlen) d[o++] = src[i++];
-    return (int64_t)(dlen - o) - (int64_t)(slen - i);
-}
+// (RLE0, reference QB3encode.cpp:271-332 / QB3decode.cpp:267-307, runs on the device: k_rle0.hip)
 
 // ---------------------------------------------------------------- encode
 static size_t stored_encode_host(encsp p, const void *source, void *destination) {
@@ -533,25 +485,33 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     const size_t len_ref = len - (ixt.base ? ix_total_bytes(ixt) : 0);      // what the reference's container measures
 
     if (rle) {
-        // byte-serial post pass on the host (reference QB3encode.cpp:536-565)
+        // the RLE0 post pass (reference QB3encode.cpp:536-565)
         p->mode = mode;
-        // ... and only worth a trip to the host when the stream has a run of four zero bytes at all (probed on the device)
+        // ... which can only win when the stream has a run of four zero bytes at all (a cheap probe first)
         int has_run = 1;
         if (len_ref <= maxsz / 2 && len - hdr >= 4) {
             uint8_t *flag = (uint8_t *)p->d_ws.p;       // the workspace is idle now; its first word serves as the flag
             if (zero_run_probe(out_dev, hdr, len - hdr, flag, &has_run, st)) has_run = 1;
         }
         if (len_ref <= maxsz / 2 && has_run) {
-            std::vector<uint8_t> data(len - hdr);
-            HIPOK(hipMemcpyAsync(data.data(), out_dev + hdr, data.size(), hipMemcpyDeviceToHost, st));
-            HIPOK(hipStreamSynchronize(st));
-            const size_t rsz = rle0(data.data(), data.size(), nullptr);
-            if (rsz <= maxsz - len_ref && rsz < data.size()) {
-                std::vector<uint8_t> packed(64 + rsz);
-                const size_t h2 = write_headers(p, packed.data());
-                rle0(data.data(), data.size(), packed.data() + h2);
-                if (on_host) memcpy(host_dst, packed.data(), h2 + rsz);
-                else { HIPOK(hipMemcpyAsync(d_dst, packed.data(), h2 + rsz, hipMemcpyHostToDevice, st)); HIPOK(hipStreamSynchronize(st)); }
+            // the byte pass on the device (k_rle0.hip): its size first, the bytes only when it wins -- into a buffer of its
+            // own (the passes run in parallel: not in place), then behind the RLE mode's header
+            const size_t n = len - hdr;
+            uint64_t rsz64 = 0;
+            if (!p->d_rle.ensure(rle0_ws_bytes(n)) || rle0_device_size(out_dev + hdr, n, p->d_rle.p, false, &rsz64, st)) { p->error = QB3E_LIBERR; return 0; }
+            const size_t rsz = (size_t)rsz64;
+            if (rsz <= maxsz - len_ref && rsz < n) {
+                uint8_t hdr2[80];
+                const size_t h2 = write_headers(p, hdr2);
+                if (!p->d_q.ensure(rsz) || rle0_device_write(out_dev + hdr, n, p->d_rle.p, false, p->d_q.p, st)) { p->error = QB3E_LIBERR; return 0; }
+                if (on_host) {
+                    memcpy(host_dst, hdr2, h2);
+                    if (!download(p->stager, (uint8_t *)host_dst + h2, p->d_q.p, rsz, st)) { p->error = QB3E_LIBERR; return 0; }
+                } else {
+                    HIPOK(hipMemcpyAsync((uint8_t *)d_dst + h2, p->d_q.p, rsz, hipMemcpyDeviceToDevice, st));
+                    HIPOK(hipMemcpyAsync(d_dst, hdr2, h2, hipMemcpyHostToDevice, st));
+                    HIPOK(hipStreamSynchronize(st));
+                }
                 return h2 + rsz;
             }
         }
@@ -675,7 +635,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
 // ---------------------------------------------------------------- decoder handle
 QB3_API void qb3_destroy_decoder(decsp p) {
     if (!p) return;
-    p->d_in.release(); p->d_img.release(); p->d_ws.release(); p->d_ix.release(); p->d_tab.release(); p->stager.release();
+    p->d_in.release(); p->d_img.release(); p->d_ws.release(); p->d_ix.release(); p->d_rle.release(); p->d_tab.release(); p->stager.release();
     delete p;
 }
 QB3_API size_t qb3_decoded_size(const decsp p) { return p->xsize * p->ysize * p->nbands * szof(p->type); }
@@ -896,27 +856,27 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
     // locate the block stream on the device
     const uint8_t *dev_buf = nullptr;
     size_t off = 0, nbytes = p->s_size;
-    std::vector<uint8_t> unrle;
     const bool rle = is_rle_mode(p->mode);
-    if (rle) {                               // byte-serial expansion on the host (reference QB3decode.cpp:396-413)
-        std::vector<uint8_t> packed;
-        const uint8_t *src = p->s_in;
-        if (!on_host) {
-            packed.resize(p->s_size);
-            HIPOK(hipMemcpyAsync(packed.data(), (const uint8_t *)d_src + data_off, p->s_size, hipMemcpyDeviceToHost, st));
-            HIPOK(hipStreamSynchronize(st));
-            src = packed.data();
+    if (rle) {
+        // the RLE0 expansion on the device (k_rle0.hip; reference QB3decode.cpp:396-413): size first, then the bytes
+        const uint8_t *packed = (const uint8_t *)d_src + data_off;
+        const size_t wsb = (rle0_ws_bytes(p->s_size) + 15) & ~(size_t)15;
+        if (!p->d_rle.ensure(wsb + (on_host ? p->s_size : 0))) { p->error = QB3E_LIBERR; return 0; }
+        if (on_host) {
+            uint8_t *up = (uint8_t *)p->d_rle.p + wsb;
+            if (!upload(p->stager, up, p->s_in, p->s_size, st)) { p->error = QB3E_LIBERR; return 0; }
+            packed = up;
         }
-        const size_t sz = derle0_size(src, p->s_size);
+        uint64_t sz = 0;
+        if (rle0_device_size(packed, p->s_size, p->d_rle.p, true, &sz, st)) { p->error = QB3E_LIBERR; return 0; }
         if (sz > total) { p->error = QB3E_ERR; return 0; }
-        unrle.resize(sz ? sz : 1);
-        if (derle0(src, p->s_size, unrle.data(), sz)) { p->error = QB3E_EINV; return 0; }
-        nbytes = sz;
-    }
-    if (on_host || rle) {
-        const uint8_t *src = rle ? unrle.data() : p->s_in;
+        if (!p->d_in.ensure((size_t)sz + 8)) { p->error = QB3E_LIBERR; return 0; }
+        if (rle0_device_write(packed, p->s_size, p->d_rle.p, true, p->d_in.p, st)) { p->error = QB3E_LIBERR; return 0; }
+        nbytes = (size_t)sz;
+        dev_buf = (const uint8_t *)p->d_in.p; off = 0;
+    } else if (on_host) {
         if (!p->d_in.ensure(nbytes + 8)) { p->error = QB3E_LIBERR; return 0; }
-        if (!upload(p->stager, p->d_in.p, src, nbytes, st)) { p->error = QB3E_LIBERR; return 0; }
+        if (!upload(p->stager, p->d_in.p, p->s_in, nbytes, st)) { p->error = QB3E_LIBERR; return 0; }
         dev_buf = (const uint8_t *)p->d_in.p; off = 0;
     } else { dev_buf = (const uint8_t *)d_src; off = data_off; }
 
@@ -1106,6 +1066,22 @@ QB3_API uint64_t qb3x_fnv1a64(const void *data, size_t n, uint64_t seed) {
     const uint8_t *b = (const uint8_t *)data;
     for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ull;
     return h;
+}
+// The RLE0 byte pass on device buffers (k_rle0.hip): the coded (decode = 0) or expanded (decode != 0) form of the n bytes
+// at d_src.  d_dst == NULL: the size only.  Returns the size, 0 on failure or when it exceeds dst_cap.
+QB3_API size_t qb3x_rle0_device(const void *d_src, size_t n, void *d_dst, size_t dst_cap, int decode, void *stream) {
+    if (!d_src || !n) return 0;
+    DevBuf ws;
+    if (!ws.ensure(rle0_ws_bytes(n))) return 0;
+    uint64_t total = 0;
+    size_t ret = 0;
+    if (rle0_device_size(d_src, n, ws.p, decode != 0, &total, stream) == 0) {
+        if (!d_dst) ret = (size_t)total;
+        else if (total <= dst_cap && rle0_device_write(d_src, n, ws.p, decode != 0, d_dst, stream) == 0 &&
+                 hipStreamSynchronize((hipStream_t)stream) == hipSuccess) ret = (size_t)total;
+    }
+    ws.release();
+    return ret;
 }
 QB3_API void qb3x_profile_enable(int level) { prof_enable(level < 0 ? 0 : level); }
 QB3_API void qb3x_profile_reset(void) { prof_reset(); }

@@ -149,6 +149,14 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
                   void *walk_tab = nullptr, size_t walk_tab_bytes = 0,     // table memory for plain 8-bit streams (null: the one-wave walk)
                   bool full_staging = false);   // 16-bit data: worst-case LDS staging (after a call that ended with status bit 4)
 
+// The RLE0 byte pass of the *_RLE modes on device buffers (k_rle0.hip; reference QB3encode.cpp:271-332, QB3decode.cpp:267-307).
+// ws: rle0_ws_bytes(n) bytes of device memory.  rle0_device_size returns the size of the coded (decode = false) or
+// expanded (decode = true) form and synchronises the stream; rle0_device_write, called next with the same arguments,
+// writes it (does not synchronise).
+size_t rle0_ws_bytes(uint64_t n);
+int rle0_device_size(const void *d_src, uint64_t n, void *ws, bool decode, uint64_t *total, void *stream);
+int rle0_device_write(const void *d_src, uint64_t n, void *ws, bool decode, void *d_dst, void *stream);
+
 // RLE0 can only win on a stream with a run of four zero bytes: *has_run says whether bytes [off, off+nbytes) of d_buf have one
 int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, int *has_run, void *stream);
 

@@ -243,6 +243,65 @@ def test_encode_rle_modes(qb3, oracle, mode):
         check_encode(qb3, oracle, img, dt, mode)
 
 
+def _rle_patterns():
+    """byte strings that exercise every branch of the reference's RLE0 loops: runs of 00 and ff of every length around the
+    thresholds (4, 258, 2 x 258), ff before zeros, runs that reach the end, runs across the 4 KB chunks the device skips by"""
+    rng = np.random.default_rng(11)
+    pats = []
+    for n in (0, 1, 2, 3, 4, 5, 6, 7):
+        pats.append(np.zeros(n, np.uint8)); pats.append(np.full(n, 0xff, np.uint8))
+    for L in (3, 4, 5, 257, 258, 259, 261, 262, 516, 517, 520, 4095, 4096, 4097, 8192 + 5, 3 * 4096 + 259):
+        for lead in (b"", b"\x07", b"\xff", b"\xff\xff", b"\xff\xff\xff", b"\x00\x01"):
+            for tail in (b"", b"\x09", b"\xff", b"\x00\x09", b"\x09\x09\x09"):
+                pats.append(np.frombuffer(lead + bytes(L) + tail, np.uint8))
+                pats.append(np.frombuffer(lead + b"\xff" * L + tail, np.uint8))
+    for _ in range(40):             # random mixtures of short runs of 00, ff and other bytes
+        parts = []
+        for _ in range(int(rng.integers(1, 60))):
+            kind = int(rng.integers(0, 4))
+            k = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9, 258, 259, 300]))
+            parts.append(bytes(k) if kind == 0 else b"\xff" * k if kind == 1 else rng.integers(1, 255, k, dtype=np.uint8).tobytes() if kind == 2
+                         else rng.choice([0, 0xff, 5], k).astype(np.uint8).tobytes())
+        pats.append(np.frombuffer(b"".join(parts), np.uint8))
+    big = rng.integers(0, 256, 300000, dtype=np.uint8)          # a larger one: mostly noise with planted runs
+    for off, k, v in ((10, 5000, 0), (9000, 9000, 0xff), (100000, 258 * 40 + 3, 0), (250000, 49999, 0), (299990, 10, 0xff)):
+        big[off:off + k] = v
+    pats.append(big)
+    return [p for p in pats if p.size]
+
+
+def test_rle0_on_the_device_matches_the_reference_loops(qb3, oracle):
+    """qb3x_rle0_device (k_rle0.hip) against the oracle's restatement of the reference's serial RLE0 coder and decoder:
+    coded bytes identical, the expansion of the coded bytes identical to the input"""
+    import ctypes as C
+    import torch
+    L = qb3.lib
+    O = oracle.lib
+    for pat in _rle_patterns():
+        n = pat.size
+        src = np.ascontiguousarray(pat)
+        ref = np.zeros(n * 3 // 2 + 16, np.uint8)
+        rsz = O.qb3o_rle0(src.ctypes.data, n, ref.ctypes.data)
+        assert rsz == O.qb3o_rle0_size(src.ctypes.data, n)
+        d_src = torch.from_numpy(src.copy()).cuda()
+        assert L.qb3x_rle0_device(d_src.data_ptr(), n, None, 0, 0, None) == rsz, (n, bytes(src[:32]))
+        d_dst = torch.zeros(rsz + 8, dtype=torch.uint8, device="cuda")
+        assert L.qb3x_rle0_device(d_src.data_ptr(), n, d_dst.data_ptr(), rsz, 0, None) == rsz
+        assert np.array_equal(d_dst[:rsz].cpu().numpy(), ref[:rsz]), (n, bytes(src[:32]))
+        # and back: the expansion of the coded form, and of the RAW pattern read as coded bytes (any bytes are a valid input)
+        for coded in (ref[:rsz].copy(), src):
+            m = coded.size
+            want = O.qb3o_derle0_size(coded.ctypes.data, m)
+            exp = np.zeros(want + 1, np.uint8)
+            assert O.qb3o_derle0(coded.ctypes.data, m, exp.ctypes.data, want) == 0
+            d_c = torch.from_numpy(coded.copy()).cuda()
+            assert L.qb3x_rle0_device(d_c.data_ptr(), m, None, 0, 1, None) == want
+            if want:
+                d_e = torch.zeros(want, dtype=torch.uint8, device="cuda")
+                assert L.qb3x_rle0_device(d_c.data_ptr(), m, d_e.data_ptr(), want, 1, None) == want
+                assert np.array_equal(d_e.cpu().numpy(), exp[:want]), (m, bytes(coded[:32]))
+
+
 @pytest.mark.parametrize("dtype", [0, 1, 3, 5])
 @pytest.mark.parametrize("q,away", [(2, False), (2, True), (3, False), (4, True), (10, False), (10, True)])
 def test_quanta(qb3, oracle, dtype, q, away):
