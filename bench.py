@@ -535,7 +535,24 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
         return float(t.item())
 
     dt = timed(True)
+    prof = Prof(qdev)                                    # rank 0's kernels, over the coding-only leg
+    if rank == 0:
+        prof.start()
     dt_code = timed(False)
+    roofline = None
+    if rank == 0:
+        avg = prof.stop()
+        raw_tile = w * h * 3
+        sizes_all = [int(s) for s in tc.sizes[:count]]
+        # an encode launch covers a batch of nb tiles, a decode launch all of the rank's tiles
+        algo_batch = nb * raw_tile + sum(sizes_all) * nb // max(1, count)
+        algo_all = count * raw_tile + sum(sizes_all)
+        cand = {k: v for k, v in avg.items() if k in ENC_KERNELS + DEC_KERNELS}
+        if cand:
+            dom = max(cand, key=lambda k: cand[k][0])
+            algo = algo_all if dom in DEC_KERNELS else algo_batch
+            roofline = roofline_of({dom: cand[dom]}, algo, (dom,))
+            roofline["launch_covers"] = f"{count if dom in DEC_KERNELS else nb} tiles of 4096x4096x3 (rank 0)"
     bytes_root = None
     if rank == 0:
         bytes_root = sum(sum(sl) for (_, sls) in got for sl in sls[1:])
@@ -555,7 +572,7 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
         "coding_only": {"ms_per_step": round(dt_code / args.steps * 1e3, 3), "MPixel_s": round(px / (dt_code / args.steps) / 1e6, 1)},
         "gather": {"bytes_into_root_per_step": bytes_root, "GBps_into_root": round(bytes_root / (dt / args.steps) / 1e9, 1) if bytes_root else None,
                    "containers_intact": intact, "backend": "nccl (RCCL) send/recv" if args.backend == "nccl" else args.backend + " (rehearsal)"},
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roofline, "cpu_baseline": None,
     }
     return line
 
