@@ -70,14 +70,20 @@ decsp qb3x_read_start(void *header, size_t header_size, size_t stream_size, size
 size_t qb3x_header_size_bound(const void *container, size_t avail);
 
 /* Self-indexing containers (off by default: the container then differs from the reference's by a few chunks).
- * When on, qb3_encode / qb3x_encode_device put a restart table -- the bit position and band state at about every
- * 1024th unit, 0.1-0.2 % of a typical stream -- into the container in front of "DT", as ignorable (lower-case) chunks:
- * "ix" chunks of at most 64 KB, each followed by a 4-byte pad chunk "zz".  The reference's decoder steps over them
+ * When on, qb3_encode / qb3x_encode_device put a restart table -- the bit position and band state at the start of every
+ * index segment of an FTL/BASE stream (64 blocks of 8-bit grey/RGB/RGBA: 12 bytes, 0.7 % of a typical stream), at about
+ * every 64th unit of a common-factor stream (1.5-3 %) -- into the container in front of "DT", as ignorable (lower-case)
+ * chunks: "ix" chunks of at most 64 KB, each followed by a 4-byte pad chunk "zz".
+ * An "ix" chunk: 'i' 'x', u16 length of the whole chunk, u8 version (2), u8 flags (bit 0: entries carry common factors),
+ * u16 reserved, u32 blocks per entry, then the entries; an entry: 6-byte little-endian bit position of its first unit
+ * (from the first stream bit), a rung byte per band, the value entering each band (the type's width, little-endian),
+ * and with flag bit 0 the common factor entering each band likewise.  Entry k starts at block k * (blocks per entry);
+ * every chunk but the last holds the same number of entries.  The reference's decoder steps over them
  * (QB3decode.cpp:251-255) and decodes the same pixels: it skips an unknown chunk by its length field counted from the
  * chunk START, so the field holds the whole chunk size, and the pad makes the container parse the same for a reader
  * that adds the 4 head bytes to it.  This library's decoder uses the table when no out-of-band index is given:
- * qb3_read_data / qb3x_decode_device(d_index = NULL) then walk the stream from every entry at once (one lane each)
- * instead of serially.  qb3_max_encoded_size() grows by the table's size while the switch is on.  Not written for
+ * qb3_read_data / qb3x_decode_device(d_index = NULL) then walk (FTL/BASE) or decode (common-factor modes) the stream
+ * from every entry at once, one lane each, instead of serially.  qb3_max_encoded_size() grows by the table's size while the switch is on.  Not written for
  * RLE0 modes, narrow images and STORED output.  A decoder handle for the device flavour needs a host copy of the
  * container up to its "DT" mark: qb3x_header_size_bound() bytes always suffice (qb3x_read_start).
  * Callers that only know the reference API (LD_PRELOAD, relinked tools) can set QB3X_INDEX_CHUNK=1 in the
@@ -96,7 +102,7 @@ size_t qb3_decode(decsp p, void *destination);                                  
 /* Per-kernel timing for benchmarks: when enabled, every kernel the library launches is bracketed by HIP
  * events on the launch stream; totals are resolved at the library's own synchronisation points.
  * Kernel names: enc_units, enc_scan, enc_concat, enc_seams, enc_best_units, enc_best_scan, enc_best_recode,
- * dec_index_serial, dec_index_prev, dec_index_scan, dec_units, dec_segments.
+ * dec_index_table, dec_index_serial, dec_index_prev, dec_index_scan, dec_units, dec_segments.
  * level: 0 off, 1 every kernel, 2 all but the microsecond kernels (enc_scan, enc_seams, enc_best_scan), whose two
  * events cost more than they take. */
 void qb3x_profile_enable(int level);
