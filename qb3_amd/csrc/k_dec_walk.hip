@@ -231,7 +231,8 @@ template <uint32_t UB> __device__ __forceinline__ uint32_t walk_unit(uint32_t rp
 }
 
 template <uint32_t UB, int BT>     // BT: bands at compile time (8-bit data), 0: run time
-__global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a, const uint32_t stage_bytes) {
+__global__ void __launch_bounds__(64) dec_walk_lanes_kernel(const DecArgs a0, const uint32_t stage_bytes) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
     // LDS: the 64 windows, then (stage_bytes per lane, 0: none) the unit lengths the wave finds, laid out like the
     // part of the length table they belong to: a lane's lengths are scattered bytes, the wave's are one contiguous run
     // that leaves as whole cache lines at the end
@@ -1019,8 +1020,8 @@ size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits, uint32_t tsz) {
 size_t walk_table_min_bytes(uint32_t ntiles, uint32_t tsz) { return walk_table_bytes(ntiles, 2 * 16 * (tsz == 2 ? chain16::CW : chain::CW), tsz); }
 
 void launch_dec_walk(const DecArgs &a, hipStream_t st) {
-    if (a.ix && a.ntiles == 1) {            // the container's own restart table: a lane per entry
-        const dim3 grid((a.ix_K + 63) / 64), block(64);
+    if (a.ix) {                             // the containers' own restart tables: a lane per entry
+        const dim3 grid((a.ix_K + 63) / 64, a.ntiles), block(64);
         // unit lengths staged in LDS when a lane's share is small enough (it is when an entry is one index segment)
         // unit lengths leave through a small per-lane ring in LDS (sixteen blocks for 8-bit data, 64 bytes otherwise)
         const uint32_t stage = 1;

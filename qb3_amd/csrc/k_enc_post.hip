@@ -150,7 +150,8 @@ __global__ void write_header_kernel(const EncArgs a0) {
 // Chunk head: "ix", length (the whole chunk: the reference skips unknown chunks by that many bytes from the chunk
 // start, QB3decode.cpp:254-255), version 2, flags (bit 0: entries carry the common factors), 2 reserved bytes,
 // blocks per entry.  The pad makes the container parse the same if a reader adds the 4 head bytes to the length.
-__global__ void ix_fill_kernel(const EncArgs a) {
+__global__ void ix_fill_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, B = a.g.bands, tsz = a.g.tsz;
     if (k >= a.ix_K) return;
     const uint32_t c = k / a.ix_per_chunk, j = k - c * a.ix_per_chunk;
@@ -195,7 +196,7 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     ProfScope ps("enc_seams", st);
     hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256, nt), dim3(256), 0, st, a);
     if (a.hdr_len) hipLaunchKernelGGL(write_header_kernel, dim3(1, nt), dim3(64), 0, st, a);
-    if (a.ix_dst && a.have_idx && nt == 1) hipLaunchKernelGGL(ix_fill_kernel, dim3((a.ix_K + 255) / 256), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx) hipLaunchKernelGGL(ix_fill_kernel, dim3((a.ix_K + 255) / 256, nt), dim3(256), 0, st, a);
 }
 
 }  // namespace qb3dev

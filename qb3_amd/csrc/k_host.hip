@@ -407,12 +407,12 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     const bool use_px = plan.px && !best && a.g.tsz == 1;
     const bool use_px16 = plan.px16 && !best && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0;
     // 32/64-bit FTL/BASE streams that bring a restart table with an entry per index segment: the lengths-only walk too
-    const bool wide_walk = rebuild && a.ix && a.ntiles == 1 && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
+    const bool wide_walk = rebuild && a.ix && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
     if (rebuild && (use_px || use_px16 || wide_walk) && !tuning().slow_index) {
         // index-less stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
         // produce the values entering the segments (totals pass + scan)
         // plain 8-bit stream: through the table of unit lengths by position when the caller brought memory for it
-        const bool has_ix = a.ix && a.ntiles == 1;
+        const bool has_ix = a.ix != nullptr;
         if ((use_px || use_px16) && !has_ix && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk) launch_dec_walk_table(a, st, walk_tab, walk_tab_bytes, max_bits);
         else { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
         if (!(a.ix && a.ix_blocks == a.g.seg_blocks) && !wide_walk) {         // (an entry per segment: the walk copied the entering values)
@@ -469,7 +469,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     a.in_cap_full = plan_in.px_cap_dw;
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
     a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = a.ix_per_chunk = a.ix_pad = 0;
-    if (ix.base && !tb.n && ix.blocks && ix.per_chunk && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&
+    if (ix.base && ix.blocks && ix.per_chunk && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&
         ix.K == (g.nblocks + ix.blocks - 1) / ix.blocks) {
         a.ix = ix.base; a.ix_K = ix.K; a.ix_blocks = ix.blocks; a.ix_E = ix.entry_bytes; a.ix_per_chunk = ix.per_chunk;
         a.ix_pad = ix.pads ? IX_PAD : 0;

@@ -584,8 +584,8 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
         return k;
     }
 
-    uint8_t hdrbuf[64];
-    const size_t hdr = write_headers(p, hdrbuf);
+    uint8_t hdrbuf[80];
+    size_t hdr = write_headers(p, hdrbuf);
     Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, p->mode, p->cband, nullptr);
     EncPlan plan = plan_encode(g, !p->no_single_pass);
     size_t wsp = (plan.ws_bytes + 255) & ~(size_t)255;
@@ -593,6 +593,21 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
     if (batch > n) batch = n;
     if (batch > 65535) batch = 65535;
     if (!p->d_ws.ensure(batch * wsp)) { p->error = QB3E_LIBERR; return 0; }
+    // self-indexing containers (qb3x_set_encoder_index_chunk): every tile gets its own restart table, at the same place
+    IxTable ixt;
+    size_t hdr_stamp = hdr, ix_bytes = 0, isz_all = isz;
+    void *index_all = d_index;
+    if (ix_room(p)) {
+        ixt = ix_layout(g);
+        hdr_stamp = write_headers(p, hdrbuf, false);
+        ix_bytes = ix_total_bytes(ixt);
+        hdr = hdr_stamp + ix_bytes + 2;                   // chunks, then "DT": both written by ix_fill_kernel
+        if (!index_all) {                                 // the table is a sample of the index: make one per tile of a batch
+            isz_all = (index_bytes(g) + 7) & ~(size_t)7;
+            if (!p->d_idx.ensure(batch * isz_all)) { p->error = QB3E_LIBERR; return 0; }
+            index_all = p->d_idx.p;
+        }
+    }
     BandState bs;
     memset(&bs, 0, sizeof(bs));             // tiles are independent streams: every tile starts from the reset state
     std::vector<EncResult> res(batch);
@@ -600,10 +615,13 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
     for (size_t first = 0; first < n; first += batch) {
         const size_t cnt = (n - first < batch) ? n - first : batch;
         TileBatch tb;
-        tb.n = (uint32_t)cnt; tb.src_pitch = src_pitch; tb.dst_pitch = dst_pitch; tb.ws_pitch = wsp; tb.idx_pitch = isz;
+        tb.n = (uint32_t)cnt; tb.src_pitch = src_pitch; tb.dst_pitch = dst_pitch; tb.ws_pitch = wsp; tb.idx_pitch = isz_all;
         uint8_t *out0 = (uint8_t *)d_dst + first * dst_pitch;
+        if (ix_bytes) ixt.base = out0 + hdr_stamp;
+        // (the caller's index array is indexed by tile; the internal one by tile of the batch)
+        void *index_here = !index_all ? nullptr : (d_index ? (uint8_t *)d_index + first * isz : (uint8_t *)index_all);
         if (launch_encode(g, plan, (const uint8_t *)d_src + first * src_pitch, (uint32_t *)(out0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), bs,
-                          p->d_ws.p, d_index ? (uint8_t *)d_index + first * isz : nullptr, st, tb, hdrbuf, (uint32_t)hdr)) { p->error = QB3E_LIBERR; return done; }
+                          p->d_ws.p, index_here, st, tb, hdrbuf, (uint32_t)hdr_stamp, ixt)) { p->error = QB3E_LIBERR; return done; }
         const uint8_t *dres = (const uint8_t *)p->d_ws.p + plan.ws_bytes - sizeof(EncResult);
         hipError_t e = hipMemcpy2DAsync(res.data(), sizeof(EncResult), dres, wsp, sizeof(EncResult), cnt, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -619,7 +637,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
         const size_t raw = p->xsize * p->ysize * p->nbands * tsz;
         for (size_t i = 0; i < cnt; i++) {
             const size_t len = hdr + (size_t)((res[i].total_bits + 7) / 8);
-            if (raw > len) { sizes[first + i] = len; done++; }
+            if (raw > len - ix_bytes) { sizes[first + i] = len; done++; }         // (the table does not take part in the decision)
             else done += encode_tiles_loop(p, d_src, first + i, 1, src_pitch, d_dst, dst_pitch, d_index, isz, sizes, stream, mode);   // STORED fallback
         }
         // handle state as after a loop over the tiles: the state left by the last one
@@ -1002,7 +1020,20 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
     }
     const bool batchable = !is_rle_mode(p->mode) && p->mode != QB3M_STORED && p->quanta <= 1 && p->xsize >= 4 && p->ysize >= 4 &&
                            p->xsize * p->ysize >= 16;
+    // restart tables (tile 0 has one, parsed by qb3_read_info): usable for the batch when every tile of it has its "ix" tag
+    // and its "DT" mark where tile 0 has them (equally shaped tiles written by one encoder do); else the plain walk
+    bool use_ix = !d_index && p->ix_K && hdr >= 2;
+    std::vector<uint8_t> tags;
+    if (use_ix) {
+        tags.resize(4 * n);
+        hipError_t e = hipMemcpy2DAsync(tags.data(), 4, (const uint8_t *)d_src + p->ix_off, src_pitch, 2, n, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpy2DAsync(tags.data() + 2, 4, (const uint8_t *)d_src + hdr - 2, src_pitch, 2, n, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("decode tiles: table tags", (int)e); p->error = QB3E_LIBERR; return 0; }
+    }
     auto in_batch = [&](size_t i) { return batchable && modes[i] == (uint8_t)p->mode && sizes[i] > hdr; };
+    for (size_t i = 0; i < n && use_ix; i++)
+        if (in_batch(i) && !(tags[4 * i] == 'i' && tags[4 * i + 1] == 'x' && tags[4 * i + 2] == 'D' && tags[4 * i + 3] == 'T')) use_ix = false;
     size_t done = 0;
     if (batchable) {
         uint8_t cband[QB3_MAXBANDS];
@@ -1026,13 +1057,18 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
             TileBatch tb;
             tb.n = (uint32_t)cnt; tb.src_pitch = src_pitch; tb.dst_pitch = dst_pitch; tb.idx_pitch = isz;
             for (size_t i = 0; i < cnt; i++) if (bits[i] > tb.max_bits) tb.max_bits = bits[i];
-            if (!d_index && !walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
+            IxTable ixt;
+            if (use_ix) {
+                ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads;
+                ixt.base = (uint8_t *)d_src + first * src_pitch + p->ix_off;
+            }
+            if (!d_index && !use_ix && !walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
             const uint8_t *src0 = (const uint8_t *)d_src + first * src_pitch;
             uint32_t *d_status = nullptr;
             for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the streams' average)
                 if (launch_decode(g, plan, (const uint32_t *)(src0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), 0, (uint8_t *)d_dst + first * dst_pitch,
                                   d_index ? (const uint8_t *)d_index + first * isz : nullptr, p->d_ws.p, &d_status, st, tb, (const uint64_t *)p->d_in.p,
-                                  IxTable(), p->d_tab.p, p->d_tab.cap, full != 0)) { p->error = QB3E_LIBERR; return done; }
+                                  ixt, p->d_tab.p, p->d_tab.cap, full != 0)) { p->error = QB3E_LIBERR; return done; }
                 e = hipMemcpyAsync(status.data(), d_status, 4 * cnt, hipMemcpyDeviceToHost, st);
                 if (e == hipSuccess) e = hipStreamSynchronize(st);
                 if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }

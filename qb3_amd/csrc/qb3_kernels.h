@@ -237,6 +237,7 @@ __device__ __forceinline__ EncArgs enc_for_tile(EncArgs a, uint32_t t) {
         a.cw_has = shift_ptr(a.cw_has, w); a.cw_val = shift_ptr(a.cw_val, w); a.centry = shift_ptr(a.centry, w); a.cw_used = shift_ptr(a.cw_used, w); a.seg_from_entry = shift_ptr(a.seg_from_entry, w); a.recode_need = shift_ptr(a.recode_need, w); a.recode_list = shift_ptr(a.recode_list, w); a.recode_n = shift_ptr(a.recode_n, w); a.centry_parts = shift_ptr(a.centry_parts, w); a.lookback = shift_ptr(a.lookback, w);
         a.idx.bitpos = shift_ptr(a.idx.bitpos, x); a.idx.prev = shift_ptr(a.idx.prev, x); a.idx.cf = shift_ptr(a.idx.cf, x);
         a.idx.rung = shift_ptr(a.idx.rung, x); a.idx.ulen = shift_ptr(a.idx.ulen, x);
+        a.ix_dst = shift_ptr(a.ix_dst, t * a.ts_out);     // (the restart table sits at the same place in every tile's container)
     }
     return a;
 }
@@ -335,6 +336,7 @@ __device__ __forceinline__ DecArgs dec_for_tile(DecArgs a, uint32_t t) {
         const uint64_t x = t * a.ts_idx;
         a.idx.bitpos = shift_ptr(a.idx.bitpos, x); a.idx.prev = shift_ptr(a.idx.prev, x); a.idx.cf = shift_ptr(a.idx.cf, x);
         a.idx.rung = shift_ptr(a.idx.rung, x); a.idx.ulen = shift_ptr(a.idx.ulen, x);
+        a.ix = shift_ptr(a.ix, t * a.ts_in);               // (the restart table sits at the same place in every tile's container)
         a.status += t;
     }
     return a;

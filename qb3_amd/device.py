@@ -112,12 +112,15 @@ class TileBatchCoder:
     """qb3x_encode_tiles / qb3x_decode_tiles on torch tensors: n independent tiles of one geometry per call, tile i of
     the input at i * raw_bytes, its container at i * pitch of `dst`, its out-of-band index at i * index_bytes."""
 
-    def __init__(self, w, h, bands, dtype, n, mode=QB3M_FTL, device="cuda", want_index=True):
+    def __init__(self, w, h, bands, dtype, n, mode=QB3M_FTL, device="cuda", want_index=True, index_chunk=False):
+        """index_chunk: every tile's container carries its own restart table (include/qb3x.h), so that decode(use_index=False)
+        needs nothing but the containers"""
         self.w, self.h, self.bands, self.dtype, self.n, self.mode = w, h, bands, dtype, n, mode
         self.p = lib.qb3_create_encoder(w, h, bands, dtype)
         if not self.p:
             raise ValueError("qb3_create_encoder refused the parameters")
         lib.qb3_set_encoder_mode(self.p, mode)
+        lib.qb3x_set_encoder_index_chunk(self.p, 1 if index_chunk else 0)
         self.raw_bytes = w * h * bands * TYPESIZE[dtype]
         self.pitch = (lib.qb3_max_encoded_size(self.p) + 3) // 4 * 4
         self.index_bytes = lib.qb3x_index_size(self.p) if want_index else 0
@@ -156,7 +159,9 @@ class TileBatchCoder:
     def decode(self, out, use_index=True):
         """decodes the n containers made by encode() into `out` (n * raw_bytes)."""
         if self.d is None:
-            head = self.dst[:min(int(self.sizes[0]), 256)].cpu().numpy()
+            first = self.dst[:min(int(self.sizes[0]), 64)].cpu().numpy()
+            need = lib.qb3x_header_size_bound(first.ctypes.data_as(_vp), first.size)         # (a restart table makes the header long)
+            head = np.ascontiguousarray(self.dst[:min(int(self.sizes[0]), max(need, 64))].cpu().numpy())
             dims = (_sz * 3)()
             self.d = lib.qb3x_read_start(head.ctypes.data_as(_vp), head.size, int(self.sizes[0]), dims)
             if not self.d or not lib.qb3_read_info(self.d):

@@ -458,6 +458,66 @@ def test_tiles_api(qb3, oracle, shape):
     L.qb3_destroy_decoder(d)
 
 
+@pytest.mark.parametrize("shape", [(256, 192, 3, 0, FTL), (200, 136, 1, 0, BASE), (256, 128, 8, 2, BASE), (192, 128, 1, 5, FTL), (256, 192, 3, 0, 5)],
+                         ids=lambda s: "%dx%dx%d-t%d-m%d" % s)
+def test_tiles_with_restart_tables(qb3, oracle, shape):
+    """qb3x_encode_tiles with qb3x_set_encoder_index_chunk: every tile's container is what qb3_encode writes for it with the
+    switch on (the reference's stream between this library's table chunks), and qb3x_decode_tiles(index = NULL) decodes the
+    batch from the containers alone -- also when one tile of the batch is raw-stored and one lost its table"""
+    import ctypes as C
+    import torch
+    from qb3_amd import synth
+    L = qb3.lib
+    w, h, b, dt, mode = shape
+    tsz = oracle.TYPESIZE[dt]
+    n = 5
+    gen = "NOISY3" if dt == 0 else ("LANDSAT16" if dt == 2 else "DEM")
+    imgs = torch.stack([synth.generate(w, h, b, dt, gen, 4000 + t) for t in range(n)])
+    if dt == 0 and b == 3 and mode == FTL:
+        imgs[3] = synth.generate(w, h, b, dt, "RANDOM", 7)               # this one falls back to QB3M_STORED
+    p = L.qb3_create_encoder(w, h, b, dt)
+    L.qb3_set_encoder_mode(p, mode)
+    L.qb3x_set_encoder_index_chunk(p, 1)
+    pitch = (L.qb3_max_encoded_size(p) + 3) // 4 * 4
+    dst = torch.zeros(n * pitch, dtype=torch.uint8, device="cuda")
+    sizes = (C.c_size_t * n)()
+    raw = w * h * b * tsz
+    assert L.qb3x_encode_tiles(p, imgs.data_ptr(), n, raw, dst.data_ptr(), pitch, None, sizes, None) == n
+    host = dst.cpu().numpy()
+    for t in range(n):
+        one = host[t * pitch:t * pitch + sizes[t]]
+        ref = oracle.encode(imgs[t].cpu().numpy().view(oracle.NPTYPE[dt]), dt, mode)
+        if one[10] == 255:
+            assert np.array_equal(one, ref)
+            continue
+        # the reference's container with this library's chunks inserted in front of "DT"
+        extra = len(one) - len(ref)
+        dt_at = bytes(ref).index(b"DT", 11)
+        assert extra > 0 and bytes(one[dt_at:dt_at + 2]) == b"ix"
+        assert bytes(one[:dt_at]) == bytes(ref[:dt_at]) and bytes(one[dt_at + extra:]) == bytes(ref[dt_at:]), "tile %d" % t
+    dims = (C.c_size_t * 3)()
+    need = L.qb3x_header_size_bound(host[:64].copy().ctypes.data, 64)
+    hdr = host[:max(need, 64)].copy()
+    d = L.qb3x_read_start(hdr.ctypes.data, hdr.size, sizes[0], dims)
+    assert d and L.qb3_read_info(d)
+    if b not in (1, 3, 4):
+        L.qb3x_set_decoder_compat(d, 0)     # identity map when the container has no CB chunk (the default)
+    out = torch.zeros_like(imgs)
+    L.qb3x_profile_reset()
+    L.qb3x_profile_enable(1)
+    assert L.qb3x_decode_tiles(d, dst.data_ptr(), n, pitch, sizes, out.data_ptr(), raw, None, None) == n
+    L.qb3x_profile_enable(0)
+    names = C.create_string_buffer(1024)
+    L.qb3x_profile_names(names, 1024)
+    assert torch.equal(out, imgs)
+    # the tables were used: no table of unit lengths by position was built, no index rebuilt by parsing
+    assert b"dec_index_table" not in names.value, names.value
+    if mode == 5:
+        assert b"dec_index_serial" not in names.value, names.value
+    L.qb3_destroy_decoder(d)
+    L.qb3_destroy_encoder(p)
+
+
 @pytest.mark.parametrize("stored_at", [0, 2, 5])
 def test_tiles_api_with_a_stored_tile(qb3, oracle, stored_at):
     """a batch in which one tile is incompressible: qb3x_encode_tiles writes it raw (QB3M_STORED, another header layout),
