@@ -217,12 +217,34 @@ def measure_tiles(torch, qb3_amd, synth, qdev, dev, ntiles, steps, seed0=1000):
     t0 = time.perf_counter()
     tc.decode(out, use_index=False)
     t_plain = time.perf_counter() - t0
+    # the same tiles as self-indexed containers (every tile carries its restart table): encode, and decode from the containers alone
+    tci = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, ntiles, device=dev, want_index=False, index_chunk=True)
+    sizes_i = tci.encode(imgs)
+    out.zero_()
+    tci.decode(out, use_index=False)
+    if not torch.equal(out, imgs):
+        sys.exit("bench.py: self-indexed tiles: decode(encode(x)) != x -- refusing to report a number")
+    torch.cuda.synchronize()
+    t_enc_i = t_dec_i = 0.0
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        tci.encode(imgs)
+        t1 = time.perf_counter()
+        tci.decode(out, use_index=False)
+        t2 = time.perf_counter()
+        t_enc_i += t1 - t0
+        t_dec_i += t2 - t1
+    table_bytes_all = int(sum(sizes_i) - sum(sizes))
+    tci.close()
     px = ntiles * w * h
     res = {"workload": f"{ntiles} tiles of {w}x{h}x3 uint8 NOISY3 (seeds {seed0}..{seed0 + ntiles - 1}) per call, QB3M_FTL, qb3x_encode_tiles + qb3x_decode_tiles",
            "stream_bytes": int(sum(sizes)), "ratio": round(sum(sizes) / raw, 4), "bit_identical_to_reference": checks,
            "encode_ms_wall": round(t_enc / steps * 1e3, 3), "decode_ms_wall": round(t_dec / steps * 1e3, 3),
            "encode_MPixel_s": round(px / (t_enc / steps) / 1e6, 1), "decode_out_of_band_index_MPixel_s": round(px / (t_dec / steps) / 1e6, 1),
            "decode_plain_containers_ms_wall": round(t_plain * 1e3, 2), "decode_plain_containers_MPixel_s": round(px / t_plain / 1e6, 1),
+           "self_indexed": {"encode_ms_wall": round(t_enc_i / steps * 1e3, 3), "decode_from_containers_ms_wall": round(t_dec_i / steps * 1e3, 3),
+                            "encode_MPixel_s": round(px / (t_enc_i / steps) / 1e6, 1), "decode_from_containers_MPixel_s": round(px / (t_dec_i / steps) / 1e6, 1),
+                            "restart_table_bytes": table_bytes_all},
            "kernels": kernel_table(avg, algo), "roofline": roofline_of(avg, algo, ENC_KERNELS + DEC_KERNELS)}
     return res, tc, imgs, out
 
@@ -492,7 +514,7 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
     total = args.tiles_per_rank * world
     first, count = tiles.shard_range(total, rank, world)
     imgs = torch.stack([synth.generate(w, h, 3, qb3_amd.QB3_U8, "NOISY3", 1000 + first + t, device=dev) for t in range(count)])
-    tc = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, count, device=dev)
+    tc = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, count, device=dev, want_index=False, index_chunk=True)
     out = torch.empty_like(imgs)
     nb = max(1, min(args.batch_tiles, count))
     batches = [(lo, min(nb, count - lo)) for lo in range(0, count, nb)]
@@ -507,7 +529,7 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
             if gather:
                 pend.append(tiles.start_gather(tc.dst[lo * tc.pitch:(lo + cnt) * tc.pitch], tc.pitch, sizes, root=0,
                                                recv_bufs=recv[b] if recv else None))
-        tc.decode(out, use_index=True)
+        tc.decode(out, use_index=False)                   # from the containers alone: every tile carries its restart table
         got = [p.wait() for p in pend]
         return got
 
@@ -567,7 +589,7 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{total} independent 4096x4096x3 uint8 NOISY3 tiles (seeds 1000..), {args.tiles_per_rank} per GPU, QB3M_FTL: qb3x_encode_tiles in batches of "
                                f"{nb}, containers gathered on rank 0 ({'RCCL send/recv' if args.backend == 'nccl' else args.backend + ' rehearsal'}) beside the coding "
-                               "of the next batch, qb3x_decode_tiles (out-of-band index) of every rank's own tiles; the gather is inside the step",
+                               "of the next batch, qb3x_decode_tiles of every rank's own tiles from the containers alone (index = NULL; every tile carries its restart table); the gather is inside the step",
                    "tiles_total": total, "tiles_per_gpu": args.tiles_per_rank, "parallelism": f"tiles sharded over {world} GPUs, no data-path collective but the gather"},
         "coding_only": {"ms_per_step": round(dt_code / args.steps * 1e3, 3), "MPixel_s": round(px / (dt_code / args.steps) / 1e6, 1)},
         "gather": {"bytes_into_root_per_step": bytes_root, "GBps_into_root": round(bytes_root / (dt / args.steps) / 1e9, 1) if bytes_root else None,

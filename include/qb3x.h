@@ -49,14 +49,17 @@ size_t qb3x_decode_device(decsp p, const void *d_src, void *d_dst, const void *d
  * written at d_dst + i*dst_pitch (dst_pitch >= qb3_max_encoded_size, multiple of 4), index i at
  * d_index + i*qb3x_index_size (or NULL).  sizes[i] receives the container size (0 = failed).
  * The band state is reset before every tile (tiles are independent streams).  Returns the number of
- * tiles encoded.  One host synchronisation for the whole batch. */
+ * tiles encoded.  One host synchronisation for the whole batch.  With qb3x_set_encoder_index_chunk on, every tile's
+ * container carries its own restart table (at the same offset in all of them). */
 size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t src_pitch,
                          void *d_dst, size_t dst_pitch, void *d_index, size_t *sizes, void *stream);
 
 /* Batched decode of n containers of the image size and type of handle p (parsed from tile 0);
  * sizes[i] = container size of tile i.  Tiles whose header matches tile 0's go through one set of launches; a tile
  * of another kind -- a raw-stored tile in a batch of coded ones, as qb3x_encode_tiles writes for incompressible
- * data, or the reverse -- is parsed and decoded on its own.  Returns the number of tiles decoded;
+ * data, or the reverse -- is parsed and decoded on its own.  d_index = NULL: the restart tables inside the containers
+ * are used when every tile of the batch has one where tile 0 has it, else the streams are walked.  Returns the number
+ * of tiles decoded;
  * qb3x_decode_tile_ok(p, i) then tells which (1 = tile i of the last call was decoded). */
 size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
                          void *d_dst, size_t dst_pitch, const void *d_index, void *stream);
