@@ -428,6 +428,71 @@ __global__ void __launch_bounds__(64) dec_index_serial(const DecArgs a0) {
     if (!ok) atomicOr(a.status, 1u);
 }
 
+// The same walk for a stream WITHOUT a table, one wave per tile: the wave stages a window of the stream in LDS with
+// coalesced loads, lane 0 parses whole blocks out of it while the longest possible block still fits, the wave moves the
+// window on.  (A lane refilling its bit buffer straight from global memory waits a memory round trip for every word.)
+constexpr uint32_t SERIAL_WIN = 4096;       // dwords of stream per window
+template <typename T, int MODE>
+__global__ void __launch_bounds__(64) dec_index_staged(const DecArgs a0, uint32_t block_bits) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    __shared__ __attribute__((aligned(16))) uint32_t stage[SERIAL_WIN + 4];
+    __shared__ uint64_t st_prev[MAXBANDS], st_cf[MAXBANDS], s_P;
+    __shared__ uint32_t st_rung[MAXBANDS], s_gb, s_bad;
+    const uint32_t bands = a.g.bands, S = a.g.seg_blocks, lane = threadIdx.x, nblocks = (uint32_t)a.g.nblocks;
+    if (lane < bands) { st_prev[lane] = 0; st_cf[lane] = 0; st_rung[lane] = 0; }
+    if (lane == 0) { s_P = a.in_bit0; s_gb = 0; s_bad = 0; }
+    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
+    __syncthreads();
+    while (true) {
+        const uint64_t P = s_P;
+        const uint32_t gb0 = s_gb;
+        if (gb0 >= nblocks || s_bad) break;
+        const uint64_t w0 = (P >> 5) & ~(uint64_t)3;
+        for (uint32_t i = lane; i < SERIAL_WIN + 4; i += 64) stage[i] = w0 + i < endw_abs ? a.in32[w0 + i] : 0u;
+        __syncthreads();
+        if (lane == 0) {
+            ReaderT<LdsWords> rd;
+            rd.init((LdsWords)stage, P - 32 * w0, 32ull * (SERIAL_WIN + 4));
+            T g[16];
+            bool ok = true;
+            uint32_t gb = gb0;
+            // a block is parsed only while the longest possible one still ends inside the window
+            while (gb < nblocks && ok && rd.position() + block_bits + 64 <= 32ull * SERIAL_WIN) {
+                if (gb % S == 0) {
+                    const uint64_t seg = gb / S;
+                    a.idx.bitpos[seg] = 32 * w0 + rd.position() - a.in_bit0;
+                    for (uint32_t c = 0; c < bands; c++) {
+                        ((T *)a.idx.prev)[seg * bands + c] = (T)st_prev[c];
+                        if (MODE == CM_BEST) ((T *)a.idx.cf)[seg * bands + c] = (T)st_cf[c];
+                        a.idx.rung[seg * bands + c] = (uint8_t)st_rung[c];
+                    }
+                }
+                for (uint32_t c = 0; c < bands; c++) {
+                    uint32_t rung = st_rung[c];
+                    T cf = (T)st_cf[c];
+                    const uint64_t ustart = rd.position();
+                    ok = parse_unit<T, MODE, ReaderT<LdsWords>>(rd, rung, cf, g) && ok;
+                    if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint8_t)(rd.position() - ustart);
+                    else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint16_t)(rd.position() - ustart);
+                    T sum = 0;
+#pragma unroll
+                    for (uint32_t i = 0; i < 16; i++) sum = (T)(sum + smag_t<T>(g[i]));
+                    st_prev[c] = (T)((T)st_prev[c] + sum);
+                    st_cf[c] = cf;
+                    st_rung[c] = rung;
+                }
+                gb++;
+            }
+            s_P = 32 * w0 + rd.position();
+            if (gb == gb0 && ok) ok = false;        // (no block fits the window: cannot happen for a valid geometry; do not spin)
+            s_gb = gb;
+            if (!ok) s_bad = 1;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && s_bad) atomicOr(a.status, 1u);
+}
+
 template <typename T>
 static void launch_dec_generic_t(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     if (plan.fast && a.g.mode != CM_BEST) {
@@ -454,6 +519,18 @@ void launch_dec_generic(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
 }
 template <typename T>
 static void launch_dec_index_serial_t(const DecArgs &a, hipStream_t st) {
+    if (!a.ix) {        // no table: a wave per tile, the stream staged through LDS
+        const uint32_t block_bits = a.g.bands * max_unit_bits(a.g.tsz, a.g.mode);
+        if (block_bits + 64 + 64 <= 32 * SERIAL_WIN) {
+            const dim3 grid(a.ntiles), block(64);
+            switch (a.g.mode) {
+            case CM_FTL: hipLaunchKernelGGL((dec_index_staged<T, CM_FTL>), grid, block, 0, st, a, block_bits); break;
+            case CM_BASE: hipLaunchKernelGGL((dec_index_staged<T, CM_BASE>), grid, block, 0, st, a, block_bits); break;
+            default: hipLaunchKernelGGL((dec_index_staged<T, CM_BEST>), grid, block, 0, st, a, block_bits); break;
+            }
+            return;
+        }
+    }
     const dim3 grid(a.ntiles, a.ix ? (a.ix_K + 63) / 64 : 1), block(64);
     switch (a.g.mode) {
     case CM_FTL: hipLaunchKernelGGL((dec_index_serial<T, CM_FTL>), grid, block, 0, st, a); break;
