@@ -75,7 +75,7 @@ size_t qb3x_header_size_bound(const void *container, size_t avail);
 /* Self-indexing containers (off by default: the container then differs from the reference's by a few chunks).
  * When on, qb3_encode / qb3x_encode_device put a restart table -- the bit position and band state at the start of every
  * index segment of an FTL/BASE stream (64 blocks of 8-bit grey/RGB/RGBA: 12 bytes, 0.7 % of a typical stream), at about
- * every 64th unit of a common-factor stream (1.5-3 %) -- into the container in front of "DT", as ignorable (lower-case)
+ * every 64th unit of a common-factor stream (every 32nd for 32/64-bit data; 1.5-6 %) -- into the container in front of "DT", as ignorable (lower-case)
  * chunks: "ix" chunks of at most 64 KB, each followed by a 4-byte pad chunk "zz".
  * An "ix" chunk: 'i' 'x', u16 length of the whole chunk, u8 version (2), u8 flags (bit 0: entries carry common factors),
  * u16 reserved, u32 blocks per entry, then the entries; an entry: 6-byte little-endian bit position of its first unit

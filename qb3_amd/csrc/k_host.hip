@@ -158,7 +158,9 @@ IxTable ix_layout(const Geometry &g) {
     const bool per_seg = g.mode != CM_BEST;
     // (common-factor streams: the lane that starts at an entry parses whole units from global memory, bound by latency --
     // 64 units an entry keeps four times the lanes in flight that 256 did, for 1.5-3 % of the stream)
-    const uint64_t spe = (per_seg || units_per_seg >= 64) ? 1 : 64 / units_per_seg;        // index segments per entry
+    // (... and 32 for 32/64-bit data, whose images have fewer units for the same bytes: a 4096 x 4096 band is 1 M units)
+    const uint64_t target = g.tsz >= 4 ? 32 : 64;
+    const uint64_t spe = (per_seg || units_per_seg >= target) ? 1 : target / units_per_seg; // index segments per entry
     t.blocks = (uint32_t)(spe * g.seg_blocks);
     t.K = (uint32_t)((g.nseg + spe - 1) / spe);
     t.per_chunk = (65535 - IX_HEAD) / t.entry_bytes;
