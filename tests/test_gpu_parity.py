@@ -363,6 +363,19 @@ def test_16bit_segments_far_longer_than_the_average(qb3, oracle, bands, mode):
     assert torch.equal(dec.decode(dst, index=None).view(torch.uint8), dimg)
 
 
+@pytest.mark.parametrize("case", [(260, 130, 16, BASE), (515, 257, 12, FTL), (300, 200, 10, BASE), (640, 480, 14, BASE), (333, 222, 2, FTL), (400, 300, 1, BASE)],
+                         ids=lambda c: "%dx%dx%d-m%d" % c)
+def test_plain_16bit_streams_of_many_bands(qb3, oracle, case):
+    """reference-made 16-bit containers (no index, no table) through the 16-bit table walk: blocks of up to 16 units, longer
+    than a window of the walk, so the walk changes windows inside blocks; one and two bands take their own loops"""
+    w, h, b, mode = case
+    img = oracle.generate(w, h, b, 2, "LANDSAT16", 11)
+    cb = [1, 1, 1] + list(range(3, b)) if b >= 3 else None
+    stream = oracle.encode(img, 2, mode, cband=cb)
+    out, dims, dtype, _ = qb3.decode(stream)
+    assert dims == (w, h, b) and dtype == 2 and np.array_equal(out, img.view(np.uint8).ravel())
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 3), (40, 3, 1), (1, 17, 2), (300, 1, 3), (3, 3, 1)])
 def test_narrow_images(qb3, oracle, shape):
     w, h, b = shape
