@@ -426,6 +426,11 @@ def main():
     if roofline is not None:
         roofline["valu"] = valu if args.size == 16384 else None
         roofline["device_copy_GBps"] = copy_peak(torch, dev)
+        if roofline.get("traffic"):
+            # what the kernel actually moves (PMC: more than the algorithmic bytes -- slots, index) against what a plain copy reaches here
+            dom_ms = avg[roofline["kernel"]][0]
+            roofline["traffic_GBps"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9, 1)
+            roofline["traffic_frac_of_device_copy"] = round(roofline["traffic_GBps"] / roofline["device_copy_GBps"], 3)
 
     workloads = None
     if not args.no_workloads and args.size == 16384:
