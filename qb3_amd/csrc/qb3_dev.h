@@ -70,7 +70,8 @@ struct EncPlan {
     size_t ws_bytes;        // chunk counts/offsets, seam table, per-chunk scratch slots, EncResult (last)
     uint32_t nbp;           // payload blocks per chunk
     bool persistent;        // ... with persistent workgroups (a chunk's pixels arrive while the previous chunk's bits leave)
-    bool single_pass;       // ... and writes the stream in place (persistent workgroups, look-back) instead of slots + concatenate
+    int single_pass;        // ... and writes the stream in place (persistent workgroups, look-back) instead of slots + concatenate; 2: by super-chunks
+    uint32_t sc_cap_dw;     //     ... dwords of the LDS stream buffer then
     bool px;                // 8-bit 1/3/4-band register-resident kernel applies (lane per block)
     bool px_rgb;            //   ... with the default R-G,G,B-G map (else identity)
     bool px16;              // 16-bit register-resident kernel applies (lane per block and band group)

@@ -207,7 +207,8 @@ struct EncArgs {
     uint8_t *seg_from_entry;    //   ... per index segment and band: its factor entry is the chunk's entering factor
     uint32_t *recode_need, *recode_list, *recode_n;    //   ... chunks to code again: flag per chunk, list, count
     uint64_t *lookback;     // single-pass encoder: per chunk {state, bit count} words, then the abort flag (zeroed per launch)
-    uint32_t single_pass;   // the chunks were written in place: no scan, no concatenation, index positions are final
+    uint32_t single_pass;   // the chunks were written in place: no scan, no concatenation, index positions are final (2: by super-chunks)
+    uint32_t sc_cap_dw;     // ... by super-chunks: dwords of the LDS stream buffer
     uint32_t ntiles;
     uint64_t ts_img, ts_out, ts_ws, ts_idx;     // batched tiles: byte strides from tile to tile (blockIdx.y = tile)
     uint32_t hdr_len;       // container header bytes to put in front of the stream (write_header_kernel)
@@ -529,7 +530,7 @@ struct ProfScope {
 };
 
 // process-wide debugging switches, read once from the environment (k_host.hip)
-struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool single_pass; bool persistent; size_t walk_tab_kb; };
+struct Tuning { bool no_px; bool slow_index; bool slow_walk; int single_pass; bool persistent; size_t walk_tab_kb; };
 const Tuning &tuning();
 
 uint32_t magic_div(uint32_t d);
