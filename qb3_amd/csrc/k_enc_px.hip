@@ -189,9 +189,11 @@ __device__ __forceinline__ void px_code_chunk(const EncArgs &a, const EncArgs &a
             for (int c = 0; c < B; c++) { a.res->prev[c] = lastv[c]; a.res->rung[c] = (rp_packed >> (4 * c)) & 15u; a.res->cf[c] = a0.st.cf[c]; }
         }
         if (a.have_idx) {
-            uint8_t *ul = (uint8_t *)a.idx.ulen + (uint64_t)gblk * B;
+            if (!a.idx_no_ulen) {
+                uint8_t *ul = (uint8_t *)a.idx.ulen + (uint64_t)gblk * B;
 #pragma unroll
-            for (int c = 0; c < B; c++) ul[c] = (uint8_t)lens[c];
+                for (int c = 0; c < B; c++) ul[c] = (uint8_t)lens[c];
+            }
             const uint32_t seg = gblk / a.g.seg_blocks;
             if (seg * a.g.seg_blocks == gblk) {
 #pragma unroll

@@ -230,9 +230,11 @@ __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
             for (int c = 0; c < BG; c++) { a.res->prev[band0 + c] = lastv[c]; a.res->rung[band0 + c] = (rp_packed >> (4 * c)) & 15u; a.res->cf[band0 + c] = a0.st.cf[band0 + c]; }
         }
         if (a.have_idx) {
-            uint16_t *ul = (uint16_t *)a.idx.ulen + (uint64_t)gblk * B + band0;
+            if (!a.idx_no_ulen) {
+                uint16_t *ul = (uint16_t *)a.idx.ulen + (uint64_t)gblk * B + band0;
 #pragma unroll
-            for (int c = 0; c < BG; c++) ul[c] = (uint16_t)lens[c];
+                for (int c = 0; c < BG; c++) ul[c] = (uint16_t)lens[c];
+            }
             const uint32_t seg = gblk / a.g.seg_blocks;
             if (seg * a.g.seg_blocks == gblk) {
 #pragma unroll

@@ -350,6 +350,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.res = (EncResult *)(w + L.res);
     a.st = st_in;
     a.have_idx = index != nullptr;
+    a.idx_no_ulen = index && ix.base && ix.own_index;
     a.idx = index ? index_view(g, index) : IndexView{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (g.tsz != 1 && g.tsz != 2 && g.tsz != 4 && g.tsz != 8) { set_error("encode: bad value size", 0); return -1; }
     return launch_encode_all(a, plan, (hipStream_t)stream);

@@ -474,6 +474,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
         if (!d_index) {                                   // the table is a sample of the index: make one
             if (!p->d_idx.ensure(index_bytes(g))) { p->error = QB3E_LIBERR; return 0; }
             d_index = p->d_idx.p;
+            ixt.own_index = true;
         }
     }
     uint64_t bits = 0;
@@ -606,6 +607,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
             isz_all = (index_bytes(g) + 7) & ~(size_t)7;
             if (!p->d_idx.ensure(batch * isz_all)) { p->error = QB3E_LIBERR; return 0; }
             index_all = p->d_idx.p;
+            ixt.own_index = true;
         }
     }
     BandState bs;

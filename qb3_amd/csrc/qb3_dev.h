@@ -89,6 +89,7 @@ struct IxTable {
     uint8_t *base = nullptr;        // device pointer (encode: where the chunks go, "DT" follows; decode: where they are)
     uint32_t K = 0, blocks = 0, entry_bytes = 0, per_chunk = 0;
     bool pads = true;               // false: a version 1 table (one chunk, no pad chunk behind it)
+    bool own_index = false;         // encode: the index is the library's own, only sampled for the table -- no unit lengths needed
 };
 uint32_t ix_entry_bytes(const Geometry &g);
 // the table this library writes for a geometry (needs seg_blocks, nseg, bands, tsz, mode); K == 0: none

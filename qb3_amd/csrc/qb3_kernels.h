@@ -223,6 +223,7 @@ struct EncArgs {
     BandState st;
     IndexView idx;
     uint32_t have_idx;
+    uint32_t idx_no_ulen;   // the index is the library's own, only sampled for the restart table: segment entries, no unit lengths
 };
 
 
