@@ -953,6 +953,33 @@ def test_handles_are_independent_across_threads(qb3, oracle):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("case", [(1024, 1024, 3, 0, "NOISY3", 4), (509, 259, 1, 0, "GRAD", 8), (1024, 768, 8, 2, "LANDSAT16", 4),
+                                  (300, 200, 2, 2, "LANDSAT16", 8), (512, 512, 1, 4, "DEM", 8), (256, 256, 1, 7, "DEM", 4)])
+def test_restart_table_does_not_depend_on_the_index_request(qb3, oracle, case):
+    """a self-indexed container is the same bytes whether the caller asks for the out-of-band index or not (without one the
+    library keeps an index of its own that holds segment entries only -- no unit lengths), and both decode from the container
+    alone; minus the table chunks they are the reference's container"""
+    import torch
+    from qb3_amd import synth, device as qdev
+    w, h, b, dt, gen, mode = case
+    img = synth.generate(w, h, b, dt, gen, 21)
+    cb = None if b in (1, 3, 4) else list(range(b))
+    e0 = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cb, want_index=False, index_chunk=True)
+    e1 = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cb, want_index=True, index_chunk=True)
+    d0, n0, _ = e0.encode(img)
+    d1, n1, index = e1.encode(img)
+    assert n0 == n1 and torch.equal(d0[:n0], d1[:n1])
+    host = d0[:n0].cpu().numpy()
+    assert bytes(host.tobytes()).find(b"ix", 11) > 0
+    raw = img.reshape(-1).view(torch.uint8)
+    dec = qdev.DeviceDecoder(d0, n0)
+    assert torch.equal(dec.decode(d0, index=None), raw)
+    assert torch.equal(dec.decode(d0, index=index), raw)
+    ref = oracle.encode(oracle.generate(w, h, b, dt, gen, 21), dt, mode, cband=cb)
+    extra, dt_at = n0 - len(ref), bytes(ref).index(b"DT", 11)
+    assert bytes(host[:dt_at]) == bytes(ref[:dt_at]) and bytes(host[dt_at + extra:]) == bytes(ref[dt_at:])
+
+
 @pytest.mark.parametrize("switch", ["QB3_SINGLE_PASS", "QB3_SINGLE_PASS=2", "QB3_PERSISTENT", "QB3_NO_PX", "QB3_SLOW_INDEX", "QB3_SLOW_WALK", "QB3_WALK_TAB_KB=2048"])
 def test_alternative_kernel_paths(qb3, oracle, switch, tmp_path):
     """the paths that are not the default -- the single-pass (look-back per chunk, per super-chunk) and the persistent 8-bit encoders, the generic
