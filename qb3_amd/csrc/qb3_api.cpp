@@ -12,6 +12,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <cstdio>
+#include <chrono>
 #include <vector>
 #include <limits>
 #include <thread>
@@ -49,6 +50,32 @@ static bool device_ok() {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) { set_error("no usable HIP device (the block codec has no CPU fallback)", (int)e); return false; }
     return true;
+}
+
+// Waiting for a stream whose work is short: the runtime's blocking wait costs tens of microseconds to wake up, a kernel
+// sequence of this library takes a few hundred.  Poll for a bounded time first.
+static hipError_t wait_stream(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0;; i++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) break;
+    }
+    return hipStreamSynchronize(st);
+}
+// A few result bytes from the device, then the wait: through pinned memory of the calling thread (a copy into pageable
+// memory goes through the runtime's staging path)
+static hipError_t fetch_small(void *dst, const void *d_src, size_t n, hipStream_t st) {
+    static thread_local void *pinned = nullptr;
+    if (!pinned && hipHostMalloc(&pinned, 1024, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
+    if (!pinned || n > 1024) {
+        hipError_t e = hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, st);
+        return e == hipSuccess ? hipStreamSynchronize(st) : e;
+    }
+    hipError_t e = hipMemcpyAsync(pinned, d_src, n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = wait_stream(st);
+    if (e == hipSuccess) memcpy(dst, pinned, n);
+    return e;
 }
 
 // ---------------------------------------------------------------- host <-> device copies of the host-pointer API
@@ -364,8 +391,7 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     EncResult res;
     const uint8_t *dres = (const uint8_t *)p->d_ws.p + plan.ws_bytes - sizeof(EncResult);
     if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st, TileBatch(), hdrbytes, (uint32_t)hdr_stamp, ix)) return false;
-    hipError_t e = hipMemcpyAsync(&res, dres, sizeof(res), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    const hipError_t e = fetch_small(&res, dres, sizeof(res), st);
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
     prof_collect();
     if (res.error && plan.single_pass) {
@@ -837,8 +863,7 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
         if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st, TileBatch(), nullptr, ix,
                           p->d_tab.p, p->d_tab.cap, full != 0))
             return false;
-        hipError_t e = hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        const hipError_t e = fetch_small(&status, d_status, 4, st);
         if (e != hipSuccess) { set_error("decode kernels", (int)e); return false; }
         if (!(status & 16)) break;
     }
