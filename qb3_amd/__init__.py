@@ -116,7 +116,7 @@ def encode(img, dtype, mode=QB3M_FTL, cband=None, stride=0, quanta=1, away=False
     try:
         lib.qb3_set_encoder_mode(p, mode)
         if index_chunk:
-            lib.qb3x_set_encoder_index_chunk(p, 1)
+            lib.qb3x_set_encoder_index_chunk(p, int(index_chunk))      # 1: restart table; 2: with block lengths
         if cband is not None:
             arr = (_sz * b)(*cband)
             lib.qb3_set_encoder_coreband(p, b, arr)

@@ -3,7 +3,11 @@
 
 namespace qb3dev {
 
-template <int B, bool RGB, uint64_t ORDER, bool STEP>
+// BL: no index -- the container's restart table has an entry per segment that ends with the bit lengths of the segment's
+// blocks (qb3x_set_encoder_index_chunk level 2): bit position, entering rungs and values come from the entry, a block's
+// place from the scan of the lengths, and a unit's place from where the band before it ended (the bands of a block are
+// decoded one after the other anyway).  No walk, no index: the decode is this one kernel.
+template <int B, bool RGB, uint64_t ORDER, bool STEP, bool BL>
 __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -25,10 +29,23 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
     const bool act = live && lane < nb_here;
-    const uint64_t P0 = a.idx.bitpos[segc];
-    const uint64_t P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
+    uint64_t P0, P1;
     uint32_t ul_[B], rg0[B], pv0[B], blen = 0;
-    {
+    if (BL) {
+        const uint8_t *e = ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, (uint32_t)segc);
+        auto pos6 = [](const uint8_t *q) { uint64_t v = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 6; i++) v |= (uint64_t)q[i] << (8 * i);
+            return v; };
+        P0 = pos6(e);
+        P1 = (segc + 1 < a.g.nseg) ? pos6(ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, (uint32_t)segc + 1)) : a.in_bits;
+#pragma unroll
+        for (int c = 0; c < B; c++) { ul_[c] = 0; rg0[c] = e[6 + c] & 7u; pv0[c] = e[6 + B + c]; }
+        const uint8_t *bl = e + 6 + 2 * B + ((IX_BL_BITS * lane) >> 3);
+        blen = act ? (((uint32_t)bl[0] | (uint32_t)bl[1] << 8) >> ((IX_BL_BITS * lane) & 7)) & ((1u << IX_BL_BITS) - 1) : 0u;
+    } else {
+        P0 = a.idx.bitpos[segc];
+        P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
         const uint8_t *ul = (const uint8_t *)a.idx.ulen + ((uint64_t)g0 + lane) * B;
 #pragma unroll
         for (int c = 0; c < B; c++) {
@@ -59,8 +76,9 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
             if (i < ndw + 8) stage[i] = sw[k];
         }
     }
+    if (!BL)
 #pragma unroll
-    for (int c = 0; c < B; c++) blen += ul_[c];
+        for (int c = 0; c < B; c++) blen += ul_[c];
     // the wave reads what its own lanes staged: LDS operations of a wave execute in order, the fence is for the compiler
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -72,29 +90,46 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     const uint32_t binc = wave_iscan32(blen);           // inclusive: lane 63 holds the bits of the segment
     // rung switches of the lane's units
     uint32_t gpos[B], pos = cpos + binc - blen, dpk[NW];
-#pragma unroll
-    for (int k = 0; k < NW; k++) dpk[k] = 0;
-#pragma unroll
-    for (int c = 0; c < B; c++) {
-        pos = pos < limit ? pos : limit;
-        bool sig; uint32_t csl;
-        const uint32_t d = px_switch(pos, &csl, &sig);
-        gpos[c] = pos + csl;
-        if (act && sig && STEP) bad = true;             // common-factor / index unit: not handled here
-        dpk[c >> 1] |= (act ? d : 0u) << (16 * (c & 1));
-        pos += ul_[c];
-    }
-#pragma unroll
-    for (int k = 0; k < NW; k++) dpk[k] = wave_iscan32(dpk[k]);                 // inclusive, 16 bits per band
-    // decode the units; running sums in curve order, two 16-bit lanes per register
     uint32_t rp[B][8], spk[NW], sinc[NW];
 #pragma unroll
-    for (int k = 0; k < NW; k++) spk[k] = 0;
+    for (int k = 0; k < NW; k++) { dpk[k] = 0; spk[k] = 0; }
+    if (BL) {
+        // band after band: the switch, the band's rungs across the segment (a scan of the switches), the unit, and
+        // where it ended is where the next band's unit starts
+        const uint32_t blk_end = pos + blen;
 #pragma unroll
-    for (int c = 0; c < B; c++) {
-        const uint32_t rung = (rg0[c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 7u;
-        const uint32_t tot = px_group<STEP>(gpos[c], rung, rp[c]) & 0xffu;
-        spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
+        for (int c = 0; c < B; c++) {
+            pos = pos < limit ? pos : limit;
+            bool sig; uint32_t csl;
+            const uint32_t d = px_switch(pos, &csl, &sig);
+            if (act && sig && STEP) bad = true;         // common-factor / index unit: not handled here
+            const uint32_t rung = (rg0[c] + wave_iscan32(act ? d : 0u)) & 7u;
+            uint32_t end;
+            const uint32_t tot = px_group<STEP>(pos + csl, rung, rp[c], &end) & 0xffu;
+            spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
+            pos = end;
+        }
+        if (act && pos != blk_end) bad = true;          // the table's lengths are not this stream's
+    } else {
+#pragma unroll
+        for (int c = 0; c < B; c++) {
+            pos = pos < limit ? pos : limit;
+            bool sig; uint32_t csl;
+            const uint32_t d = px_switch(pos, &csl, &sig);
+            gpos[c] = pos + csl;
+            if (act && sig && STEP) bad = true;         // common-factor / index unit: not handled here
+            dpk[c >> 1] |= (act ? d : 0u) << (16 * (c & 1));
+            pos += ul_[c];
+        }
+#pragma unroll
+        for (int k = 0; k < NW; k++) dpk[k] = wave_iscan32(dpk[k]);             // inclusive, 16 bits per band
+        // decode the units; running sums in curve order, two 16-bit lanes per register
+#pragma unroll
+        for (int c = 0; c < B; c++) {
+            const uint32_t rung = (rg0[c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 7u;
+            const uint32_t tot = px_group<STEP>(gpos[c], rung, rp[c]) & 0xffu;
+            spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
+        }
     }
 #pragma unroll
     for (int k = 0; k < NW; k++) sinc[k] = wave_iscan32(spk[k]);
@@ -173,10 +208,17 @@ template <int B, bool RGB>
 static void launch_dec_px_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
     dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
-    if (!z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, false>), grid, block, plan.lds_px, st, a);
-    else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);
-    else if (z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, false>), grid, block, plan.lds_px, st, a);
-    else hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, true>), grid, block, plan.lds_px, st, a);
+    if (a.bl_mode) {
+        if (!z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, false, true>), grid, block, plan.lds_px, st, a);
+        else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true, true>), grid, block, plan.lds_px, st, a);
+        else if (z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, false, true>), grid, block, plan.lds_px, st, a);
+        else hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, true, true>), grid, block, plan.lds_px, st, a);
+        return;
+    }
+    if (!z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, false, false>), grid, block, plan.lds_px, st, a);
+    else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true, false>), grid, block, plan.lds_px, st, a);
+    else if (z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, false, false>), grid, block, plan.lds_px, st, a);
+    else hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, true, false>), grid, block, plan.lds_px, st, a);
 }
 void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     if (a.g.bands == 1) launch_dec_px_b<1, false>(a, plan, st);

@@ -160,12 +160,13 @@ __global__ void ix_fill_kernel(const EncArgs a0) {
     if (j == 0) {
         const uint32_t len = IX_HEAD + here * a.ix_E;
         chunk[0] = 'i'; chunk[1] = 'x'; chunk[2] = (uint8_t)len; chunk[3] = (uint8_t)(len >> 8);
-        chunk[4] = 2; chunk[5] = a.g.mode == CM_BEST ? 1 : 0; chunk[6] = 0; chunk[7] = 0;
+        chunk[4] = 2; chunk[5] = (a.g.mode == CM_BEST ? 1 : 0) | (a.ix_bl ? 2 : 0); chunk[6] = 0; chunk[7] = 0;
         for (uint32_t i = 0; i < 4; i++) chunk[8 + i] = (uint8_t)(a.ix_blocks >> (8 * i));
         uint8_t *pad = chunk + len;
         pad[0] = 'z'; pad[1] = 'z'; pad[2] = 4; pad[3] = 0;
         if (c * a.ix_per_chunk + here == a.ix_K) { pad[4] = 'D'; pad[5] = 'T'; }
     }
+    if (a.ix_bl) return;                    // (entries with block lengths: ix_bl_fill_kernel writes their fixed fields too)
     const uint64_t s = (uint64_t)k * a.ix_spe;
     uint8_t *e = chunk + IX_HEAD + (uint64_t)j * a.ix_E;
     const uint64_t bp = a.idx.bitpos[s];
@@ -179,6 +180,50 @@ __global__ void ix_fill_kernel(const EncArgs a0) {
         e += B * tsz;
         const uint8_t *cf = (const uint8_t *)a.idx.cf + s * B * tsz;
         for (uint32_t i = 0; i < B * tsz; i++) e[i] = cf[i];
+    }
+}
+
+// Block lengths behind the entries' fixed fields (tables of level 2).  A block's bit length is the sum of its units'
+// lengths (the index has them).  Four ten-bit fields are five whole bytes and an entry's 64 blocks are sixteen such
+// groups: a thread per group of four blocks reads their 4 * B length bytes (whole dwords) and writes five bytes of
+// the entry -- no two threads share a byte.
+__global__ void __launch_bounds__(256) ix_bl_fill_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    static_assert(IX_BL_BITS == 10, "groups of four fields are five bytes");
+    const uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // blocks 4 * grp .. 4 * grp + 3
+    const uint32_t B = a.g.bands;
+    const uint64_t k = grp >> 4;                                                // 16 groups an entry
+    if (k >= a.ix_K) return;
+    const uint64_t nblocks = a.g.nblocks, blk0 = 4 * grp;
+    uint32_t len[4] = {0, 0, 0, 0};
+    if (blk0 + 4 <= nblocks && ((uintptr_t)a.idx.ulen & 3) == 0) {
+        const uint32_t *ul = (const uint32_t *)((const uint8_t *)a.idx.ulen + blk0 * B);    // 4 * B bytes: B dwords
+        if (B == 1) { const uint32_t v = ul[0]; len[0] = v & 255; len[1] = (v >> 8) & 255; len[2] = (v >> 16) & 255; len[3] = v >> 24; }
+        else if (B == 3) {
+            const uint32_t v0 = ul[0], v1 = ul[1], v2 = ul[2];
+            len[0] = (v0 & 255) + ((v0 >> 8) & 255) + ((v0 >> 16) & 255);
+            len[1] = (v0 >> 24) + (v1 & 255) + ((v1 >> 8) & 255);
+            len[2] = ((v1 >> 16) & 255) + (v1 >> 24) + (v2 & 255);
+            len[3] = ((v2 >> 8) & 255) + ((v2 >> 16) & 255) + (v2 >> 24);
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) { const uint32_t v = ul[q]; len[q] = (v & 255) + ((v >> 8) & 255) + ((v >> 16) & 255) + (v >> 24); }
+        }
+    } else {
+        const uint8_t *ul = (const uint8_t *)a.idx.ulen + blk0 * B;
+        for (uint32_t q = 0; q < 4; q++)
+            if (blk0 + q < nblocks) for (uint32_t c = 0; c < B; c++) len[q] += ul[q * B + c];
+    }
+    const uint64_t bits = (uint64_t)len[0] | (uint64_t)len[1] << 10 | (uint64_t)len[2] << 20 | (uint64_t)len[3] << 30;
+    const uint32_t c = (uint32_t)(k / a.ix_per_chunk), jj = (uint32_t)(k - (uint64_t)c * a.ix_per_chunk);
+    uint8_t *e0 = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E) + IX_HEAD + (uint64_t)jj * a.ix_E;
+    uint8_t *e = e0 + 6 + 2 * B + 5 * (uint32_t)(grp & 15);
+#pragma unroll
+    for (uint32_t i = 0; i < 5; i++) e[i] = (uint8_t)(bits >> (8 * i));
+    if ((grp & 15) == 0) {                  // the entry's fixed fields (an entry per segment: ix_spe == 1, 8-bit values, no factors)
+        const uint64_t bp = a.idx.bitpos[k];
+        for (uint32_t i = 0; i < 6; i++) e0[i] = (uint8_t)(bp >> (8 * i));
+        for (uint32_t c2 = 0; c2 < B; c2++) { e0[6 + c2] = a.idx.rung[k * B + c2]; e0[6 + B + c2] = ((const uint8_t *)a.idx.prev)[k * B + c2]; }
     }
 }
 
@@ -197,6 +242,7 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256, nt), dim3(256), 0, st, a);
     if (a.hdr_len) hipLaunchKernelGGL(write_header_kernel, dim3(1, nt), dim3(64), 0, st, a);
     if (a.ix_dst && a.have_idx) hipLaunchKernelGGL(ix_fill_kernel, dim3((a.ix_K + 255) / 256, nt), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx && a.ix_bl) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
 }
 
 }  // namespace qb3dev

@@ -44,6 +44,7 @@ const Tuning &tuning() {
         // 8-bit lane-per-block encoder: look-back and in-place writes instead of slots + concatenate; 1: a look-back per chunk
         // 2: per super-chunk (both measured slower than slots + concatenate)
         { const char *e = getenv("QB3_SINGLE_PASS"); v.single_pass = e && e[0] ? atoi(e) : 0; }
+        v.no_bl = on("QB3_NO_BLOCK_LENGTHS");        // containers whose table carries block lengths: walk them like the others
         v.persistent = on("QB3_PERSISTENT");         // 8-bit lane-per-block encoder: persistent workgroups instead of a workgroup per chunk (measured slower)
         return v;
     }();
@@ -148,14 +149,23 @@ uint32_t seg_blocks_for(const Geometry &g) {
     uint32_t s = 12 / g.bands;
     return s ? s : 1;
 }
-uint32_t ix_entry_bytes(const Geometry &g) { return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)); }
+uint32_t ix_entry_bytes(const Geometry &g, bool block_lens) {
+    return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)) + (block_lens ? (g.seg_blocks * IX_BL_BITS + 7) / 8 : 0);
+}
+// Block lengths: for the rasters the 8-bit lane-per-block decoder takes (a block of at most four units of at most 149 bits
+// fits ten bits), an entry per 64-block segment
+bool ix_block_lens_ok(const Geometry &g) {
+    return g.tsz == 1 && (g.bands == 1 || g.bands == 3 || g.bands == 4) && g.mode != CM_BEST && g.seg_blocks == 64 &&
+           (g.order == HILBERT || g.order == ZCURVE);
+}
 // One entry per index segment for FTL/BASE streams (a lane then walks one segment, lengths only, and the segment's
 // entering values come straight from its entry), one per about 64 units for the common-factor modes.  For 8-bit RGB
 // that is 12 bytes per 64 blocks: 0.7 % of a typical stream.
-IxTable ix_layout(const Geometry &g) {
+IxTable ix_layout(const Geometry &g, int level) {
     IxTable t;
     if (!g.seg_blocks || !g.nseg) return t;
-    t.entry_bytes = ix_entry_bytes(g);
+    t.block_lens = level >= 2 && ix_block_lens_ok(g);
+    t.entry_bytes = ix_entry_bytes(g, t.block_lens);
     const uint64_t units_per_seg = (uint64_t)g.seg_blocks * g.bands;
     const bool per_seg = g.mode != CM_BEST;
     // (common-factor streams: the lane that starts at an entry parses whole units from global memory, bound by latency --
@@ -350,7 +360,8 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.res = (EncResult *)(w + L.res);
     a.st = st_in;
     a.have_idx = index != nullptr;
-    a.idx_no_ulen = index && ix.base && ix.own_index;
+    a.idx_no_ulen = index && ix.base && ix.own_index && !ix.block_lens;      // (block lengths are sums of the unit lengths)
+    a.ix_bl = ix.base && ix.block_lens;
     a.idx = index ? index_view(g, index) : IndexView{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (g.tsz != 1 && g.tsz != 2 && g.tsz != 4 && g.tsz != 8) { set_error("encode: bad value size", 0); return -1; }
     return launch_encode_all(a, plan, (hipStream_t)stream);
@@ -418,6 +429,15 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     const bool use_px16 = plan.px16 && !best && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0;
     // 32/64-bit FTL/BASE streams that bring a restart table with an entry per index segment: the lengths-only walk too
     const bool wide_walk = rebuild && a.ix && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
+    if (rebuild && use_px && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
+        // the container's table carries block lengths: the lane-per-block decoder works from the entries alone
+        DecArgs t = a;
+        t.bl_mode = 1;
+        ProfScope ps("dec_units", st);
+        launch_dec_px(t, plan, st);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (rebuild && (use_px || use_px16 || wide_walk) && !tuning().slow_index) {
         // index-less stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
         // produce the values entering the segments (totals pass + scan)
@@ -478,11 +498,13 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     }
     a.in_cap_full = plan_in.px_cap_dw;
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
-    a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = a.ix_per_chunk = a.ix_pad = 0;
-    if (ix.base && ix.blocks && ix.per_chunk && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g) &&
+    a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = a.ix_per_chunk = a.ix_pad = 0; a.ix_bl = 0;
+    if (ix.base && ix.blocks && ix.per_chunk && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g, ix.block_lens) &&
+        (!ix.block_lens || (ix_block_lens_ok(g) && ix.blocks == g.seg_blocks)) &&
         ix.K == (g.nblocks + ix.blocks - 1) / ix.blocks) {
         a.ix = ix.base; a.ix_K = ix.K; a.ix_blocks = ix.blocks; a.ix_E = ix.entry_bytes; a.ix_per_chunk = ix.per_chunk;
         a.ix_pad = ix.pads ? IX_PAD : 0;
+        a.ix_bl = ix.block_lens;
     }
     // lane-per-segment decoder: LDS for the stream words of a workgroup's segments, half as much again as the average,
     // when that is at most 24 KB (more would cost more in resident workgroups than the staging saves; a longer span is
@@ -512,6 +534,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16) ? plan.px_cap_dw : plan.in_cap_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.totals_only = 0;
+    a.bl_mode = 0;
     a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.dst_pitch & 3);
     a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;

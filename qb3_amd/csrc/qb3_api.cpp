@@ -177,7 +177,7 @@ struct encs {
     qb3_mode mode;
     qb3_dtype type;
     bool away;
-    bool ix_chunk;          // qb3x_set_encoder_index_chunk: embed the restart table ("ix" chunks)
+    int ix_chunk;           // qb3x_set_encoder_index_chunk: embed the restart table ("ix" chunks); 2: with block lengths
     bool no_single_pass;    // the single-pass encoder gave up once on this handle: slots + concatenation from then on
     DevBuf d_img, d_out, d_ws, d_q, d_idx, d_rle;      // d_rle: workspace of the RLE0 passes (k_rle0.hip)
     Stager stager;
@@ -198,6 +198,7 @@ struct decs {
     size_t hdr_avail;       // bytes readable at s_start (the whole stream, or the header copy given to qb3x_read_start)
     size_t ix_off;          // restart table found in the container: offset of its first chunk from s_start (0: none)
     uint32_t ix_K, ix_blocks, ix_E, ix_per_chunk;
+    bool ix_bl;             // ... its entries carry block lengths
     bool ix_pads, ix_bad;   // pad chunks behind the table chunks (version 2); the chunks seen do not form one table
     std::vector<uint8_t> tile_ok;   // qb3x_decode_tiles: per tile outcome of the last call
     DevBuf d_in, d_img, d_ws, d_ix, d_rle, d_tab;      // d_rle: RLE0 workspace (+ the packed bytes of a host call); d_tab: the unit-length table a plain 8-bit stream is walked through
@@ -245,7 +246,7 @@ QB3_API encsp qb3_create_encoder(size_t w, size_t h, size_t b, qb3_dtype dt) {
     encs *p = new encs();
     p->xsize = w; p->ysize = h; p->nbands = b; p->type = dt;
     p->stride = 0; p->order = 0; p->quanta = 1; p->away = false; p->mode = QB3M_DEFAULT; p->error = 0;
-    { const char *e = getenv("QB3X_INDEX_CHUNK"); p->ix_chunk = e && atoi(e) != 0; }
+    { const char *e = getenv("QB3X_INDEX_CHUNK"); p->ix_chunk = e ? (atoi(e) >= 2 ? 2 : atoi(e) != 0) : 0; }
     p->no_single_pass = false;     // for callers that only know the reference API
     for (size_t c = 0; c < QB3_MAXBANDS; c++) p->cband[c] = c < b ? c : 0;
     if (b == 3 || b == 4) p->cband[0] = p->cband[2] = 1;
@@ -304,7 +305,7 @@ static size_t ix_room(const encs *p) {
     // (an RLE0 mode codes the stream of its base mode; the table stays when the RLE0 pass does not win)
     const int m = is_rle_mode(p->mode) ? (int)p->mode - 2 : (int)p->mode;
     const Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, m, p->cband, nullptr);
-    return ix_total_bytes(ix_layout(g));
+    return ix_total_bytes(ix_layout(g, p->ix_chunk));
 }
 QB3_API size_t qb3_max_encoded_size(const encsp p) { return max_encoded_size_ref(p) + ix_room(p); }
 
@@ -493,7 +494,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     IxTable ixt;
     size_t hdr_stamp = hdr;                               // header bytes prepared on the host
     if (ixroom && !narrow) {
-        ixt = ix_layout(g);
+        ixt = ix_layout(g, p->ix_chunk);
         hdr_stamp = write_headers(p, hdrbuf, false);
         hdr = hdr_stamp + ix_total_bytes(ixt) + 2;        // chunks, then "DT": both written by ix_fill_kernel
         ixt.base = out_dev + hdr_stamp;
@@ -572,7 +573,7 @@ QB3_API size_t qb3x_encode_device(encsp p, const void *d_src, void *d_dst, void 
     return encode_common(p, nullptr, nullptr, d_src, d_dst, d_index, (hipStream_t)stream);
 }
 
-QB3_API void qb3x_set_encoder_index_chunk(encsp p, int on) { if (p) p->ix_chunk = on != 0; }
+QB3_API void qb3x_set_encoder_index_chunk(encsp p, int on) { if (p) p->ix_chunk = on >= 2 ? 2 : on != 0; }
 
 QB3_API size_t qb3x_index_size(const encsp p) {
     if (!p || p->xsize < 4 || p->ysize < 4) return 0;
@@ -625,7 +626,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
     size_t hdr_stamp = hdr, ix_bytes = 0, isz_all = isz;
     void *index_all = d_index;
     if (ix_room(p)) {
-        ixt = ix_layout(g);
+        ixt = ix_layout(g, p->ix_chunk);
         hdr_stamp = write_headers(p, hdrbuf, false);
         ix_bytes = ix_total_bytes(ixt);
         hdr = hdr_stamp + ix_bytes + 2;                   // chunks, then "DT": both written by ix_fill_kernel
@@ -717,7 +718,7 @@ static decsp read_start_impl(void *source, size_t hdr_avail, size_t source_size,
     p->s_in = p->s_start + 11; p->s_size = source_size - 11;
     p->hdr_avail = hdr_avail < source_size ? hdr_avail : source_size;
     p->saw_cb = false; p->compat = 0;
-    p->ix_off = 0; p->ix_K = p->ix_blocks = p->ix_E = p->ix_per_chunk = 0; p->ix_pads = false; p->ix_bad = false;
+    p->ix_off = 0; p->ix_K = p->ix_blocks = p->ix_E = p->ix_per_chunk = 0; p->ix_pads = false; p->ix_bad = false; p->ix_bl = false;
     image_size[0] = p->xsize; image_size[1] = p->ysize; image_size[2] = p->nbands;
     if (mode <= (int)QB3M_CF_RLE) p->order = ZCURVE;
     return p;
@@ -738,8 +739,11 @@ QB3_API size_t qb3x_header_size_bound(const void *container, size_t avail) {
     if (!tsz || nb > QB3_MAXBANDS) return 0;
     // an entry covers at least 12 units (one common-factor segment) and takes at most 6 + bands * (1 + 2 * tsz) bytes
     const size_t units = ((w + 3) / 4) * ((h + 3) / 4) * nb, E = 6 + nb * (1 + 2 * tsz);
-    const size_t K = units / 12 + 1, per_chunk = (65535 - IX_HEAD) / E;
-    return 128 + K * E + (K / per_chunk + 1) * (IX_HEAD + IX_PAD);
+    const size_t K = units / 12 + 1;
+    // ... and a table of 8-bit data may carry ten bits per block on top (an entry per 64 blocks)
+    const size_t nblk = ((w + 3) / 4) * ((h + 3) / 4), bl = tsz == 1 ? (nblk / 64 + 1) * ((64 * IX_BL_BITS + 7) / 8) : 0;
+    const size_t bytes = K * E + bl;
+    return 128 + bytes + (bytes / 60000 + 1) * (IX_HEAD + IX_PAD);
 }
 
 static bool valid_curve(uint64_t v) {
@@ -803,18 +807,19 @@ QB3_API bool qb3_read_info(decsp p) {
                 // this library's restart table (include/qb3x.h): a run of such chunks, all but the last of the same
                 // size, each followed by a 4-byte pad chunk (version 2).  Remember where it is, check it later.
                 const size_t tsz = szof(p->type);
-                const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * ((rd(pos + 5) & 1) ? 2 : 1)));
                 const uint32_t blocks = rd(pos + 8) | (rd(pos + 9) << 8) | (rd(pos + 10) << 16) | (rd(pos + 11) << 24);
+                const bool bl = (rd(pos + 5) & 2) != 0;     // entries end with their blocks' bit lengths
+                const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * ((rd(pos + 5) & 1) ? 2 : 1))) + (bl && blocks <= 4096 ? (blocks * IX_BL_BITS + 7) / 8 : 0);
                 const size_t at = (size_t)(p->s_in - p->s_start) + pos;
                 const bool v2 = rd(pos + 4) == 2;
                 if ((len - IX_HEAD) % E || pos + len > n) p->ix_bad = true;
                 else if (!p->ix_K) {        // the first chunk
-                    p->ix_off = at; p->ix_E = E; p->ix_blocks = blocks; p->ix_pads = v2;
+                    p->ix_off = at; p->ix_E = E; p->ix_blocks = blocks; p->ix_pads = v2; p->ix_bl = bl;
                     p->ix_per_chunk = p->ix_K = (len - IX_HEAD) / E;
                 } else {                    // a further one: in place, same shape, and only the last may be short
                     const size_t full = IX_HEAD + (size_t)p->ix_per_chunk * E + (p->ix_pads ? IX_PAD : 0);
                     const uint32_t here = (len - IX_HEAD) / E;
-                    if (!v2 || !p->ix_pads || E != p->ix_E || blocks != p->ix_blocks || p->ix_K % p->ix_per_chunk ||
+                    if (!v2 || !p->ix_pads || E != p->ix_E || blocks != p->ix_blocks || bl != p->ix_bl || p->ix_K % p->ix_per_chunk ||
                         at != p->ix_off + (p->ix_K / p->ix_per_chunk) * full || here > p->ix_per_chunk) p->ix_bad = true;
                     else p->ix_K += here;
                 }
@@ -947,7 +952,7 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
     // the plain path)
     IxTable ixt;
     if (!d_index && p->ix_K && !rle && !narrow) {
-        ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads;
+        ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads; ixt.block_lens = p->ix_bl;
         if (on_host) {
             const size_t bytes = ix_total_bytes(ixt);
             if (!p->d_ix.ensure(bytes)) { p->error = QB3E_LIBERR; return 0; }
@@ -1086,7 +1091,7 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
             for (size_t i = 0; i < cnt; i++) if (bits[i] > tb.max_bits) tb.max_bits = bits[i];
             IxTable ixt;
             if (use_ix) {
-                ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads;
+                ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads; ixt.block_lens = p->ix_bl;
                 ixt.base = (uint8_t *)d_src + first * src_pitch + p->ix_off;
             }
             if (!d_index && !use_ix && !walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }

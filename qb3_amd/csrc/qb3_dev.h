@@ -85,15 +85,18 @@ EncPlan plan_encode(const Geometry &g, bool allow_single_pass = true);
 // (the last one may hold fewer), each [12-byte head][entries][4-byte "zz" pad chunk]; `base` points at the first
 // chunk's first byte.  With it a stream that arrives without the out-of-band index is walked from K points at once.
 constexpr uint32_t IX_HEAD = 12, IX_PAD = 4;
+constexpr uint32_t IX_BL_BITS = 10;       // bits of a block length in a table entry (8-bit data, at most four bands: 4 x 149 < 1024)
 struct IxTable {
     uint8_t *base = nullptr;        // device pointer (encode: where the chunks go, "DT" follows; decode: where they are)
     uint32_t K = 0, blocks = 0, entry_bytes = 0, per_chunk = 0;
     bool pads = true;               // false: a version 1 table (one chunk, no pad chunk behind it)
+    bool block_lens = false;        // entries carry the bit length of every block of their segment (10 bits each): 8-bit lane-per-block rasters
     bool own_index = false;         // encode: the index is the library's own, only sampled for the table -- no unit lengths needed
 };
-uint32_t ix_entry_bytes(const Geometry &g);
+uint32_t ix_entry_bytes(const Geometry &g, bool block_lens = false);
+bool ix_block_lens_ok(const Geometry &g);         // can a table for this geometry carry block lengths
 // the table this library writes for a geometry (needs seg_blocks, nseg, bands, tsz, mode); K == 0: none
-IxTable ix_layout(const Geometry &g);
+IxTable ix_layout(const Geometry &g, int level = 1);       // level 2: with block lengths where the geometry allows
 inline size_t ix_chunks(const IxTable &t) { return t.per_chunk ? (t.K + t.per_chunk - 1) / t.per_chunk : 0; }
 inline size_t ix_total_bytes(const IxTable &t) { return ix_chunks(t) * (IX_HEAD + (t.pads ? IX_PAD : 0)) + (size_t)t.K * t.entry_bytes; }
 

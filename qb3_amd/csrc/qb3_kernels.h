@@ -218,6 +218,7 @@ struct EncArgs {
     uint32_t px_aligned;            // lane-per-block kernels: every row of every block is dword aligned (plain dword loads)
     uint8_t *ix_dst;                // restart table: where its first chunk goes (null: none), "DT" right after the last
     uint32_t ix_K, ix_spe, ix_E;    //   ... entries, fine segments per entry, bytes per entry
+    uint32_t ix_bl;                 //   ... entries end with their segment's block lengths (IX_BL_BITS bits each)
     uint32_t ix_per_chunk, ix_blocks;   // ... entries per chunk, blocks per entry
     EncResult *res;
     BandState st;
@@ -317,6 +318,8 @@ struct DecArgs {
     uint32_t px_aligned;            // lane-per-block kernels: every row of every block is dword aligned (plain dword stores)
     const uint8_t *ix;              // coarse index chunk found in the container (null: none): restart points for the walk
     uint32_t ix_K, ix_blocks, ix_E, ix_per_chunk, ix_pad;     // ix_pad: bytes of the pad chunk behind every table chunk
+    uint32_t ix_bl;                 // the entries carry block lengths: the lane-per-block decoder needs no walk and no index
+    uint32_t bl_mode;               // ... and this launch decodes from them
     // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
     uint32_t ntiles;
     uint64_t ts_in, ts_img, ts_idx;
@@ -531,7 +534,7 @@ struct ProfScope {
 };
 
 // process-wide debugging switches, read once from the environment (k_host.hip)
-struct Tuning { bool no_px; bool slow_index; bool slow_walk; int single_pass; bool persistent; size_t walk_tab_kb; };
+struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool no_bl; int single_pass; bool persistent; size_t walk_tab_kb; };
 const Tuning &tuning();
 
 uint32_t magic_div(uint32_t d);

@@ -185,12 +185,14 @@ __device__ __forceinline__ uint32_t px_switch(uint32_t pos, uint32_t *cslen, boo
 
 // the 16 values of an 8-bit unit whose codes start at bit `gpos`: rp[k] = running sums of values 2k, 2k+1 as two
 // 16-bit lanes (low byte = the sum mod 256); returns the unit total (garbage above bit 7)
+// (*end, when asked for: the bit behind the unit)
 template <bool STEP>
-__device__ __forceinline__ uint32_t px_group(uint32_t gpos, uint32_t rung, uint32_t (&rp)[8]) {
+__device__ __forceinline__ uint32_t px_group(uint32_t gpos, uint32_t rung, uint32_t (&rp)[8], uint32_t *end = nullptr) {
     uint32_t acc = 0;
     if (rung == 0) {
         const uint32_t x = lds_bits(gpos);
         const uint32_t bits = (x & 1) ? (x >> 1) & 0xffffu : 0u;
+        if (end) *end = gpos + ((x & 1) ? 17 : 1);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             acc -= (bits >> i) & 1u;                    // mag-sign 1 is -1
@@ -212,6 +214,7 @@ __device__ __forceinline__ uint32_t px_group(uint32_t gpos, uint32_t rung, uint3
         if (STEP) fl |= ((e >> 16) & 3u) << (2 * i);
         if (i & 1) rp[i >> 1] |= acc << 16; else rp[i >> 1] = acc & 0xffffu;
     }
+    if (end) *end = pos;
     if (STEP) {                                         // undo the step (reference QB3decode.h:285-289)
         const uint32_t tb = fl & 0x55555555u, u = tb | (tb << 1);
         const uint32_t m = __popc(tb);

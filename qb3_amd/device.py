@@ -28,7 +28,7 @@ class DeviceEncoder:
             raise ValueError("qb3_create_encoder refused the parameters")
         self.mode = lib.qb3_set_encoder_mode(self.p, mode)
         if index_chunk:             # self-indexing container (qb3x.h): one more chunk, up to 64 KB
-            lib.qb3x_set_encoder_index_chunk(self.p, 1)
+            lib.qb3x_set_encoder_index_chunk(self.p, int(index_chunk))   # 1: restart table; 2: with block lengths
         if cband is not None:
             arr = (_sz * bands)(*cband)
             lib.qb3_set_encoder_coreband(self.p, bands, arr)
@@ -120,7 +120,7 @@ class TileBatchCoder:
         if not self.p:
             raise ValueError("qb3_create_encoder refused the parameters")
         lib.qb3_set_encoder_mode(self.p, mode)
-        lib.qb3x_set_encoder_index_chunk(self.p, 1 if index_chunk else 0)
+        lib.qb3x_set_encoder_index_chunk(self.p, int(index_chunk))
         self.raw_bytes = w * h * bands * TYPESIZE[dtype]
         self.pitch = (lib.qb3_max_encoded_size(self.p) + 3) // 4 * 4
         self.index_bytes = lib.qb3x_index_size(self.p) if want_index else 0

@@ -980,6 +980,122 @@ def test_restart_table_does_not_depend_on_the_index_request(qb3, oracle, case):
     assert bytes(host[:dt_at]) == bytes(ref[:dt_at]) and bytes(host[dt_at + extra:]) == bytes(ref[dt_at:])
 
 
+BL_CASES = [(256, 256, 3, "NOISY3", FTL), (509, 259, 3, "NOISY3", BASE), (768, 512, 1, "GRAD", FTL), (333, 77, 4, "NOISY3", BASE),
+            (1024, 1024, 3, "NOISY3", 0), (2048, 1536, 1, "NOISY3", FTL), (4096, 2048, 3, "NOISY3", FTL), (64, 16, 3, "RANDOM", FTL)]
+
+
+@pytest.mark.parametrize("case", BL_CASES, ids=lambda c: "%dx%dx%d-%s-m%d" % c)
+def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
+    """qb3x_set_encoder_index_chunk level 2: the table's entries end with the bit lengths of their segment's blocks (ten bits
+    each), and the 8-bit lane-per-block decoder then needs neither a walk nor an index -- ONE kernel.  The container is the
+    reference's plus ignorable chunks (which the reference's reader steps over), the host flavour decodes it too, the walker
+    still can (QB3_NO_BLOCK_LENGTHS), and lengths that are not the stream's are reported, not followed"""
+    import subprocess
+    import sys
+    import ctypes as C
+    import torch
+    from qb3_amd import synth, device as qdev
+    w, h, b, gen, mode = case
+    img = synth.generate(w, h, b, 0, gen, 31)
+    raw = img.reshape(-1).view(torch.uint8)
+    ref = oracle.encode(oracle.generate(w, h, b, 0, gen, 31), 0, mode)
+    enc = qdev.DeviceEncoder(w, h, b, 0, mode=mode, want_index=False, index_chunk=2)
+    dst, n, _ = enc.encode(img)
+    host = dst[:n].cpu().numpy()
+    if ref[10] == 255:                  # raw-stored: no table at all
+        assert n == len(ref) and np.array_equal(host, ref)
+        return
+    extra, dt_at = n - len(ref), bytes(ref).index(b"DT", 11)
+    assert bytes(host[:dt_at]) == bytes(ref[:dt_at]) and bytes(host[dt_at + extra:]) == bytes(ref[dt_at:])
+    _, seen = walk_chunks(host, False)
+    mine = [c for c in seen if c[1] >= dt_at]
+    nseg = (((w + 3) // 4) * ((h + 3) // 4) + 63) // 64
+    assert mine[0][0] == b"ix" and host[mine[0][1] + 5] & 2, "entries are flagged as carrying block lengths"
+    assert sum(c[2] - 12 for c in mine if c[0] == b"ix") == nseg * (6 + 2 * b + 80)
+    out, _, _, _ = oracle.decode(host, identity=True)
+    assert out is not None and np.array_equal(out, raw.cpu().numpy()), "the reference decoder must step over the chunks"
+    out, _, _, _ = qb3.decode(host)
+    assert np.array_equal(out, raw.cpu().numpy())
+    got = qb3.encode(img.cpu().numpy(), 0, mode, index_chunk=2)
+    assert np.array_equal(got, host), "host and device flavour write the same container"
+    L = qb3.lib
+    L.qb3x_profile_enable(1); L.qb3x_profile_reset()
+    dec = qdev.DeviceDecoder(dst, n)
+    res = dec.decode(dst, index=None)
+    torch.cuda.synchronize()
+    buf = C.create_string_buffer(1024)
+    L.qb3x_profile_names(buf, 1024)
+    L.qb3x_profile_enable(0)
+    assert torch.equal(res, raw)
+    assert buf.value == b"dec_units", buf.value          # no walk, no index rebuild
+    # lengths that are not the stream's: a reported failure (or, if they happen to add up, the right pixels), never a crash
+    at = mine[0][1] + 12 + 6 + 2 * b
+    bad = dst.clone()
+    bad[at + 1] ^= 0x5a
+    try:
+        res = qdev.DeviceDecoder(bad, n).decode(bad, index=None)
+        assert torch.equal(res, raw)
+    except RuntimeError:
+        pass
+    assert torch.equal(dec.decode(dst, index=None), raw)
+    # the same container through the walker (the switch is read once per process: a child)
+    f = tmp_path / "c.qb3"
+    f.write_bytes(bytes(host))
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import qb3_amd
+from qb3_amd import synth, device as qdev
+c = torch.from_numpy(np.fromfile(%r, dtype=np.uint8)).cuda()
+raw = synth.generate(%d, %d, %d, 0, %r, 31).reshape(-1).view(torch.uint8)
+assert torch.equal(qdev.DeviceDecoder(c, c.numel()).decode(c, index=None), raw)
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(f), w, h, b, gen)
+    env = dict(os.environ)
+    env["QB3_NO_BLOCK_LENGTHS"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_block_lengths_only_where_the_decoder_uses_them(qb3, oracle):
+    """level 2 asked for a raster the 8-bit lane-per-block decoder does not take (16-bit, five bands, a common-factor mode):
+    the table is the level 1 table"""
+    for (w, h, b, dt, gen, mode) in [(256, 128, 2, 2, "LANDSAT16", FTL), (160, 120, 5, 0, "NOISY3", FTL), (256, 256, 3, 0, "NOISY3", 7)]:
+        img = oracle.generate(w, h, b, dt, gen, 3)
+        cb = None if b in (1, 3, 4) else list(range(b))
+        one = qb3.encode(img, dt, mode, cband=cb, index_chunk=1)
+        two = qb3.encode(img, dt, mode, cband=cb, index_chunk=2)
+        assert np.array_equal(one, two)
+        out, _, _, _ = qb3.decode(two)
+        assert np.array_equal(out, img.view(np.uint8).ravel())
+
+
+def test_tiles_with_block_length_tables(qb3, oracle):
+    """a batch of tiles whose containers carry level 2 tables: decoded from the containers alone, one kernel"""
+    import torch
+    from qb3_amd import synth, device as qdev
+    w, h, n = 512, 384, 6
+    imgs = torch.stack([synth.generate(w, h, 3, 0, "NOISY3", 700 + t) for t in range(n)])
+    tc = qdev.TileBatchCoder(w, h, 3, 0, n, want_index=False, index_chunk=2)
+    tc.encode(imgs)
+    host = tc.dst.cpu().numpy()
+    for t in range(n):
+        ref = oracle.encode(imgs[t].cpu().numpy(), 0, FTL)
+        c = host[t * tc.pitch:t * tc.pitch + tc.sizes[t]]
+        extra, dt_at = len(c) - len(ref), bytes(ref).index(b"DT", 11)
+        assert bytes(c[:dt_at]) == bytes(ref[:dt_at]) and bytes(c[dt_at + extra:]) == bytes(ref[dt_at:]), t
+    out = torch.zeros_like(imgs)
+    L = qb3.lib
+    L.qb3x_profile_enable(1); L.qb3x_profile_reset()
+    tc.decode(out, use_index=False)
+    torch.cuda.synchronize()
+    import ctypes as C
+    buf = C.create_string_buffer(1024)
+    L.qb3x_profile_names(buf, 1024)
+    L.qb3x_profile_enable(0)
+    assert torch.equal(out, imgs) and buf.value == b"dec_units", buf.value
+
+
 @pytest.mark.parametrize("switch", ["QB3_SINGLE_PASS", "QB3_SINGLE_PASS=2", "QB3_PERSISTENT", "QB3_NO_PX", "QB3_SLOW_INDEX", "QB3_SLOW_WALK", "QB3_WALK_TAB_KB=2048"])
 def test_alternative_kernel_paths(qb3, oracle, switch, tmp_path):
     """the paths that are not the default -- the single-pass (look-back per chunk, per super-chunk) and the persistent 8-bit encoders, the generic
