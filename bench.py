@@ -6,7 +6,8 @@
 
 N = 1 -- BASELINE.json configs[1]: ONE 16384x16384 3-band uint8 raster (NOISY3, seed 2), resident in HBM before the
 clock starts.  A step = qb3x_encode_device (the container, self-indexed: the restart table travels INSIDE it as
-ignorable chunks; d_index = NULL, nothing is written beside it) followed by qb3x_decode_device of that container ALONE
+ignorable chunks -- level 2 by default: an entry per 64-block segment that ends with the bit lengths of its blocks, 5.5 % on top of
+the stream, so that the decoder needs no walk; --table-level 1: 0.7 %, with a walk; d_index = NULL, nothing is written beside it) followed by qb3x_decode_device of that container ALONE
 (index = NULL): what `value` counts is
 decode from the stream, as the reference's contract has it (QB3decode.cpp:455-464).  The same decode with this
 library's out-of-band index, and of a plain (reference-made) container with nothing to help, are reported beside it
@@ -219,7 +220,7 @@ def measure_tiles(torch, qb3_amd, synth, qdev, dev, ntiles, steps, seed0=1000):
     tc.decode(out, use_index=False)
     t_plain = time.perf_counter() - t0
     # the same tiles as self-indexed containers (every tile carries its restart table): encode, and decode from the containers alone
-    tci = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, ntiles, device=dev, want_index=False, index_chunk=True)
+    tci = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, ntiles, device=dev, want_index=False, index_chunk=2)
     sizes_i = tci.encode(imgs)
     out.zero_()
     tci.decode(out, use_index=False)
@@ -399,6 +400,27 @@ def main():
     torch.cuda.synchronize()
     oob = prof.stop()
     oob_ms = sum(oob[k][0] for k in DEC_KERNELS if k in oob)
+    # ---- ... and of the container with the OTHER table level (1: an entry per segment, 0.7 % of the stream, the decoder
+    # walks the segments' unit lengths first; 2: entries with their blocks' bit lengths, 5.5 %, no walk)
+    other_level = 3 - args.table_level
+    enc_o = qdev.DeviceEncoder(W, H, bands, dtype, mode=qb3_amd.QB3M_FTL, want_index=False, index_chunk=other_level)
+    dst_o, n_o, _ = enc_o.encode(img)
+    dec_o = qdev.DeviceDecoder(dst_o, n_o)
+    out.zero_()
+    dec_o.decode(dst_o, out=out, index=None)
+    if not torch.equal(out, raw):
+        sys.exit("bench.py: decode(encode(x)) != x with the other table level -- refusing to report a number")
+    prof.start(1)
+    for _ in range(5):
+        enc_o.encode(img)
+        dec_o.decode(dst_o, out=out, index=None)
+    torch.cuda.synchronize()
+    oth = prof.stop()
+    other = {"table_level": other_level, "container_bytes": int(n_o), "table_bytes": int(n_o) - (int(n) - table_bytes(host)),
+             "encode_ms_kernels": round(sum(oth[k][0] for k in ENC_KERNELS if k in oth), 4),
+             "decode_from_container_ms_kernels": round(sum(oth[k][0] for k in DEC_KERNELS if k in oth), 4)}
+    del enc_o, dec_o, dst_o
+    torch.cuda.empty_cache()
     fence()
     s0 = time.perf_counter()
     sustained_steps = 0
@@ -463,8 +485,9 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{W}x{H}x3 uint8 NOISY3 seed 2; QB3M_FTL qb3x_encode_device (self-indexed container) + qb3x_decode_device of "
-                               "that container alone (index = NULL, restart table inside the container)",
+        "config": {"workload": f"{W}x{H}x3 uint8 NOISY3 seed 2; QB3M_FTL qb3x_encode_device (self-indexed container, table level {args.table_level}) + "
+                               "qb3x_decode_device of that container alone (index = NULL, restart table inside the container)",
+                   "table_level": args.table_level, "table_bytes": table_bytes(host),
                    "stream_bytes": stream_bytes, "ratio": round(stream_bytes / raw_bytes, 4), "container_bytes": int(n),
                    "bit_identical_to_reference": ident, "fnv1a64_without_table_chunks": fnv},
         "value_uses": "decode_from_container",
@@ -472,7 +495,8 @@ def main():
         "decode_MPixel_s_kernels": round(W * H / dec_ms / 1e3, 1) if dec_ms else None,
         "decode": {"from_container_ms_kernels": round(dec_ms, 4), "out_of_band_index_ms_kernels": round(oob_ms, 4),
                    "out_of_band_index_MPixel_s_kernels": round(W * H / oob_ms / 1e3, 1) if oob_ms else None,
-                   "out_of_band_index_bytes": oob_index_bytes if workloads is None else None, "plain_container": plain},
+                   "out_of_band_index_bytes": oob_index_bytes if workloads is None else None, "other_table_level": other,
+                   "plain_container": plain},
         "sustained": {"seconds": round(sustained, 2), "steps": sustained_steps, "MPixel_s": round(sustained_steps * W * H / sustained / 1e6, 1)},
         "kernels": kernels,
         "roofline": roofline,
@@ -533,7 +557,7 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
     total = args.tiles_per_rank * world
     first, count = tiles.shard_range(total, rank, world)
     imgs = torch.stack([synth.generate(w, h, 3, qb3_amd.QB3_U8, "NOISY3", 1000 + first + t, device=dev) for t in range(count)])
-    tc = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, count, device=dev, want_index=False, index_chunk=True)
+    tc = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, count, device=dev, want_index=False, index_chunk=2)
     out = torch.empty_like(imgs)
     nb = max(1, min(args.batch_tiles, count))
     batches = [(lo, min(nb, count - lo)) for lo in range(0, count, nb)]
@@ -608,7 +632,7 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{total} independent 4096x4096x3 uint8 NOISY3 tiles (seeds 1000..), {args.tiles_per_rank} per GPU, QB3M_FTL: qb3x_encode_tiles in batches of "
                                f"{nb}, containers gathered on rank 0 ({'RCCL send/recv' if args.backend == 'nccl' else args.backend + ' rehearsal'}) beside the coding "
-                               "of the next batch, qb3x_decode_tiles of every rank's own tiles from the containers alone (index = NULL; every tile carries its restart table); the gather is inside the step",
+                               "of the next batch, qb3x_decode_tiles of every rank's own tiles from the containers alone (index = NULL; every tile carries its restart table, level 2: entries with block lengths, 5.5 % on top of the stream); the gather is inside the step",
                    "tiles_total": total, "tiles_per_gpu": args.tiles_per_rank, "parallelism": f"tiles sharded over {world} GPUs, no data-path collective but the gather"},
         "coding_only": {"ms_per_step": round(dt_code / args.steps * 1e3, 3), "MPixel_s": round(px / (dt_code / args.steps) / 1e6, 1)},
         "gather": {"bytes_into_root_per_step": bytes_root, "GBps_into_root": round(bytes_root / (dt / args.steps) / 1e9, 1) if bytes_root else None,
