@@ -557,7 +557,9 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
     total = args.tiles_per_rank * world
     first, count = tiles.shard_range(total, rank, world)
     imgs = torch.stack([synth.generate(w, h, 3, qb3_amd.QB3_U8, "NOISY3", 1000 + first + t, device=dev) for t in range(count)])
-    tc = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, count, device=dev, want_index=False, index_chunk=2)
+    # table level 1 here: the step is bound by the gather (a rank's 0.87 GB of containers over one xGMI link: 5.7 ms against
+    # 2.3 ms of coding), so the 5.5 % of bytes a level 2 table adds cost more than the walk it spares the decoder
+    tc = qdev.TileBatchCoder(w, h, 3, qb3_amd.QB3_U8, count, device=dev, want_index=False, index_chunk=1)
     out = torch.empty_like(imgs)
     nb = max(1, min(args.batch_tiles, count))
     batches = [(lo, min(nb, count - lo)) for lo in range(0, count, nb)]
@@ -632,7 +634,7 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{total} independent 4096x4096x3 uint8 NOISY3 tiles (seeds 1000..), {args.tiles_per_rank} per GPU, QB3M_FTL: qb3x_encode_tiles in batches of "
                                f"{nb}, containers gathered on rank 0 ({'RCCL send/recv' if args.backend == 'nccl' else args.backend + ' rehearsal'}) beside the coding "
-                               "of the next batch, qb3x_decode_tiles of every rank's own tiles from the containers alone (index = NULL; every tile carries its restart table, level 2: entries with block lengths, 5.5 % on top of the stream); the gather is inside the step",
+                               "of the next batch, qb3x_decode_tiles of every rank's own tiles from the containers alone (index = NULL; every tile carries its restart table, level 1: 0.7 % on top of the stream -- the step is bound by the gather, bytes on the link cost more than the decoder's walk); the gather is inside the step",
                    "tiles_total": total, "tiles_per_gpu": args.tiles_per_rank, "parallelism": f"tiles sharded over {world} GPUs, no data-path collective but the gather"},
         "coding_only": {"ms_per_step": round(dt_code / args.steps * 1e3, 3), "MPixel_s": round(px / (dt_code / args.steps) / 1e6, 1)},
         "gather": {"bytes_into_root_per_step": bytes_root, "GBps_into_root": round(bytes_root / (dt / args.steps) / 1e9, 1) if bytes_root else None,
