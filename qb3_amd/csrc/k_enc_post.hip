@@ -220,11 +220,12 @@ __global__ void __launch_bounds__(256) ix_bl_fill_kernel(const EncArgs a0) {
     uint8_t *e = e0 + 6 + 2 * B + 5 * (uint32_t)(grp & 15);
 #pragma unroll
     for (uint32_t i = 0; i < 5; i++) e[i] = (uint8_t)(bits >> (8 * i));
-    if ((grp & 15) == 0) {                  // the entry's fixed fields (an entry per segment: ix_spe == 1, 8-bit values, no factors)
-        const uint64_t bp = a.idx.bitpos[k];
-        for (uint32_t i = 0; i < 6; i++) e0[i] = (uint8_t)(bp >> (8 * i));
-        for (uint32_t c2 = 0; c2 < B; c2++) { e0[6 + c2] = a.idx.rung[k * B + c2]; e0[6 + B + c2] = ((const uint8_t *)a.idx.prev)[k * B + c2]; }
-    }
+    // the entry's fixed fields (an entry per segment: ix_spe == 1, 8-bit values, no factors): at most 14 bytes, one per thread of
+    // the entry's sixteen
+    const uint32_t t = (uint32_t)(grp & 15);
+    if (t < 6) e0[t] = (uint8_t)(a.idx.bitpos[k] >> (8 * t));
+    else if (t < 6 + B) e0[t] = a.idx.rung[k * B + (t - 6)];
+    else if (t < 6 + 2 * B) e0[t] = ((const uint8_t *)a.idx.prev)[k * B + (t - 6 - B)];
 }
 
 void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
