@@ -1038,6 +1038,18 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     except RuntimeError:
         pass
     assert torch.equal(dec.decode(dst, index=None), raw)
+    if w * h <= 512 * 512:              # ... and any byte of the table: positions, rungs, values, lengths -- no crash, whatever comes out
+        rng = np.random.default_rng(w * h + b)
+        t0, t1 = mine[0][1], dt_at + extra
+        for _ in range(24):
+            bad = dst.clone()
+            at = int(rng.integers(t0 + 12, t1))
+            bad[at] ^= int(rng.integers(1, 256))
+            try:
+                qdev.DeviceDecoder(bad, n).decode(bad, index=None)
+            except (RuntimeError, ValueError):
+                pass
+        assert torch.equal(dec.decode(dst, index=None), raw)
     # the same container through the walker (the switch is read once per process: a child)
     f = tmp_path / "c.qb3"
     f.write_bytes(bytes(host))
