@@ -1179,7 +1179,8 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("case", [(1100, 700, 3, 0, 256, []), (1024, 512, 1, 0, 512, ["-b"]), (600, 300, 3, 2, 128, ["-f"]), (1100, 700, 3, 0, 256, ["-f", "-i"])],
+@pytest.mark.parametrize("case", [(1100, 700, 3, 0, 256, []), (1024, 512, 1, 0, 512, ["-b"]), (600, 300, 3, 2, 128, ["-f"]), (1100, 700, 3, 0, 256, ["-f", "-i"]),
+                                  (1100, 700, 3, 0, 256, ["-f", "-I"])],
                          ids=lambda c: "%dx%dx%d-t%d-tile%d%s" % (c[0], c[1], c[2], c[3], c[4], "".join(c[5])))
 def test_tile_batcher_tool(qb3, oracle, tmp_path, case):
     """tools/qb3tiles.cpp, the GDAL-MRF-style caller of qb3x_encode_tiles / qb3x_decode_tiles: a raster cut into tiles,
@@ -1211,7 +1212,7 @@ def test_tile_batcher_tool(qb3, oracle, tmp_path, case):
         want = oracle.encode(tile, dt, mode)
         off, size = int(tab[k, 0]), int(tab[k, 1])
         one = f[off:off + size]
-        if "-i" in flags:       # the reference's container with the restart table's chunks in front of "DT"
+        if "-i" in flags or "-I" in flags:       # the reference's container with the restart table's chunks in front of "DT"
             extra, dt_at = size - len(want), bytes(want).index(b"DT", 11)
             assert extra > 0 and bytes(one[dt_at:dt_at + 2]) == b"ix", "tile %d" % k
             assert bytes(one[:dt_at]) == bytes(want[:dt_at]) and bytes(one[dt_at + extra:]) == bytes(want[dt_at:]), "tile %d" % k

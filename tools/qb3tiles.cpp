@@ -99,7 +99,7 @@ struct QtsEntry { uint64_t off, size; };
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int encode(const std::string &in, const std::string &out, size_t T, int mode, bool verbose, bool tables) {
+int encode(const std::string &in, const std::string &out, size_t T, int mode, bool verbose, int tables) {
     Raster r;
     if (!read_pnm(in, r)) return fail("cannot read " + in + " as binary PNM");
     if (T < 4 || T > 65536) return fail("tile edge out of range");
@@ -121,7 +121,7 @@ int encode(const std::string &in, const std::string &out, size_t T, int mode, bo
     encsp p = qb3_create_encoder(T, T, r.bands, (qb3_dtype)r.type);
     if (!p) return fail("qb3_create_encoder refused the tile geometry");
     qb3_set_encoder_mode(p, (qb3_mode)mode);
-    if (tables) qb3x_set_encoder_index_chunk(p, 1);      // every tile carries its restart table: the set decodes in parallel inside every tile
+    if (tables) qb3x_set_encoder_index_chunk(p, tables);  // every tile carries its restart table (2: with block lengths): the set decodes in parallel inside every tile
     const size_t pitch = (qb3_max_encoded_size(p) + 3) / 4 * 4;
     DevMem d_src(n * raw), d_dst(n * pitch);
     if (!d_src.p || !d_dst.p) { qb3_destroy_encoder(p); return fail("out of device memory"); }
@@ -224,7 +224,8 @@ int extract(const std::string &in, size_t k, const std::string &out) {
 }  // namespace
 
 int main(int argc, char **argv) {
-    bool enc = false, dec = false, ext = false, verbose = false, tables = false;
+    bool enc = false, dec = false, ext = false, verbose = false;
+    int tables = 0;
     int mode = QB3M_DEFAULT;
     size_t T = 512;
     std::vector<std::string> pos;
@@ -236,7 +237,8 @@ int main(int argc, char **argv) {
         else if (a == "-v") verbose = true;
         else if (a == "-b") mode = QB3M_BEST;
         else if (a == "-f") mode = QB3M_FTL;
-        else if (a == "-i") tables = true;
+        else if (a == "-i") tables = 1;
+        else if (a == "-I") tables = 2;
         else if (a == "-t" && i + 1 < argc) T = strtoull(argv[++i], nullptr, 10);
         else pos.push_back(a);
     }
@@ -244,6 +246,6 @@ int main(int argc, char **argv) {
     if (enc && pos.size() == 2) return encode(pos[0], pos[1], T, mode, verbose, tables);
     if (dec && pos.size() == 2) return decode(pos[0], pos[1], verbose);
     if (ext && pos.size() == 3) return extract(pos[0], strtoull(pos[1].c_str(), nullptr, 10), pos[2]);
-    fprintf(stderr, "qb3tiles -e [-v] [-b|-f] [-i] [-t N] input.pnm out.qts      (-i: tiles carry restart tables)\nqb3tiles -d [-v] in.qts output.pnm\nqb3tiles -x in.qts K out.qb3\n");
+    fprintf(stderr, "qb3tiles -e [-v] [-b|-f] [-i|-I] [-t N] input.pnm out.qts      (-i: tiles carry restart tables, -I: with block lengths)\nqb3tiles -d [-v] in.qts output.pnm\nqb3tiles -x in.qts K out.qb3\n");
     return 2;
 }
