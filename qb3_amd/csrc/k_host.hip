@@ -6,20 +6,32 @@ namespace qb3dev {
 // RLE0 (reference QB3encode.cpp:536-565) can only shorten a stream that holds a run of four zero bytes; looking for one
 // on the device spares the host pass (a copy of the whole stream over PCIe and a byte loop) whenever there is none.
 __global__ void zero_run_probe_kernel(const uint32_t *buf, uint64_t first_byte, uint64_t end_byte, uint32_t *flag) {
-    const uint64_t ndw = (end_byte + 3) >> 2;
+    const uint64_t ndw = (end_byte + 3) >> 2, d0 = first_byte >> 2;
     bool found = false;
-    for (uint64_t d = (first_byte >> 2) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndw; d += (uint64_t)gridDim.x * blockDim.x) {
-        // bytes outside [first_byte, end_byte) count as non-zero
-        auto dw = [&](uint64_t i) -> uint32_t {
-            if (i >= ndw) return 0xffffffffu;
-            uint32_t v = buf[i];
-            if (4 * i < first_byte) v |= 0xffffffffu >> (8 * (4 - (uint32_t)(first_byte - 4 * i)));
-            if (4 * i + 4 > end_byte) v |= 0xffffffffu << (8 * (uint32_t)(end_byte - 4 * i));
-            return v;
-        };
-        const uint32_t cur = dw(d), nxt = dw(d + 1);
-        found = found || cur == 0 || __builtin_amdgcn_alignbit(nxt, cur, 8) == 0 || __builtin_amdgcn_alignbit(nxt, cur, 16) == 0 ||
-                __builtin_amdgcn_alignbit(nxt, cur, 24) == 0;
+    // bytes outside [first_byte, end_byte) count as non-zero
+    auto dw = [&](uint64_t i) -> uint32_t {
+        if (i >= ndw) return 0xffffffffu;
+        uint32_t v = buf[i];
+        if (4 * i < first_byte) v |= 0xffffffffu >> (8 * (4 - (uint32_t)(first_byte - 4 * i)));
+        if (4 * i + 4 > end_byte) v |= 0xffffffffu << (8 * (uint32_t)(end_byte - 4 * i));
+        return v;
+    };
+    auto pair = [&](uint32_t cur, uint32_t nxt) {
+        return cur == 0 || __builtin_amdgcn_alignbit(nxt, cur, 8) == 0 || __builtin_amdgcn_alignbit(nxt, cur, 16) == 0 ||
+               __builtin_amdgcn_alignbit(nxt, cur, 24) == 0;
+    };
+    // a thread takes four dwords a step (one sixteen-byte load when they lie wholly inside the range) and the dword behind them
+    for (uint64_t d = d0 + 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x); d < ndw; d += 4 * (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v[5];
+        if (4 * d >= first_byte && 4 * (d + 5) <= end_byte) {
+            const u32x4_a4 t = *(const u32x4_a4 *)(buf + d);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = buf[d + 4];
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 5; k++) v[k] = dw(d + k);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) found = found || pair(v[k], v[k + 1]);
     }
     if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
@@ -472,7 +484,7 @@ int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, i
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(d_flag, 0, 4, st));
     const uint64_t ndw = (off + nbytes + 3) / 4 - off / 4;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, (ndw + 255) / 256 ? (ndw + 255) / 256 : 1);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, (ndw + 1023) / 1024 ? (ndw + 1023) / 1024 : 1);     // (a thread takes four dwords a step)
     hipLaunchKernelGGL(zero_run_probe_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *)d_buf, (uint64_t)off, (uint64_t)(off + nbytes), (uint32_t *)d_flag);
     uint32_t f = 0;
     HIPCHK(hipMemcpyAsync(&f, d_flag, 4, hipMemcpyDeviceToHost, st));
