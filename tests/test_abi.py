@@ -57,6 +57,36 @@ def test_max_encoded_size_matches(qb3, oracle, w, h, b, dt):
         assert e.max_size() == 912262144
 
 
+@pytest.mark.parametrize("w,h,b,dt,mode,lens", [(512, 512, 3, 0, 8, True), (509, 259, 1, 0, 4, True), (640, 384, 4, 0, 0, True), (16384, 16384, 3, 0, 8, True),
+                                                  (512, 512, 3, 0, 7, False), (256, 256, 5, 0, 8, False), (256, 256, 3, 2, 8, False), (256, 256, 1, 7, 4, False)])
+def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
+    """qb3_max_encoded_size grows by exactly the table's chunks while qb3x_set_encoder_index_chunk is on (host logic, no GPU):
+    level 1 -- an entry per segment (FTL/BASE) of 6 + bands * (1 + size) bytes; level 2 -- 80 more bytes an entry where the
+    8-bit lane-per-block decoder applies, else the level 1 table; chunks of at most 65535 bytes, each with a 12-byte head and
+    a 4-byte pad chunk"""
+    L = qb3.lib
+    p = L.qb3_create_encoder(w, h, b, dt)
+    L.qb3_set_encoder_mode(p, mode)
+    base = L.qb3_max_encoded_size(p)
+    L.qb3x_set_encoder_index_chunk(p, 1)
+    one = L.qb3_max_encoded_size(p) - base
+    L.qb3x_set_encoder_index_chunk(p, 2)
+    two = L.qb3_max_encoded_size(p) - base
+    L.qb3x_set_encoder_index_chunk(p, 0)
+    assert L.qb3_max_encoded_size(p) == base
+    L.qb3_destroy_encoder(p)
+    assert one > 0
+    if not lens:
+        assert two == one
+        return
+    nseg = (((w + 3) // 4) * ((h + 3) // 4) + 63) // 64
+
+    def room(entry):
+        per_chunk = (65535 - 12) // entry
+        return nseg * entry + ((nseg + per_chunk - 1) // per_chunk) * 16
+    assert one == room(6 + 2 * b) and two == room(6 + 2 * b + 80)
+
+
 def test_setters_match_oracle(qb3, oracle):
     L = qb3.lib
     p = L.qb3_create_encoder(16, 16, 5, 2)
