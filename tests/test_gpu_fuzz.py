@@ -75,10 +75,11 @@ def test_random_cases_match_the_oracle(qb3, oracle, block):
         out, dims, dtype, m = qb3.decode(ref)
         assert dims == (w, h, b) and np.array_equal(out, want), tag
         if rng.random() < 0.3 and mode in (8, 4, 0, 5, 1):      # and through the self-indexing container
-            s2 = _encode_strided(qb3, src, w, h, b, dt, mode, cb, stride, chunk=True) if stride else \
-                qb3.encode(img, dt, mode, cband=cb, quanta=q, away=away, index_chunk=True)
+            level = 1 + (k & 1)         # the restart table, with block lengths every other time (where the raster takes them)
+            s2 = _encode_strided(qb3, src, w, h, b, dt, mode, cb, stride, chunk=level) if stride else \
+                qb3.encode(img, dt, mode, cband=cb, quanta=q, away=away, index_chunk=level)
             out2, _, _, _ = qb3.decode(s2)
-            assert np.array_equal(out2, want), tag + " (index chunk)"
+            assert np.array_equal(out2, want), tag + " (index chunk, level %d)" % level
 
 
 def _encode_strided(qb3, buf, w, h, b, dt, mode, cb, stride, chunk=False):
@@ -89,7 +90,7 @@ def _encode_strided(qb3, buf, w, h, b, dt, mode, cb, stride, chunk=False):
     try:
         L.qb3_set_encoder_mode(p, mode)
         if chunk:
-            L.qb3x_set_encoder_index_chunk(p, 1)
+            L.qb3x_set_encoder_index_chunk(p, int(chunk))
         if cb is not None:
             arr = (C.c_size_t * b)(*cb)
             L.qb3_set_encoder_coreband(p, b, arr)
