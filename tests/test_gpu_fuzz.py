@@ -115,13 +115,14 @@ def test_damaged_streams_fail_or_decode_but_never_fault(qb3, oracle, case):
     img = oracle.generate(w, h, b, dt, gen, 7)
     good = oracle.encode(img, dt, mode, cband=None if b in (1, 3, 4) else list(range(b)))
     chunked = qb3.encode(img, dt, mode if mode not in (2, 3, 6, 7) else 5, cband=None if b in (1, 3, 4) else list(range(b)), index_chunk=True)
+    chunked2 = qb3.encode(img, dt, mode if mode not in (2, 3, 6, 7) else 5, cband=None if b in (1, 3, 4) else list(range(b)), index_chunk=2)
     rng = random.Random(99)
     data0 = bytes(good).index(b"DT", 11) + 2
     outcomes = {"ok": 0, "error": 0}
     for trial in range(40):
-        base = good if trial % 3 else chunked
+        base = good if trial % 3 else (chunked2 if trial % 6 else chunked)       # (the table with block lengths, where the raster takes them)
         s = base.copy()
-        lo = data0 if base is good else 11          # the self-indexing container: damage the restart table too
+        lo = data0 if base is good else 11          # the self-indexing containers: damage the restart table too
         kind = trial % 4
         if kind == 0:
             for _ in range(rng.randrange(1, 4)):
