@@ -136,7 +136,7 @@ def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen
     img = synth.generate(w, h, bands, dtype, gen, seed, device=dev)
     raw = img.reshape(-1).view(torch.uint8)
     raw_bytes = raw.numel()
-    enc = qdev.DeviceEncoder(w, h, bands, dtype, mode=mode, index_chunk=True)
+    enc = qdev.DeviceEncoder(w, h, bands, dtype, mode=mode, index_chunk=2)      # (level 2 where the raster takes it: 8-bit 1/3/4 bands, 16-bit 4/8 bands; else the level 1 table)
     dst, n, index = enc.encode(img)
     host = dst[:n].cpu().numpy()
     ok, fnv = container_check(qb3_amd, np, host, tag) if tag in ANCHORS else (None, None)

@@ -29,13 +29,14 @@ __device__ __forceinline__ uint32_t px16_switch(uint32_t pos, uint32_t *cslen, b
 // code: several reads in flight instead of one (the kernel is bound by that latency, not by issue: SQ_INSTS_VALU x 2 /
 // SIMD = 28 % of its duration when the bands were walked one after the other).  A band whose rung is below 8 walks
 // along with a harmless result (its reads stay inside the staged words and their zero margin); the caller overwrites it.
-template <bool STEP, int N>         // N bands at a time: two is what the registers hold without spilling
-__device__ __forceinline__ void px16_groups_hi(const uint32_t *gpos, const uint32_t *rung, uint32_t (*rp)[8], uint32_t *tot) {
+// RS: the N bands are RS apart in the caller's arrays; endp (when given): the bit behind each unit.
+template <bool STEP, int N, int RS = 1>         // N bands at a time: two is what the registers hold without spilling
+__device__ __forceinline__ void px16_groups_hi(const uint32_t *gpos, const uint32_t *rung, uint32_t (*rp)[8], uint32_t *tot, uint32_t *endp = nullptr) {
     constexpr int BG = N;
     uint32_t pos[BG], acc[BG], fl[BG], top[BG], half[BG];
     uint64_t buf[BG];
 #pragma unroll
-    for (int c = 0; c < BG; c++) { pos[c] = gpos[c]; acc[c] = 0; fl[c] = 0; top[c] = 1u << rung[c]; half[c] = top[c] >> 1; buf[c] = 0; }
+    for (int c = 0; c < BG; c++) { pos[c] = gpos[c * RS]; acc[c] = 0; fl[c] = 0; top[c] = 1u << rung[c * RS]; half[c] = top[c] >> 1; buf[c] = 0; }
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         if (i % 3 == 0) {                               // three codes are at most 51 bits
@@ -50,16 +51,17 @@ __device__ __forceinline__ void px16_groups_hi(const uint32_t *gpos, const uint3
         for (int c = 0; c < BG; c++) {
             const uint32_t x = (uint32_t)buf[c];
             const bool c1 = x & 1, c2 = (x & 3) == 3;
-            const uint32_t len = rung[c] + c1 + c2;
+            const uint32_t len = rung[c * RS] + c1 + c2;
             const uint32_t v = c2 ? (((x >> 2) & (top[c] - 1)) | top[c]) : c1 ? (((x >> 2) & (half[c] - 1)) | half[c]) : ((x & (top[c] - 1)) >> 1);
             buf[c] >>= len; pos[c] += len;
             acc[c] += (v >> 1) ^ (0u - (v & 1u));       // undo mag-sign, accumulate (mod 2^16 in the packed halves)
             if (STEP) fl[c] |= ((uint32_t)c2 | ((v & 1u) << 1)) << (2 * i);
-            if (i & 1) rp[c][i >> 1] |= acc[c] << 16; else rp[c][i >> 1] = acc[c] & 0xffffu;
+            if (i & 1) rp[c * RS][i >> 1] |= acc[c] << 16; else rp[c * RS][i >> 1] = acc[c] & 0xffffu;
         }
     }
 #pragma unroll
     for (int c = 0; c < BG; c++) {
+        if (endp) endp[c * RS] = pos[c];
         if (STEP) {                                     // undo the step (reference QB3decode.h:285-289), as in px_group
             const uint32_t tb = fl[c] & 0x55555555u, u = tb | (tb << 1);
             const uint32_t m = __popc(tb);
@@ -69,12 +71,12 @@ __device__ __forceinline__ void px16_groups_hi(const uint32_t *gpos, const uint3
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const uint32_t pair = (ge >> (2 * k)) & 3u;
-                    rp[c][k] = pk_add16(rp[c][k], ((pair | (pair << 15)) & 0x00010001u) * c16);
+                    rp[c * RS][k] = pk_add16(rp[c * RS][k], ((pair | (pair << 15)) & 0x00010001u) * c16);
                 }
                 acc[c] += c16;
             }
         }
-        tot[c] = acc[c];
+        tot[c * RS] = acc[c];
     }
 }
 
@@ -96,7 +98,10 @@ __device__ __forceinline__ void group_iscan(uint32_t (&v)[NW], uint32_t NG) {
     }
 }
 
-template <int BG, bool RGB, uint64_t ORDER, bool STEP>
+// BL (four bands a lane): no index -- the container's table has an entry per segment that ends with two band-pair lengths per
+// lane (qb3x_set_encoder_index_chunk level 2).  Bands 0 and 2 of a lane start where the pair lengths say and walk in
+// lockstep; bands 1 and 3 start where those ended.  No walk, no index.
+template <int BG, bool RGB, uint64_t ORDER, bool STEP, bool BL = false>
 __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -118,10 +123,33 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
     const bool act = live && slot < nb_here;
-    const uint64_t P0 = a.idx.bitpos[segc];
-    const uint64_t P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
-    uint32_t ul_[BG], rg0[BG], pv0[BG], blen = 0;
-    {   // a lane's BG lengths, rungs and entering values are contiguous: one load each where the address allows
+    uint64_t P0, P1;
+    uint32_t ul_[BG], rg0[BG], pv0[BG], blen = 0, f0 = 0, f1 = 0;
+    if (BL) {
+        const uint8_t *e = ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, (uint32_t)segc);
+        auto pos6 = [](const uint8_t *q) { uint64_t v = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 6; i++) v |= (uint64_t)q[i] << (8 * i);
+            return v; };
+        P0 = pos6(e);
+        P1 = (segc + 1 < a.g.nseg) ? pos6(ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, (uint32_t)segc + 1)) : a.in_bits;
+#pragma unroll
+        for (int c = 0; c < BG; c++) {
+            ul_[c] = 0;
+            rg0[c] = e[6 + band0 + c] & 15u;
+            const uint8_t *pv = e + 6 + B + 2 * (band0 + c);
+            pv0[c] = (uint32_t)pv[0] | (uint32_t)pv[1] << 8;
+        }
+        const uint32_t bit = 2 * IX_BL_BITS * lane;                 // the lane's two fields
+        const uint8_t *fp = e + 6 + 3 * B + (bit >> 3);
+        const uint32_t v = ((uint32_t)fp[0] | (uint32_t)fp[1] << 8 | (uint32_t)fp[2] << 16) >> (bit & 7);
+        f0 = act ? v & ((1u << IX_BL_BITS) - 1) : 0u;
+        f1 = act ? (v >> IX_BL_BITS) & ((1u << IX_BL_BITS) - 1) : 0u;
+        blen = f0 + f1;
+    } else {
+        P0 = a.idx.bitpos[segc];
+        P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
+        // a lane's BG lengths, rungs and entering values are contiguous: one load each where the address allows
         const uint16_t *ul = (const uint16_t *)a.idx.ulen + ((uint64_t)g0 + slot) * B + band0;
         const uint16_t *pvp = (const uint16_t *)a.idx.prev + segc * B + band0;
         const uint8_t *rgp = a.idx.rung + segc * B + band0;
@@ -171,8 +199,9 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
             if (i < ndw + 16) *(uint4 *)(stage + i) = sw[q];
         }
     }
+    if (!BL)
 #pragma unroll
-    for (int c = 0; c < BG; c++) blen += ul_[c];
+        for (int c = 0; c < BG; c++) blen += ul_[c];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -182,42 +211,84 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
     bool bad = !fits;
     const uint32_t binc = wave_iscan32(blen);           // lanes are in stream order
     uint32_t gpos[BG], pos = cpos + binc - blen, dpk[NW];
-#pragma unroll
-    for (int k = 0; k < NW; k++) dpk[k] = 0;
-#pragma unroll
-    for (int c = 0; c < BG; c++) {
-        pos = pos < limit ? pos : limit;
-        bool sig; uint32_t csl;
-        const uint32_t d = px16_switch(pos, &csl, &sig);
-        gpos[c] = pos + csl;
-        if (act && sig && STEP) bad = true;             // common-factor / index unit: not handled here
-        dpk[c >> 1] |= (act ? d : 0u) << (16 * (c & 1));
-        pos += ul_[c];
-    }
-    group_iscan<NW>(dpk, NG);                           // inclusive, 16 bits per band
     uint32_t rp[BG][8], spk[NW], sinc[NW];
 #pragma unroll
-    for (int k = 0; k < NW; k++) spk[k] = 0;
-    {
-        uint32_t rungs[BG], tots[BG];
-        bool lane_hi = false, lane_lo = false;
+    for (int k = 0; k < NW; k++) { dpk[k] = 0; spk[k] = 0; }
+    if (BL && BG == 4) {
+        // two rounds: bands 0 and 2 of the lane (their starts are known), then bands 1 and 3 (they start where 0 and 2 ended)
+        uint32_t rungs[BG], tots[BG], ends[BG];
+        const uint32_t lane0 = pos;
+        uint32_t start[2] = { pos, pos + f0 };
 #pragma unroll
-        for (int c = 0; c < BG; c++) {
-            rungs[c] = (rg0[c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 15u;
-            lane_hi = lane_hi || rungs[c] >= 8; lane_lo = lane_lo || rungs[c] < 8;
-            tots[c] = 0;
-        }
-        if (__any(lane_hi)) {                           // the lane's bands in lockstep, two at a time
-            if (BG >= 2) px16_groups_hi<STEP, 2>(&gpos[0], &rungs[0], &rp[0], &tots[0]);
-            if (BG == 4) px16_groups_hi<STEP, 2>(&gpos[2], &rungs[2], &rp[2], &tots[2]);
-            if (BG & 1) px16_groups_hi<STEP, 1>(&gpos[BG - 1], &rungs[BG - 1], &rp[BG - 1], &tots[BG - 1]);
-        }
-        if (__any(lane_lo)) {                           // values below 256: the table path of the 8-bit kernel
+        for (int r = 0; r < 2; r++) {
+            uint32_t dd = 0;
 #pragma unroll
-            for (int c = 0; c < BG; c++) if (rungs[c] < 8) tots[c] = px_group<STEP>(gpos[c], rungs[c], rp[c]);
+            for (int h = 0; h < 2; h++) {
+                const int c = 2 * h + r;                // round 0: bands 0, 2; round 1: bands 1, 3
+                uint32_t p0 = start[h];
+                p0 = p0 < limit ? p0 : limit;
+                bool sig; uint32_t csl;
+                const uint32_t d = px16_switch(p0, &csl, &sig);
+                gpos[c] = p0 + csl;
+                if (act && sig && STEP) bad = true;     // common-factor / index unit: not handled here
+                dd |= (act ? d : 0u) << (16 * h);
+            }
+            uint32_t dsc[1] = { dd };
+            group_iscan<1>(dsc, NG);                    // inclusive, the two bands' rung changes 16 bits each
+            bool lane_hi = false, lane_lo = false;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int c = 2 * h + r;
+                rungs[c] = (rg0[c] + ((dsc[0] >> (16 * h)) & 0xffffu)) & 15u;
+                lane_hi = lane_hi || rungs[c] >= 8; lane_lo = lane_lo || rungs[c] < 8;
+                tots[c] = 0; ends[c] = 0;
+            }
+            if (__any(lane_hi)) px16_groups_hi<STEP, 2, 2>(&gpos[r], &rungs[r], &rp[r], &tots[r], &ends[r]);
+            if (__any(lane_lo)) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int c = 2 * h + r;
+                    if (rungs[c] < 8) tots[c] = px_group<STEP>(gpos[c], rungs[c], rp[c], &ends[c]);
+                }
+            }
+            start[0] = ends[r]; start[1] = ends[2 + r];
         }
+        if (act && (ends[1] != lane0 + f0 || ends[3] != lane0 + f0 + f1)) bad = true;     // the table's lengths are not this stream's
 #pragma unroll
         for (int c = 0; c < BG; c++) spk[c >> 1] |= (act ? tots[c] & 0xffffu : 0u) << (16 * (c & 1));
+    } else {
+#pragma unroll
+        for (int c = 0; c < BG; c++) {
+            pos = pos < limit ? pos : limit;
+            bool sig; uint32_t csl;
+            const uint32_t d = px16_switch(pos, &csl, &sig);
+            gpos[c] = pos + csl;
+            if (act && sig && STEP) bad = true;             // common-factor / index unit: not handled here
+            dpk[c >> 1] |= (act ? d : 0u) << (16 * (c & 1));
+            pos += ul_[c];
+        }
+        group_iscan<NW>(dpk, NG);                           // inclusive, 16 bits per band
+        {
+            uint32_t rungs[BG], tots[BG];
+            bool lane_hi = false, lane_lo = false;
+#pragma unroll
+            for (int c = 0; c < BG; c++) {
+                rungs[c] = (rg0[c] + ((dpk[c >> 1] >> (16 * (c & 1))) & 0xffffu)) & 15u;
+                lane_hi = lane_hi || rungs[c] >= 8; lane_lo = lane_lo || rungs[c] < 8;
+                tots[c] = 0;
+            }
+            if (__any(lane_hi)) {                           // the lane's bands in lockstep, two at a time
+                if (BG >= 2) px16_groups_hi<STEP, 2>(&gpos[0], &rungs[0], &rp[0], &tots[0]);
+                if (BG == 4) px16_groups_hi<STEP, 2>(&gpos[2], &rungs[2], &rp[2], &tots[2]);
+                if (BG & 1) px16_groups_hi<STEP, 1>(&gpos[BG - 1], &rungs[BG - 1], &rp[BG - 1], &tots[BG - 1]);
+            }
+            if (__any(lane_lo)) {                           // values below 256: the table path of the 8-bit kernel
+#pragma unroll
+                for (int c = 0; c < BG; c++) if (rungs[c] < 8) tots[c] = px_group<STEP>(gpos[c], rungs[c], rp[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < BG; c++) spk[c >> 1] |= (act ? tots[c] & 0xffffu : 0u) << (16 * (c & 1));
+        }
     }
     {   // per-band scan of the unit totals modulo 2^16: the two halves of a word must not carry into each other
         uint32_t lo[NW], hi[NW];
@@ -313,6 +384,13 @@ template <int BG, bool RGB>
 static void launch_dec_px16_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
     dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
+    if (BG == 4 && a.bl_mode) {
+        if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG == 4 ? 4 : BG, RGB, HILBERT, false, BG == 4>), grid, block, plan.lds_px, st, a);
+        else if (!z && step) hipLaunchKernelGGL((dec_px16_kernel<BG == 4 ? 4 : BG, RGB, HILBERT, true, BG == 4>), grid, block, plan.lds_px, st, a);
+        else if (z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG == 4 ? 4 : BG, RGB, ZCURVE, false, BG == 4>), grid, block, plan.lds_px, st, a);
+        else hipLaunchKernelGGL((dec_px16_kernel<BG == 4 ? 4 : BG, RGB, ZCURVE, true, BG == 4>), grid, block, plan.lds_px, st, a);
+        return;
+    }
     if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, false>), grid, block, plan.lds_px, st, a);
     else if (!z && step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);
     else if (z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, ZCURVE, false>), grid, block, plan.lds_px, st, a);

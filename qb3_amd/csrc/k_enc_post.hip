@@ -228,6 +228,41 @@ __global__ void __launch_bounds__(256) ix_bl_fill_kernel(const EncArgs a0) {
     else if (t < 6 + 2 * B) e0[t] = ((const uint8_t *)a.idx.prev)[k * B + (t - 6 - B)];
 }
 
+// The same for 16-bit rasters of four or eight bands: a field is the bit length of a band PAIR (two units), two fields per
+// lane of the decoder's wave (lane = block of the segment x band group of four), 128 fields an entry.  A thread per four
+// fields (two lanes): five whole bytes; the entry's first 6 + 3 * bands threads also write one byte each of its fixed part.
+__global__ void __launch_bounds__(256) ix_bl16_fill_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    static_assert(IX_BL_BITS == 10, "groups of four fields are five bytes");
+    const uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // fields 4 * grp .. 4 * grp + 3 of entry grp / 32
+    const uint32_t B = a.g.bands, NG = B / 4, NB = 64 / NG;
+    const uint64_t k = grp >> 5;
+    if (k >= a.ix_K) return;
+    const uint32_t t = (uint32_t)(grp & 31);
+    uint64_t bits = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t field = 4 * t + q, lane = field >> 1, pair = field & 1;
+        const uint32_t slot = lane / NG, g4 = lane - slot * NG;
+        const uint64_t blk = k * NB + slot;
+        uint32_t len = 0;
+        if (blk < a.g.nblocks) {
+            const uint16_t *ul = (const uint16_t *)a.idx.ulen + blk * B + 4 * g4 + 2 * pair;
+            len = (uint32_t)ul[0] + ul[1];
+        }
+        bits |= (uint64_t)len << (IX_BL_BITS * q);
+    }
+    const uint32_t c = (uint32_t)(k / a.ix_per_chunk), jj = (uint32_t)(k - (uint64_t)c * a.ix_per_chunk);
+    uint8_t *e0 = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E) + IX_HEAD + (uint64_t)jj * a.ix_E;
+    uint8_t *e = e0 + 6 + 3 * B + 5 * t;
+#pragma unroll
+    for (uint32_t i = 0; i < 5; i++) e[i] = (uint8_t)(bits >> (8 * i));
+    // fixed part: bit position, a rung byte per band, the entering values (two bytes a band): 6 + 3 * B <= 30 bytes
+    if (t < 6) e0[t] = (uint8_t)(a.idx.bitpos[k] >> (8 * t));
+    else if (t < 6 + B) e0[t] = a.idx.rung[k * B + (t - 6)];
+    else if (t < 6 + 3 * B) e0[t] = ((const uint8_t *)a.idx.prev)[k * 2 * B + (t - 6 - B)];
+}
+
 void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const uint32_t nt = a.ntiles;
     if (!a.single_pass) {
@@ -243,7 +278,8 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256, nt), dim3(256), 0, st, a);
     if (a.hdr_len) hipLaunchKernelGGL(write_header_kernel, dim3(1, nt), dim3(64), 0, st, a);
     if (a.ix_dst && a.have_idx) hipLaunchKernelGGL(ix_fill_kernel, dim3((a.ix_K + 255) / 256, nt), dim3(256), 0, st, a);
-    if (a.ix_dst && a.have_idx && a.ix_bl) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 2) hipLaunchKernelGGL(ix_bl16_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 32 + 255) / 256), nt), dim3(256), 0, st, a);
 }
 
 }  // namespace qb3dev

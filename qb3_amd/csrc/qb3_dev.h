@@ -95,6 +95,7 @@ struct IxTable {
 };
 uint32_t ix_entry_bytes(const Geometry &g, bool block_lens = false);
 bool ix_block_lens_ok(const Geometry &g);         // can a table for this geometry carry block lengths
+uint32_t ix_bl_fields(const Geometry &g);         // ... how many fields an entry then ends with
 // the table this library writes for a geometry (needs seg_blocks, nseg, bands, tsz, mode); K == 0: none
 IxTable ix_layout(const Geometry &g, int level = 1);       // level 2: with block lengths where the geometry allows
 inline size_t ix_chunks(const IxTable &t) { return t.per_chunk ? (t.K + t.per_chunk - 1) / t.per_chunk : 0; }

@@ -980,11 +980,14 @@ def test_restart_table_does_not_depend_on_the_index_request(qb3, oracle, case):
     assert bytes(host[:dt_at]) == bytes(ref[:dt_at]) and bytes(host[dt_at + extra:]) == bytes(ref[dt_at:])
 
 
-BL_CASES = [(256, 256, 3, "NOISY3", FTL), (509, 259, 3, "NOISY3", BASE), (768, 512, 1, "GRAD", FTL), (333, 77, 4, "NOISY3", BASE),
-            (1024, 1024, 3, "NOISY3", 0), (2048, 1536, 1, "NOISY3", FTL), (4096, 2048, 3, "NOISY3", FTL), (64, 16, 3, "RANDOM", FTL)]
+BL_CASES = [(256, 256, 3, 0, "NOISY3", FTL), (509, 259, 3, 0, "NOISY3", BASE), (768, 512, 1, 0, "GRAD", FTL), (333, 77, 4, 0, "NOISY3", BASE),
+            (1024, 1024, 3, 0, "NOISY3", 0), (2048, 1536, 1, 0, "NOISY3", FTL), (4096, 2048, 3, 0, "NOISY3", FTL), (64, 16, 3, 0, "RANDOM", FTL),
+            # 16-bit, eight and four bands: two band-pair lengths per lane of the decoder's wave
+            (256, 256, 8, 2, "LANDSAT16", BASE), (509, 259, 8, 2, "LANDSAT16", FTL), (300, 200, 4, 2, "LANDSAT16", BASE), (640, 384, 8, 3, "GRAD", FTL),
+            (2048, 1024, 8, 2, "LANDSAT16", 0), (333, 77, 4, 3, "DEM", FTL)]
 
 
-@pytest.mark.parametrize("case", BL_CASES, ids=lambda c: "%dx%dx%d-%s-m%d" % c)
+@pytest.mark.parametrize("case", BL_CASES, ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % c)
 def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     """qb3x_set_encoder_index_chunk level 2: the table's entries end with the bit lengths of their segment's blocks (ten bits
     each), and the 8-bit lane-per-block decoder then needs neither a walk nor an index -- ONE kernel.  The container is the
@@ -995,11 +998,12 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     import ctypes as C
     import torch
     from qb3_amd import synth, device as qdev
-    w, h, b, gen, mode = case
-    img = synth.generate(w, h, b, 0, gen, 31)
+    w, h, b, dt, gen, mode = case
+    cb = None if b in (1, 3, 4) else list(range(b))
+    img = synth.generate(w, h, b, dt, gen, 31)
     raw = img.reshape(-1).view(torch.uint8)
-    ref = oracle.encode(oracle.generate(w, h, b, 0, gen, 31), 0, mode)
-    enc = qdev.DeviceEncoder(w, h, b, 0, mode=mode, want_index=False, index_chunk=2)
+    ref = oracle.encode(oracle.generate(w, h, b, dt, gen, 31), dt, mode, cband=cb)
+    enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cb, want_index=False, index_chunk=2)
     dst, n, _ = enc.encode(img)
     host = dst[:n].cpu().numpy()
     if ref[10] == 255:                  # raw-stored: no table at all
@@ -1009,18 +1013,22 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     assert bytes(host[:dt_at]) == bytes(ref[:dt_at]) and bytes(host[dt_at + extra:]) == bytes(ref[dt_at:])
     _, seen = walk_chunks(host, False)
     mine = [c for c in seen if c[1] >= dt_at]
-    nseg = (((w + 3) // 4) * ((h + 3) // 4) + 63) // 64
+    nblocks = ((w + 3) // 4) * ((h + 3) // 4)
+    per_seg = 64 if dt == 0 else 64 // (b // 4)         # blocks of a decoder wave
+    nseg, entry = (nblocks + per_seg - 1) // per_seg, (6 + 2 * b + 80) if dt == 0 else (6 + 3 * b + 160)
     assert mine[0][0] == b"ix" and host[mine[0][1] + 5] & 2, "entries are flagged as carrying block lengths"
-    assert sum(c[2] - 12 for c in mine if c[0] == b"ix") == nseg * (6 + 2 * b + 80)
+    assert sum(c[2] - 12 for c in mine if c[0] == b"ix") == nseg * entry
     out, _, _, _ = oracle.decode(host, identity=True)
     assert out is not None and np.array_equal(out, raw.cpu().numpy()), "the reference decoder must step over the chunks"
     out, _, _, _ = qb3.decode(host)
     assert np.array_equal(out, raw.cpu().numpy())
-    got = qb3.encode(img.cpu().numpy(), 0, mode, index_chunk=2)
+    got = qb3.encode(img.cpu().numpy(), dt, mode, cband=cb, index_chunk=2)
     assert np.array_equal(got, host), "host and device flavour write the same container"
     L = qb3.lib
     L.qb3x_profile_enable(1); L.qb3x_profile_reset()
     dec = qdev.DeviceDecoder(dst, n)
+    if cb is not None:
+        L.qb3x_set_decoder_compat(dec.p, 0)
     res = dec.decode(dst, index=None)
     torch.cuda.synchronize()
     buf = C.create_string_buffer(1024)
@@ -1029,7 +1037,7 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     assert torch.equal(res, raw)
     assert buf.value == b"dec_units", buf.value          # no walk, no index rebuild
     # lengths that are not the stream's: a reported failure (or, if they happen to add up, the right pixels), never a crash
-    at = mine[0][1] + 12 + 6 + 2 * b
+    at = mine[0][1] + 12 + entry - (80 if dt == 0 else 160)
     bad = dst.clone()
     bad[at + 1] ^= 0x5a
     try:
@@ -1059,10 +1067,12 @@ sys.path.insert(0, %r)
 import qb3_amd
 from qb3_amd import synth, device as qdev
 c = torch.from_numpy(np.fromfile(%r, dtype=np.uint8)).cuda()
-raw = synth.generate(%d, %d, %d, 0, %r, 31).reshape(-1).view(torch.uint8)
-assert torch.equal(qdev.DeviceDecoder(c, c.numel()).decode(c, index=None), raw)
+raw = synth.generate(%d, %d, %d, %d, %r, 31).reshape(-1).view(torch.uint8)
+d = qdev.DeviceDecoder(c, c.numel())
+qb3_amd.lib.qb3x_set_decoder_compat(d.p, 0)
+assert torch.equal(d.decode(c, index=None), raw)
 print("ok")
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(f), w, h, b, gen)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(f), w, h, b, dt, gen)
     env = dict(os.environ)
     env["QB3_NO_BLOCK_LENGTHS"] = "1"
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
