@@ -58,11 +58,12 @@ def test_max_encoded_size_matches(qb3, oracle, w, h, b, dt):
 
 
 @pytest.mark.parametrize("w,h,b,dt,mode,lens", [(512, 512, 3, 0, 8, True), (509, 259, 1, 0, 4, True), (640, 384, 4, 0, 0, True), (16384, 16384, 3, 0, 8, True),
-                                                  (512, 512, 3, 0, 7, False), (256, 256, 5, 0, 8, False), (256, 256, 3, 2, 8, False), (256, 256, 1, 7, 4, False)])
+                                                  (512, 512, 3, 0, 7, False), (256, 256, 5, 0, 8, False), (256, 256, 3, 2, 8, False), (256, 256, 1, 7, 4, False),
+                                                  (8192, 8192, 8, 2, 4, True), (300, 200, 4, 3, 8, True), (256, 256, 16, 2, 8, False)])
 def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
     """qb3_max_encoded_size grows by exactly the table's chunks while qb3x_set_encoder_index_chunk is on (host logic, no GPU):
     level 1 -- an entry per segment (FTL/BASE) of 6 + bands * (1 + size) bytes; level 2 -- 80 more bytes an entry where the
-    8-bit lane-per-block decoder applies, else the level 1 table; chunks of at most 65535 bytes, each with a 12-byte head and
+    8-bit lane-per-block decoder applies, 160 more for 16-bit rasters of four or eight bands, else the level 1 table; chunks of at most 65535 bytes, each with a 12-byte head and
     a 4-byte pad chunk"""
     L = qb3.lib
     p = L.qb3_create_encoder(w, h, b, dt)
@@ -79,12 +80,16 @@ def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
     if not lens:
         assert two == one
         return
-    nseg = (((w + 3) // 4) * ((h + 3) // 4) + 63) // 64
+    nblocks = ((w + 3) // 4) * ((h + 3) // 4)
+    per_seg = 64 if dt == 0 else 64 // (b // 4)         # 16-bit: four bands a lane of the decoder's wave
+    nseg = (nblocks + per_seg - 1) // per_seg
+    tsz = 1 if dt == 0 else 2
 
     def room(entry):
         per_chunk = (65535 - 12) // entry
         return nseg * entry + ((nseg + per_chunk - 1) // per_chunk) * 16
-    assert one == room(6 + 2 * b) and two == room(6 + 2 * b + 80)
+    fixed = 6 + b * (1 + tsz)
+    assert one == room(fixed) and two == room(fixed + (80 if dt == 0 else 160))
 
 
 def test_setters_match_oracle(qb3, oracle):
