@@ -212,7 +212,9 @@ __device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos
     for (uint32_t i = 0; i < 16; i++) { acc = (T)(acc + smag_t<T>(run[i])); run[i] = acc; }
 }
 
-template <typename T, bool STEP>
+// BL (32/64-bit data): no index -- position, entering rungs and values and a twelve-bit length per unit come from the segment's
+// entry of the container's restart table (qb3x_set_encoder_index_chunk level 2)
+template <typename T, bool STEP, bool BL = false>
 __global__ void dec3_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
@@ -240,12 +242,18 @@ __global__ void dec3_kernel(const DecArgs a0) {
     fill_dec_tab(dtab);
 
     // the compressed range of this segment, in bits from a.in32
-    const uint64_t P0 = a.idx.bitpos[seg];
-    const uint64_t P1 = (seg + 1 < a.g.nseg) ? a.idx.bitpos[seg + 1] : a.in_bits;
+    const uint8_t *ent = BL ? ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, (uint32_t)seg) : nullptr;
+    auto pos6 = [](const uint8_t *q) { uint64_t v = 0;
+        for (uint32_t i = 0; i < 6; i++) v |= (uint64_t)q[i] << (8 * i);
+        return v; };
+    const uint64_t P0 = BL ? pos6(ent) : a.idx.bitpos[seg];
+    const uint64_t P1 = (seg + 1 < a.g.nseg) ? (BL ? pos6(ix_entry_at(a.ix, a.ix_per_chunk, a.ix_E, a.ix_pad, (uint32_t)seg + 1)) : a.idx.bitpos[seg + 1]) : a.in_bits;
     const uint64_t w0 = (a.in_bit0 + P0) >> 5;
     const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
     const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0 + 2;
-    const bool staged = ndw64 <= a.in_cap_dw;          // workgroup uniform
+    // (positions out of a container's table are not to be trusted: a segment that does not lie inside the stream reads nothing)
+    const bool sane = !BL || (P0 <= P1 && P1 <= a.in_bits);
+    const bool staged = sane && ndw64 <= a.in_cap_dw;  // workgroup uniform
     const uint32_t ndw = (uint32_t)ndw64;
     if (staged)
         for (uint32_t base = 0; base < ndw; base += 4 * nthr) {        // four loads in flight per thread, then four LDS stores
@@ -255,7 +263,8 @@ __global__ void dec3_kernel(const DecArgs a0) {
 #pragma unroll
             for (int q = 0; q < 4; q++) { const uint32_t i = base + tid + q * nthr; if (i < ndw) stage[i] = sw[q]; }
         }
-    const uint32_t endw_g = (uint32_t)((endw_abs - w0 < 0xffffffffull) ? endw_abs - w0 : 0xffffffffull);
+    // words readable from w0 on (none when the segment is said to start behind the stream's end: a truncated stream, a table that lies)
+    const uint32_t endw_g = (!sane || w0 >= endw_abs) ? 0u : (uint32_t)((endw_abs - w0 < 0xffffffffull) ? endw_abs - w0 : 0xffffffffull);
     for (uint32_t sl = tid; sl < nb_here; sl += nthr) {
         const uint32_t g = g0 + sl, by = g / nbx, bx = g - by * nbx;
         const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;
@@ -263,8 +272,16 @@ __global__ void dec3_kernel(const DecArgs a0) {
         slot_base[sl] = (uint64_t)y0 * stride + (uint64_t)x0 * bands;
     }
     if (tid < bands) {
-        cprev[tid] = (uint64_t)((const T *)a.idx.prev)[seg * bands + tid];
-        crung[tid] = a.idx.rung[seg * bands + tid];
+        if (BL) {
+            const uint8_t *pv = ent + 6 + bands + tid * sizeof(T);
+            uint64_t v = 0;
+            for (uint32_t i = 0; i < sizeof(T); i++) v |= (uint64_t)pv[i] << (8 * i);
+            cprev[tid] = v;
+            crung[tid] = ent[6 + tid] & UMASK;
+        } else {
+            cprev[tid] = (uint64_t)((const T *)a.idx.prev)[seg * bands + tid];
+            crung[tid] = a.idx.rung[seg * bands + tid];
+        }
     }
     uint32_t cpos = (uint32_t)(a.in_bit0 + P0 - 32 * w0);     // bit position of the pass, relative to word w0
     const uint32_t c = fastdiv(tid, BPP, a.magic_bpp), b = tid - c * BPP;
@@ -272,7 +289,7 @@ __global__ void dec3_kernel(const DecArgs a0) {
     const uint64_t order = a.g.order;
     T *tt = (T *)tile;
     const uint32_t rowel = NB * 4 * bands;       // tile elements per pixel row
-    bool bad = false;
+    bool bad = !sane;
     __syncthreads();
 
     for (uint32_t p = 0; p < a.passes; p++) {
@@ -280,7 +297,14 @@ __global__ void dec3_kernel(const DecArgs a0) {
         const uint32_t nbp = pb0 >= nb_here ? 0 : ((nb_here - pb0 < BPP) ? nb_here - pb0 : BPP);
         // unit lengths of this pass (contiguous in the table)
         const uint64_t ubase = ((uint64_t)g0 + pb0) * bands;
-        if (a.g.ulen_sz == 1) for (uint32_t i = tid; i < nbp * bands; i += nthr) ulen_s[i] = ((const uint8_t *)a.idx.ulen)[ubase + i];
+        if (BL) {           // twelve-bit fields behind the entry's fixed part, unit by unit of the segment
+            const uint8_t *fl = ent + 6 + bands * (1 + sizeof(T));
+            for (uint32_t i = tid; i < nbp * bands; i += nthr) {
+                const uint32_t f = pb0 * bands + i, bit = 12 * f;
+                const uint8_t *q = fl + (bit >> 3);
+                ulen_s[i] = (uint16_t)((((uint32_t)q[0] | (uint32_t)q[1] << 8) >> (bit & 7)) & 0xfffu);
+            }
+        } else if (a.g.ulen_sz == 1) for (uint32_t i = tid; i < nbp * bands; i += nthr) ulen_s[i] = ((const uint8_t *)a.idx.ulen)[ubase + i];
         else for (uint32_t i = tid; i < nbp * bands; i += nthr) ulen_s[i] = ((const uint16_t *)a.idx.ulen)[ubase + i];
         __syncthreads();
         uint32_t blen = 0;
@@ -497,6 +521,11 @@ template <typename T>
 static void launch_dec_generic_t(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     if (plan.fast && a.g.mode != CM_BEST) {
         const dim3 grid((uint32_t)a.g.nseg, a.ntiles), block(plan.threads2);
+        if (a.bl_mode && sizeof(T) >= 4) {
+            if (a.g.mode == CM_BASE) hipLaunchKernelGGL((dec3_kernel<T, true, sizeof(T) >= 4>), grid, block, plan.lds2_bytes, st, a);
+            else hipLaunchKernelGGL((dec3_kernel<T, false, sizeof(T) >= 4>), grid, block, plan.lds2_bytes, st, a);
+            return;
+        }
         if (a.g.mode == CM_BASE) hipLaunchKernelGGL((dec3_kernel<T, true>), grid, block, plan.lds2_bytes, st, a);
         else hipLaunchKernelGGL((dec3_kernel<T, false>), grid, block, plan.lds2_bytes, st, a);
         return;

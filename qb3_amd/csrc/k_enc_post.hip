@@ -263,6 +263,35 @@ __global__ void __launch_bounds__(256) ix_bl16_fill_kernel(const EncArgs a0) {
     else if (t < 6 + 3 * B) e0[t] = ((const uint8_t *)a.idx.prev)[k * 2 * B + (t - 6 - B)];
 }
 
+// 32/64-bit rasters: a twelve-bit length per UNIT of the segment (the unit-parallel decoder wants every unit's place).
+// A thread per two fields: three whole bytes; the entry's threads share its fixed part a byte each.
+__global__ void __launch_bounds__(256) ix_blw_fill_kernel(const EncArgs a0, const uint32_t tpe) {     // tpe: threads per entry
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    static_assert(IX_BL_BITS_WIDE == 12, "pairs of fields are three bytes");
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t B = a.g.bands, tsz = a.g.tsz, upe = a.ix_blocks * B;         // units per entry
+    const uint64_t k = idx / tpe;
+    if (k >= a.ix_K) return;
+    const uint32_t t = (uint32_t)(idx - k * tpe);
+    const uint64_t u0 = k * upe, nunits = a.g.nblocks * B;
+    uint32_t len[2] = {0, 0};
+    for (uint32_t q = 0; q < 2; q++) {
+        const uint32_t f = 2 * t + q;
+        if (f < upe && u0 + f < nunits) len[q] = ((const uint16_t *)a.idx.ulen)[u0 + f];
+    }
+    const uint32_t bits = len[0] | len[1] << 12;
+    const uint32_t c = (uint32_t)(k / a.ix_per_chunk), jj = (uint32_t)(k - (uint64_t)c * a.ix_per_chunk);
+    uint8_t *e0 = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E) + IX_HEAD + (uint64_t)jj * a.ix_E;
+    const uint32_t fixed = 6 + B * (1 + tsz), nbytes = (upe * 12 + 7) / 8;
+    uint8_t *e = e0 + fixed + 3 * t;
+    for (uint32_t i = 0; i < 3; i++) if (3 * t + i < nbytes) e[i] = (uint8_t)(bits >> (8 * i));
+    for (uint32_t i = t; i < fixed; i += tpe) {         // bit position, a rung byte per band, the entering values
+        if (i < 6) e0[i] = (uint8_t)(a.idx.bitpos[k] >> (8 * i));
+        else if (i < 6 + B) e0[i] = a.idx.rung[k * B + (i - 6)];
+        else e0[i] = ((const uint8_t *)a.idx.prev)[k * B * tsz + (i - 6 - B)];
+    }
+}
+
 void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const uint32_t nt = a.ntiles;
     if (!a.single_pass) {
@@ -279,6 +308,10 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     if (a.hdr_len) hipLaunchKernelGGL(write_header_kernel, dim3(1, nt), dim3(64), 0, st, a);
     if (a.ix_dst && a.have_idx) hipLaunchKernelGGL(ix_fill_kernel, dim3((a.ix_K + 255) / 256, nt), dim3(256), 0, st, a);
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz >= 4) {
+        const uint32_t tpe = (a.ix_blocks * a.g.bands + 1) / 2;
+        hipLaunchKernelGGL(ix_blw_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * tpe + 255) / 256), nt), dim3(256), 0, st, a, tpe);
+    }
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 2) hipLaunchKernelGGL(ix_bl16_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 32 + 255) / 256), nt), dim3(256), 0, st, a);
 }
 

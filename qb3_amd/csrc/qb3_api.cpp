@@ -742,7 +742,8 @@ QB3_API size_t qb3x_header_size_bound(const void *container, size_t avail) {
     const size_t K = units / 12 + 1;
     // ... and a table of 8-bit data may carry ten bits per block on top (an entry per 64 blocks)
     const size_t nblk = ((w + 3) / 4) * ((h + 3) / 4);
-    const size_t bl = tsz == 1 ? (nblk / 64 + 1) * ((64 * IX_BL_BITS + 7) / 8) : tsz == 2 ? (nblk * (nb / 4 + 1) / 64 + 1) * ((128 * IX_BL_BITS + 7) / 8) : 0;
+    const size_t bl = tsz == 1 ? (nblk / 64 + 1) * ((64 * IX_BL_BITS + 7) / 8) : tsz == 2 ? (nblk * (nb / 4 + 1) / 64 + 1) * ((128 * IX_BL_BITS + 7) / 8)
+                               : (nblk * nb * IX_BL_BITS_WIDE) / 8 + (nblk / 12 + 1) * 2 + 64;       // (32/64-bit: a length per unit, an odd byte per entry)
     const size_t bytes = K * E + bl;
     return 128 + bytes + (bytes / 60000 + 1) * (IX_HEAD + IX_PAD);
 }
@@ -810,7 +811,7 @@ QB3_API bool qb3_read_info(decsp p) {
                 const size_t tsz = szof(p->type);
                 const uint32_t blocks = rd(pos + 8) | (rd(pos + 9) << 8) | (rd(pos + 10) << 16) | (rd(pos + 11) << 24);
                 const bool bl = (rd(pos + 5) & 2) != 0;     // entries end with their blocks' bit lengths
-                const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * ((rd(pos + 5) & 1) ? 2 : 1))) + (bl && blocks <= 4096 ? ((tsz == 1 ? blocks : 128u) * IX_BL_BITS + 7) / 8 : 0);
+                const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * ((rd(pos + 5) & 1) ? 2 : 1))) + (bl && blocks <= 4096 ? ((tsz == 1 ? blocks : tsz == 2 ? 128u : blocks * (uint32_t)p->nbands) * ix_bl_bits((uint32_t)tsz) + 7) / 8 : 0);
                 const size_t at = (size_t)(p->s_in - p->s_start) + pos;
                 const bool v2 = rd(pos + 4) == 2;
                 if ((len - IX_HEAD) % E || pos + len > n) p->ix_bad = true;

@@ -85,6 +85,7 @@ EncPlan plan_encode(const Geometry &g, bool allow_single_pass = true);
 // (the last one may hold fewer), each [12-byte head][entries][4-byte "zz" pad chunk]; `base` points at the first
 // chunk's first byte.  With it a stream that arrives without the out-of-band index is walked from K points at once.
 constexpr uint32_t IX_HEAD = 12, IX_PAD = 4;
+constexpr uint32_t IX_BL_BITS_WIDE = 12;  // ... of a unit length in a table of 32/64-bit data (a unit is at most 1048 bits; two fields are three whole bytes)
 constexpr uint32_t IX_BL_BITS = 10;       // bits of a block length in a table entry (8-bit data, at most four bands: 4 x 149 < 1024)
 struct IxTable {
     uint8_t *base = nullptr;        // device pointer (encode: where the chunks go, "DT" follows; decode: where they are)
@@ -96,6 +97,7 @@ struct IxTable {
 uint32_t ix_entry_bytes(const Geometry &g, bool block_lens = false);
 bool ix_block_lens_ok(const Geometry &g);         // can a table for this geometry carry block lengths
 uint32_t ix_bl_fields(const Geometry &g);         // ... how many fields an entry then ends with
+inline uint32_t ix_bl_bits(uint32_t tsz) { return tsz >= 4 ? IX_BL_BITS_WIDE : IX_BL_BITS; }
 // the table this library writes for a geometry (needs seg_blocks, nseg, bands, tsz, mode); K == 0: none
 IxTable ix_layout(const Geometry &g, int level = 1);       // level 2: with block lengths where the geometry allows
 inline size_t ix_chunks(const IxTable &t) { return t.per_chunk ? (t.K + t.per_chunk - 1) / t.per_chunk : 0; }

