@@ -58,7 +58,7 @@ def test_max_encoded_size_matches(qb3, oracle, w, h, b, dt):
 
 
 @pytest.mark.parametrize("w,h,b,dt,mode,lens", [(512, 512, 3, 0, 8, True), (509, 259, 1, 0, 4, True), (640, 384, 4, 0, 0, True), (16384, 16384, 3, 0, 8, True),
-                                                  (512, 512, 3, 0, 7, False), (256, 256, 5, 0, 8, False), (256, 256, 3, 2, 8, False), (256, 256, 1, 7, 4, False),
+                                                  (512, 512, 3, 0, 7, False), (256, 256, 5, 0, 8, False), (256, 256, 3, 2, 8, False), (256, 256, 1, 7, 5, False),
                                                   (8192, 8192, 8, 2, 4, True), (300, 200, 4, 3, 8, True), (256, 256, 16, 2, 8, False)])
 def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
     """qb3_max_encoded_size grows by exactly the table's chunks while qb3x_set_encoder_index_chunk is on (host logic, no GPU):
@@ -90,6 +90,22 @@ def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
         return nseg * entry + ((nseg + per_chunk - 1) // per_chunk) * 16
     fixed = 6 + b * (1 + tsz)
     assert one == room(fixed) and two == room(fixed + (80 if dt == 0 else 160))
+
+
+@pytest.mark.parametrize("w,h,b,dt,mode", [(4096, 4096, 1, 5, 8), (520, 300, 1, 7, 4), (160, 120, 5, 4, 8)])
+def test_room_for_unit_lengths_of_wide_types(qb3, w, h, b, dt, mode):
+    """32/64-bit rasters: a level 2 table carries twelve bits per unit on top of the level 1 table (host logic, no GPU)"""
+    L = qb3.lib
+    p = L.qb3_create_encoder(w, h, b, dt)
+    L.qb3_set_encoder_mode(p, mode)
+    base = L.qb3_max_encoded_size(p)
+    L.qb3x_set_encoder_index_chunk(p, 1)
+    one = L.qb3_max_encoded_size(p) - base
+    L.qb3x_set_encoder_index_chunk(p, 2)
+    two = L.qb3_max_encoded_size(p) - base
+    L.qb3_destroy_encoder(p)
+    units = ((w + 3) // 4) * ((h + 3) // 4) * b
+    assert one > 0 and units * 12 // 8 <= two - one <= units * 12 // 8 + units // 4 + 4096
 
 
 def test_setters_match_oracle(qb3, oracle):
