@@ -192,7 +192,9 @@ IxTable ix_layout(const Geometry &g, int level) {
     // (common-factor streams: the lane that starts at an entry parses whole units from global memory, bound by latency --
     // 64 units an entry keeps four times the lanes in flight that 256 did, for 1.5-3 % of the stream)
     // (... and 32 for 32/64-bit data, whose images have fewer units for the same bytes: a 4096 x 4096 band is 1 M units)
-    const uint64_t target = g.tsz >= 4 ? 32 : 64;
+    // (level 2, common-factor streams: the entries closer together -- 24 units, 12 for 32/64-bit data: two to three times the lanes,
+    // each with a piece as much shorter, for 10-20 % of the stream)
+    const uint64_t target = level >= 2 ? (g.tsz >= 4 ? 12 : 24) : (g.tsz >= 4 ? 32 : 64);
     const uint64_t spe = (per_seg || units_per_seg >= target) ? 1 : target / units_per_seg; // index segments per entry
     t.blocks = (uint32_t)(spe * g.seg_blocks);
     t.K = (uint32_t)((g.nseg + spe - 1) / spe);

@@ -1092,9 +1092,10 @@ print("ok")
 
 
 def test_block_lengths_only_where_the_decoder_uses_them(qb3, oracle):
-    """level 2 asked for a raster the 8-bit lane-per-block decoder does not take (16-bit, five bands, a common-factor mode):
-    the table is the level 1 table"""
-    for (w, h, b, dt, gen, mode) in [(256, 128, 2, 2, "LANDSAT16", FTL), (160, 120, 5, 0, "NOISY3", FTL), (256, 256, 3, 0, "NOISY3", 7)]:
+    """level 2 asked for a raster whose decoder takes no lengths (16-bit of two bands, 8-bit of five): the table is the level 1
+    table.  A common-factor stream has no length table at any level; its level 2 table has the entries closer together
+    (24 units, 12 for 32/64-bit data), and decodes from the container alone like the level 1 one"""
+    for (w, h, b, dt, gen, mode) in [(256, 128, 2, 2, "LANDSAT16", FTL), (160, 120, 5, 0, "NOISY3", FTL)]:
         img = oracle.generate(w, h, b, dt, gen, 3)
         cb = None if b in (1, 3, 4) else list(range(b))
         one = qb3.encode(img, dt, mode, cband=cb, index_chunk=1)
@@ -1102,6 +1103,24 @@ def test_block_lengths_only_where_the_decoder_uses_them(qb3, oracle):
         assert np.array_equal(one, two)
         out, _, _, _ = qb3.decode(two)
         assert np.array_equal(out, img.view(np.uint8).ravel())
+    for (w, h, b, dt, gen, mode) in [(256, 256, 3, 0, "NOISY3", 7), (300, 200, 1, 0, "PALETTE", 5), (256, 192, 8, 2, "LANDSAT16", 1),
+                                     (200, 160, 1, 5, "DEM", 5), (128, 128, 1, 7, "TERRACE", 7), (1024, 1024, 3, 0, "FEW", 5)]:
+        img = oracle.generate(w, h, b, dt, gen, 3)
+        cb = None if b in (1, 3, 4) else list(range(b))
+        ref = oracle.encode(img, dt, mode, cband=cb)
+        one = qb3.encode(img, dt, mode, cband=cb, index_chunk=1)
+        two = qb3.encode(img, dt, mode, cband=cb, index_chunk=2)
+        if ref[10] in (255, 2, 3, 6, 7):            # raw-stored, or the RLE0 pass won: no table either way
+            assert np.array_equal(one, ref) and np.array_equal(two, ref)
+            continue
+        assert len(two) > len(one) > len(ref)
+        extra, dt_at = len(two) - len(ref), bytes(ref).index(b"DT", 11)
+        assert bytes(two[:dt_at]) == bytes(ref[:dt_at]) and bytes(two[dt_at + extra:]) == bytes(ref[dt_at:])
+        want, _, _, _ = oracle.decode(two, identity=True)
+        assert want is not None and np.array_equal(want, img.view(np.uint8).ravel()), "the reference decoder must step over the chunks"
+        for c in (one, two):
+            out, _, _, _ = qb3.decode(c)
+            assert np.array_equal(out, img.view(np.uint8).ravel()), (w, h, b, dt, gen, mode)
 
 
 def test_tiles_with_block_length_tables(qb3, oracle):
