@@ -78,7 +78,10 @@ def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
     L.qb3_destroy_encoder(p)
     assert one > 0
     if not lens:
-        assert two == one
+        if mode in (1, 3, 5, 7):        # common-factor streams: no lengths, but the level 2 entries are closer together
+            assert one < two <= 3 * one
+        else:
+            assert two == one
         return
     nblocks = ((w + 3) // 4) * ((h + 3) // 4)
     per_seg = 64 if dt == 0 else 64 // (b // 4)         # 16-bit: four bands a lane of the decoder's wave
