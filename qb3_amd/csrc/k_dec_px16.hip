@@ -140,11 +140,12 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
             const uint8_t *pv = e + 6 + B + 2 * (band0 + c);
             pv0[c] = (uint32_t)pv[0] | (uint32_t)pv[1] << 8;
         }
-        const uint32_t bit = 2 * IX_BL_BITS * lane;                 // the lane's two fields
+        constexpr uint32_t FPL = BG == 4 ? 2 : 1;                   // fields a lane: two band pairs, or the one unit of a single band
+        const uint32_t bit = FPL * IX_BL_BITS * lane;
         const uint8_t *fp = e + 6 + 3 * B + (bit >> 3);
-        const uint32_t v = ((uint32_t)fp[0] | (uint32_t)fp[1] << 8 | (uint32_t)fp[2] << 16) >> (bit & 7);
+        const uint32_t v = ((uint32_t)fp[0] | (uint32_t)fp[1] << 8 | (FPL == 2 ? (uint32_t)fp[2] << 16 : 0u)) >> (bit & 7);
         f0 = act ? v & ((1u << IX_BL_BITS) - 1) : 0u;
-        f1 = act ? (v >> IX_BL_BITS) & ((1u << IX_BL_BITS) - 1) : 0u;
+        f1 = act && FPL == 2 ? (v >> IX_BL_BITS) & ((1u << IX_BL_BITS) - 1) : 0u;
         blen = f0 + f1;
     } else {
         P0 = a.idx.bitpos[segc];
@@ -214,7 +215,23 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
     uint32_t rp[BG][8], spk[NW], sinc[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) { dpk[k] = 0; spk[k] = 0; }
-    if (BL && BG == 4) {
+    if (BL && BG == 1) {
+        // a single band: the lane's unit starts where the scan of the lengths says
+        uint32_t rungs[1], tots[1] = { 0 }, ends[1] = { 0 };
+        const uint32_t lane0 = pos;
+        pos = pos < limit ? pos : limit;
+        bool sig; uint32_t csl;
+        const uint32_t d = px16_switch(pos, &csl, &sig);
+        gpos[0] = pos + csl;
+        if (act && sig && STEP) bad = true;             // common-factor / index unit: not handled here
+        uint32_t dsc[1] = { act ? d : 0u };
+        group_iscan<1>(dsc, NG);
+        rungs[0] = (rg0[0] + dsc[0]) & 15u;
+        if (__any(rungs[0] >= 8)) px16_groups_hi<STEP, 1>(&gpos[0], &rungs[0], &rp[0], &tots[0], &ends[0]);
+        if (rungs[0] < 8) tots[0] = px_group<STEP>(gpos[0], rungs[0], rp[0], &ends[0]);
+        if (act && ends[0] != lane0 + f0) bad = true;   // the table's length is not this unit's
+        spk[0] |= act ? tots[0] & 0xffffu : 0u;
+    } else if (BL && BG == 4) {
         // two rounds: bands 0 and 2 of the lane (their starts are known), then bands 1 and 3 (they start where 0 and 2 ended)
         uint32_t rungs[BG], tots[BG], ends[BG];
         const uint32_t lane0 = pos;
@@ -384,11 +401,12 @@ template <int BG, bool RGB>
 static void launch_dec_px16_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
     dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
-    if (BG == 4 && a.bl_mode) {
-        if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG == 4 ? 4 : BG, RGB, HILBERT, false, BG == 4>), grid, block, plan.lds_px, st, a);
-        else if (!z && step) hipLaunchKernelGGL((dec_px16_kernel<BG == 4 ? 4 : BG, RGB, HILBERT, true, BG == 4>), grid, block, plan.lds_px, st, a);
-        else if (z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG == 4 ? 4 : BG, RGB, ZCURVE, false, BG == 4>), grid, block, plan.lds_px, st, a);
-        else hipLaunchKernelGGL((dec_px16_kernel<BG == 4 ? 4 : BG, RGB, ZCURVE, true, BG == 4>), grid, block, plan.lds_px, st, a);
+    if ((BG == 4 || BG == 1) && a.bl_mode) {
+        constexpr bool bl = BG == 4 || BG == 1;
+        if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, false, bl>), grid, block, plan.lds_px, st, a);
+        else if (!z && step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, true, bl>), grid, block, plan.lds_px, st, a);
+        else if (z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, ZCURVE, false, bl>), grid, block, plan.lds_px, st, a);
+        else hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, ZCURVE, true, bl>), grid, block, plan.lds_px, st, a);
         return;
     }
     if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, false>), grid, block, plan.lds_px, st, a);

@@ -235,20 +235,21 @@ __global__ void __launch_bounds__(256) ix_bl16_fill_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     static_assert(IX_BL_BITS == 10, "groups of four fields are five bytes");
     const uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // fields 4 * grp .. 4 * grp + 3 of entry grp / 32
-    const uint32_t B = a.g.bands, NG = B / 4, NB = 64 / NG;
-    const uint64_t k = grp >> 5;
+    // (a single band: one field per lane -- the unit's length -- 64 fields an entry, 16 threads)
+    const uint32_t B = a.g.bands, FPL = B == 1 ? 1 : 2, NG = B == 1 ? 1 : B / 4, NB = 64 / NG, tpe = 16 * FPL;
+    const uint64_t k = grp / tpe;
     if (k >= a.ix_K) return;
-    const uint32_t t = (uint32_t)(grp & 31);
+    const uint32_t t = (uint32_t)(grp - k * tpe);
     uint64_t bits = 0;
 #pragma unroll
     for (uint32_t q = 0; q < 4; q++) {
-        const uint32_t field = 4 * t + q, lane = field >> 1, pair = field & 1;
+        const uint32_t field = 4 * t + q, lane = field / FPL, pair = field - lane * FPL;
         const uint32_t slot = lane / NG, g4 = lane - slot * NG;
         const uint64_t blk = k * NB + slot;
         uint32_t len = 0;
         if (blk < a.g.nblocks) {
             const uint16_t *ul = (const uint16_t *)a.idx.ulen + blk * B + 4 * g4 + 2 * pair;
-            len = (uint32_t)ul[0] + ul[1];
+            len = B == 1 ? (uint32_t)ul[0] : (uint32_t)ul[0] + ul[1];
         }
         bits |= (uint64_t)len << (IX_BL_BITS * q);
     }
@@ -312,7 +313,7 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
         const uint32_t tpe = (a.ix_blocks * a.g.bands + 1) / 2;
         hipLaunchKernelGGL(ix_blw_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * tpe + 255) / 256), nt), dim3(256), 0, st, a, tpe);
     }
-    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 2) hipLaunchKernelGGL(ix_bl16_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 32 + 255) / 256), nt), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 2) hipLaunchKernelGGL(ix_bl16_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * (a.g.bands == 1 ? 16 : 32) + 255) / 256), nt), dim3(256), 0, st, a);
 }
 
 }  // namespace qb3dev

@@ -164,7 +164,7 @@ uint32_t seg_blocks_for(const Geometry &g) {
 // fields of IX_BL_BITS bits behind an entry's fixed part: a block length per block of the segment (8-bit data) or two
 // band-pair lengths per lane of the decoder's wave (16-bit data, four bands a lane: 64 lanes)
 // ... or a unit length per unit of the segment (32/64-bit data: the unit-parallel decoder)
-uint32_t ix_bl_fields(const Geometry &g) { return g.tsz == 1 ? g.seg_blocks : g.tsz == 2 ? 128 : g.seg_blocks * g.bands; }
+uint32_t ix_bl_fields(const Geometry &g) { return g.tsz == 1 ? g.seg_blocks : g.tsz == 2 ? (g.bands == 1 ? 64 : 128) : g.seg_blocks * g.bands; }
 uint32_t ix_entry_bytes(const Geometry &g, bool block_lens) {
     return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)) + (block_lens ? (ix_bl_fields(g) * ix_bl_bits(g.tsz) + 7) / 8 : 0);
 }
@@ -177,6 +177,8 @@ bool ix_block_lens_ok(const Geometry &g) {
     if (!(g.order == HILBERT || g.order == ZCURVE)) return false;
     if (g.tsz == 1) return (g.bands == 1 || g.bands == 3 || g.bands == 4) && g.seg_blocks == 64;
     // 16-bit, four or eight bands: a lane of the decoder owns four bands = two pairs (two units of at most 278 bits fit ten bits)
+    // (a single band: a lane owns one unit, one field)
+    if (g.tsz == 2 && g.bands == 1) return g.seg_blocks == 64;
     return g.tsz == 2 && (g.bands == 4 || g.bands == 8) && g.seg_blocks == 64 / (g.bands / 4);
 }
 // One entry per index segment for FTL/BASE streams (a lane then walks one segment, lengths only, and the segment's
@@ -453,7 +455,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     // 32/64-bit FTL/BASE streams that bring a restart table with an entry per index segment: the lengths-only walk too
     const bool wide_walk = rebuild && a.ix && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
     const bool unit_parallel = !use_px && !use_px16 && plan.fast && !best && a.g.tsz >= 4;
-    if (rebuild && (use_px || (use_px16 && plan.px16_bg == 4) || unit_parallel) && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
+    if (rebuild && (use_px || (use_px16 && (plan.px16_bg == 4 || (plan.px16_bg == 1 && a.g.bands == 1))) || unit_parallel) && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
         // the container's table carries block (16-bit data: band pair) lengths: the lane-per-block decoder works from the entries alone
         DecArgs t = a;
         t.bl_mode = 1;

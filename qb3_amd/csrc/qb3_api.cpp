@@ -811,7 +811,7 @@ QB3_API bool qb3_read_info(decsp p) {
                 const size_t tsz = szof(p->type);
                 const uint32_t blocks = rd(pos + 8) | (rd(pos + 9) << 8) | (rd(pos + 10) << 16) | (rd(pos + 11) << 24);
                 const bool bl = (rd(pos + 5) & 2) != 0;     // entries end with their blocks' bit lengths
-                const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * ((rd(pos + 5) & 1) ? 2 : 1))) + (bl && blocks <= 4096 ? ((tsz == 1 ? blocks : tsz == 2 ? 128u : blocks * (uint32_t)p->nbands) * ix_bl_bits((uint32_t)tsz) + 7) / 8 : 0);
+                const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * ((rd(pos + 5) & 1) ? 2 : 1))) + (bl && blocks <= 4096 ? ((tsz == 1 ? blocks : tsz == 2 ? (p->nbands == 1 ? 64u : 128u) : blocks * (uint32_t)p->nbands) * ix_bl_bits((uint32_t)tsz) + 7) / 8 : 0);
                 const size_t at = (size_t)(p->s_in - p->s_start) + pos;
                 const bool v2 = rd(pos + 4) == 2;
                 if ((len - IX_HEAD) % E || pos + len > n) p->ix_bad = true;

@@ -59,7 +59,7 @@ def test_max_encoded_size_matches(qb3, oracle, w, h, b, dt):
 
 @pytest.mark.parametrize("w,h,b,dt,mode,lens", [(512, 512, 3, 0, 8, True), (509, 259, 1, 0, 4, True), (640, 384, 4, 0, 0, True), (16384, 16384, 3, 0, 8, True),
                                                   (512, 512, 3, 0, 7, False), (256, 256, 5, 0, 8, False), (256, 256, 3, 2, 8, False), (256, 256, 1, 7, 5, False),
-                                                  (8192, 8192, 8, 2, 4, True), (300, 200, 4, 3, 8, True), (256, 256, 16, 2, 8, False)])
+                                                  (8192, 8192, 8, 2, 4, True), (300, 200, 4, 3, 8, True), (256, 256, 16, 2, 8, False), (700, 300, 1, 2, 8, True)])
 def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
     """qb3_max_encoded_size grows by exactly the table's chunks while qb3x_set_encoder_index_chunk is on (host logic, no GPU):
     level 1 -- an entry per segment (FTL/BASE) of 6 + bands * (1 + size) bytes; level 2 -- 80 more bytes an entry where the
@@ -84,7 +84,7 @@ def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
             assert two == one
         return
     nblocks = ((w + 3) // 4) * ((h + 3) // 4)
-    per_seg = 64 if dt == 0 else 64 // (b // 4)         # 16-bit: four bands a lane of the decoder's wave
+    per_seg = 64 if dt == 0 else 64 // max(1, b // 4)   # 16-bit: four bands a lane of the decoder's wave (or the one band there is)
     nseg = (nblocks + per_seg - 1) // per_seg
     tsz = 1 if dt == 0 else 2
 
@@ -92,7 +92,7 @@ def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
         per_chunk = (65535 - 12) // entry
         return nseg * entry + ((nseg + per_chunk - 1) // per_chunk) * 16
     fixed = 6 + b * (1 + tsz)
-    assert one == room(fixed) and two == room(fixed + (80 if dt == 0 else 160))
+    assert one == room(fixed) and two == room(fixed + (80 if (dt == 0 or b == 1) else 160))
 
 
 @pytest.mark.parametrize("w,h,b,dt,mode", [(4096, 4096, 1, 5, 8), (520, 300, 1, 7, 4), (160, 120, 5, 4, 8)])

@@ -985,6 +985,7 @@ BL_CASES = [(256, 256, 3, 0, "NOISY3", FTL), (509, 259, 3, 0, "NOISY3", BASE), (
             # 16-bit, eight and four bands: two band-pair lengths per lane of the decoder's wave
             (256, 256, 8, 2, "LANDSAT16", BASE), (509, 259, 8, 2, "LANDSAT16", FTL), (300, 200, 4, 2, "LANDSAT16", BASE), (640, 384, 8, 3, "GRAD", FTL),
             (2048, 1024, 8, 2, "LANDSAT16", 0), (333, 77, 4, 3, "DEM", FTL),
+            (768, 512, 1, 2, "LANDSAT16", FTL), (509, 259, 1, 3, "DEM", BASE), (2048, 1024, 1, 2, "DEM", 0),     # one band: a field per lane
             # 32/64-bit: a twelve-bit length per unit, the unit-parallel decoder
             (256, 256, 1, 4, "DEM", FTL), (509, 259, 1, 5, "DEM", BASE), (300, 200, 3, 4, "DEM", FTL), (256, 256, 1, 6, "RUNG63", FTL),
             (520, 300, 1, 7, "DEM", BASE), (160, 120, 5, 4, "DEM", FTL), (1024, 1024, 1, 7, "DEM", 0)]
@@ -1021,9 +1022,9 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     per_seg = 64 if dt == 0 else 64 // max(1, b // 4)   # blocks of a decoder wave (8- and 16-bit data)
     assert mine[0][0] == b"ix" and host[mine[0][1] + 5] & 2, "entries are flagged as carrying block lengths"
     if dt <= 3:
-        nseg, entry = (nblocks + per_seg - 1) // per_seg, (6 + 2 * b + 80) if dt == 0 else (6 + 3 * b + 160)
+        lens_bytes = 80 if (dt == 0 or b == 1) else 160
+        nseg, entry = (nblocks + per_seg - 1) // per_seg, 6 + (2 if dt == 0 else 3) * b + lens_bytes
         assert sum(c[2] - 12 for c in mine if c[0] == b"ix") == nseg * entry
-        lens_bytes = 80 if dt == 0 else 160
     else:                               # blocks per entry are in the chunk head; a twelve-bit field per unit
         per_seg = int.from_bytes(bytes(host[mine[0][1] + 8:mine[0][1] + 12]), "little")
         lens_bytes = (per_seg * b * 12 + 7) // 8
