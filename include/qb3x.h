@@ -95,9 +95,9 @@ size_t qb3x_header_size_bound(const void *container, size_t avail);
  * Hilbert or Z order) the "ix" chunks' flag bit 1 is set and every entry (one per 64-block segment) ends with the bit
  * lengths of its segment's blocks, ten bits each, little endian: 80 more bytes, 5.5 % of a typical RGB stream instead of
  * 0.7 %.  The decoder then needs neither a walk nor an index -- one kernel, twice the decode rate from the container alone
- * (16384 x 16384 x 3: 0.37 ms instead of 0.65).  16-bit rasters of four or eight bands (FTL/BASE): an entry (one per 64 lanes of
- * the decoder's wave: 64 or 32 blocks) ends with two fields per lane -- the bit lengths of the lane's two band PAIRS, ten
- * bits each, 160 bytes -- about 5 % of a typical stream (8192 x 8192 x 8: 0.65 ms instead of 0.94); 16-bit rasters of ONE band:
+ * (16384 x 16384 x 3: 0.37 ms instead of 0.65).  16-bit rasters of 2, 3, 4, 6 or 8 bands (FTL/BASE): an entry (one per 64 lanes of
+ * the decoder's wave; a lane owns up to four bands of a block) ends with two fields per lane -- four bands: the bit lengths of the
+ * band PAIRS (0,1) and (2,3); three: of (0,1) and of band 2; two: of each band -- ten bits each, 160 bytes -- about 5 % of a typical stream (8192 x 8192 x 8: 0.65 ms instead of 0.94); 16-bit rasters of ONE band:
  * a field per block (its unit's length), 80 bytes an entry.  32/64-bit rasters
  * (FTL/BASE, where the unit-parallel decoder applies): an entry ends with a twelve-bit length per UNIT of its segment
  * (band-minor, little endian) -- about 10 % of a stream of small units (4096 x 4096 int32: 0.06 ms instead of 0.40).

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
             const uint8_t *pv = e + 6 + B + 2 * (band0 + c);
             pv0[c] = (uint32_t)pv[0] | (uint32_t)pv[1] << 8;
         }
-        constexpr uint32_t FPL = BG == 4 ? 2 : 1;                   // fields a lane: two band pairs, or the one unit of a single band
+        constexpr uint32_t FPL = BG == 1 ? 1 : 2;                   // fields a lane: two (band pairs; pair and band; two bands), or the one unit of a single band
         const uint32_t bit = FPL * IX_BL_BITS * lane;
         const uint8_t *fp = e + 6 + 3 * B + (bit >> 3);
         const uint32_t v = ((uint32_t)fp[0] | (uint32_t)fp[1] << 8 | (FPL == 2 ? (uint32_t)fp[2] << 16 : 0u)) >> (bit & 7);
@@ -231,18 +231,21 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
         if (rungs[0] < 8) tots[0] = px_group<STEP>(gpos[0], rungs[0], rp[0], &ends[0]);
         if (act && ends[0] != lane0 + f0) bad = true;   // the table's length is not this unit's
         spk[0] |= act ? tots[0] & 0xffffu : 0u;
-    } else if (BL && BG == 4) {
-        // two rounds: bands 0 and 2 of the lane (their starts are known), then bands 1 and 3 (they start where 0 and 2 ended)
+    } else if (BL && BG >= 2) {
+        // The lane's fields give two starts.  Four bands: the pairs (0,1) and (2,3) -- bands 0 and 2 walk in lockstep, then bands 1
+        // and 3 from where those ended.  Three: (0,1) and band 2 -- bands 0 and 2, then band 1.  Two: a field per band, one round.
         uint32_t rungs[BG], tots[BG], ends[BG];
-        const uint32_t lane0 = pos;
-        uint32_t start[2] = { pos, pos + f0 };
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
+        for (int c = 0; c < BG; c++) { rungs[c] = 0; tots[c] = 0; ends[c] = 0; }
+        const uint32_t lane0 = pos;
+        auto round = [&](auto nc, auto rsc, auto c0c, uint32_t s0, uint32_t s1) {
+            constexpr int N = decltype(nc)::value, RS = decltype(rsc)::value, C0 = decltype(c0c)::value;
+            const uint32_t st[2] = { s0, s1 };
             uint32_t dd = 0;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int c = 2 * h + r;                // round 0: bands 0, 2; round 1: bands 1, 3
-                uint32_t p0 = start[h];
+            for (int h = 0; h < N; h++) {
+                const int c = C0 + h * RS;
+                uint32_t p0 = st[h];
                 p0 = p0 < limit ? p0 : limit;
                 bool sig; uint32_t csl;
                 const uint32_t d = px16_switch(p0, &csl, &sig);
@@ -251,26 +254,38 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
                 dd |= (act ? d : 0u) << (16 * h);
             }
             uint32_t dsc[1] = { dd };
-            group_iscan<1>(dsc, NG);                    // inclusive, the two bands' rung changes 16 bits each
+            group_iscan<1>(dsc, NG);                    // inclusive, the bands' rung changes 16 bits each
             bool lane_hi = false, lane_lo = false;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int c = 2 * h + r;
+            for (int h = 0; h < N; h++) {
+                const int c = C0 + h * RS;
                 rungs[c] = (rg0[c] + ((dsc[0] >> (16 * h)) & 0xffffu)) & 15u;
                 lane_hi = lane_hi || rungs[c] >= 8; lane_lo = lane_lo || rungs[c] < 8;
-                tots[c] = 0; ends[c] = 0;
             }
-            if (__any(lane_hi)) px16_groups_hi<STEP, 2, 2>(&gpos[r], &rungs[r], &rp[r], &tots[r], &ends[r]);
+            if (__any(lane_hi)) px16_groups_hi<STEP, N, RS>(&gpos[C0], &rungs[C0], &rp[C0], &tots[C0], &ends[C0]);
             if (__any(lane_lo)) {
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int c = 2 * h + r;
+                for (int h = 0; h < N; h++) {
+                    const int c = C0 + h * RS;
                     if (rungs[c] < 8) tots[c] = px_group<STEP>(gpos[c], rungs[c], rp[c], &ends[c]);
                 }
             }
-            start[0] = ends[r]; start[1] = ends[2 + r];
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        bool ok;
+        if constexpr (BG == 4) {
+            round(I2(), I2(), I0(), pos, pos + f0);
+            round(I2(), I2(), I1(), ends[0], ends[2]);
+            ok = ends[1] == lane0 + f0 && ends[3] == lane0 + f0 + f1;
+        } else if constexpr (BG == 3) {
+            round(I2(), I2(), I0(), pos, pos + f0);
+            round(I1(), I1(), I1(), ends[0], 0u);
+            ok = ends[1] == lane0 + f0 && ends[2] == lane0 + f0 + f1;
+        } else {
+            round(I2(), I1(), I0(), pos, pos + f0);
+            ok = ends[0] == lane0 + f0 && ends[1] == lane0 + f0 + f1;
         }
-        if (act && (ends[1] != lane0 + f0 || ends[3] != lane0 + f0 + f1)) bad = true;     // the table's lengths are not this stream's
+        if (act && !ok) bad = true;                     // the table's lengths are not this stream's
 #pragma unroll
         for (int c = 0; c < BG; c++) spk[c >> 1] |= (act ? tots[c] & 0xffffu : 0u) << (16 * (c & 1));
     } else {
@@ -401,8 +416,8 @@ template <int BG, bool RGB>
 static void launch_dec_px16_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
     dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
-    if ((BG == 4 || BG == 1) && a.bl_mode) {
-        constexpr bool bl = BG == 4 || BG == 1;
+    if (a.bl_mode) {
+        constexpr bool bl = true;
         if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, false, bl>), grid, block, plan.lds_px, st, a);
         else if (!z && step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, true, bl>), grid, block, plan.lds_px, st, a);
         else if (z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, ZCURVE, false, bl>), grid, block, plan.lds_px, st, a);

@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) ix_bl16_fill_kernel(const EncArgs a0) {
     static_assert(IX_BL_BITS == 10, "groups of four fields are five bytes");
     const uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // fields 4 * grp .. 4 * grp + 3 of entry grp / 32
     // (a single band: one field per lane -- the unit's length -- 64 fields an entry, 16 threads)
-    const uint32_t B = a.g.bands, FPL = B == 1 ? 1 : 2, NG = B == 1 ? 1 : B / 4, NB = 64 / NG, tpe = 16 * FPL;
+    const uint32_t B = a.g.bands, BG = B <= 4 ? B : (B % 4 == 0 ? 4 : 2), FPL = B == 1 ? 1 : 2, NG = B / BG, NB = 64 / NG, tpe = 16 * FPL;
     const uint64_t k = grp / tpe;
     if (k >= a.ix_K) return;
     const uint32_t t = (uint32_t)(grp - k * tpe);
@@ -247,9 +247,13 @@ __global__ void __launch_bounds__(256) ix_bl16_fill_kernel(const EncArgs a0) {
         const uint32_t slot = lane / NG, g4 = lane - slot * NG;
         const uint64_t blk = k * NB + slot;
         uint32_t len = 0;
-        if (blk < a.g.nblocks) {
-            const uint16_t *ul = (const uint16_t *)a.idx.ulen + blk * B + 4 * g4 + 2 * pair;
-            len = B == 1 ? (uint32_t)ul[0] : (uint32_t)ul[0] + ul[1];
+        if (slot < NB && blk < a.g.nblocks) {       // (lanes behind the segment's blocks x groups: nothing)
+            // the lane's bands: BG from band BG * g4; four: the pairs (0,1), (2,3); three: (0,1) and band 2; two: a field a band; one: the unit
+            const uint16_t *ul = (const uint16_t *)a.idx.ulen + blk * B + BG * g4;
+            if (BG == 1) len = ul[0];
+            else if (BG == 2) len = ul[pair];
+            else if (BG == 3) len = pair ? (uint32_t)ul[2] : (uint32_t)ul[0] + ul[1];
+            else len = (uint32_t)ul[2 * pair] + ul[2 * pair + 1];
         }
         bits |= (uint64_t)len << (IX_BL_BITS * q);
     }

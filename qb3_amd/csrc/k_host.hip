@@ -177,9 +177,11 @@ bool ix_block_lens_ok(const Geometry &g) {
     if (!(g.order == HILBERT || g.order == ZCURVE)) return false;
     if (g.tsz == 1) return (g.bands == 1 || g.bands == 3 || g.bands == 4) && g.seg_blocks == 64;
     // 16-bit, four or eight bands: a lane of the decoder owns four bands = two pairs (two units of at most 278 bits fit ten bits)
-    // (a single band: a lane owns one unit, one field)
-    if (g.tsz == 2 && g.bands == 1) return g.seg_blocks == 64;
-    return g.tsz == 2 && (g.bands == 4 || g.bands == 8) && g.seg_blocks == 64 / (g.bands / 4);
+    // 16-bit data the lane-per-block decoder takes, up to eight bands: a lane owns up to four bands (a single band: one unit, one field)
+    if (g.tsz != 2 || g.bands > 8) return false;
+    uint32_t bg = 0, ng = 0;
+    px16_split(g.bands, &bg, &ng);
+    return bg != 0 && g.seg_blocks == 64 / ng;
 }
 // One entry per index segment for FTL/BASE streams (a lane then walks one segment, lengths only, and the segment's
 // entering values come straight from its entry), one per about 64 units for the common-factor modes.  For 8-bit RGB
@@ -455,7 +457,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     // 32/64-bit FTL/BASE streams that bring a restart table with an entry per index segment: the lengths-only walk too
     const bool wide_walk = rebuild && a.ix && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
     const bool unit_parallel = !use_px && !use_px16 && plan.fast && !best && a.g.tsz >= 4;
-    if (rebuild && (use_px || (use_px16 && (plan.px16_bg == 4 || (plan.px16_bg == 1 && a.g.bands == 1))) || unit_parallel) && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
+    if (rebuild && (use_px || (use_px16 && ix_block_lens_ok(a.g)) || unit_parallel) && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
         // the container's table carries block (16-bit data: band pair) lengths: the lane-per-block decoder works from the entries alone
         DecArgs t = a;
         t.bl_mode = 1;

@@ -58,8 +58,8 @@ def test_max_encoded_size_matches(qb3, oracle, w, h, b, dt):
 
 
 @pytest.mark.parametrize("w,h,b,dt,mode,lens", [(512, 512, 3, 0, 8, True), (509, 259, 1, 0, 4, True), (640, 384, 4, 0, 0, True), (16384, 16384, 3, 0, 8, True),
-                                                  (512, 512, 3, 0, 7, False), (256, 256, 5, 0, 8, False), (256, 256, 3, 2, 8, False), (256, 256, 1, 7, 5, False),
-                                                  (8192, 8192, 8, 2, 4, True), (300, 200, 4, 3, 8, True), (256, 256, 16, 2, 8, False), (700, 300, 1, 2, 8, True)])
+                                                  (512, 512, 3, 0, 7, False), (256, 256, 5, 0, 8, False), (256, 256, 3, 2, 8, True), (256, 128, 5, 2, 8, False), (256, 256, 1, 7, 5, False),
+                                                  (8192, 8192, 8, 2, 4, True), (300, 200, 4, 3, 8, True), (256, 256, 16, 2, 8, False), (700, 300, 1, 2, 8, True), (300, 200, 3, 2, 4, True), (320, 240, 6, 3, 8, True)])
 def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
     """qb3_max_encoded_size grows by exactly the table's chunks while qb3x_set_encoder_index_chunk is on (host logic, no GPU):
     level 1 -- an entry per segment (FTL/BASE) of 6 + bands * (1 + size) bytes; level 2 -- 80 more bytes an entry where the
@@ -84,7 +84,8 @@ def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
             assert two == one
         return
     nblocks = ((w + 3) // 4) * ((h + 3) // 4)
-    per_seg = 64 if dt == 0 else 64 // max(1, b // 4)   # 16-bit: four bands a lane of the decoder's wave (or the one band there is)
+    bg16 = b if b <= 4 else (4 if b % 4 == 0 else 2)    # 16-bit: bands a lane of the decoder's wave owns
+    per_seg = 64 if dt == 0 else 64 // (b // bg16)
     nseg = (nblocks + per_seg - 1) // per_seg
     tsz = 1 if dt == 0 else 2
 

@@ -986,6 +986,7 @@ BL_CASES = [(256, 256, 3, 0, "NOISY3", FTL), (509, 259, 3, 0, "NOISY3", BASE), (
             (256, 256, 8, 2, "LANDSAT16", BASE), (509, 259, 8, 2, "LANDSAT16", FTL), (300, 200, 4, 2, "LANDSAT16", BASE), (640, 384, 8, 3, "GRAD", FTL),
             (2048, 1024, 8, 2, "LANDSAT16", 0), (333, 77, 4, 3, "DEM", FTL),
             (768, 512, 1, 2, "LANDSAT16", FTL), (509, 259, 1, 3, "DEM", BASE), (2048, 1024, 1, 2, "DEM", 0),     # one band: a field per lane
+            (300, 200, 3, 2, "LANDSAT16", FTL), (256, 256, 2, 3, "DEM", BASE), (320, 240, 6, 2, "LANDSAT16", FTL), (1024, 512, 3, 2, "LANDSAT16", 0),
             # 32/64-bit: a twelve-bit length per unit, the unit-parallel decoder
             (256, 256, 1, 4, "DEM", FTL), (509, 259, 1, 5, "DEM", BASE), (300, 200, 3, 4, "DEM", FTL), (256, 256, 1, 6, "RUNG63", FTL),
             (520, 300, 1, 7, "DEM", BASE), (160, 120, 5, 4, "DEM", FTL), (1024, 1024, 1, 7, "DEM", 0)]
@@ -1019,7 +1020,8 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
     _, seen = walk_chunks(host, False)
     mine = [c for c in seen if c[1] >= dt_at]
     nblocks = ((w + 3) // 4) * ((h + 3) // 4)
-    per_seg = 64 if dt == 0 else 64 // max(1, b // 4)   # blocks of a decoder wave (8- and 16-bit data)
+    bg16 = b if b <= 4 else (4 if b % 4 == 0 else 2)    # 16-bit: bands a lane of the decoder owns
+    per_seg = 64 if dt == 0 else 64 // (b // bg16)      # blocks of a decoder wave (8- and 16-bit data)
     assert mine[0][0] == b"ix" and host[mine[0][1] + 5] & 2, "entries are flagged as carrying block lengths"
     if dt <= 3:
         lens_bytes = 80 if (dt == 0 or b == 1) else 160
@@ -1093,10 +1095,10 @@ print("ok")
 
 
 def test_block_lengths_only_where_the_decoder_uses_them(qb3, oracle):
-    """level 2 asked for a raster whose decoder takes no lengths (16-bit of two bands, 8-bit of five): the table is the level 1
+    """level 2 asked for a raster whose decoder takes no lengths (16-bit or 8-bit of five bands): the table is the level 1
     table.  A common-factor stream has no length table at any level; its level 2 table has the entries closer together
     (24 units, 12 for 32/64-bit data), and decodes from the container alone like the level 1 one"""
-    for (w, h, b, dt, gen, mode) in [(256, 128, 2, 2, "LANDSAT16", FTL), (160, 120, 5, 0, "NOISY3", FTL)]:
+    for (w, h, b, dt, gen, mode) in [(256, 128, 5, 2, "LANDSAT16", FTL), (160, 120, 5, 0, "NOISY3", FTL)]:
         img = oracle.generate(w, h, b, dt, gen, 3)
         cb = None if b in (1, 3, 4) else list(range(b))
         one = qb3.encode(img, dt, mode, cband=cb, index_chunk=1)
