@@ -116,14 +116,14 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
 __global__ void enc_seam_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-    if (a.have_idx && !a.single_pass)        // (the single-pass encoder wrote final positions)
+    if (a.have_idx)
         for (uint64_t sgi = k; sgi < a.g.nseg; sgi += nthreads) {
             const uint64_t v = a.idx.bitpos[sgi];
             a.idx.bitpos[sgi] = chunk_start(a, (uint32_t)(v >> 32)) + (v & 0xffffffffu);
         }
     if (k > a.nchunks) return;
     const uint64_t Ek = (uint64_t)a.out_bit0 + chunk_start(a, k);
-    if (k == a.nchunks) { a.res->total_bits = Ek - a.out_bit0; a.res->error = a.single_pass ? (uint32_t)a.lookback[a.nchunks] : 0u; }
+    if (k == a.nchunks) { a.res->total_bits = Ek - a.out_bit0; a.res->error = 0u; }
     if ((Ek & 31) == 0) return;
     const uint64_t d = Ek >> 5;
     if (k > 0) { const uint64_t Ep = (uint64_t)a.out_bit0 + chunk_start(a, k - 1); if ((Ep >> 5) == d && (Ep & 31)) return; }
@@ -299,12 +299,12 @@ __global__ void __launch_bounds__(256) ix_blw_fill_kernel(const EncArgs a0, cons
 
 void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const uint32_t nt = a.ntiles;
-    if (!a.single_pass) {
-        {
-            ProfScope ps("enc_scan", st);
-            hipLaunchKernelGGL(enc_scan_kernel, dim3((plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP, nt), dim3(SCAN_GROUP / 4), 0, st, a);
-            hipLaunchKernelGGL(enc_scan2_kernel, dim3(1, nt), dim3(1024), 0, st, a);
-        }
+    {
+        ProfScope ps("enc_scan", st);
+        hipLaunchKernelGGL(enc_scan_kernel, dim3((plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP, nt), dim3(SCAN_GROUP / 4), 0, st, a);
+        hipLaunchKernelGGL(enc_scan2_kernel, dim3(1, nt), dim3(1024), 0, st, a);
+    }
+    {
         ProfScope ps("enc_concat", st);
         hipLaunchKernelGGL(enc_concat_kernel, dim3((plan.nchunks + 3) / 4, nt), dim3(256), 0, st, a);
     }

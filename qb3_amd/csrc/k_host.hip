@@ -53,11 +53,7 @@ const Tuning &tuning() {
         const char *cap = getenv("QB3_WALK_TAB_KB"); // plain 8-bit streams: bytes of table memory (a small one means many rounds)
         v.walk_tab_kb = cap ? (size_t)strtoull(cap, nullptr, 10) : 0;
         v.slow_index = on("QB3_SLOW_INDEX");         // index-less streams: the one-lane index rebuild instead of the walkers
-        // 8-bit lane-per-block encoder: look-back and in-place writes instead of slots + concatenate; 1: a look-back per chunk
-        // 2: per super-chunk (both measured slower than slots + concatenate)
-        { const char *e = getenv("QB3_SINGLE_PASS"); v.single_pass = e && e[0] ? atoi(e) : 0; }
         v.no_bl = on("QB3_NO_BLOCK_LENGTHS");        // containers whose table carries block lengths: walk them like the others
-        v.persistent = on("QB3_PERSISTENT");         // 8-bit lane-per-block encoder: persistent workgroups instead of a workgroup per chunk (measured slower)
         return v;
     }();
     return t;
@@ -234,8 +230,8 @@ uint32_t max_unit_bits(uint32_t tsz, uint32_t mode) {
 }
 
 // encoder workspace layout (all 8-byte aligned), EncResult last
-struct EncWs { size_t bits, off, gsum, lookback, seams, scratch, cwhas, cwval, centry, cparts, cwused, segfe, rneed, rlist, res, total; uint32_t slot_dw, ngroups; };
-static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, uint32_t threads, bool with_slots = true) {
+struct EncWs { size_t bits, off, gsum, seams, scratch, cwhas, cwval, centry, cparts, cwused, segfe, rneed, rlist, res, total; uint32_t slot_dw, ngroups; };
+static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, uint32_t threads) {
     EncWs w;
     // a multiple of 4 dwords: slots are 16-byte aligned (the px kernel copies them out as uint4)
     w.slot_dw = (uint32_t)(((31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1 + 3) & ~(size_t)3);
@@ -244,10 +240,9 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, ui
     w.bits = o; o += align8(4 * (size_t)nchunks);
     w.off = o; o += 8 * (size_t)nchunks;
     w.gsum = o; o += 8 * ((size_t)w.ngroups + 1);
-    w.lookback = o; o += 8 * ((size_t)nchunks + 2);        // (right behind gsum: the single-pass encoder zeroes both with one memset; + abort flag, ticket counter)
     w.seams = o; o += 8 * (size_t)nchunks;
     o = (o + 15) & ~(size_t)15;
-    w.scratch = o; o += with_slots ? align8(4 * (size_t)nchunks * w.slot_dw) : 0;      // (the single-pass encoder has no slots)
+    w.scratch = o; o += align8(4 * (size_t)nchunks * w.slot_dw);
     const size_t nb = g.mode == CM_BEST ? (size_t)nchunks * g.bands : 0;
     w.cwhas = o; o += align8(nb);
     w.cwval = o; o += 8 * nb;
@@ -296,23 +291,16 @@ static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *
     return ident || def;
 }
 
-EncPlan plan_encode(const Geometry &g, bool allow_single_pass) {
+EncPlan plan_encode(const Geometry &g) {
     EncPlan p;
     const uint32_t dpr = g.bands * g.tsz;
     p.px = px_eligible(g, &p.px_rgb);
     p.px16 = false; p.px16_bg = p.px16_ng = 0;
-    p.single_pass = 0; p.persistent = false; p.sc_cap_dw = 0;
     if (p.px) {
-        p.single_pass = allow_single_pass ? tuning().single_pass : 0;
-        p.persistent = tuning().persistent;
         p.threads = 256; p.slots = 256; p.nbp = 255;
         p.nchunks = (uint32_t)((g.nblocks + 254) / 255);
-        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp, p.threads, !p.single_pass);
-        p.lds_bytes = 2048 + 256 + 4 * (size_t)L.slot_dw + 16;      // (+16: the single-pass write-out reads whole 16-byte groups)
-        if (p.single_pass == 2) {       // the stream buffer of a super-chunk: three workgroups share a CU's 160 KB
-            p.sc_cap_dw = 12544;       // (LDS is handed out in granules: 3 x the rounded size must fit)
-            p.lds_bytes = 2048 + 256 + 256 + 4 * (size_t)p.sc_cap_dw + 16;
-        }
+        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp, p.threads);
+        p.lds_bytes = 2048 + 256 + 4 * (size_t)L.slot_dw;
         p.ws_bytes = L.total;
         return p;
     }
@@ -341,11 +329,6 @@ EncPlan plan_encode(const Geometry &g, bool allow_single_pass) {
 static int launch_encode_all(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     if (a.g.mode == CM_BEST) launch_enc_best(a, plan, st);
     else if (plan.px && a.g.tsz == 1) {
-        if (a.single_pass) {        // the look-back words, the abort flag behind them, the (unused) group sums in front: zero per launch
-            const size_t bytes = 8 * ((size_t)(plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP + 1) + 8 * ((size_t)plan.nchunks + 2);
-            if (a.ntiles > 1) HIPCHK(hipMemset2DAsync(a.group_sum, a.ts_ws, 0, bytes, a.ntiles, st));
-            else HIPCHK(hipMemsetAsync(a.group_sum, 0, bytes, st));
-        }
         ProfScope ps("enc_units", st);
         launch_enc_px(a, plan, st);
     }
@@ -370,15 +353,12 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
     a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
     uint8_t *w = (uint8_t *)ws;
-    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp, plan.threads, !(plan.px && plan.single_pass));
+    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp, plan.threads);
     a.chunk_bits = (uint32_t *)(w + L.bits);
     a.chunk_off = (uint64_t *)(w + L.off);
     a.group_sum = (uint64_t *)(w + L.gsum);
     a.seams = (uint32_t *)(w + L.seams);
     a.scratch = (uint32_t *)(w + L.scratch);
-    a.lookback = (uint64_t *)(w + L.lookback);
-    a.single_pass = (plan.px && plan.single_pass && g.tsz == 1 && g.mode != CM_BEST) ? (uint32_t)plan.single_pass : 0u;
-    a.sc_cap_dw = plan.sc_cap_dw;
     a.cw_has = w + L.cwhas; a.cw_val = (uint64_t *)(w + L.cwval); a.centry = (uint64_t *)(w + L.centry); a.centry_parts = (uint32_t *)(w + L.cparts); a.recode_n = a.centry_parts + 32 * MAXBANDS;
     a.cw_used = w + L.cwused; a.seg_from_entry = w + L.segfe; a.recode_need = (uint32_t *)(w + L.rneed); a.recode_list = (uint32_t *)(w + L.rlist);
     a.slot_dw = L.slot_dw;

@@ -178,7 +178,6 @@ struct encs {
     qb3_dtype type;
     bool away;
     int ix_chunk;           // qb3x_set_encoder_index_chunk: embed the restart table ("ix" chunks); 2: with block lengths
-    bool no_single_pass;    // the single-pass encoder gave up once on this handle: slots + concatenation from then on
     DevBuf d_img, d_out, d_ws, d_q, d_idx, d_rle;      // d_rle: workspace of the RLE0 passes (k_rle0.hip)
     Stager stager;
 };
@@ -247,7 +246,6 @@ QB3_API encsp qb3_create_encoder(size_t w, size_t h, size_t b, qb3_dtype dt) {
     p->xsize = w; p->ysize = h; p->nbands = b; p->type = dt;
     p->stride = 0; p->order = 0; p->quanta = 1; p->away = false; p->mode = QB3M_DEFAULT; p->error = 0;
     { const char *e = getenv("QB3X_INDEX_CHUNK"); p->ix_chunk = e ? (atoi(e) >= 2 ? 2 : atoi(e) != 0) : 0; }
-    p->no_single_pass = false;     // for callers that only know the reference API
     for (size_t c = 0; c < QB3_MAXBANDS; c++) p->cband[c] = c < b ? c : 0;
     if (b == 3 || b == 4) p->cband[0] = p->cband[2] = 1;
     qb3_reset_encoder(p);
@@ -381,7 +379,7 @@ static size_t stored_encode_host(encsp p, const void *source, void *destination)
 static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, uint8_t *d_out, size_t hdr,
                                  void *d_index, hipStream_t st, bool carry, uint64_t *bits, const uint8_t *hdrbytes,
                                  size_t hdr_stamp, const IxTable &ix) {
-    EncPlan plan = plan_encode(g, !p->no_single_pass);
+    EncPlan plan = plan_encode(g);
     if (!p->d_ws.ensure(plan.ws_bytes)) return false;
     BandState bs;
     memset(&bs, 0, sizeof(bs));
@@ -395,13 +393,6 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     const hipError_t e = fetch_small(&res, dres, sizeof(res), st);
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
     prof_collect();
-    if (res.error && plan.single_pass) {
-        // the single-pass encoder gave up on a look-back wait (a workgroup of its grid was not resident: the occupancy
-        // query promised more than the device admitted).  Nothing is lost: code again through slots + concatenation,
-        // and keep doing so on this handle.
-        p->no_single_pass = true;
-        return encode_blocks_device(p, g, d_img, d_out, hdr, d_index, st, carry, bits, hdrbytes, hdr_stamp, ix);
-    }
     *bits = res.total_bits;
     if (carry)
         for (size_t c = 0; c < p->nbands; c++) {
@@ -615,7 +606,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
     uint8_t hdrbuf[80];
     size_t hdr = write_headers(p, hdrbuf);
     Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, p->mode, p->cband, nullptr);
-    EncPlan plan = plan_encode(g, !p->no_single_pass);
+    EncPlan plan = plan_encode(g);
     size_t wsp = (plan.ws_bytes + 255) & ~(size_t)255;
     size_t batch = (size_t)8 << 30 >= wsp ? ((size_t)8 << 30) / wsp : 1;     // keep the workspace under 8 GiB
     if (batch > n) batch = n;
@@ -656,13 +647,6 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("encode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
         prof_collect();
-        bool gave_up = false;
-        for (size_t i = 0; i < cnt; i++) gave_up = gave_up || (res[i].error && plan.single_pass);
-        if (gave_up) {          // see encode_blocks_device: the whole call again, through the slots
-            p->no_single_pass = true;
-            p->mode = mode;
-            return qb3x_encode_tiles(p, d_src, n, src_pitch, d_dst, dst_pitch, d_index, sizes, stream);
-        }
         const size_t raw = p->xsize * p->ysize * p->nbands * tsz;
         for (size_t i = 0; i < cnt; i++) {
             const size_t len = hdr + (size_t)((res[i].total_bits + 7) / 8);

@@ -69,15 +69,12 @@ struct EncPlan {
     size_t lds_bytes;
     size_t ws_bytes;        // chunk counts/offsets, seam table, per-chunk scratch slots, EncResult (last)
     uint32_t nbp;           // payload blocks per chunk
-    bool persistent;        // ... with persistent workgroups (a chunk's pixels arrive while the previous chunk's bits leave)
-    int single_pass;        // ... and writes the stream in place (persistent workgroups, look-back) instead of slots + concatenate; 2: by super-chunks
-    uint32_t sc_cap_dw;     //     ... dwords of the LDS stream buffer then
     bool px;                // 8-bit 1/3/4-band register-resident kernel applies (lane per block)
     bool px_rgb;            //   ... with the default R-G,G,B-G map (else identity)
     bool px16;              // 16-bit register-resident kernel applies (lane per block and band group)
     uint32_t px16_bg, px16_ng;      //   ... bands per lane (1..4), lanes per block
 };
-EncPlan plan_encode(const Geometry &g, bool allow_single_pass = true);
+EncPlan plan_encode(const Geometry &g);
 
 // Optional restart table carried INSIDE the container as ignorable chunks ("ix", include/qb3x.h): K entries, one per
 // `blocks` blocks: [bit position, 6 bytes][rung, 1 byte per band][prev, tsz bytes per band][cf, the same,

@@ -10,10 +10,9 @@
 //   previous block, and the rung-switch code needs only the previous block's rung, so a chunk is self-contained
 //   once it also looks at ONE halo block.  Units are coded once, into an LDS bit buffer starting at bit 0 of the
 //   chunk; the only global dependency is the chunk's bit offset (64-bit: a 16384^2 x 3 stream exceeds 2^32 bits).
-//   Two ways to resolve it: (a) slots -- the chunk's bits go to a private slot in the workspace, a two-level scan
-//   of the chunk totals gives the offsets, enc_concat_kernel funnel-shifts every slot into place; (b) single pass
-//   -- a persistent workgroup publishes its chunk total, sums its predecessors' (decoupled look-back) and writes
-//   from LDS straight to the final position (k_enc_px.hip).  Dwords shared by two chunks are assembled by
+//   The chunk's bits go to a private slot in the workspace, a two-level scan of the chunk totals gives the offsets,
+//   enc_concat_kernel funnel-shifts every slot into place (single-pass variants with a decoupled look-back were built
+//   and measured slower on this part).  Dwords shared by two chunks are assembled by
 //   enc_seam_kernel from a two-entry-per-chunk seam table: no memset of the output, no global atomics on it.
 //   8-bit grey/RGB/RGBA and 16-bit rasters use lane-per-block kernels that keep the block in registers
 //   (k_enc_px.hip, k_enc_px16.hip); everything else the unit-per-lane kernels (k_enc_generic.hip, k_enc_best.hip).
@@ -206,9 +205,6 @@ struct EncArgs {
     uint8_t *cw_used;       //   ... per chunk and band: something in the chunk depended on the factor on entry
     uint8_t *seg_from_entry;    //   ... per index segment and band: its factor entry is the chunk's entering factor
     uint32_t *recode_need, *recode_list, *recode_n;    //   ... chunks to code again: flag per chunk, list, count
-    uint64_t *lookback;     // single-pass encoder: per chunk {state, bit count} words, then the abort flag (zeroed per launch)
-    uint32_t single_pass;   // the chunks were written in place: no scan, no concatenation, index positions are final (2: by super-chunks)
-    uint32_t sc_cap_dw;     // ... by super-chunks: dwords of the LDS stream buffer
     uint32_t ntiles;
     uint64_t ts_img, ts_out, ts_ws, ts_idx;     // batched tiles: byte strides from tile to tile (blockIdx.y = tile)
     uint32_t hdr_len;       // container header bytes to put in front of the stream (write_header_kernel)
@@ -237,7 +233,7 @@ __device__ __forceinline__ EncArgs enc_for_tile(EncArgs a, uint32_t t) {
         const uint64_t w = t * a.ts_ws, x = t * a.ts_idx;
         a.chunk_bits = shift_ptr(a.chunk_bits, w); a.chunk_off = shift_ptr(a.chunk_off, w); a.group_sum = shift_ptr(a.group_sum, w);
         a.scratch = shift_ptr(a.scratch, w); a.seams = shift_ptr(a.seams, w); a.res = shift_ptr(a.res, w);
-        a.cw_has = shift_ptr(a.cw_has, w); a.cw_val = shift_ptr(a.cw_val, w); a.centry = shift_ptr(a.centry, w); a.cw_used = shift_ptr(a.cw_used, w); a.seg_from_entry = shift_ptr(a.seg_from_entry, w); a.recode_need = shift_ptr(a.recode_need, w); a.recode_list = shift_ptr(a.recode_list, w); a.recode_n = shift_ptr(a.recode_n, w); a.centry_parts = shift_ptr(a.centry_parts, w); a.lookback = shift_ptr(a.lookback, w);
+        a.cw_has = shift_ptr(a.cw_has, w); a.cw_val = shift_ptr(a.cw_val, w); a.centry = shift_ptr(a.centry, w); a.cw_used = shift_ptr(a.cw_used, w); a.seg_from_entry = shift_ptr(a.seg_from_entry, w); a.recode_need = shift_ptr(a.recode_need, w); a.recode_list = shift_ptr(a.recode_list, w); a.recode_n = shift_ptr(a.recode_n, w); a.centry_parts = shift_ptr(a.centry_parts, w);
         a.idx.bitpos = shift_ptr(a.idx.bitpos, x); a.idx.prev = shift_ptr(a.idx.prev, x); a.idx.cf = shift_ptr(a.idx.cf, x);
         a.idx.rung = shift_ptr(a.idx.rung, x); a.idx.ulen = shift_ptr(a.idx.ulen, x);
         a.ix_dst = shift_ptr(a.ix_dst, t * a.ts_out);     // (the restart table sits at the same place in every tile's container)
@@ -534,7 +530,7 @@ struct ProfScope {
 };
 
 // process-wide debugging switches, read once from the environment (k_host.hip)
-struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool no_bl; int single_pass; bool persistent; size_t walk_tab_kb; };
+struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool no_bl; size_t walk_tab_kb; };
 const Tuning &tuning();
 
 uint32_t magic_div(uint32_t d);

@@ -1152,9 +1152,9 @@ def test_tiles_with_block_length_tables(qb3, oracle):
     assert torch.equal(out, imgs) and buf.value == b"dec_units", buf.value
 
 
-@pytest.mark.parametrize("switch", ["QB3_SINGLE_PASS", "QB3_SINGLE_PASS=2", "QB3_PERSISTENT", "QB3_NO_PX", "QB3_SLOW_INDEX", "QB3_SLOW_WALK", "QB3_WALK_TAB_KB=2048"])
+@pytest.mark.parametrize("switch", ["QB3_NO_PX", "QB3_SLOW_INDEX", "QB3_SLOW_WALK", "QB3_WALK_TAB_KB=2048"])
 def test_alternative_kernel_paths(qb3, oracle, switch, tmp_path):
-    """the paths that are not the default -- the single-pass (look-back per chunk, per super-chunk) and the persistent 8-bit encoders, the generic
+    """the paths that are not the default -- the generic
     kernels on rasters the lane-per-block kernels would take, the one-lane index rebuild, the one-wave walk of a plain
     stream, the table walk in many rounds (a table of 2 MiB) -- give the same bytes and pixels.
     (The switches are read once per process: a child process each.)"""
@@ -1200,20 +1200,6 @@ assert L.qb3_read_info(d)
 out = torch.zeros_like(imgs)
 assert L.qb3x_decode_tiles(d, dst.data_ptr(), n, pitch, sizes, out.data_ptr(), w * h * b, None, None) == n     # the streams alone
 assert torch.equal(out, imgs)
-import os
-if os.environ.get("QB3_SINGLE_PASS"):
-    # ... and it was the single-pass encoder that ran, not its fall-back: several rounds of its persistent grid, no concatenate pass
-    w, h = 8192, 4096
-    img = synth.generate(w, h, 1, 0, "NOISY3", 12)
-    enc = qdev.DeviceEncoder(w, h, 1, 0, mode=8)
-    L.qb3x_profile_enable(1); L.qb3x_profile_reset()
-    dst, n, index = enc.encode(img)
-    torch.cuda.synchronize()
-    buf = C.create_string_buffer(1024)
-    L.qb3x_profile_names(buf, 1024)
-    L.qb3x_profile_enable(0)
-    assert b"enc_units" in buf.value and b"enc_concat" not in buf.value, buf.value
-    assert torch.equal(qdev.DeviceDecoder(dst, n).decode(dst, index=index), img.reshape(-1))
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
