@@ -260,7 +260,7 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, ui
 // the 8-bit lane-per-block kernels need: uint8, 1/3/4 bands, rows of whole blocks at dword-aligned addresses,
 // Hilbert or Z curve, identity or default RGB(A) band map
 static bool px_eligible(const Geometry &g, bool *rgb) {
-    if (g.tsz != 1 || !(g.bands == 1 || g.bands == 3 || g.bands == 4) || g.mode == CM_BEST) return false;
+    if (g.tsz != 1 || !(g.bands == 1 || g.bands == 3 || g.bands == 4)) return false;
     if (g.w < 4 || g.h < 4) return false;                  // any width, stride and pointer: rows are read and written unaligned
     if (g.order != HILBERT && g.order != ZCURVE) return false;
     bool ident = true, def = g.bands >= 3;
@@ -300,7 +300,7 @@ EncPlan plan_encode(const Geometry &g) {
         p.threads = 256; p.slots = 256; p.nbp = 255;
         p.nchunks = (uint32_t)((g.nblocks + 254) / 255);
         const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp, p.threads);
-        p.lds_bytes = 2048 + 256 + 4 * (size_t)L.slot_dw;
+        p.lds_bytes = (g.mode == CM_BEST ? PXB_LDS_FIXED : 2048 + 256) + 4 * (size_t)L.slot_dw;
         p.ws_bytes = L.total;
         return p;
     }
@@ -327,7 +327,7 @@ EncPlan plan_encode(const Geometry &g) {
 }
 
 static int launch_encode_all(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
-    if (a.g.mode == CM_BEST) launch_enc_best(a, plan, st);
+    if (a.g.mode == CM_BEST) { if (plan.px && a.g.tsz == 1) launch_enc_px_best(a, plan, st); else launch_enc_best(a, plan, st); }
     else if (plan.px && a.g.tsz == 1) {
         ProfScope ps("enc_units", st);
         launch_enc_px(a, plan, st);
@@ -408,7 +408,7 @@ DecPlan plan_decode(const Geometry &g) {
     p.fast = simple && p.lds2_bytes <= 64 * 1024;
     // 8-bit lane-per-block kernel
     bool rgb = false;
-    p.px = p.fast && px_eligible(g, &rgb);
+    p.px = p.fast && g.mode != CM_BEST && px_eligible(g, &rgb);
     p.px_rgb = rgb;
     // staging of the px kernel: the longest valid segment (every unit at its maximum) + the word the first unit
     // starts in + 8 zero words, after the 4 KB table, the scan scratch and the unit lengths

@@ -69,12 +69,13 @@ struct EncPlan {
     size_t lds_bytes;
     size_t ws_bytes;        // chunk counts/offsets, seam table, per-chunk scratch slots, EncResult (last)
     uint32_t nbp;           // payload blocks per chunk
-    bool px;                // 8-bit 1/3/4-band register-resident kernel applies (lane per block)
+    bool px;                // 8-bit 1/3/4-band register-resident kernel applies (lane per block; also for the common-factor modes: k_enc_px_best.hip)
     bool px_rgb;            //   ... with the default R-G,G,B-G map (else identity)
     bool px16;              // 16-bit register-resident kernel applies (lane per block and band group)
     uint32_t px16_bg, px16_ng;      //   ... bands per lane (1..4), lanes per block
 };
 EncPlan plan_encode(const Geometry &g);
+constexpr uint32_t PXB_LDS_FIXED = 11664;      // LDS of the 8-bit common-factor lane-per-block encoder in front of its bit buffer
 
 // Optional restart table carried INSIDE the container as ignorable chunks ("ix", include/qb3x.h): K entries, one per
 // `blocks` blocks: [bit position, 6 bytes][rung, 1 byte per band][prev, tsz bytes per band][cf, the same,

@@ -540,6 +540,7 @@ uint32_t max_unit_bits(uint32_t tsz, uint32_t mode = CM_FTL);
 void launch_enc_generic(const EncArgs &a, const EncPlan &plan, hipStream_t st);    // k_enc_generic.hip
 void launch_enc_best(const EncArgs &a, const EncPlan &plan, hipStream_t st);       // k_enc_best.hip
 void launch_enc_px(const EncArgs &a, const EncPlan &plan, hipStream_t st);         // k_enc_px.hip
+void launch_enc_px_best(const EncArgs &a, const EncPlan &plan, hipStream_t st);    // k_enc_px_best.hip
 void launch_enc_px16(const EncArgs &a, const EncPlan &plan, hipStream_t st);       // k_enc_px16.hip
 void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st);       // k_enc_post.hip: scan, concat, seams, header, ix
 void launch_dec_generic(const DecArgs &a, const DecPlan &plan, hipStream_t st);    // k_dec_generic.hip: dec3_kernel / dec_kernel
