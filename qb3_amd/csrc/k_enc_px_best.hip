@@ -22,11 +22,20 @@ namespace qb3dev {
 
 constexpr uint32_t PXB_CAP = 256;           // queue entries a round = lanes of the workgroup
 
+// diagnostic build (-DPXB_STAMPS): the shader clock at the phase boundaries of one chunk in every 1024, read back by scratch/stamps_best.py
+#ifdef PXB_STAMPS
+__device__ unsigned long long pxb_stamps[64 * 16];
+#define PXB_STAMP(k) do { if (FIRST && threadIdx.x == 0 && (chunk & 1023u) == 512u && (chunk >> 10) < 64u) pxb_stamps[(chunk >> 10) * 16 + (k)] = (unsigned long long)clock64(); } while (0)
+#else
+#define PXB_STAMP(k) do { } while (0)
+#endif
+
 // any byte of x equal to 1 or 2 (a mag-sign value of magnitude 1)
 __device__ __forceinline__ uint32_t swar_has_mag1(uint32_t x) {
     const uint32_t u = swar_sub8(x, 0x01010101u) & 0xfefefefeu;     // byte - 1, low bit dropped: zero for 1 and 2 (0 gives fe)
     return (u - 0x01010101u) & ~u & 0x80808080u;
 }
+constexpr uint32_t multiples_mask(uint32_t p) { uint32_t m = 0; for (uint32_t k = 0; k < 32; k += p) m |= 1u << k; return m; }
 // wave-aggregated append: lanes with `want` get consecutive queue indices
 __device__ __forceinline__ uint32_t queue_take(uint32_t *counter, bool want) {
     const uint64_t m = __ballot(want);
@@ -55,6 +64,54 @@ __device__ __forceinline__ uint32_t byte_at(const uint32_t (&G)[4], uint32_t i) 
     return (uint32_t)((i < 8 ? lo : hi) >> (8 * (i & 7))) & 0xffu;
 }
 
+// The distinct values of a unit by descending count, first seen first among equals (the reference's stable insertion sort,
+// QB3encode.h:546-554): per position, byte-parallel, the count of its value, the value's first position, the value's rank
+__device__ __forceinline__ void pxb_counts(const uint32_t (&G)[4], uint32_t (&cnt)[4], uint32_t (&fp)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { cnt[q] = 0; fp[q] = 0; }
+#pragma unroll 1
+    for (int j = 15; j >= 0; j--) {
+        const uint32_t bj = byte_at(G, (uint32_t)j) * 0x01010101u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t m = swar_eq8(G[q], bj);
+            cnt[q] += m & 0x01010101u;
+            fp[q] = (fp[q] & ~m) | ((uint32_t)j * 0x01010101u & m);
+        }
+    }
+}
+__device__ __forceinline__ void pxb_ranks(const uint32_t (&G)[4], const uint32_t (&cnt)[4], const uint32_t (&fp)[4], uint32_t (&rank)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) rank[q] = 0;
+#pragma unroll 1
+    for (uint32_t j = 0; j < 16; j++) {
+        if (byte_at(fp, j) == j) {                  // position j holds the first occurrence of a value: it beats ...
+            const uint32_t bj = byte_at(G, j) * 0x01010101u, cj = byte_at(cnt, j) * 0x01010101u, jj = j * 0x01010101u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t ne = ~swar_eq8(G[q], bj);                                // ... other values
+                const uint32_t gt = ~swar_le7(cj, cnt[q]) & 0x80808080u;               // with a smaller count,
+                const uint32_t eqc = swar_eq8(cnt[q], cj) & ~swar_le7(fp[q], jj);      // or the same count and a later first position
+                rank[q] += ((ne & (gt | eqc)) >> 7) & 0x01010101u;
+            }
+        }
+    }
+}
+// the group divided by the factor, sign kept (magsdiv, QB3encode.h:95): exact through the float reciprocal
+__device__ __forceinline__ void pxb_divide(const uint32_t (&G)[4], uint32_t cf, uint32_t (&D)[4]) {
+    const float rcf = __builtin_amdgcn_rcpf((float)cf);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t d4 = 0;
+#pragma unroll 1
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t g = (G[k] >> (8 * i)) & 0xffu, q = (uint32_t)((float)((g >> 1) + (g & 1)) * rcf + 0.5f);
+            d4 |= (((q << 1) - (g & 1)) & 0xffu) << (8 * i);
+        }
+        D[k] = d4;
+    }
+}
+
 // Dense emission of one queued unit in common-factor (kind 2) or index (kind 3) form at bit `pos` of the chunk's buffer
 // (reference cfgenc QB3encode.h:283-361, ienc :557-613).  tb0: byte address of the code table in LDS.
 __device__ __forceinline__ void pxb_emit(uint32_t *outbuf, uint32_t pos, const uint32_t (&G)[4], uint32_t rung, uint32_t oldrung, uint32_t kind,
@@ -64,19 +121,8 @@ __device__ __forceinline__ void pxb_emit(uint32_t *outbuf, uint32_t pos, const u
     LdsWriter w;
     w.init(outbuf, pos);
     if (kind == 2) {
-        // the group divided by the factor, sign kept (magsdiv, QB3encode.h:95): exact through the float reciprocal
-        uint32_t D[4] = {0, 0, 0, 0};
-        const float rcf = __builtin_amdgcn_rcpf((float)cf);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t d4 = 0;
-#pragma unroll 1
-            for (uint32_t i = 0; i < 4; i++) {
-                const uint32_t g = (G[k] >> (8 * i)) & 0xffu, q = (uint32_t)((float)((g >> 1) + (g & 1)) * rcf + 0.5f);
-                d4 |= (((q << 1) - (g & 1)) & 0xffu) << (8 * i);
-            }
-            D[k] = d4;
-        }
+        uint32_t D[4];
+        pxb_divide(G, cf, D);
         const T cfm = (T)(cf - 2);
         const uint32_t cfrung = topbit_t<T>(cfm);
         put_signal<UB>(w);
@@ -99,32 +145,9 @@ __device__ __forceinline__ void pxb_emit(uint32_t *outbuf, uint32_t pos, const u
 #pragma unroll
         for (int k = 0; k < 6; k++) w.put(pc[k], pl[k]);
     } else {
-        // distinct values by descending count, first seen first among equals (the reference's stable insertion sort,
-        // QB3encode.h:546-554): per position, byte-parallel, the count of its value, the value's first position, its rank
-        uint32_t cnt[4] = {0, 0, 0, 0}, fp[4] = {0, 0, 0, 0}, rank[4] = {0, 0, 0, 0};
-#pragma unroll 1
-        for (int j = 15; j >= 0; j--) {
-            const uint32_t bj = byte_at(G, (uint32_t)j) * 0x01010101u;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t m = swar_eq8(G[q], bj);
-                cnt[q] += m & 0x01010101u;
-                fp[q] = (fp[q] & ~m) | ((uint32_t)j * 0x01010101u & m);
-            }
-        }
-#pragma unroll 1
-        for (uint32_t j = 0; j < 16; j++) {
-            if (byte_at(fp, j) == j) {                  // position j holds the first occurrence of a value: it beats ...
-                const uint32_t bj = byte_at(G, j) * 0x01010101u, cj = byte_at(cnt, j) * 0x01010101u, jj = j * 0x01010101u;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t ne = ~swar_eq8(G[q], bj);                                // ... other values
-                    const uint32_t gt = ~swar_le7(cj, cnt[q]) & 0x80808080u;               // with a smaller count,
-                    const uint32_t eqc = swar_eq8(cnt[q], cj) & ~swar_le7(fp[q], jj);      // or the same count and a later first position
-                    rank[q] += ((ne & (gt | eqc)) >> 7) & 0x01010101u;
-                }
-            }
-        }
+        uint32_t cnt[4], fp[4], rank[4];
+        pxb_counts(G, cnt, fp);
+        pxb_ranks(G, cnt, fp, rank);
         put_signal<UB>(w);
         put_sw_noflag<UB>(w, UMASK - oldrung);
         put_sw_noflag<UB>(w, rung - oldrung);
@@ -173,6 +196,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     uint32_t *hq = (uint32_t *)(smem + PXB_HQ);                 // [5][PXB_CAP]: four dwords of mag-sign values, one of rungs and flags
     uint32_t *hr = (uint32_t *)(smem + PXB_HR);                 // [3][PXB_CAP]: analysis results / bit position
     uint32_t *outbuf = (uint32_t *)(smem + PXB_OUT);            // slot_dw dwords
+    PXB_STAMP(0);
     const uint4 tabv = ((const uint4 *)px_enc_tab.e)[tid & 127];
     for (uint32_t i = tid; i < a.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) { wsum[40] = 0; wsum[41] = 0; }
@@ -187,34 +211,53 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     PxFront<B> f;
     px_front<B, RGB, ORDER>(a0, gblk, w, pd, etab, wsum, tabv, f);      // (one barrier)
     const uint32_t rp_packed = f.rp_packed, prp = f.prp;
+    PXB_STAMP(1);
 
-    // ---- per band: is the unit settled without analysis.  A magnitude of 1 means there is no common factor.  The index form
-    // (QB3encode.h:702) is only tried for rungs above 3 -- there the plain size, at least 16 * rung + 1, always reaches the
-    // threshold 45 + 2 * rung -- and only with at most eight distinct values: the bitmap of the low five bits bounds those from below
-    uint32_t qi[B];
+    // ---- per band: is the unit settled without analysis.
+    // Common factor: a bitmap of the sixteen magnitudes (exact while they are below 32: rungs up to 5; magnitude 32 falls on
+    // bit 0 and is ignored, which can only make a unit look harder) -- a factor exists exactly when some prime divides every
+    // magnitude in the bitmap, eleven mask tests; above rung 5 a magnitude of 1 settles it, else the unit is hard.
+    // Index form (QB3encode.h:702): only tried for rungs above 3 -- there the plain size, at least 16 * rung + 1, always
+    // reaches the threshold 45 + 2 * rung -- and only with at most eight distinct values: the bitmap of the values' low five
+    // bits bounds those from below.
+    uint32_t qi[B], idxm = 0;
 #pragma unroll
     for (int c = 0; c < B; c++) {
         bool hard = false;
         const uint32_t rung = (rp_packed >> (4 * c)) & 15u, prung = (prp >> (4 * c)) & 15u;
         if (payload && f.usedv[c] > 1) {
-            const uint32_t has1 = swar_has_mag1(f.gp[c][0]) | swar_has_mag1(f.gp[c][1]) | swar_has_mag1(f.gp[c][2]) | swar_has_mag1(f.gp[c][3]);
-            bool idx_may = false;
-            if (__any(rung > 3)) {
-                uint32_t bm = 0;
+            uint32_t bm = 0, bma = 0;
 #pragma unroll
-                for (int i = 0; i < 16; i++) bm |= 1u << ((f.gp[c][i >> 2] >> (8 * (i & 3))) & 31u);
-                idx_may = rung > 3 && __popc(bm) <= 8;
+            for (int q = 0; q < 4; q++) {
+                const uint32_t gq = f.gp[c][q], aq = ((gq >> 1) & 0x7f7f7f7fu) + (gq & 0x01010101u);      // magnitudes: (g >> 1) + (g & 1)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    bm |= 1u << ((gq >> (8 * i)) & 31u);
+                    bma |= 1u << ((aq >> (8 * i)) & 31u);
+                }
             }
-            hard = !has1 || idx_may;
+            bma &= ~1u;
+            bool factor = false;
+            constexpr uint32_t primes[11] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31};
+#pragma unroll
+            for (int k = 0; k < 11; k++) factor = factor || (bma & ~multiples_mask(primes[k])) == 0;
+            if (__any(rung > 5)) {
+                const uint32_t has1 = swar_has_mag1(f.gp[c][0]) | swar_has_mag1(f.gp[c][1]) | swar_has_mag1(f.gp[c][2]) | swar_has_mag1(f.gp[c][3]);
+                if (rung > 5) factor = !has1;
+            }
+            const bool idx_may = rung > 3 && __popc(bm) <= 8;
+            hard = factor || idx_may;
+            idxm |= (uint32_t)idx_may << c;
         }
         qi[c] = queue_take(&wsum[40], hard);
         if (qi[c] < PXB_CAP) {
 #pragma unroll
             for (int q = 0; q < 4; q++) hq[q * PXB_CAP + qi[c]] = f.gp[c][q];
-            hq[4 * PXB_CAP + qi[c]] = rung | (prung << 4);
+            hq[4 * PXB_CAP + qi[c]] = rung | (prung << 4) | (((idxm >> c) & 1u) << 8);
         }
     }
     __syncthreads();
+    PXB_STAMP(2);
     // ---- dense analysis of the hard units: cf | trung << 8 | writer << 12, szBase | szCf << 16, index size
     uint32_t res0[B], res1[B], res2[B];
 #pragma unroll
@@ -228,11 +271,12 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
                     const uint32_t j = qi[c] - r0;
 #pragma unroll
                     for (int q = 0; q < 4; q++) hq[q * PXB_CAP + j] = f.gp[c][q];
-                    hq[4 * PXB_CAP + j] = ((rp_packed >> (4 * c)) & 15u) | (((prp >> (4 * c)) & 15u) << 4);
+                    hq[4 * PXB_CAP + j] = ((rp_packed >> (4 * c)) & 15u) | (((prp >> (4 * c)) & 15u) << 4) | (((idxm >> c) & 1u) << 8);
                 }
             __syncthreads();
         }
         if (r0 + tid < nh) {
+            // (the unit-per-lane kernels' analysis, unrolled: what this phase costs the workgroup is ONE unit's latency)
             uint8_t g[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) g[i] = (uint8_t)(hq[(i >> 2) * PXB_CAP + tid] >> (8 * (i & 3)));
@@ -254,6 +298,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
         if (r0 + PXB_CAP < nh) __syncthreads();
     }
 
+    PXB_STAMP(3);
     // ---- who wrote the band's factor last: a ballot per band and wave, the value per lane
 #pragma unroll
     for (int c = 0; c < B; c++) {
@@ -279,6 +324,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     }
     if (FIRST && summary_only) return;  // (workgroup uniform)
 
+    PXB_STAMP(4);
     // ---- the coding of every unit and its length (QB3encode.h:679-713)
     const uint32_t seg = gblk / a.g.seg_blocks;
     const bool seg_start = payload && a.have_idx && seg * a.g.seg_blocks == gblk;
@@ -317,6 +363,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     const uint32_t myblen = blen[0];
     block_exscan_dpp<1>(blen, wsum);            // (one barrier)
     const uint32_t pos = blen[0], total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    PXB_STAMP(5);
 
     // ---- emission: plain units from the lane's pieces, the others queued for the dense lanes
     uint32_t qe[B], upos[B];
@@ -358,7 +405,11 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
         }
     }
     __syncthreads();                    // every unit to emit densely is counted (and the analysis queue is free again)
+    PXB_STAMP(6);
     const uint32_t ne = wsum[41];
+#ifdef PXB_STAMPS
+    if (FIRST && tid == 0 && (chunk & 1023u) == 512u && (chunk >> 10) < 64u) { pxb_stamps[(chunk >> 10) * 16 + 10] = nh; pxb_stamps[(chunk >> 10) * 16 + 11] = ne; }
+#endif
     for (uint32_t r0 = 0; r0 < ne; r0 += PXB_CAP) {
 #pragma unroll
         for (int c = 0; c < B; c++)
@@ -378,11 +429,13 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
         }
         __syncthreads();
     }
+    PXB_STAMP(7);
     // the chunk's bits go to its slot; enc_concat_kernel moves them into place once every chunk is counted
     const uint32_t nd4 = (total + 127) >> 7;
     uint4 *slot = (uint4 *)(a.scratch + (uint64_t)chunk * a.slot_dw);
     for (uint32_t d = tid; d < nd4; d += 256) slot[d] = ((const uint4 *)outbuf)[d];
     if (tid == 0) a.chunk_bits[chunk] = total;
+    PXB_STAMP(8);
     if (FIRST) {
         if (tid < B) a.cw_used[(uint64_t)chunk * B + tid] = (uint8_t)used_entry[tid];
         if (tid == 0) a.recode_need[chunk] = 0;
@@ -446,3 +499,9 @@ void launch_enc_px_best(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
 }
 
 }  // namespace qb3dev
+
+#ifdef PXB_STAMPS
+extern "C" __attribute__((visibility("default"))) int qb3x_debug_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qb3dev::pxb_stamps), sizeof(qb3dev::pxb_stamps));
+}
+#endif
