@@ -434,10 +434,13 @@ __global__ void __launch_bounds__(64) dec_index_serial(const DecArgs a0) {
             seg++;
         }
         if (++inseg == S) inseg = 0;
+        uint32_t bt = 0;                     // block table entry (ulen_sz == 4): the block's bits | entering rungs << 16
+        const uint64_t bstart = rd.position();
         for (uint32_t c = 0; c < bands; c++) {
             uint32_t rung = st_rung[c];
             T cf = (T)st_cf[c];
             const uint64_t ustart = rd.position();
+            if (c < 4) bt |= (rung & 15u) << (16 + 4 * c);
             ok = parse_unit<T, MODE, Reader>(rd, rung, cf, g) && ok;
             if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint8_t)(rd.position() - ustart);
             else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint16_t)(rd.position() - ustart);
@@ -448,6 +451,7 @@ __global__ void __launch_bounds__(64) dec_index_serial(const DecArgs a0) {
             st_cf[c] = cf;
             st_rung[c] = rung;
         }
+        if (a.g.ulen_sz == 4) ((uint32_t *)a.idx.ulen)[gb] = bt | (uint32_t)((rd.position() - bstart) & 0xffffu);
     }
     if (!ok) atomicOr(a.status, 1u);
 }
@@ -491,10 +495,13 @@ __global__ void __launch_bounds__(64) dec_index_staged(const DecArgs a0, uint32_
                         a.idx.rung[seg * bands + c] = (uint8_t)st_rung[c];
                     }
                 }
+                uint32_t bt = 0;
+                const uint64_t bstart = rd.position();
                 for (uint32_t c = 0; c < bands; c++) {
                     uint32_t rung = st_rung[c];
                     T cf = (T)st_cf[c];
                     const uint64_t ustart = rd.position();
+                    if (c < 4) bt |= (rung & 15u) << (16 + 4 * c);
                     ok = parse_unit<T, MODE, ReaderT<LdsWords>>(rd, rung, cf, g) && ok;
                     if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint8_t)(rd.position() - ustart);
                     else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint16_t)(rd.position() - ustart);
@@ -505,6 +512,7 @@ __global__ void __launch_bounds__(64) dec_index_staged(const DecArgs a0, uint32_
                     st_cf[c] = cf;
                     st_rung[c] = rung;
                 }
+                if (a.g.ulen_sz == 4) ((uint32_t *)a.idx.ulen)[gb] = bt | (uint32_t)((rd.position() - bstart) & 0xffffu);
                 gb++;
             }
             s_P = 32 * w0 + rd.position();

@@ -49,7 +49,9 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
     wb.vals = (uint64_t *)(f.outbuf + ((outdw + 1) & ~1u));     // nthr values, then one mask per wave, then a "used the entry state" word per band
     wb.masks = wb.vals + nthr;
     uint32_t *used_entry = (uint32_t *)(wb.masks + 16);
+    uint32_t *blk_tab = used_entry + MAXBANDS + 2;             // a word per block slot: the index's block table (ulen_sz == 4)
     if (FIRST && tid < bands) used_entry[tid] = 0;
+    if (a.have_idx && a.g.ulen_sz == 4 && tid < slots) blk_tab[tid] = 0;
 
     uint32_t oldrung = 0;
     BestUnit<T> u;
@@ -97,6 +99,7 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
         }
     }
     uint32_t total;
+    if (payload && a.have_idx && a.g.ulen_sz == 4) atomicAdd(&blk_tab[f.s], len | (oldrung << (16 + 4 * c)));     // (block_exscan has the barrier)
     const uint32_t pos = block_exscan(len, f.wsum, &total);
 
     if (payload) {
@@ -173,6 +176,7 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
             // (the band's final factor: best_scan_kernel, from the chunk summaries)
         }
         if (a.have_idx) {
+            if (a.g.ulen_sz == 4 && c == 0) ((uint32_t *)a.idx.ulen)[gblk] = blk_tab[f.s];
             const uint32_t seg = gblk / a.g.seg_blocks;
             if (seg * a.g.seg_blocks == gblk) {
                 ((T *)a.idx.prev)[(uint64_t)seg * bands + c] = f.pv;

@@ -228,6 +228,38 @@ __global__ void __launch_bounds__(256) ix_bl_fill_kernel(const EncArgs a0) {
     else if (t < 6 + 2 * B) e0[t] = ((const uint8_t *)a.idx.prev)[k * B + (t - 6 - B)];
 }
 
+// The same for 8-bit common-factor streams (grey / RGB / RGBA): a three-byte field per block -- its bits (12) and the rungs its
+// units are entered with (3 bits a band) -- from the index's block table; a thread per four blocks writes twelve bytes
+// and one byte of the entry's fixed part (position, rungs, entering values, factors in force: at most 6 + 3 * 4 bytes)
+__global__ void __launch_bounds__(256) ix_bl_best_fill_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    const uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // blocks 4 * grp .. 4 * grp + 3
+    const uint32_t B = a.g.bands;
+    const uint64_t k = grp >> 4;                                                // 16 groups an entry (64 blocks)
+    if (k >= a.ix_K) return;
+    const uint64_t nblocks = a.g.nblocks, blk0 = 4 * grp;
+    const uint32_t c = (uint32_t)(k / a.ix_per_chunk), jj = (uint32_t)(k - (uint64_t)c * a.ix_per_chunk);
+    uint8_t *e0 = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E) + IX_HEAD + (uint64_t)jj * a.ix_E;
+    const uint32_t t = (uint32_t)(grp & 15), fixed = 6 + 3 * B;
+    uint8_t *e = e0 + fixed + 4 * IX_BL_BEST_BYTES * t;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t bt = blk0 + q < nblocks ? ((const uint32_t *)a.idx.ulen)[blk0 + q] : 0u;
+        uint32_t f = bt & 0xfffu;
+#pragma unroll
+        for (uint32_t cc = 0; cc < 4; cc++) f |= ((bt >> (16 + 4 * cc)) & 7u) << (12 + 3 * cc);
+        e[3 * q] = (uint8_t)f; e[3 * q + 1] = (uint8_t)(f >> 8); e[3 * q + 2] = (uint8_t)(f >> 16);
+    }
+    for (uint32_t i = t; i < fixed; i += 16) {
+        uint8_t v;
+        if (i < 6) v = (uint8_t)(a.idx.bitpos[k] >> (8 * i));
+        else if (i < 6 + B) v = a.idx.rung[k * B + (i - 6)];
+        else if (i < 6 + 2 * B) v = ((const uint8_t *)a.idx.prev)[k * B + (i - 6 - B)];
+        else v = ((const uint8_t *)a.idx.cf)[k * B + (i - 6 - 2 * B)];
+        e0[i] = v;
+    }
+}
+
 // The same for 16-bit rasters of four or eight bands: a field is the bit length of a band PAIR (two units), two fields per
 // lane of the decoder's wave (lane = block of the segment x band group of four), 128 fields an entry.  A thread per four
 // fields (two lanes): five whole bytes; the entry's first 6 + 3 * bands threads also write one byte each of its fixed part.
@@ -312,7 +344,8 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256, nt), dim3(256), 0, st, a);
     if (a.hdr_len) hipLaunchKernelGGL(write_header_kernel, dim3(1, nt), dim3(64), 0, st, a);
     if (a.ix_dst && a.have_idx) hipLaunchKernelGGL(ix_fill_kernel, dim3((a.ix_K + 255) / 256, nt), dim3(256), 0, st, a);
-    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1 && a.g.mode == CM_BEST) hipLaunchKernelGGL(ix_bl_best_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
+    else if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz >= 4) {
         const uint32_t tpe = (a.ix_blocks * a.g.bands + 1) / 2;
         hipLaunchKernelGGL(ix_blw_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * tpe + 255) / 256), nt), dim3(256), 0, st, a, tpe);

@@ -153,6 +153,8 @@ uint32_t seg_blocks_for(const Geometry &g) {
         while (passes > 1 && bpp * passes > 256) passes--;
         return bpp * passes;
     }
+    // common-factor modes, 8-bit grey/RGB/RGBA: a wave of the lane-per-block decoder owns a segment (the index has a dword per block)
+    if (best_block_table(g.tsz, g.mode, g.bands)) return 64;
     // common-factor modes: a lane walks the segment serially, keep it short (12 units)
     uint32_t s = 12 / g.bands;
     return s ? s : 1;
@@ -162,12 +164,14 @@ uint32_t seg_blocks_for(const Geometry &g) {
 // ... or a unit length per unit of the segment (32/64-bit data: the unit-parallel decoder)
 uint32_t ix_bl_fields(const Geometry &g) { return g.tsz == 1 ? g.seg_blocks : g.tsz == 2 ? (g.bands == 1 ? 64 : 128) : g.seg_blocks * g.bands; }
 uint32_t ix_entry_bytes(const Geometry &g, bool block_lens) {
-    return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)) + (block_lens ? (ix_bl_fields(g) * ix_bl_bits(g.tsz) + 7) / 8 : 0);
+    return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)) + (block_lens ? ix_bl_bytes(g.tsz, g.bands, g.seg_blocks, g.mode == CM_BEST) : 0);
 }
 // Block lengths: for the rasters the 8-bit lane-per-block decoder takes (a block of at most four units of at most 149 bits
 // fits ten bits), an entry per 64-block segment
 bool ix_block_lens_ok(const Geometry &g) {
-    if (g.mode == CM_BEST) return false;
+    // 8-bit common-factor streams of 1/3/4 bands: a field per block of the 64-block segment (its bits and entering rungs),
+    // what the lane-per-block decoder needs besides the entry's fixed part; without it a lane would walk 64 blocks
+    if (g.mode == CM_BEST) return best_block_table(g.tsz, g.mode, g.bands) && g.seg_blocks == 64;
     // 32/64-bit data: where the unit-parallel decoder applies (its workgroup's tile fits LDS), a twelve-bit length per unit
     if (g.tsz >= 4) return g.seg_blocks != 0 && plan_decode(g).fast && 6 + g.bands * (1 + g.tsz) + (g.seg_blocks * g.bands * IX_BL_BITS_WIDE + 7) / 8 <= 32768;
     if (!(g.order == HILBERT || g.order == ZCURVE)) return false;
@@ -185,7 +189,7 @@ bool ix_block_lens_ok(const Geometry &g) {
 IxTable ix_layout(const Geometry &g, int level) {
     IxTable t;
     if (!g.seg_blocks || !g.nseg) return t;
-    t.block_lens = level >= 2 && ix_block_lens_ok(g);
+    t.block_lens = (level >= 2 || best_block_table(g.tsz, g.mode, g.bands)) && ix_block_lens_ok(g);
     t.entry_bytes = ix_entry_bytes(g, t.block_lens);
     const uint64_t units_per_seg = (uint64_t)g.seg_blocks * g.bands;
     const bool per_seg = g.mode != CM_BEST;
@@ -201,12 +205,12 @@ IxTable ix_layout(const Geometry &g, int level) {
     t.per_chunk = (65535 - IX_HEAD) / t.entry_bytes;
     return t;
 }
-uint32_t ulen_size_for(uint32_t tsz, uint32_t mode) { return mode == CM_BEST ? 0 : (tsz == 1 ? 1 : 2); }
+uint32_t ulen_size_for(uint32_t tsz, uint32_t mode, uint32_t bands) { return mode == CM_BEST ? (best_block_table(tsz, mode, bands) ? 4 : 0) : (tsz == 1 ? 1 : 2); }
 
 static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 size_t index_bytes(const Geometry &g) {
     const size_t n = (size_t)g.nseg * g.bands;
-    return align8(8 * (size_t)g.nseg) + 2 * align8(n * g.tsz) + align8(n) + align8((size_t)g.nblocks * g.bands * g.ulen_sz);
+    return align8(8 * (size_t)g.nseg) + 2 * align8(n * g.tsz) + align8(n) + align8(ulen_table_bytes(g));
 }
 IndexView index_view(const Geometry &g, void *base) {
     IndexView v;
@@ -321,7 +325,7 @@ EncPlan plan_encode(const Geometry &g) {
     p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
     const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1;
     p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * ((outdw + 1) & ~(size_t)1);
-    if (g.mode == CM_BEST) p.lds_bytes += 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8;     // the writer board: a value per lane, a ballot per wave, a word per band
+    if (g.mode == CM_BEST) p.lds_bytes += 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8 + 4 * (size_t)p.slots;     // the writer board: a value per lane, a ballot per wave, a word per band; a word per block (the index's block table)
     p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp, p.threads).total;
     return p;
 }
@@ -415,6 +419,9 @@ DecPlan plan_decode(const Geometry &g) {
     p.px_cap_dw = (uint32_t)(((size_t)NB * g.bands * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
     p.px = p.px && NB <= 64;
     p.lds_px = 4096 + 4 * 4 * ((size_t)p.px_cap_dw + 8);       // table + four waves' staging
+    // ... and its common-factor counterpart (the index has a dword per block: ulen_sz == 4)
+    p.px_best = false;
+    if (g.mode == CM_BEST && g.ulen_sz == 4 && NB == 64 && px_eligible(g, &rgb)) { p.px_best = true; p.px_rgb = rgb; }
     p.px16 = false; p.px16_bg = p.px16_ng = 0;
     bool rgb16 = false;
     if (!p.px && p.fast && px16_eligible(g, &rgb16, &p.px16_bg, &p.px16_ng) && NB * p.px16_ng <= 64) {
@@ -437,6 +444,16 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     // 32/64-bit FTL/BASE streams that bring a restart table with an entry per index segment: the lengths-only walk too
     const bool wide_walk = rebuild && a.ix && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
     const bool unit_parallel = !use_px && !use_px16 && plan.fast && !best && a.g.tsz >= 4;
+    const bool best_px = best && plan.px_best && a.g.tsz == 1;
+    if (rebuild && best_px && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
+        // the container's table has a field per block (bits, entering rungs): the lane-per-block decoder works from the entries alone
+        DecArgs t = a;
+        t.bl_mode = 1;
+        ProfScope ps("dec_units", st);
+        launch_dec_px_best(t, plan, st);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (rebuild && (use_px || (use_px16 && ix_block_lens_ok(a.g)) || unit_parallel) && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
         // the container's table carries block (16-bit data: band pair) lengths: the lane-per-block decoder works from the entries alone
         DecArgs t = a;
@@ -467,7 +484,8 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         ProfScope ps("dec_index_serial", st);
         launch_dec_index_serial(a, st);
     }
-    if (use_px) { ProfScope ps("dec_units", st); launch_dec_px(a, plan, st); }
+    if (best_px && !a.from_ix) { ProfScope ps("dec_units", st); launch_dec_px_best(a, plan, st); }
+    else if (use_px) { ProfScope ps("dec_units", st); launch_dec_px(a, plan, st); }
     else if (use_px16) { ProfScope ps("dec_units", st); launch_dec_px16(a, plan, st); }
     else { ProfScope ps(plan.fast && !best ? "dec_units" : "dec_segments", st); launch_dec_generic(a, plan, st); }
     HIPCHK(hipGetLastError());
@@ -539,7 +557,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     HIPCHK(hipMemsetAsync(a.status, 0, status_bytes, st));
     a.lane_dw = dec_lane_dwords(g);
     a.dpr = g.bands * g.tsz;
-    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16) ? plan.px_cap_dw : plan.in_cap_dw;
+    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16 || plan.px_best) ? plan.px_cap_dw : plan.in_cap_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.totals_only = 0;
     a.bl_mode = 0;

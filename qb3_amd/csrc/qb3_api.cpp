@@ -332,7 +332,7 @@ static Geometry make_geometry(size_t w, size_t h, size_t bands, int dtype, size_
     g.nbx = (uint32_t)((w + 3) / 4); g.nby = (uint32_t)((h + 3) / 4);
     g.nblocks = (uint64_t)g.nbx * g.nby;
     g.mode = codec_mode(mode);
-    g.ulen_sz = ulen_size_for(g.tsz, g.mode);
+    g.ulen_sz = ulen_size_for(g.tsz, g.mode, g.bands);
     for (size_t c = 0; c < bands; c++) g.cband[c] = cband_sz ? (uint8_t)cband_sz[c] : cband_u8[c];
     g.seg_blocks = seg_blocks_for(g);
     g.nseg = (g.nblocks + g.seg_blocks - 1) / g.seg_blocks;
@@ -726,7 +726,7 @@ QB3_API size_t qb3x_header_size_bound(const void *container, size_t avail) {
     const size_t K = units / 12 + 1;
     // ... and a table of 8-bit data may carry ten bits per block on top (an entry per 64 blocks)
     const size_t nblk = ((w + 3) / 4) * ((h + 3) / 4);
-    const size_t bl = tsz == 1 ? (nblk / 64 + 1) * ((64 * IX_BL_BITS + 7) / 8) : tsz == 2 ? (nblk * (nb / 4 + 1) / 64 + 1) * ((128 * IX_BL_BITS + 7) / 8)
+    const size_t bl = tsz == 1 ? (nblk / 64 + 1) * (64 * IX_BL_BEST_BYTES) : tsz == 2 ? (nblk * (nb / 4 + 1) / 64 + 1) * ((128 * IX_BL_BITS + 7) / 8)
                                : (nblk * nb * IX_BL_BITS_WIDE) / 8 + (nblk / 12 + 1) * 2 + 64;       // (32/64-bit: a length per unit, an odd byte per entry)
     const size_t bytes = K * E + bl;
     return 128 + bytes + (bytes / 60000 + 1) * (IX_HEAD + IX_PAD);
@@ -795,7 +795,8 @@ QB3_API bool qb3_read_info(decsp p) {
                 const size_t tsz = szof(p->type);
                 const uint32_t blocks = rd(pos + 8) | (rd(pos + 9) << 8) | (rd(pos + 10) << 16) | (rd(pos + 11) << 24);
                 const bool bl = (rd(pos + 5) & 2) != 0;     // entries end with their blocks' bit lengths
-                const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * ((rd(pos + 5) & 1) ? 2 : 1))) + (bl && blocks <= 4096 ? ((tsz == 1 ? blocks : tsz == 2 ? (p->nbands == 1 ? 64u : 128u) : blocks * (uint32_t)p->nbands) * ix_bl_bits((uint32_t)tsz) + 7) / 8 : 0);
+                const bool cfe = (rd(pos + 5) & 1) != 0;     // entries carry the common factors
+                const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * (cfe ? 2 : 1))) + (bl && blocks <= 4096 ? ix_bl_bytes((uint32_t)tsz, (uint32_t)p->nbands, blocks, cfe) : 0);
                 const size_t at = (size_t)(p->s_in - p->s_start) + pos;
                 const bool v2 = rd(pos + 4) == 2;
                 if ((len - IX_HEAD) % E || pos + len > n) p->ix_bad = true;

@@ -22,7 +22,8 @@ struct Geometry {
     uint32_t mode;                  // CodecMode
     uint32_t seg_blocks;            // blocks per index segment
     uint64_t nseg;                  // number of index segments
-    uint32_t ulen_sz;               // bytes per entry of the per-unit bit-length table (1, 2; 0 = none)
+    uint32_t ulen_sz;               // bytes per entry of the per-unit bit-length table (1, 2; 0 = none); 4: a dword per BLOCK instead
+                                    // (8-bit common-factor streams of 1/3/4 bands: the block's bits | entering rungs << 16, four bits a band)
     uint8_t cband[MAXBANDS];
 };
 
@@ -49,7 +50,9 @@ struct IndexView {
 size_t index_bytes(const Geometry &g);
 IndexView index_view(const Geometry &g, void *base);
 uint32_t seg_blocks_for(const Geometry &g);      // needs w, h, bands, tsz, stride, order, mode, cband
-uint32_t ulen_size_for(uint32_t tsz, uint32_t mode);
+uint32_t ulen_size_for(uint32_t tsz, uint32_t mode, uint32_t bands);
+inline size_t ulen_table_bytes(const Geometry &g) { return g.ulen_sz == 4 ? (size_t)g.nblocks * 4 : (size_t)g.nblocks * g.bands * g.ulen_sz; }
+inline bool best_block_table(uint32_t tsz, uint32_t mode, uint32_t bands) { return mode == CM_BEST && tsz == 1 && (bands == 1 || bands == 3 || bands == 4); }
 
 // Results the encoder hands back to the host (device resident, copied once per encode)
 struct EncResult {
@@ -96,6 +99,13 @@ uint32_t ix_entry_bytes(const Geometry &g, bool block_lens = false);
 bool ix_block_lens_ok(const Geometry &g);         // can a table for this geometry carry block lengths
 uint32_t ix_bl_fields(const Geometry &g);         // ... how many fields an entry then ends with
 inline uint32_t ix_bl_bits(uint32_t tsz) { return tsz >= 4 ? IX_BL_BITS_WIDE : IX_BL_BITS; }
+constexpr uint32_t IX_BL_BEST_BYTES = 3;  // ... of a block's field in a table of 8-bit common-factor data: the block's bits (12) | the rungs its units are entered with (3 bits a band) << 12
+// bytes of the fields behind the fixed part of an entry that covers `blocks` blocks (cf: the stream is a common-factor one)
+inline uint32_t ix_bl_bytes(uint32_t tsz, uint32_t bands, uint32_t blocks, bool cf) {
+    if (cf) return IX_BL_BEST_BYTES * blocks;
+    const uint32_t fields = tsz == 1 ? blocks : tsz == 2 ? (bands == 1 ? 64u : 128u) : blocks * bands;
+    return (fields * ix_bl_bits(tsz) + 7) / 8;
+}
 // the table this library writes for a geometry (needs seg_blocks, nseg, bands, tsz, mode); K == 0: none
 IxTable ix_layout(const Geometry &g, int level = 1);       // level 2: with block lengths where the geometry allows
 inline size_t ix_chunks(const IxTable &t) { return t.per_chunk ? (t.K + t.per_chunk - 1) / t.per_chunk : 0; }
@@ -141,6 +151,7 @@ struct DecPlan {
     uint32_t px_cap_dw;     // staging capacity (dwords) of the lane-per-block kernels, per wave
     bool px16;              // 16-bit lane-per-(block, band group) kernel applies
     uint32_t px16_bg, px16_ng;
+    bool px_best;           // 8-bit common-factor streams: the lane-per-block decoder applies (k_dec_px_best.hip)
 };
 DecPlan plan_decode(const Geometry &g);
 

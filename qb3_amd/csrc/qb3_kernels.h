@@ -547,6 +547,7 @@ void launch_dec_generic(const DecArgs &a, const DecPlan &plan, hipStream_t st); 
 void launch_dec_index_serial(const DecArgs &a, hipStream_t st);                    // k_dec_generic.hip
 void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st);         // k_dec_px.hip
 void launch_dec_px16(const DecArgs &a, const DecPlan &plan, hipStream_t st);       // k_dec_px16.hip
+void launch_dec_px_best(const DecArgs &a, const DecPlan &plan, hipStream_t st);    // k_dec_px_best.hip
 void launch_dec_walk(const DecArgs &a, hipStream_t st);                            // k_dec_walk.hip: unit lengths of an index-less 8/16-bit stream
 void launch_prev_scan(const DecArgs &a, hipStream_t st);                           // k_dec_walk.hip
 void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);   // k_dec_walk.hip: plain 8- and 16-bit streams

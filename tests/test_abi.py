@@ -78,7 +78,14 @@ def test_room_for_the_restart_table(qb3, w, h, b, dt, mode, lens):
     L.qb3_destroy_encoder(p)
     assert one > 0
     if not lens:
-        if mode in (1, 3, 5, 7):        # common-factor streams: no lengths, but the level 2 entries are closer together
+        if mode in (1, 3, 5, 7) and dt <= 1 and b in (1, 3, 4):
+            # 8-bit common-factor streams of 1/3/4 bands: an entry per 64-block segment that always ends with a three-byte field
+            # per block (its bits and entering rungs) -- the lane-per-block decoder's table, whatever the level
+            nseg = -(-(-(-w // 4) * -(-h // 4)) // 64)
+            E = 6 + 3 * b + 3 * 64
+            per_chunk = (65535 - 12) // E
+            assert one == two == nseg * E + -(-nseg // per_chunk) * 16
+        elif mode in (1, 3, 5, 7):      # other common-factor streams: no lengths, but the level 2 entries are closer together
             assert one < two <= 3 * one
         else:
             assert two == one

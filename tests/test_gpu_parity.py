@@ -1096,8 +1096,10 @@ print("ok")
 
 def test_block_lengths_only_where_the_decoder_uses_them(qb3, oracle):
     """level 2 asked for a raster whose decoder takes no lengths (16-bit or 8-bit of five bands): the table is the level 1
-    table.  A common-factor stream has no length table at any level; its level 2 table has the entries closer together
-    (24 units, 12 for 32/64-bit data), and decodes from the container alone like the level 1 one"""
+    table.  A common-factor stream has no unit-length table at any level; its level 2 table has the entries closer together
+    (24 units, 12 for 32/64-bit data), and decodes from the container alone like the level 1 one.  The exception: 8-bit
+    common-factor streams of 1/3/4 bands, whose table has a field per block (bits, entering rungs) at EITHER level -- what the
+    lane-per-block decoder of those streams works from"""
     for (w, h, b, dt, gen, mode) in [(256, 128, 5, 2, "LANDSAT16", FTL), (160, 120, 5, 0, "NOISY3", FTL)]:
         img = oracle.generate(w, h, b, dt, gen, 3)
         cb = None if b in (1, 3, 4) else list(range(b))
@@ -1116,7 +1118,10 @@ def test_block_lengths_only_where_the_decoder_uses_them(qb3, oracle):
         if ref[10] in (255, 2, 3, 6, 7):            # raw-stored, or the RLE0 pass won: no table either way
             assert np.array_equal(one, ref) and np.array_equal(two, ref)
             continue
-        assert len(two) > len(one) > len(ref)
+        if dt <= 1 and b in (1, 3, 4):
+            assert np.array_equal(one, two) and len(one) > len(ref)
+        else:
+            assert len(two) > len(one) > len(ref)
         extra, dt_at = len(two) - len(ref), bytes(ref).index(b"DT", 11)
         assert bytes(two[:dt_at]) == bytes(ref[:dt_at]) and bytes(two[dt_at + extra:]) == bytes(ref[dt_at:])
         want, _, _, _ = oracle.decode(two, identity=True)
@@ -1323,3 +1328,55 @@ def test_common_factor_data_in_best_mode(qb3, oracle, case):
     assert n == len(want if False else oracle.encode(img, dt, 7)) and np.array_equal(dst[:n].cpu().numpy(), oracle.encode(img, dt, 7))
     dec = qdev.DeviceDecoder(dst, n)
     assert torch.equal(dec.decode(dst, index=index), dimg.reshape(-1)) and torch.equal(dec.decode(dst, index=None), dimg.reshape(-1))
+
+
+def _cf_rasters(w, h, b, seed):
+    """8-bit rasters that exercise every form of a common-factor stream: values scaled by 3 and by 16 (a factor in every
+    unit, written once then "same as before"), a handful of distinct values (index form), and a patchwork of the three
+    with noise between them (the factor state changes hands inside chunks and across them)"""
+    rng = np.random.default_rng(seed)
+    def scaled(k, hh=h, ww=w):
+        return (rng.integers(0, 256 // k, size=(hh, ww, b), dtype=np.uint8) * k).astype(np.uint8)
+    def few(hh=h, ww=w, n=5):
+        return rng.integers(0, 256, size=n, dtype=np.uint8)[rng.integers(0, n, size=(hh, ww, b))]
+    out = {"scaled3": scaled(3), "scaled16": scaled(16), "few": few()}
+    mixed = rng.integers(0, 256, size=(h, w, b), dtype=np.uint8) // 8 + np.arange(w, dtype=np.uint8)[None, :, None]
+    mixed[: h // 3] = scaled(6, h // 3)
+    mixed[h // 3: h // 2, : w // 2] = few(h // 2 - h // 3, w // 2)
+    mixed[h // 2:, w // 2:] = (mixed[h // 2:, w // 2:] // 4) * 4
+    out["mixed"] = np.ascontiguousarray(mixed)
+    return out
+
+
+@pytest.mark.parametrize("mode", [1, 5, 7])
+@pytest.mark.parametrize("shape", [(64, 48, 3), (509, 259, 3), (1024, 768, 1), (131, 77, 4), (1028, 260, 4), (2048, 520, 3)],
+                         ids=lambda s: "%dx%dx%d" % s)
+def test_common_factor_8bit_lane_per_block(qb3, oracle, shape, mode):
+    """QB3M_BEST family on 8-bit grey / RGB / RGBA through the lane-per-block kernels (k_enc_px_best.hip, k_dec_px_best.hip):
+    the container equals the oracle's for data with factors everywhere, index-form data and mixtures; it decodes with the
+    out-of-band index (segment entries + a dword per block), from a plain container (index rebuilt), and from a self-indexed
+    container alone (a field per block in the table), which the reference's reader steps over
+    (reference QB3encode.h:283-361,557-724; QB3decode.h:578-741)"""
+    import torch
+    from qb3_amd import device as qdev
+    w, h, b = shape
+    for name, host in _cf_rasters(w, h, b, 11 * w + b).items():
+        for cband in ([None, list(range(b))] if b >= 3 else [None]):
+            ref = oracle.encode(host, 0, mode, cband=cband)
+            img = torch.from_numpy(host).cuda()
+            enc = qdev.DeviceEncoder(w, h, b, 0, mode=mode, cband=cband)
+            dst, n, index = enc.encode(img)
+            got = dst[:n].cpu().numpy()
+            assert n == len(ref) and np.array_equal(got, ref), (name, cband, n, len(ref), first_diff(got, ref))
+            if ref[10] in (255, 2, 3, 6, 7):
+                continue
+            dec = qdev.DeviceDecoder(dst, n)
+            assert torch.equal(dec.decode(dst, index=index), img.reshape(-1)), (name, cband, "indexed")
+            assert torch.equal(dec.decode(dst, index=None), img.reshape(-1)), (name, cband, "plain")
+            if cband is None:
+                enc2 = qdev.DeviceEncoder(w, h, b, 0, mode=mode, want_index=False, index_chunk=1)
+                d2, n2, _ = enc2.encode(img)
+                c2 = d2[:n2].cpu().numpy()
+                want, _, _, _ = oracle.decode(c2, identity=False)
+                assert n2 > n and want is not None and np.array_equal(want, host.ravel()), (name, "the reference's reader and the table")
+                assert torch.equal(qdev.DeviceDecoder(d2, n2).decode(d2, index=None), img.reshape(-1)), (name, "container alone")
