@@ -121,10 +121,13 @@ def roofline_of(avg, algo_bytes, names, traffic=None, extra=None):
     return r
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, workload=None):
+    """HBM bytes per launch (PMC, corrected) and the VALU summary of a kernel from the committed rocprofv3 passes
+    (profiles/collect.sh); the other workloads' records sit under their name in `workloads`"""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(kernel, {})
+            rec = json.load(f)
+        rec = (rec.get(workload, {}) if workload else rec).get(kernel, {})
         return rec.get("hbm_bytes_per_launch"), rec.get("valu")
     except (OSError, ValueError):
         return None, None
@@ -180,6 +183,10 @@ def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen
         "roofline": roofline_of({**e, **d_oob}, algo, ENC_KERNELS + DEC_KERNELS,
                                 extra={"restart_table_in_container": int(n) - stream_bytes, "out_of_band_index": enc.index_bytes}),
     })
+    if res["roofline"]:             # HBM bytes of the dominant kernel by the PMC passes of this workload (profiles/collect.sh)
+        res["roofline"]["traffic"], valu = pmc_traffic(res["roofline"]["kernel"], tag)
+        if valu:
+            res["roofline"]["valu"] = valu
     del enc, dec, img, out
     return res
 

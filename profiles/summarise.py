@@ -26,7 +26,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # library profile names (qb3x_profile_names) by a substring of the kernel symbol
-KEYS = [("enc_px_sp_kernel", "enc_units"), ("enc_px_kernel", "enc_units"), ("enc_px16_kernel", "enc_units"), ("enc_kernel", "enc_units"),
+KEYS = [("enc_px_best_sample_kernel", "enc_best_sample"), ("enc_best_sample_kernel", "enc_best_sample"),
+        ("enc_px_best_kernel", "enc_best_units"), ("dec_px_best_kernel", "dec_units"), ("ix_bl_best_fill", "ix_bl_fill"),
+        ("best_idx_fix", "enc_best_idx_fix"), ("enc_px_kernel", "enc_units"), ("enc_px16_kernel", "enc_units"), ("enc_kernel", "enc_units"),
         ("enc_best_kernel<unsigned char, false>", "enc_best_recode"), ("enc_best_kernel<unsigned short, false>", "enc_best_recode"),
         ("enc_best_kernel<unsigned int, false>", "enc_best_recode"), ("enc_best_kernel<unsigned long, false>", "enc_best_recode"),
         ("enc_best_kernel", "enc_best_units"), ("best_scan", "enc_best_scan"),
@@ -40,6 +42,8 @@ KEYS = [("enc_px_sp_kernel", "enc_units"), ("enc_px_kernel", "enc_units"), ("enc
 def key_of(name):
     if "qb3dev" not in name:
         return None
+    if "enc_px_best_kernel" in name and name.rstrip().rstrip(")").rstrip("(qb3dev::EncArgs").rstrip().endswith("false>"):
+        return "enc_best_recode"
     for sub, key in KEYS:
         if sub in name:
             return key
@@ -77,7 +81,74 @@ def pmc(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
+def subtag_of(wl, name):
+    """the key of bench.py's `workloads` a kernel of workload wl belongs to (config 4 runs four rasters in one process)"""
+    if wl == "c4":
+        t = "i64" if "unsigned long" in name else "i32"
+        best = any(k in name for k in ("enc_best", "best_scan", "best_idx_fix", "dec_kernel<", "dec_index"))
+        return "c4_%s_%s" % (t, "best" if best else "ftl")
+    return {"c2best": "c2_best", "c5": "c5_one_rank"}.get(wl, wl)
+
+
+def pmc_by_name(d, counter):
+    rows = list(csv.DictReader(open(find(d, "counter_collection.csv"))))
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] == counter and "qb3dev" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def workload_counters(tag, wl, fetch_dir, write_dir, sq_dir, cmd):
+    """TAG_WL_pmc_hbm.csv / TAG_WL_sq.csv per kernel SYMBOL, and pmc_traffic.json[subtag][profile name] for bench.py"""
+    fetch, nf = pmc_by_name(fetch_dir, "FETCH_SIZE")
+    write, _ = pmc_by_name(write_dir, "WRITE_SIZE")
+    path = os.path.join(HERE, "pmc_traffic.json")
+    try:
+        traffic = json.load(open(path))
+    except (OSError, ValueError):
+        traffic = {}
+    short = lambda n: n.replace("qb3dev::", "").replace("(EncArgs)", "").replace("(DecArgs)", "").replace("void ", "")
+    with open(os.path.join(HERE, "%s_%s_pmc_hbm.csv" % (tag, wl)), "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- %s\n" % cmd)
+        f.write("# KiB per dispatch, averaged; gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE x2, WRITE_SIZE x1\n")
+        f.write("workload,kernel,symbol,dispatches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_per_launch_corrected\n")
+        for name in sorted(set(fetch) | set(write)):
+            fk, wk = fetch.get(name, 0.0), write.get(name, 0.0)
+            b = int(round((2 * fk + wk) * 1024))
+            st, k = subtag_of(wl, name), key_of(name)
+            f.write('%s,%s,"%s",%d,%.1f,%.1f,%d\n' % (st, k, short(name), nf.get(name, 0), fk, wk, b))
+            rec = traffic.setdefault(st, {}).setdefault(k, {"hbm_bytes_per_launch": 0, "source": "profiles/%s_%s_pmc_hbm.csv" % (tag, wl)})
+            # several symbols under one profile name (a sample kernel beside the main one): what the name's launches move in sum
+            rec["hbm_bytes_per_launch"] = b if rec.get("_fresh") != tag else rec["hbm_bytes_per_launch"] + b
+            rec["_fresh"] = tag
+    names = ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")
+    vals = {n: pmc_by_name(sq_dir, n)[0] for n in names}
+    with open(os.path.join(HERE, "%s_%s_sq.csv" % (tag, wl)), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc %s -- %s\n" % (" ".join(names), cmd))
+        f.write("# per dispatch, summed over the 8 XCDs. valu_issue_frac = SQ_INSTS_VALU*2/1024 / (GRBM_GUI_ACTIVE/8); "
+                "lds_busy_frac = SQ_LDS_IDX_ACTIVE/256 / (GRBM_GUI_ACTIVE/8)\n")
+        f.write("workload,kernel,symbol," + ",".join(names) + ",valu_per_wave,valu_issue_frac,lds_busy_frac\n")
+        for name in sorted(vals["SQ_WAVES"]):
+            v = {n: vals[n].get(name, 0.0) for n in names}
+            dur = v["GRBM_GUI_ACTIVE"] / 8 or 1.0
+            vpw = v["SQ_INSTS_VALU"] / (v["SQ_WAVES"] or 1.0)
+            vf, lf = v["SQ_INSTS_VALU"] * 2 / 1024 / dur, v["SQ_LDS_IDX_ACTIVE"] / 256 / dur
+            st, k = subtag_of(wl, name), key_of(name)
+            f.write('%s,%s,"%s",' % (st, k, short(name)) + ",".join("%.0f" % v[n] for n in names) + ",%.0f,%.3f,%.3f\n" % (vpw, vf, lf))
+            rec = traffic.setdefault(st, {}).setdefault(k, {})
+            if "valu" not in rec or v["SQ_INSTS_VALU"] > rec.get("_valu_insts", 0):
+                rec["valu"] = {"insts_per_wave": round(vpw), "issue_time_frac": round(vf, 3), "lds_busy_frac": round(lf, 3), "source": "profiles/%s_%s_sq.csv" % (tag, wl)}
+                rec["_valu_insts"] = v["SQ_INSTS_VALU"]
+    with open(path, "w") as f:
+        json.dump(traffic, f, indent=1)
+
+
 def main():
+    if sys.argv[1] == "--workload":         # TAG WL FETCH_DIR WRITE_DIR SQ_DIR
+        tag, wl, fetch_dir, write_dir, sq_dir = sys.argv[2:7]
+        workload_counters(tag, wl, fetch_dir, write_dir, sq_dir, os.environ.get("PROFILE_CMD", ""))
+        return
     stats_only = sys.argv[1] == "--stats-only"
     if stats_only:
         sys.argv.pop(1)
@@ -124,8 +195,14 @@ def main():
                 if k in traffic:
                     traffic[k]["valu"] = {"insts_per_wave": round(vpw), "issue_time_frac": round(vf, 3), "lds_busy_frac": round(lf, 3),
                                           "source": "profiles/%s_sq.csv" % tag}
-    with open(os.path.join(HERE, "pmc_traffic.json"), "w") as f:
-        json.dump(traffic, f, indent=1)
+    path = os.path.join(HERE, "pmc_traffic.json")
+    try:        # (the other workloads' records, keyed by their name in bench.py's `workloads`, stay)
+        old = {k: v for k, v in json.load(open(path)).items() if isinstance(v, dict) and "hbm_bytes_per_launch" not in v and "valu" not in v}
+    except (OSError, ValueError):
+        old = {}
+    old.update(traffic)
+    with open(path, "w") as f:
+        json.dump(old, f, indent=1)
     for name, n, tot, avg, lo, hi in stats:
         print("%-28s calls %3d avg %9.1f us" % (key_of(name), n, avg / 1e3))
 

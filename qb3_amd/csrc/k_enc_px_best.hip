@@ -112,6 +112,93 @@ __device__ __forceinline__ void pxb_divide(const uint32_t (&G)[4], uint32_t cf, 
     }
 }
 
+// ---- cooperative analysis of the hard units: SIXTEEN LANES A UNIT, a lane a value.  What this phase costs the workgroup is
+// the latency of one unit's analysis (everybody waits for it), so the unit is spread out: reductions over a row of sixteen
+// lanes are four DPP instructions, comparing every value with every other is fifteen row rotations.
+template <uint32_t CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false); }
+// all-reduce over the sixteen lanes of a DPP row: pairs, quads, eights (half mirror), the row (mirror)
+#define ROW_ALLREDUCE(x, OP) do { x = OP(x, dpp_mov<0xB1>(x)); x = OP(x, dpp_mov<0x4E>(x)); x = OP(x, dpp_mov<0x141>(x)); x = OP(x, dpp_mov<0x140>(x)); } while (0)
+__device__ __forceinline__ uint32_t op_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t op_or(uint32_t a, uint32_t b) { return a | b; }
+__device__ __forceinline__ uint32_t op_add(uint32_t a, uint32_t b) { return a + b; }
+
+// One unit per row: v = the lane's mag-sign value (lane i of the row: value i), meta = rung | oldrung << 4 | idx_may << 8.
+// Results as best_analyse's (qb3_best.h; reference encode_best QB3encode.h:617-724), the same in every lane of the row:
+// r0 = cf | trung << 8 | writer << 12, r1 = szBase | szCf << 16, r2 = size of the index form (all ones: none)
+__device__ __forceinline__ void pxb_analyse_row(uint32_t v, uint32_t meta, bool on, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
+    constexpr uint32_t UB = 3, UMASK = 7;
+    typedef uint8_t T;
+    const uint32_t lane = threadIdx.x & 63, i = lane & 15, row = lane >> 4;
+    const uint32_t rung = meta & 15u, oldrung = (meta >> 4) & 15u;
+    const bool idx_may = (meta >> 8) & 1u;
+    // gcd of the non-zero magnitudes (QB3encode.h:98-126): Euclid on the whole row at once -- x = the smallest, every value
+    // modulo x, the smallest remainder is the next x (x itself stays in the set), until every remainder is zero
+    uint32_t a = (v >> 1) + (v & 1), x = a ? a : 255u;
+    ROW_ALLREDUCE(x, op_min);
+    bool done = !on || x == 1;
+    while (__any(!done)) {
+        uint32_t r = mod_t<T>((T)a, (T)x), m = r ? r : 255u;
+        ROW_ALLREDUCE(m, op_min);
+        if (!done) {
+            if (m == 255u) done = true;                 // every value is a multiple of x
+            else { a = (r == 0 && a == x) ? x : r; x = m; done = x == 1; }
+        }
+    }
+    const uint32_t cf = on ? x : 1u, thr = 45 + 2 * rung;
+    uint32_t szBase = 0, szCf = 0, trung = 0, size = 0;
+    if (__any(cf >= 2)) {
+        uint32_t d = cf >= 2 ? (uint32_t)mdiv_t<T>((T)v, (T)cf) : 0u, usedd = d;
+        ROW_ALLREDUCE(usedd, op_or);
+        trung = topbit32(usedd | 1);
+        // the step (QB3encode.h:169-176): the rung bits of the row's sixteen values are sixteen bits of a ballot
+        const uint32_t rowbits = (uint32_t)(__ballot((d >> trung) & 1u) >> (16 * row)) & 0xffffu;
+        if (trung && rowbits && (rowbits & (rowbits + 1)) == 0 && i + 1 == (uint32_t)__popc(rowbits)) d ^= 1u << trung;
+        const uint32_t top = 1u << trung, half = top >> 1;
+        uint32_t xx = d;
+        if (xx == top || xx == top - 1) xx ^= 2 * top - 1;         // the middle swap (all rungs of 8-bit data)
+        uint32_t grp = trung + (xx >= half) + (xx >= top);
+        ROW_ALLREDUCE(grp, op_add);
+        if (!trung) grp = 16;
+        szBase = (UB + 2) + sw_noflag_len<UB>(trung - oldrung) + 1 + grp;
+        const T cfm = (T)(cf - 2);
+        const uint32_t cfrung = topbit_t<T>(cfm);
+        if (trung >= cfrung && (trung < cfrung + UB || cfrung == 0)) szCf = 1 + vlen_t<T>(cfm, trung);
+        else szCf = cs_len<UB>((cfrung - trung) & UMASK) + vlen_t<T>((T)(cfm ^ (T)((T)1 << cfrung)), cfrung - 1);
+        if (cf < 2) { szBase = 0; szCf = 0; trung = 0; }
+        size = szBase + szCf;
+    }
+    // index form (QB3encode.h:557-613, tried per :702; a plain unit above rung 3 always reaches the threshold)
+    uint32_t idx = 0xffffffffu;
+    const bool want = on && idx_may && rung > 3 && (cf < 2 || size >= thr);
+    if (__any(want)) {
+        // the count of the lane's value and its first position in the row: fifteen rotations, the value from i - j each
+        uint32_t cnt = 1, fp = i;
+#define PXB_ROT1(j) { const uint32_t w = dpp_mov<0x120 + j>(v), src = (i - j) & 15u; const bool eq = w == v; cnt += eq; fp = (eq && src < fp) ? src : fp; }
+        PXB_ROT1(1) PXB_ROT1(2) PXB_ROT1(3) PXB_ROT1(4) PXB_ROT1(5) PXB_ROT1(6) PXB_ROT1(7) PXB_ROT1(8)
+        PXB_ROT1(9) PXB_ROT1(10) PXB_ROT1(11) PXB_ROT1(12) PXB_ROT1(13) PXB_ROT1(14) PXB_ROT1(15)
+#undef PXB_ROT1
+        const bool first = fp == i;
+        const uint32_t ndist = (uint32_t)__popc((uint32_t)(__ballot(first) >> (16 * row)) & 0xffffu);
+        // rank of the lane's value: the distinct values (at their first positions) with a larger count, or the same count and
+        // an earlier first position (the reference's stable sort by descending count, QB3encode.h:546-554)
+        const uint32_t P = v | (cnt << 8) | (i << 16) | ((uint32_t)first << 24);
+        uint32_t rank = 0;
+#define PXB_ROT2(j) { const uint32_t Q = dpp_mov<0x120 + j>(P), qc = (Q >> 8) & 0xffu; \
+                      rank += (Q >> 24) && (Q & 0xffu) != v && (qc > cnt || (qc == cnt && ((Q >> 16) & 0xffu) < fp)); }
+        PXB_ROT2(1) PXB_ROT2(2) PXB_ROT2(3) PXB_ROT2(4) PXB_ROT2(5) PXB_ROT2(6) PXB_ROT2(7) PXB_ROT2(8)
+        PXB_ROT2(9) PXB_ROT2(10) PXB_ROT2(11) PXB_ROT2(12) PXB_ROT2(13) PXB_ROT2(14) PXB_ROT2(15)
+#undef PXB_ROT2
+        uint32_t ibits = 2 + (rank >= 2) + (rank >= 4), vbits = first ? vlen_t<T>((T)v, rung) : 0u;     // a rank's code: 2, 3 or 4 bits
+        ROW_ALLREDUCE(ibits, op_add);
+        ROW_ALLREDUCE(vbits, op_add);
+        if (want && ndist <= 8) idx = (UB + 2) + sw_noflag_len<UB>(UMASK - oldrung) + sw_noflag_len<UB>(rung - oldrung) + ibits + vbits;
+    }
+    const bool writer = cf >= 2 && !(size >= thr && idx < size);
+    r0 = cf | (trung << 8) | ((uint32_t)writer << 12);
+    r1 = szBase | (szCf << 16);
+    r2 = idx;
+}
+
 // Dense emission of one queued unit in common-factor (kind 2) or index (kind 3) form at bit `pos` of the chunk's buffer
 // (reference cfgenc QB3encode.h:283-361, ienc :557-613).  tb0: byte address of the code table in LDS.
 __device__ __forceinline__ void pxb_emit(uint32_t *outbuf, uint32_t pos, const uint32_t (&G)[4], uint32_t rung, uint32_t oldrung, uint32_t kind,
@@ -258,7 +345,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     }
     __syncthreads();
     PXB_STAMP(2);
-    // ---- dense analysis of the hard units: cf | trung << 8 | writer << 12, szBase | szCf << 16, index size
+    // ---- analysis of the hard units: cf | trung << 8 | writer << 12, szBase | szCf << 16, index size
     uint32_t res0[B], res1[B], res2[B];
 #pragma unroll
     for (int c = 0; c < B; c++) { res0[c] = 1; res1[c] = 0; res2[c] = 0xffffffffu; }
@@ -275,18 +362,15 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
                 }
             __syncthreads();
         }
-        if (r0 + tid < nh) {
-            // (the unit-per-lane kernels' analysis, unrolled: what this phase costs the workgroup is ONE unit's latency)
-            uint8_t g[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) g[i] = (uint8_t)(hq[(i >> 2) * PXB_CAP + tid] >> (8 * (i & 3)));
-            const uint32_t meta = hq[4 * PXB_CAP + tid];
-            const uint8_t cf = gcf_t<uint8_t>(g, true);
-            BestUnit<uint8_t> u;
-            best_analyse<uint8_t>(g, meta & 15u, (meta >> 4) & 15u, cf, false, u);
-            hr[tid] = (uint32_t)u.cf | (u.trung << 8) | ((uint32_t)u.writer << 12);
-            hr[PXB_CAP + tid] = u.szBase | (u.szCf << 16);
-            hr[2 * PXB_CAP + tid] = u.idx;
+        // sixteen units a pass: a row of sixteen lanes per unit, a lane per value (pxb_analyse_row)
+        const uint32_t here = nh - r0 < PXB_CAP ? nh - r0 : PXB_CAP;
+        for (uint32_t s0 = 0; s0 < here; s0 += 16) {
+            const uint32_t j = s0 + (tid >> 4), i = tid & 15;
+            const bool on = j < here;
+            const uint32_t v = on ? (hq[(i >> 2) * PXB_CAP + j] >> (8 * (i & 3))) & 0xffu : 0u, meta = on ? hq[4 * PXB_CAP + j] : 0u;
+            uint32_t x0, x1, x2;
+            pxb_analyse_row(v, meta, on, x0, x1, x2);
+            if (on && i == 0) { hr[j] = x0; hr[PXB_CAP + j] = x1; hr[2 * PXB_CAP + j] = x2; }
         }
         __syncthreads();
 #pragma unroll
