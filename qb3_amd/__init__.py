@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libQB3.so")
+LIB_PATH = os.environ.get("QB3_LIB_PATH") or os.path.join(_HERE, "libQB3.so")     # (QB3_LIB_PATH: a diagnostic build of the library, scratch/variant.sh)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -37,7 +37,7 @@ __global__ void enc_scan2_kernel(const EncArgs a0) {
         if (threadIdx.x == blockDim.x - 1) carry = c0 + ex + v;
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.group_sum[ngroups] = carry;
+    if (threadIdx.x == 0) { a.group_sum[ngroups] = carry; a.res->zero_run = 0; }      // (enc_concat_kernel raises it)
 }
 
 // start of chunk k in the stream, in bits (k == nchunks: the stream length)
@@ -46,8 +46,19 @@ __device__ __forceinline__ uint64_t chunk_start(const EncArgs &a, uint32_t k) {
     return a.group_sum[k / SCAN_GROUP] + a.chunk_off[k];
 }
 
+// do two consecutive stream dwords hold four zero bytes in a row that start in the first
+__device__ __forceinline__ bool zero_run_in(uint32_t cur, uint32_t nxt) {
+    return cur == 0 || __builtin_amdgcn_alignbit(nxt, cur, 8) == 0 || __builtin_amdgcn_alignbit(nxt, cur, 16) == 0 ||
+           __builtin_amdgcn_alignbit(nxt, cur, 24) == 0;
+}
+
 // Concatenate: one WAVE per chunk reads the chunk's slot, funnel-shifts it to its bit position and stores the
 // dwords that lie wholly inside the chunk; the first and last shifted dword go to the seam table.
+// With zrun_probe (the RLE0 modes) the wave also looks for four zero bytes in a row among the dwords it moves -- RLE0
+// (reference QB3encode.cpp:536-565) can only shorten a stream that has such a run, and looking here spares a pass over the
+// finished stream.  A dword shared with a neighbouring chunk is tested as this chunk sees it (the neighbour's bits zero) and
+// so is the stream's last dword: the answer can be a false yes (the RLE0 pass then runs and decides), never a false no --
+// a run that touches a shared dword has zeros in both chunks' bits of it, and each chunk tests it against its own side.
 __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -63,6 +74,7 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     // is what this copy needs.  Output dword d = source dwords d-1, d funnel-shifted by the chunk's bit phase.
     const uint32_t ng = (nd + 3) >> 2, sh = (32 - phase) & 31;
     constexpr int NQ = 4;                                               // 16-byte loads in flight per lane
+    bool zrun = false;
     for (uint32_t gb = 0; gb < ng; gb += 64 * NQ) {
         uint4 cur[NQ];
         uint32_t before[NQ];                                            // lane 0: the dword before its group
@@ -73,6 +85,7 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
             if (g < ng && 4 * g < nsrc) cur[q] = slot4[g];
             if (lane == 0 && g && g < ng && 4 * g - 1 < nsrc) before[q] = slot[4 * g - 1];
         }
+        uint32_t first[NQ], last[NQ];                                   // (zrun_probe) a group's first and last output dword
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             const uint32_t g = gb + 64 * q + lane, d = 4 * g;
@@ -81,6 +94,7 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
             for (int k = 0; k < 4; k++) if (d + k >= nsrc) s[k] = 0;    // the slot is only defined up to nsrc
             uint32_t prv = __shfl_up(s[3], 1, 64);
             if (lane == 0) prv = before[q];
+            first[q] = last[q] = 0xffffffffu;
             if (g >= ng) continue;
             uint32_t v[4];
             if (phase) {
@@ -106,8 +120,33 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
                     }
                 }
             }
+            if (a.zrun_probe) {         // (wave uniform) runs that start in dwords 0 .. 2 of the group; dwords behind the chunk count as non-zero
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (d + k >= nd) v[k] = 0xffffffffu;
+                zrun = zrun || zero_run_in(v[0], v[1]) || zero_run_in(v[1], v[2]) || zero_run_in(v[2], v[3]);
+                first[q] = v[0]; last[q] = v[3];
+            }
+        }
+        if (a.zrun_probe) {             // ... and in a group's last dword: the dword behind it is the next lane's first, lane 63's the next batch's
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                uint32_t nxt = (uint32_t)__shfl_down((int)first[q], 1, 64);
+                const uint32_t wrap = q + 1 < NQ ? (uint32_t)__shfl((int)first[q + 1 < NQ ? q + 1 : q], 0, 64) : 0xffffffffu;
+                if (lane == 63) {
+                    nxt = wrap;
+                    if (q + 1 == NQ) {                                  // the first dword of the next round of the loop
+                        const uint32_t dn = 4 * (gb + 64 * NQ);
+                        if (dn < nd) {
+                            const uint32_t s0 = dn < nsrc ? slot[dn] : 0u, sp = dn - 1 < nsrc ? slot[dn - 1] : 0u;
+                            nxt = phase ? __builtin_amdgcn_alignbit(s0, sp, sh) : s0;
+                        }
+                    }
+                }
+                zrun = zrun || zero_run_in(last[q], nxt);
+            }
         }
     }
+    if (a.zrun_probe && __any(zrun) && lane == 0) atomicOr(&a.res->zero_run, 1u);
 }
 
 // One thread per chunk boundary: a dword that holds the end of one chunk and the start of the next is the OR of

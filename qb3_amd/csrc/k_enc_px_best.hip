@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t swar_has_mag1(uint32_t x) {
     const uint32_t u = swar_sub8(x, 0x01010101u) & 0xfefefefeu;     // byte - 1, low bit dropped: zero for 1 and 2 (0 gives fe)
     return (u - 0x01010101u) & ~u & 0x80808080u;
 }
-constexpr uint32_t multiples_mask(uint32_t p) { uint32_t m = 0; for (uint32_t k = 0; k < 32; k += p) m |= 1u << k; return m; }
+constexpr uint32_t odd_multiples_mask(uint32_t p) { uint32_t m = 0; for (uint32_t a = p; a <= 16; a += p) m |= 1u << (2 * a - 1); return m; }   // bit 2a - 1 for the multiples a of p
 // wave-aggregated append: lanes with `want` get consecutive queue indices
 __device__ __forceinline__ uint32_t queue_take(uint32_t *counter, bool want) {
     const uint64_t m = __ballot(want);
@@ -173,7 +173,9 @@ __device__ __forceinline__ void pxb_analyse_row(uint32_t v, uint32_t meta, bool 
     if (__any(want)) {
         // the count of the lane's value and its first position in the row: fifteen rotations, the value from i - j each
         uint32_t cnt = 1, fp = i;
-#define PXB_ROT1(j) { const uint32_t w = dpp_mov<0x120 + j>(v), src = (i - j) & 15u; const bool eq = w == v; cnt += eq; fp = (eq && src < fp) ? src : fp; }
+        const uint32_t vi = v | (i << 8);           // (the position travels with the value: no per-rotation constants to keep)
+        // (a scheduling barrier after every rotation: left alone the compiler issues all fifteen at once and keeps their results live)
+#define PXB_ROT1(j) { const uint32_t w = dpp_mov<0x120 + j>(vi), src = w >> 8; const bool eq = (w & 0xffu) == v; cnt += eq; fp = (eq && src < fp) ? src : fp; __builtin_amdgcn_sched_barrier(0); }
         PXB_ROT1(1) PXB_ROT1(2) PXB_ROT1(3) PXB_ROT1(4) PXB_ROT1(5) PXB_ROT1(6) PXB_ROT1(7) PXB_ROT1(8)
         PXB_ROT1(9) PXB_ROT1(10) PXB_ROT1(11) PXB_ROT1(12) PXB_ROT1(13) PXB_ROT1(14) PXB_ROT1(15)
 #undef PXB_ROT1
@@ -184,7 +186,7 @@ __device__ __forceinline__ void pxb_analyse_row(uint32_t v, uint32_t meta, bool 
         const uint32_t P = v | (cnt << 8) | (i << 16) | ((uint32_t)first << 24);
         uint32_t rank = 0;
 #define PXB_ROT2(j) { const uint32_t Q = dpp_mov<0x120 + j>(P), qc = (Q >> 8) & 0xffu; \
-                      rank += (Q >> 24) && (Q & 0xffu) != v && (qc > cnt || (qc == cnt && ((Q >> 16) & 0xffu) < fp)); }
+                      rank += (Q >> 24) && (Q & 0xffu) != v && (qc > cnt || (qc == cnt && ((Q >> 16) & 0xffu) < fp)); __builtin_amdgcn_sched_barrier(0); }
         PXB_ROT2(1) PXB_ROT2(2) PXB_ROT2(3) PXB_ROT2(4) PXB_ROT2(5) PXB_ROT2(6) PXB_ROT2(7) PXB_ROT2(8)
         PXB_ROT2(9) PXB_ROT2(10) PXB_ROT2(11) PXB_ROT2(12) PXB_ROT2(13) PXB_ROT2(14) PXB_ROT2(15)
 #undef PXB_ROT2
@@ -298,49 +300,78 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     PxFront<B> f;
     px_front<B, RGB, ORDER>(a0, gblk, w, pd, etab, wsum, tabv, f);      // (one barrier)
     const uint32_t rp_packed = f.rp_packed, prp = f.prp;
+    uint32_t usedp = 0, lastp = 0, pvp = 0;     // the bands' used / leaving / entering values, a byte each
+#pragma unroll
+    for (int c = 0; c < B; c++) { usedp |= f.usedv[c] << (8 * c); lastp |= f.lastv[c] << (8 * c); pvp |= f.pvv[c] << (8 * c); }
     PXB_STAMP(1);
 
-    // ---- per band: is the unit settled without analysis.
-    // Common factor: a bitmap of the sixteen magnitudes (exact while they are below 32: rungs up to 5; magnitude 32 falls on
-    // bit 0 and is ignored, which can only make a unit look harder) -- a factor exists exactly when some prime divides every
-    // magnitude in the bitmap, eleven mask tests; above rung 5 a magnitude of 1 settles it, else the unit is hard.
-    // Index form (QB3encode.h:702): only tried for rungs above 3 -- there the plain size, at least 16 * rung + 1, always
-    // reaches the threshold 45 + 2 * rung -- and only with at most eight distinct values: the bitmap of the values' low five
-    // bits bounds those from below.
-    uint32_t qi[B], idxm = 0;
+    // ---- per band: the plain form of the unit (QB3M_BASE's, from the lane's registers), and is the unit settled by it.
+    // One bitmap of the sixteen mag-sign values answers both questions while they are below 32 (rungs up to 4).
+    // Common factor: magnitude a is values 2a - 1 and 2a, so bit 2a - 1 of bm | bm >> 1 says "a occurs"; a factor exists
+    // exactly when some prime divides every magnitude that occurs: six mask tests (magnitudes up to 16).  From rung 5 up a
+    // magnitude of 1 settles it, else the unit is hard.
+    // Index form (QB3encode.h:557-613, tried per :702 for rungs above 3 -- where the plain size, at least 16 * rung + 1,
+    // always reaches the threshold 45 + 2 * rung): n distinct values cost at least the head, 32 + max(n - 2, 0) +
+    // max(n - 4, 0) bits of index codes (every count beyond the first value's is 1) and the values' own codes -- exact from the
+    // bitmap up to rung 4 -- and only a unit whose plain size exceeds that goes to the analysis.
+    // (state that lives across the analysis is kept small: the kernel's registers set how many workgroups a CU holds)
+    uint32_t pc[B][6], plp[B];                  // plp: the six piece lengths, five bits each (a piece is at most 27 bits)
+    uint32_t qip = 0, qip3 = 0, idxm = 0;       // qip: the places of bands 0 .. 2 in the queue of hard units, ten bits each (0x3ff: none); qip3: band 3's
+    auto qi_of = [&](int c) -> uint32_t { const uint32_t q = c < 3 ? (qip >> (10 * c)) & 0x3ffu : qip3; return q == 0x3ffu ? ~0u : q; };
+    auto plain_len = [&](int c) -> uint32_t { uint32_t n = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) n += (plp[c] >> (5 * k)) & 31u;
+        return n; };
 #pragma unroll
     for (int c = 0; c < B; c++) {
+        uint32_t pl[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pc[c][k] = 0; pl[k] = 0; }
+        uint32_t lenN = 0;
         bool hard = false;
-        const uint32_t rung = (rp_packed >> (4 * c)) & 15u, prung = (prp >> (4 * c)) & 15u;
-        if (payload && f.usedv[c] > 1) {
-            uint32_t bm = 0, bma = 0;
+        const uint32_t rung = (rp_packed >> (4 * c)) & 15u, prung = (prp >> (4 * c)) & 15u, used = (usedp >> (8 * c)) & 0xffu;
+        if (payload) {
+            const uint32_t delta = (rung - prung) & UMASK;
+            const uint32_t csl = __builtin_amdgcn_ubfe(cs3_lens(), 4 * delta, 4), csc = (uint32_t)(cs3_codes() >> (8 * delta)) & 0xffu;
+            if (used <= 1) lenN = px_unit_low(f.gp[c], used, csl, csc, pc[c], pl);
+            else {
+                lenN = px_unit_pieces<true>(f.gp[c], rung, csl, csc, etab_off + (8u << rung), pc[c], pl);
+                uint32_t bm = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t gq = f.gp[c][q], aq = ((gq >> 1) & 0x7f7f7f7fu) + (gq & 0x01010101u);      // magnitudes: (g >> 1) + (g & 1)
+                for (int i = 0; i < 16; i++) bm |= 1u << ((f.gp[c][i >> 2] >> (8 * (i & 3))) & 31u);
+                const uint32_t occ = (bm | (bm >> 1)) & 0xaaaaaaaau;        // bit 2a - 1: magnitude a occurs (a = 1 .. 16)
+                bool factor = false;
+                constexpr uint32_t primes[6] = {2, 3, 5, 7, 11, 13};
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    bm |= 1u << ((gq >> (8 * i)) & 31u);
-                    bma |= 1u << ((aq >> (8 * i)) & 31u);
+                for (int k = 0; k < 6; k++) factor = factor || (occ & ~odd_multiples_mask(primes[k])) == 0;
+                if (__any(rung > 4)) {
+                    const uint32_t has1 = swar_has_mag1(f.gp[c][0]) | swar_has_mag1(f.gp[c][1]) | swar_has_mag1(f.gp[c][2]) | swar_has_mag1(f.gp[c][3]);
+                    if (rung > 4) factor = !has1;
                 }
+                const uint32_t n = __popc(bm);             // distinct values: exact up to rung 4, else a lower bound
+                uint32_t vb = n * rung;                     // their own codes: rung bits each, one more from half the range up, two more in the top half (middle swap: QB3encode.h:30-33)
+                if (rung == 4) vb += __popc(bm & 0xffffff00u) + __popc(bm & 0xfffe8000u);
+                const uint32_t head = 5 + sw_noflag_len<3>(UMASK - prung) + sw_noflag_len<3>(rung - prung);
+                const uint32_t floor_ = head + 32 + (n > 2 ? n - 2 : 0) + (n > 4 ? n - 4 : 0) + vb;
+#ifdef PXB_EXP_NOIDX
+                const bool idx_may = false;
+#else
+                const bool idx_may = rung > 3 && n <= 8 && floor_ < lenN;
+#endif
+                hard = factor || idx_may;
+#ifdef PXB_EXP_NOHARD
+                hard = false;
+#endif
+                idxm |= (uint32_t)idx_may << c;
             }
-            bma &= ~1u;
-            bool factor = false;
-            constexpr uint32_t primes[11] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31};
-#pragma unroll
-            for (int k = 0; k < 11; k++) factor = factor || (bma & ~multiples_mask(primes[k])) == 0;
-            if (__any(rung > 5)) {
-                const uint32_t has1 = swar_has_mag1(f.gp[c][0]) | swar_has_mag1(f.gp[c][1]) | swar_has_mag1(f.gp[c][2]) | swar_has_mag1(f.gp[c][3]);
-                if (rung > 5) factor = !has1;
-            }
-            const bool idx_may = rung > 3 && __popc(bm) <= 8;
-            hard = factor || idx_may;
-            idxm |= (uint32_t)idx_may << c;
         }
-        qi[c] = queue_take(&wsum[40], hard);
-        if (qi[c] < PXB_CAP) {
+        plp[c] = pl[0] | (pl[1] << 5) | (pl[2] << 10) | (pl[3] << 15) | (pl[4] << 20) | (pl[5] << 25);
+        const uint32_t qn = queue_take(&wsum[40], hard);       // (at most 765 hard units a chunk)
+        if (c < 3) qip |= (qn & 0x3ffu) << (10 * c); else qip3 = qn & 0x3ffu;
+        if (qn < PXB_CAP) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) hq[q * PXB_CAP + qi[c]] = f.gp[c][q];
-            hq[4 * PXB_CAP + qi[c]] = rung | (prung << 4) | (((idxm >> c) & 1u) << 8);
+            for (int q = 0; q < 4; q++) hq[q * PXB_CAP + qn] = f.gp[c][q];
+            hq[4 * PXB_CAP + qn] = rung | (prung << 4) | (((idxm >> c) & 1u) << 8);
         }
     }
     __syncthreads();
@@ -354,8 +385,8 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
         if (r0) {
 #pragma unroll
             for (int c = 0; c < B; c++)
-                if (qi[c] != ~0u && qi[c] - r0 < PXB_CAP) {
-                    const uint32_t j = qi[c] - r0;
+                if (qi_of(c) != ~0u && qi_of(c) - r0 < PXB_CAP) {
+                    const uint32_t j = qi_of(c) - r0;
 #pragma unroll
                     for (int q = 0; q < 4; q++) hq[q * PXB_CAP + j] = f.gp[c][q];
                     hq[4 * PXB_CAP + j] = ((rp_packed >> (4 * c)) & 15u) | (((prp >> (4 * c)) & 15u) << 4) | (((idxm >> c) & 1u) << 8);
@@ -375,8 +406,8 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < B; c++)
-            if (qi[c] != ~0u && qi[c] - r0 < PXB_CAP) {
-                const uint32_t j = qi[c] - r0;
+            if (qi_of(c) != ~0u && qi_of(c) - r0 < PXB_CAP) {
+                const uint32_t j = qi_of(c) - r0;
                 res0[c] = hr[j]; res1[c] = hr[PXB_CAP + j]; res2[c] = hr[2 * PXB_CAP + j];
             }
         if (r0 + PXB_CAP < nh) __syncthreads();
@@ -413,15 +444,12 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     const uint32_t seg = gblk / a.g.seg_blocks;
     const bool seg_start = payload && a.have_idx && seg * a.g.seg_blocks == gblk;
     uint32_t len[B], kind[B], pcfv[B], blen[1] = { 0 };       // kind: 0 low / 1 plain (the lane's pieces), 2 common factor, 3 index
-    uint32_t pc[B][6], pl[B][6];
     bool same[B];
 #pragma unroll
     for (int c = 0; c < B; c++) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) { pc[c][k] = 0; pl[c][k] = 0; }
         len[c] = 0; kind[c] = 0; same[c] = false; pcfv[c] = 0;
         if (payload) {
-            const uint32_t rung = (rp_packed >> (4 * c)) & 15u, prung = (prp >> (4 * c)) & 15u, used = f.usedv[c], cf = res0[c] & 0xffu;
+            const uint32_t rung = (rp_packed >> (4 * c)) & 15u, used = (usedp >> (8 * c)) & 0xffu, cf = res0[c] & 0xffu;
             if (cf >= 2 || seg_start) {
                 // factor state entering this unit: the last writer before it in the chunk, else the chunk's entry state
                 uint32_t v = 0;
@@ -430,17 +458,14 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
                 if (FIRST && !mine && cf >= 2) atomicOr(&used_entry[c], 1u);
                 if (FIRST && seg_start) a.seg_from_entry[(uint64_t)seg * B + c] = (uint8_t)!mine;
             }
-            const uint32_t delta = (rung - prung) & UMASK;
-            const uint32_t csl = __builtin_amdgcn_ubfe(cs3_lens(), 4 * delta, 4), csc = (uint32_t)(cs3_codes() >> (8 * delta)) & 0xffu;
-            if (used <= 1) len[c] = px_unit_low(f.gp[c], used, csl, csc, pc[c], pl[c]);
-            else {
+            uint32_t size = plain_len(c);
+            if (used > 1) {
                 const uint32_t thr = 45 + 2 * rung;
-                uint32_t size;
+                kind[c] = 1;
                 if (cf >= 2) { same[c] = (cf - 2) == pcfv[c]; size = (res1[c] & 0xffffu) + (same[c] ? 0u : res1[c] >> 16); kind[c] = 2; }
-                else { size = px_unit_pieces<true>(f.gp[c], rung, csl, csc, etab_off + (8u << rung), pc[c], pl[c]); kind[c] = 1; }
                 if (size >= thr && res2[c] < size) { size = res2[c]; kind[c] = 3; }
-                len[c] = size;
             }
+            len[c] = size;
             blen[0] += len[c];
         }
     }
@@ -461,7 +486,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
             const bool dense = payload && kind[c] >= 2;
             if (payload && !dense) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) wr.put(pc[c][k], pl[c][k]);
+                for (int k = 0; k < 6; k++) wr.put(pc[c][k], (plp[c] >> (5 * k)) & 31u);
             }
             p += len[c];
             if (dense) { wr.finish(); wr.init(outbuf, p); }     // (the unit's bits come from another lane)
@@ -472,7 +497,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     if (payload) {
         if (gblk == nblocks - 1) {      // coder state on leaving the image (QB3encode.h:718-722; the band's final factor: best_scan_kernel)
 #pragma unroll
-            for (int c = 0; c < B; c++) { a.res->prev[c] = f.lastv[c]; a.res->rung[c] = (rp_packed >> (4 * c)) & 15u; }
+            for (int c = 0; c < B; c++) { a.res->prev[c] = (lastp >> (8 * c)) & 0xffu; a.res->rung[c] = (rp_packed >> (4 * c)) & 15u; }
         }
         if (a.have_idx) {
             // the block table of the lane-per-block decoder: the block's bits, and the rungs its units are entered with
@@ -480,7 +505,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
             if (seg_start) {
 #pragma unroll
                 for (int c = 0; c < B; c++) {
-                    ((uint8_t *)a.idx.prev)[(uint64_t)seg * B + c] = (uint8_t)f.pvv[c];
+                    ((uint8_t *)a.idx.prev)[(uint64_t)seg * B + c] = (uint8_t)(pvp >> (8 * c));
                     ((uint8_t *)a.idx.cf)[(uint64_t)seg * B + c] = (uint8_t)pcfv[c];
                     a.idx.rung[(uint64_t)seg * B + c] = (uint8_t)((prp >> (4 * c)) & 15u);
                 }

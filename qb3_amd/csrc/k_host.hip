@@ -3,39 +3,6 @@
 
 namespace qb3dev {
 
-// RLE0 (reference QB3encode.cpp:536-565) can only shorten a stream that holds a run of four zero bytes; looking for one
-// on the device spares the host pass (a copy of the whole stream over PCIe and a byte loop) whenever there is none.
-__global__ void zero_run_probe_kernel(const uint32_t *buf, uint64_t first_byte, uint64_t end_byte, uint32_t *flag) {
-    const uint64_t ndw = (end_byte + 3) >> 2, d0 = first_byte >> 2;
-    bool found = false;
-    // bytes outside [first_byte, end_byte) count as non-zero
-    auto dw = [&](uint64_t i) -> uint32_t {
-        if (i >= ndw) return 0xffffffffu;
-        uint32_t v = buf[i];
-        if (4 * i < first_byte) v |= 0xffffffffu >> (8 * (4 - (uint32_t)(first_byte - 4 * i)));
-        if (4 * i + 4 > end_byte) v |= 0xffffffffu << (8 * (uint32_t)(end_byte - 4 * i));
-        return v;
-    };
-    auto pair = [&](uint32_t cur, uint32_t nxt) {
-        return cur == 0 || __builtin_amdgcn_alignbit(nxt, cur, 8) == 0 || __builtin_amdgcn_alignbit(nxt, cur, 16) == 0 ||
-               __builtin_amdgcn_alignbit(nxt, cur, 24) == 0;
-    };
-    // a thread takes four dwords a step (one sixteen-byte load when they lie wholly inside the range) and the dword behind them
-    for (uint64_t d = d0 + 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x); d < ndw; d += 4 * (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t v[5];
-        if (4 * d >= first_byte && 4 * (d + 5) <= end_byte) {
-            const u32x4_a4 t = *(const u32x4_a4 *)(buf + d);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = buf[d + 4];
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 5; k++) v[k] = dw(d + k);
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) found = found || pair(v[k], v[k + 1]);
-    }
-    if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
-}
-
 // ------------------------------------------------------------------ host side of the kernels
 static thread_local char g_err[256] = "";
 const char *last_error() { return g_err; }
@@ -345,8 +312,9 @@ static int launch_encode_all(const EncArgs &a, const EncPlan &plan, hipStream_t 
 
 int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
                   const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb,
-                  const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix) {
+                  const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix, bool zrun_probe) {
     EncArgs a;
+    a.zrun_probe = zrun_probe ? 1u : 0u;
     a.ix_dst = ix.base; a.ix_K = ix.K; a.ix_E = ix.entry_bytes; a.ix_per_chunk = ix.per_chunk; a.ix_blocks = ix.blocks;
     a.ix_spe = g.seg_blocks ? ix.blocks / g.seg_blocks : 0;
     a.ntiles = tb.n ? tb.n : 1; a.ts_img = tb.src_pitch; a.ts_out = tb.dst_pitch; a.ts_ws = tb.ws_pitch; a.ts_idx = tb.idx_pitch;
@@ -489,21 +457,6 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     else if (use_px16) { ProfScope ps("dec_units", st); launch_dec_px16(a, plan, st); }
     else { ProfScope ps(plan.fast && !best ? "dec_units" : "dec_segments", st); launch_dec_generic(a, plan, st); }
     HIPCHK(hipGetLastError());
-    return 0;
-}
-
-// *has_run = 1 when bytes [off, off + nbytes) of the dword-aligned device buffer hold four consecutive zero bytes.
-// d_flag: one device word of scratch.  Synchronises the stream.
-int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, int *has_run, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemsetAsync(d_flag, 0, 4, st));
-    const uint64_t ndw = (off + nbytes + 3) / 4 - off / 4;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, (ndw + 1023) / 1024 ? (ndw + 1023) / 1024 : 1);     // (a thread takes four dwords a step)
-    hipLaunchKernelGGL(zero_run_probe_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *)d_buf, (uint64_t)off, (uint64_t)(off + nbytes), (uint32_t *)d_flag);
-    uint32_t f = 0;
-    HIPCHK(hipMemcpyAsync(&f, d_flag, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    *has_run = (int)f;
     return 0;
 }
 

@@ -378,7 +378,7 @@ static size_t stored_encode_host(encsp p, const void *source, void *destination)
 // d_index may be null.  Synchronises the stream.
 static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, uint8_t *d_out, size_t hdr,
                                  void *d_index, hipStream_t st, bool carry, uint64_t *bits, const uint8_t *hdrbytes,
-                                 size_t hdr_stamp, const IxTable &ix) {
+                                 size_t hdr_stamp, const IxTable &ix, int *zero_run = nullptr) {
     EncPlan plan = plan_encode(g);
     if (!p->d_ws.ensure(plan.ws_bytes)) return false;
     BandState bs;
@@ -389,11 +389,12 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     uint32_t *out32 = (uint32_t *)(d_out + (hdr & ~(size_t)3));
     EncResult res;
     const uint8_t *dres = (const uint8_t *)p->d_ws.p + plan.ws_bytes - sizeof(EncResult);
-    if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st, TileBatch(), hdrbytes, (uint32_t)hdr_stamp, ix)) return false;
+    if (launch_encode(g, plan, d_img, out32, (uint32_t)(8 * (hdr & 3)), bs, p->d_ws.p, d_index, st, TileBatch(), hdrbytes, (uint32_t)hdr_stamp, ix, zero_run != nullptr)) return false;
     const hipError_t e = fetch_small(&res, dres, sizeof(res), st);
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
     prof_collect();
     *bits = res.total_bits;
+    if (zero_run) *zero_run = (int)res.zero_run;
     if (carry)
         for (size_t c = 0; c < p->nbands; c++) {
             p->band[c].prev = (size_t)res.prev[c]; p->band[c].runbits = res.rung[c]; p->band[c].cf = (size_t)res.cf[c];
@@ -496,7 +497,8 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
         }
     }
     uint64_t bits = 0;
-    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits, hdrbuf, hdr_stamp, ixt)) {   // the index describes the block stream, RLE0 wrapped or not
+    int has_run = 1;        // (RLE0 modes: the concatenation pass looks for four zero bytes in a row, without which RLE0 cannot win)
+    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits, hdrbuf, hdr_stamp, ixt, rle ? &has_run : nullptr)) {   // the index describes the block stream, RLE0 wrapped or not
         p->error = QB3E_LIBERR; return 0;
     }
     p->error = 0;
@@ -506,12 +508,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     if (rle) {
         // the RLE0 post pass (reference QB3encode.cpp:536-565)
         p->mode = mode;
-        // ... which can only win when the stream has a run of four zero bytes at all (a cheap probe first)
-        int has_run = 1;
-        if (len_ref <= maxsz / 2 && len - hdr >= 4) {
-            uint8_t *flag = (uint8_t *)p->d_ws.p;       // the workspace is idle now; its first word serves as the flag
-            if (zero_run_probe(out_dev, hdr, len - hdr, flag, &has_run, st)) has_run = 1;
-        }
+        // ... which can only win when the stream has a run of four zero bytes at all (has_run: the encoder kernels looked)
         if (len_ref <= maxsz / 2 && has_run) {
             // the byte pass on the device (k_rle0.hip): its size first, the bytes only when it wins -- into a buffer of its
             // own (the passes run in parallel: not in place), then behind the RLE mode's header

@@ -61,7 +61,7 @@ struct EncResult {
     uint64_t cf[MAXBANDS];
     uint32_t rung[MAXBANDS];
     uint32_t error;             // reserved
-    uint32_t pad;
+    uint32_t zero_run;          // the stream holds four zero bytes in a row, or might (asked for with launch_encode's zrun_probe: RLE0 can only win then)
 };
 
 // Workspace sizes
@@ -134,7 +134,8 @@ bool walk_table_applies(const Geometry &g, const DecPlan &plan);
 int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
                   const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb = TileBatch(),
                   const uint8_t *hdr = nullptr, uint32_t hdr_len = 0,      // hdr: container header stamped before each stream
-                  const IxTable &ix = IxTable());
+                  const IxTable &ix = IxTable(),
+                  bool zrun_probe = false);     // look for four zero bytes in a row while concatenating (EncResult::zero_run)
 
 struct DecPlan {
     uint32_t threads;       // lanes per workgroup, one index segment per lane
@@ -174,8 +175,6 @@ size_t rle0_ws_bytes(uint64_t n);
 int rle0_device_size(const void *d_src, uint64_t n, void *ws, bool decode, uint64_t *total, void *stream);
 int rle0_device_write(const void *d_src, uint64_t n, void *ws, bool decode, void *d_dst, void *stream);
 
-// RLE0 can only win on a stream with a run of four zero bytes: *has_run says whether bytes [off, off+nbytes) of d_buf have one
-int zero_run_probe(const void *d_buf, size_t off, size_t nbytes, void *d_flag, int *has_run, void *stream);
 
 // Elementwise helpers on device buffers (quantisation, reference QB3encode.cpp:137-186 / QB3decode.cpp:77-107)
 int launch_quantize(void *dst, const void *src, const Geometry &g, int dtype, uint64_t q, bool away, void *stream);

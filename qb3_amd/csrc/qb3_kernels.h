@@ -220,6 +220,7 @@ struct EncArgs {
     BandState st;
     IndexView idx;
     uint32_t have_idx;
+    uint32_t zrun_probe;    // enc_concat_kernel also looks for four zero bytes in a row (res->zero_run; RLE0 can only win on such a stream)
     uint32_t idx_no_ulen;   // the index is the library's own, only sampled for the restart table: segment entries, no unit lengths
 };
 
