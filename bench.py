@@ -475,6 +475,11 @@ def main():
             roofline["traffic_GBps"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9, 1)
             roofline["traffic_frac_of_device_copy"] = round(roofline["traffic_GBps"] / roofline["device_copy_GBps"], 3)
 
+    # the reference's own entry points on host buffers (qb3_encode / qb3_read_data: upload or download included) -- reported
+    # beside the line, never part of `value`
+    host_api = None
+    if not args.no_workloads:
+        host_api = host_api_times(qb3_amd, img, W, H, args.table_level)
     workloads = None
     if not args.no_workloads and args.size == 16384:
         del img, out, enc, dec, dst
@@ -508,9 +513,49 @@ def main():
         "kernels": kernels,
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "host_api_ms": host_api,
         "workloads": workloads,
     }
     print(json.dumps(line))
+
+
+def host_api_times(qb3_amd, img, W, H, table_level):
+    """qb3_encode / qb3_read_data of the headline raster through HOST pointers (the literal drop-in calls): best of two,
+    PCIe transfers included -- not part of `value`"""
+    import numpy as np
+    L = qb3_amd.lib
+    host = np.ascontiguousarray(img.cpu().numpy()).reshape(H, W, 3)
+    out = {}
+    for name, level in (("plain_container", 0), ("self_indexed_container", table_level)):
+        p = L.qb3_create_encoder(W, H, 3, qb3_amd.QB3_U8)
+        L.qb3_set_encoder_mode(p, qb3_amd.QB3M_FTL)
+        if level:
+            L.qb3x_set_encoder_index_chunk(p, level)
+        dst = np.empty(L.qb3_max_encoded_size(p), dtype=np.uint8)
+        t_enc = []
+        for _ in range(3):
+            L.qb3_reset_encoder(p)
+            L.qb3_set_encoder_mode(p, qb3_amd.QB3M_FTL)
+            t0 = time.perf_counter()
+            n = L.qb3_encode(p, host.ctypes.data, dst.ctypes.data)
+            t_enc.append(time.perf_counter() - t0)
+        L.qb3_destroy_encoder(p)
+        rec = {"qb3_encode_ms": round(min(t_enc) * 1e3, 2), "container_bytes": int(n)}
+        if level:           # (a plain container of this size takes the serial walk: seconds, reported under decode.plain_container)
+            back = np.empty(W * H * 3, dtype=np.uint8)
+            t_dec = []
+            for _ in range(3):
+                dims = (qb3_amd._sz * 3)()
+                d = L.qb3_read_start(dst.ctypes.data, n, dims)
+                ok = d and L.qb3_read_info(d)
+                t0 = time.perf_counter()
+                m = L.qb3_read_data(d, back.ctypes.data) if ok else 0
+                t_dec.append(time.perf_counter() - t0)
+                L.qb3_destroy_decoder(d)
+            rec["qb3_read_data_ms"] = round(min(t_dec) * 1e3, 2)
+            rec["exact"] = bool(m == back.size and np.array_equal(back, host.ravel()))
+        out[name] = rec
+    return out
 
 
 def run_other(wl, args, torch, qb3_amd, synth, qdev, dev):
@@ -589,11 +634,31 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
     torch.cuda.synchronize()
     if not torch.equal(out, imgs):
         sys.exit("bench.py: decode(encode(x)) != x -- refusing to report a number")
-    intact = None
-    if rank == 0:           # what arrived from the last peer's last batch is a QB3 container of the announced size
-        bufs, size_lists = got[-1]
-        b, sl = bufs[-1], size_lists[-1]
-        intact = bool(len(sl) and bytes(b[:4].cpu().numpy()) == b"QB3\x80")
+    # What arrived at the root is what the senders made: every rank hashes its own containers (FNV-1a64, the library's),
+    # the hashes are gathered, the root hashes every container it received and compares; rank 0's own tiles 1000 / 1001 are
+    # checked against the reference's anchors (size + FNV without the table chunks).  Untimed.
+    import numpy as np
+    host_all = tc.dst[:count * tc.pitch].cpu().numpy()
+    mine = [qb3_amd.fnv(host_all[t * tc.pitch:t * tc.pitch + int(tc.sizes[t])]) for t in range(count)]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    intact, anchors_ok = None, None
+    if rank == 0:
+        intact, checked = True, 0
+        for b, (bufs, size_lists) in enumerate(got):
+            lo = batches[b][0]
+            for r in range(1, world):
+                hb = bufs[r].cpu().numpy() if bufs[r] is not None else None
+                for t, sz in enumerate(size_lists[r]):
+                    ok = hb is not None and qb3_amd.fnv(hb[t * tc.pitch:t * tc.pitch + int(sz)]) == everyone[r][lo + t]
+                    intact, checked = intact and ok, checked + 1
+        intact = bool(intact and checked == (world - 1) * count)
+        anchors_ok = all(container_check(qb3_amd, np, host_all[t * tc.pitch:t * tc.pitch + int(tc.sizes[t])], tag)[0]
+                         for t, tag in ((0, "c5_tile1000"), (1, "c5_tile1001")) if t < count)
+        if not (intact and anchors_ok):
+            sys.exit(f"bench.py: gathered containers differ from the senders' (intact={intact}) or rank 0's tiles from the reference's anchors "
+                     f"(anchors={anchors_ok}) -- refusing to report a number")
+    del host_all
     for _ in range(max(1, args.warmup) - 1):
         step()
 
@@ -645,8 +710,10 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
                    "tiles_total": total, "tiles_per_gpu": args.tiles_per_rank, "parallelism": f"tiles sharded over {world} GPUs, no data-path collective but the gather"},
         "coding_only": {"ms_per_step": round(dt_code / args.steps * 1e3, 3), "MPixel_s": round(px / (dt_code / args.steps) / 1e6, 1)},
         "gather": {"bytes_into_root_per_step": bytes_root, "GBps_into_root": round(bytes_root / (dt / args.steps) / 1e9, 1) if bytes_root else None,
-                   "containers_intact": intact, "backend": "nccl (RCCL) send/recv" if args.backend == "nccl" else args.backend + " (rehearsal)"},
-        "roofline": roofline, "cpu_baseline": None,
+                   "containers_intact": intact, "check": "FNV-1a64 of every container received at the root against its sender's; rank 0's tiles 1000 and 1001 against the reference's anchors",
+                   "tiles_1000_1001_match_reference": anchors_ok, "backend": "nccl (RCCL) send/recv" if args.backend == "nccl" else args.backend + " (rehearsal)"},
+        "roofline": roofline,
+        "cpu_baseline": None if (args.no_cpu_baseline or rank != 0) else cpu_baseline_tiles(),
     }
     return line
 
@@ -675,9 +742,44 @@ def cpu_baseline(target_s=12.0):
     return {"value": round(px / (t_enc + t_dec) / 1e6, 1), "unit": "MPixel/s", "cores": 1, "kind": "port",
             "sample": f"{reps} x (encode + decode) of a 4096x4096x3 uint8 NOISY3 tile, QB3M_FTL, single thread",
             "encode_MPixel_s": round(px / t_enc / 1e6, 1), "decode_MPixel_s": round(px / t_dec / 1e6, 1),
-            "vs_reference": "the port is the faster baseline: on the same host and input the reference's own library ran 26.5 / 29.5 MPixel/s "
-                            "(encode / decode) against the port's 46.4 / 28.9 (judge-side measurement, VERDICT round 1; the reference cannot "
-                            "be built inside this repository's rules, DESIGN.md section 2)"}
+            "vs_reference": {"note": "oracle/ (this port) against the reference's own library on one host, same input, one thread; two judge-side "
+                                     "measurements on different hosts, no direction asserted: the two are within noise of each other "
+                                     "(the reference cannot be built inside this repository's rules, DESIGN.md section 2)",
+                             "round1_MPixel_s": {"reference_enc_dec": [26.5, 29.5], "port_enc_dec": [46.4, 28.9]},
+                             "round2_MPixel_s": {"reference_enc_dec": [55.8, 59.2], "port_enc_dec": [58.7, 48.9]}}}
+
+
+def cpu_baseline_tiles(target_s=12.0):
+    """config 5's CPU counterpart: the CPU restatement on the host's cores, a thread per tile (the
+    format admits no threading inside a stream; ctypes releases the interpreter lock inside the library): every thread
+    encodes + decodes its own 4096x4096x3 NOISY3 tile for about target_s seconds."""
+    import threading
+    from oracle import pyoracle as o
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))
+    w = h = 4096
+    imgs = [o.generate(w, h, 3, 0, "NOISY3", 1000 + t) for t in range(cores)]
+    reps = [0] * cores
+    t_start = time.perf_counter()
+
+    def work(t):
+        while reps[t] < 1 or time.perf_counter() - t_start < target_s:
+            out, _, _, _ = o.decode(o.encode(imgs[t], 0, 8))
+            if out is None:
+                raise RuntimeError("oracle failed to decode its own stream")
+            reps[t] += 1
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t_start
+    px = w * h * sum(reps)
+    return {"value": round(px / dt / 1e6, 1), "unit": "MPixel/s", "cores": cores, "kind": "port", "per_core_MPixel_s": round(px / dt / 1e6 / cores, 1),
+            "sample": f"{sum(reps)} x (encode + decode) of 4096x4096x3 uint8 NOISY3 tiles (seeds 1000..), QB3M_FTL, {cores} threads, a tile each, {dt:.1f} s wall"}
 
 
 if __name__ == "__main__":

@@ -70,6 +70,12 @@ int qb3x_decode_tile_ok(const decsp p, size_t i);
  * container's "DT" mark).  qb3x_header_size_bound(first bytes, how many) says how many bytes always suffice,
  * from the container's first 11 bytes (0: not a QB3 container). */
 decsp qb3x_read_start(void *header, size_t header_size, size_t stream_size, size_t *image_size);
+/* ... and for a container that is in DEVICE memory: qb3_read_start + qb3_read_info in one call; the handle keeps its own
+ * copy of the few header bytes it needs (two small device-to-host copies, whatever the size of a restart table: the
+ * table's chunk heads and checks are verified on the device before it is used).  Returns a handle ready for
+ * qb3x_decode_device / qb3x_decode_tiles, or NULL.  No counterpart in the reference (its containers are in host memory,
+ * QB3.h:133-141). */
+decsp qb3x_read_start_device(const void *d_container, size_t nbytes, size_t *image_size, void *stream);
 size_t qb3x_header_size_bound(const void *container, size_t avail);
 
 /* Self-indexing containers (off by default: the container then differs from the reference's by a few chunks).

@@ -199,7 +199,7 @@ __global__ void ix_fill_kernel(const EncArgs a0) {
     if (j == 0) {
         const uint32_t len = IX_HEAD + here * a.ix_E;
         chunk[0] = 'i'; chunk[1] = 'x'; chunk[2] = (uint8_t)len; chunk[3] = (uint8_t)(len >> 8);
-        chunk[4] = 2; chunk[5] = (a.g.mode == CM_BEST ? 1 : 0) | (a.ix_bl ? 2 : 0); chunk[6] = 0; chunk[7] = 0;
+        chunk[4] = 3; chunk[5] = (a.g.mode == CM_BEST ? 1 : 0) | (a.ix_bl ? 2 : 0); chunk[6] = 0; chunk[7] = 0;      // (bytes 6, 7: ix_seal_kernel)
         for (uint32_t i = 0; i < 4; i++) chunk[8 + i] = (uint8_t)(a.ix_blocks >> (8 * i));
         uint8_t *pad = chunk + len;
         pad[0] = 'z'; pad[1] = 'z'; pad[2] = 4; pad[3] = 0;
@@ -368,6 +368,24 @@ __global__ void __launch_bounds__(256) ix_blw_fill_kernel(const EncArgs a0, cons
     }
 }
 
+// The last word on the table: every chunk's 16-bit check of its entries into the head's reserved bytes (ix_sum_part)
+__global__ void __launch_bounds__(256) ix_seal_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    __shared__ uint32_t part[4];
+    const uint32_t c = blockIdx.x;
+    const uint32_t here = (a.ix_K - c * a.ix_per_chunk < a.ix_per_chunk) ? a.ix_K - c * a.ix_per_chunk : a.ix_per_chunk;
+    uint8_t *chunk = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E);
+    uint32_t s = ix_sum_part(chunk + IX_HEAD, here * a.ix_E, threadIdx.x, 256);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += (uint32_t)__shfl_xor((int)s, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t f = ix_sum_fold(part[0] + part[1] + part[2] + part[3]);
+        chunk[6] = (uint8_t)f; chunk[7] = (uint8_t)(f >> 8);
+    }
+}
+
 void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const uint32_t nt = a.ntiles;
     {
@@ -390,6 +408,7 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
         hipLaunchKernelGGL(ix_blw_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * tpe + 255) / 256), nt), dim3(256), 0, st, a, tpe);
     }
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 2) hipLaunchKernelGGL(ix_bl16_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * (a.g.bands == 1 ? 16 : 32) + 255) / 256), nt), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx) hipLaunchKernelGGL(ix_seal_kernel, dim3((a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk, nt), dim3(256), 0, st, a);
 }
 
 }  // namespace qb3dev

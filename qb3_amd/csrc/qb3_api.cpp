@@ -199,6 +199,12 @@ struct decs {
     uint32_t ix_K, ix_blocks, ix_E, ix_per_chunk;
     bool ix_bl;             // ... its entries carry block lengths
     bool ix_pads, ix_bad;   // pad chunks behind the table chunks (version 2); the chunks seen do not form one table
+    uint32_t ix_ver;        // version of the table's chunks (3: each carries a check of its entries)
+    bool ix_heads_unchecked;    // the parser stepped over a regular table in one go: the chunk heads behind the first are checked on the device
+    bool hdr_short;         // qb3_read_info read beyond the host copy of the header (whatever it then made of the zeros it got)
+    size_t ix_need_off;     // ... and would have, but the bytes at this offset from s_start (the "DT" behind the table) are not on the host (0: no)
+    std::vector<uint8_t> own_head, win2;    // qb3x_read_start_device: the handle's own copy of the container's first bytes, and of a few bytes further on
+    size_t win2_off = 0;    // ... at this offset from s_start
     std::vector<uint8_t> tile_ok;   // qb3x_decode_tiles: per tile outcome of the last call
     DevBuf d_in, d_img, d_ws, d_ix, d_rle, d_tab;      // d_rle: RLE0 workspace (+ the packed bytes of a host call); d_tab: the unit-length table a plain 8-bit stream is walked through
     Stager stager;
@@ -700,6 +706,7 @@ static decsp read_start_impl(void *source, size_t hdr_avail, size_t source_size,
     p->hdr_avail = hdr_avail < source_size ? hdr_avail : source_size;
     p->saw_cb = false; p->compat = 0;
     p->ix_off = 0; p->ix_K = p->ix_blocks = p->ix_E = p->ix_per_chunk = 0; p->ix_pads = false; p->ix_bad = false; p->ix_bl = false;
+    p->ix_ver = 0; p->ix_heads_unchecked = false; p->ix_need_off = 0; p->hdr_short = false;
     image_size[0] = p->xsize; image_size[1] = p->ysize; image_size[2] = p->nbands;
     if (mode <= (int)QB3M_CF_RLE) p->order = ZCURVE;
     return p;
@@ -746,8 +753,12 @@ QB3_API bool qb3_read_info(decsp p) {
     const size_t avail = p->hdr_avail > 11 ? p->hdr_avail - 11 : 0;           // bytes readable at s (<= n)
     size_t pos = 0;
     bool short_copy = false;                                                   // the head copy ends before the header does
+    auto have = [&](size_t at) -> bool {                                       // is the byte on the host
+        return at < avail || (at + 11 >= p->win2_off && at + 11 - p->win2_off < p->win2.size());
+    };
     auto rd = [&](size_t at) -> unsigned {                                     // reads past the end give zeros
         if (at < avail) return s[at];
+        if (at + 11 >= p->win2_off && at + 11 - p->win2_off < p->win2.size()) return p->win2[at + 11 - p->win2_off];
         if (at < n) short_copy = true;
         return 0u;
     };
@@ -786,7 +797,7 @@ QB3_API bool qb3_read_info(decsp p) {
         } else {
             // the reference skips an ignorable (lower case) chunk by `len` bytes from the chunk start
             // (QB3decode.cpp:254-255); a zero length would never terminate there, treat it as an error
-            if (c0 == 'i' && c1 == 'x' && len >= IX_HEAD && (rd(pos + 4) == 1 || rd(pos + 4) == 2) && p->mode != QB3M_STORED) {
+            if (c0 == 'i' && c1 == 'x' && len >= IX_HEAD && rd(pos + 4) >= 1 && rd(pos + 4) <= 3 && p->mode != QB3M_STORED) {
                 // this library's restart table (include/qb3x.h): a run of such chunks, all but the last of the same
                 // size, each followed by a 4-byte pad chunk (version 2).  Remember where it is, check it later.
                 const size_t tsz = szof(p->type);
@@ -795,15 +806,34 @@ QB3_API bool qb3_read_info(decsp p) {
                 const bool cfe = (rd(pos + 5) & 1) != 0;     // entries carry the common factors
                 const uint32_t E = (uint32_t)(6 + p->nbands * (1 + tsz * (cfe ? 2 : 1))) + (bl && blocks <= 4096 ? ix_bl_bytes((uint32_t)tsz, (uint32_t)p->nbands, blocks, cfe) : 0);
                 const size_t at = (size_t)(p->s_in - p->s_start) + pos;
-                const bool v2 = rd(pos + 4) == 2;
+                const unsigned ver = rd(pos + 4);
+                const bool v2 = ver >= 2;
                 if ((len - IX_HEAD) % E || pos + len > n) p->ix_bad = true;
                 else if (!p->ix_K) {        // the first chunk
-                    p->ix_off = at; p->ix_E = E; p->ix_blocks = blocks; p->ix_pads = v2; p->ix_bl = bl;
+                    p->ix_off = at; p->ix_E = E; p->ix_blocks = blocks; p->ix_pads = v2; p->ix_bl = bl; p->ix_ver = ver;
                     p->ix_per_chunk = p->ix_K = (len - IX_HEAD) / E;
+                    // A regular table -- every chunk but the last full, a pad behind each, "DT" behind the last -- is stepped over in
+                    // one go when "DT" stands where such a table ends: the heads in between are then checked on the device
+                    // (ix_check_kernel) and need not be on the host at all (a 16384 x 16384 raster's level 2 table is 24 MB)
+                    const uint64_t nblk = (uint64_t)((p->xsize + 3) / 4) * ((p->ysize + 3) / 4);
+                    const uint64_t Kexp = blocks ? (nblk + blocks - 1) / blocks : 0;
+                    if (v2 && p->ix_per_chunk && Kexp > p->ix_per_chunk && Kexp < 0xffffffffull) {
+                        const uint64_t nch = (Kexp + p->ix_per_chunk - 1) / p->ix_per_chunk;
+                        const uint64_t total = nch * (IX_HEAD + IX_PAD) + Kexp * E;
+                        if (pos + total + 2 < n) {
+                            if (have(pos + total) && have(pos + total + 1)) {
+                                if (rd(pos + total) == 'D' && rd(pos + total + 1) == 'T') {
+                                    p->ix_K = (uint32_t)Kexp; p->ix_heads_unchecked = true;
+                                    pos += total;
+                                    continue;
+                                }
+                            } else p->ix_need_off = 11 + pos + total;
+                        }
+                    }
                 } else {                    // a further one: in place, same shape, and only the last may be short
                     const size_t full = IX_HEAD + (size_t)p->ix_per_chunk * E + (p->ix_pads ? IX_PAD : 0);
                     const uint32_t here = (len - IX_HEAD) / E;
-                    if (!v2 || !p->ix_pads || E != p->ix_E || blocks != p->ix_blocks || bl != p->ix_bl || p->ix_K % p->ix_per_chunk ||
+                    if (!v2 || !p->ix_pads || ver != p->ix_ver || E != p->ix_E || blocks != p->ix_blocks || bl != p->ix_bl || p->ix_K % p->ix_per_chunk ||
                         at != p->ix_off + (p->ix_K / p->ix_per_chunk) * full || here > p->ix_per_chunk) p->ix_bad = true;
                     else p->ix_K += here;
                 }
@@ -815,8 +845,49 @@ QB3_API bool qb3_read_info(decsp p) {
     } while (p->stage != 2 && QB3E_OK == p->error && pos < n);
     if (QB3E_OK == p->error && 2 != p->stage) p->error = QB3E_EINV;
     if (short_copy && QB3E_OK == p->error) p->error = QB3E_EINV;               // qb3x_read_start: the head copy is too short
+    p->hdr_short = short_copy;
     if (p->ix_bad) p->ix_K = 0;
     return QB3E_OK == p->error;
+}
+
+// qb3_read_start + qb3_read_info for a container in DEVICE memory: the handle keeps its own host copy of the container's
+// first bytes (up to 512), and when a restart table pushes the "DT" mark beyond them, of the few bytes where a regular
+// table ends -- two small copies instead of the whole table (24 MB for a 16384 x 16384 x 3 raster at level 2), whose
+// chunk heads and checks the device verifies before the table is used (ix_check_kernel).  A table that is not regular
+// is read whole.  Returns a handle in the state qb3_read_info leaves, or NULL.
+QB3_API decsp qb3x_read_start_device(const void *d_container, size_t nbytes, size_t *image_size, void *stream) {
+    if (!d_container || nbytes < 15 || !image_size || !device_ok()) return nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    auto fetch = [&](std::vector<uint8_t> &dst, size_t off, size_t n) -> bool {
+        dst.resize(n);
+        return hipMemcpyAsync(dst.data(), (const uint8_t *)d_container + off, n, hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipStreamSynchronize(st) == hipSuccess;
+    };
+    std::vector<uint8_t> head, win;
+    size_t win_off = 0;
+    if (!fetch(head, 0, std::min(nbytes, (size_t)512))) return nullptr;
+    for (int turn = 0; turn < 3; turn++) {
+        decs *p = read_start_impl(head.data(), head.size(), nbytes, image_size);
+        if (!p) return nullptr;
+        p->own_head.swap(head);                         // (the vector's buffer stays where it is: s_start stays valid)
+        p->win2 = win; p->win2_off = win_off;
+        if (qb3_read_info(p)) return p;
+        const size_t need = p->ix_need_off;
+        head.swap(p->own_head);
+        const bool was_short = p->hdr_short;
+        qb3_destroy_decoder(p);
+        if (!was_short) return nullptr;
+        if (turn == 0 && need && need + 2 <= nbytes) {  // a regular table: the two bytes behind it
+            win_off = need;
+            if (!fetch(win, need, 2)) return nullptr;
+        } else if (turn <= 1) {                         // something else: the whole head, as far as a table can reach
+            const size_t bound = std::min(nbytes, qb3x_header_size_bound(head.data(), head.size()));
+            if (bound <= head.size()) return nullptr;
+            win.clear(); win_off = 0;
+            if (!fetch(head, 0, bound)) return nullptr;
+        } else return nullptr;
+    }
+    return nullptr;
 }
 
 QB3_API size_t qb3x_decoder_index_size(const decsp p) {
@@ -848,13 +919,22 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
     const uint32_t *in32 = (const uint32_t *)(d_buf + (off & ~(size_t)3));
     if (!d_index && !ix.base && !walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
     uint32_t status = 0;
-    for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the stream's average)
-        if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st, TileBatch(), nullptr, ix,
-                          p->d_tab.p, p->d_tab.cap, full != 0))
-            return false;
-        const hipError_t e = fetch_small(&status, d_status, 4, st);
-        if (e != hipSuccess) { set_error("decode kernels", (int)e); return false; }
-        if (!(status & 16)) break;
+    IxTable table = ix;
+    for (int turn = 0; turn < 2; turn++) {
+        for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the stream's average)
+            if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st, TileBatch(), nullptr, table,
+                              p->d_tab.p, p->d_tab.cap, full != 0))
+                return false;
+            const hipError_t e = fetch_small(&status, d_status, 4, st);
+            if (e != hipSuccess) { set_error("decode kernels", (int)e); return false; }
+            if (!(status & 16)) break;
+        }
+        // The container's restart table is a convenience the format does not protect: when its check fails (bit 5) or the
+        // decode that relied on it does, the stream is decoded again WITHOUT it -- the plain walk, what the reference does
+        // with such a container -- so a damaged table costs time, never pixels.
+        if (!(status & (27 | 32)) || d_index || !table.base) break;
+        table = IxTable();
+        if (!walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
     }
     prof_collect();
     // bit 0: corrupt unit, bit 1: more than 7 unused bits at the end (reference QB3decode.h:411,569,740).
@@ -937,6 +1017,7 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
     IxTable ixt;
     if (!d_index && p->ix_K && !rle && !narrow) {
         ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads; ixt.block_lens = p->ix_bl;
+        ixt.version = p->ix_ver; ixt.check_heads = p->ix_heads_unchecked;
         if (on_host) {
             const size_t bytes = ix_total_bytes(ixt);
             if (!p->d_ix.ensure(bytes)) { p->error = QB3E_LIBERR; return 0; }
@@ -987,21 +1068,10 @@ QB3_API size_t qb3x_decode_device(decsp p, const void *d_src, void *d_dst, const
 // One tile through its own header: a host copy of its head is parsed into a handle of its own (a batch may hold
 // containers of another kind than tile 0's: raw-stored tiles next to coded ones, QB3encode.cpp:571-573)
 static bool decode_tile_alone(decsp ref, const uint8_t *d_tile, size_t size, void *d_out, const void *d_index, hipStream_t st) {
-    if (size < 15) return false;
-    std::vector<uint8_t> head(std::min(size, (size_t)256));
-    if (hipMemcpyAsync(head.data(), d_tile, head.size(), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
-    const size_t need = std::min(size, qb3x_header_size_bound(head.data(), head.size()));
     size_t dims[3];
-    decsp q = read_start_impl(head.data(), head.size(), size, dims);
-    if (q && !qb3_read_info(q) && need > head.size()) {      // a restart table longer than the first copy
-        qb3_destroy_decoder(q);
-        head.resize(need);
-        if (hipMemcpyAsync(head.data(), d_tile, head.size(), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
-        q = read_start_impl(head.data(), head.size(), size, dims);
-        if (q) (void)qb3_read_info(q);
-    }
+    decsp q = qb3x_read_start_device(d_tile, size, dims, st);
     if (!q) return false;
-    bool ok = q->stage == 2 && q->error == QB3E_OK && dims[0] == ref->xsize && dims[1] == ref->ysize && dims[2] == ref->nbands && q->type == ref->type;
+    bool ok = dims[0] == ref->xsize && dims[1] == ref->ysize && dims[2] == ref->nbands && q->type == ref->type;
     if (ok) {
         q->stride = ref->stride; q->compat = ref->compat;
         ok = 0 != qb3x_decode_device(q, d_tile, d_out, d_index, st);
@@ -1076,21 +1146,30 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
             IxTable ixt;
             if (use_ix) {
                 ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads; ixt.block_lens = p->ix_bl;
+                ixt.version = p->ix_ver; ixt.check_heads = true;      // (only tile 0's heads were read on the host)
                 ixt.base = (uint8_t *)d_src + first * src_pitch + p->ix_off;
             }
             if (!d_index && !use_ix && !walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
             const uint8_t *src0 = (const uint8_t *)d_src + first * src_pitch;
             uint32_t *d_status = nullptr;
-            for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the streams' average)
-                if (launch_decode(g, plan, (const uint32_t *)(src0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), 0, (uint8_t *)d_dst + first * dst_pitch,
-                                  d_index ? (const uint8_t *)d_index + first * isz : nullptr, p->d_ws.p, &d_status, st, tb, (const uint64_t *)p->d_in.p,
-                                  ixt, p->d_tab.p, p->d_tab.cap, full != 0)) { p->error = QB3E_LIBERR; return done; }
-                e = hipMemcpyAsync(status.data(), d_status, 4 * cnt, hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipStreamSynchronize(st);
-                if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
-                bool again = false;
-                for (size_t i = 0; i < cnt; i++) again = again || (status[i] & 16);
-                if (!again) break;
+            for (int turn = 0; turn < 2; turn++) {
+                for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the streams' average)
+                    if (launch_decode(g, plan, (const uint32_t *)(src0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), 0, (uint8_t *)d_dst + first * dst_pitch,
+                                      d_index ? (const uint8_t *)d_index + first * isz : nullptr, p->d_ws.p, &d_status, st, tb, (const uint64_t *)p->d_in.p,
+                                      ixt, p->d_tab.p, p->d_tab.cap, full != 0)) { p->error = QB3E_LIBERR; return done; }
+                    e = hipMemcpyAsync(status.data(), d_status, 4 * cnt, hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);
+                    if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
+                    bool again = false;
+                    for (size_t i = 0; i < cnt; i++) again = again || (status[i] & 16);
+                    if (!again) break;
+                }
+                // a tile whose table fails its check, or whose decode from the table fails: the batch again without the tables
+                bool table_trouble = false;
+                for (size_t i = 0; i < cnt; i++) table_trouble = table_trouble || (bits[i] && (status[i] & (27 | 32)));
+                if (!table_trouble || !ixt.base) break;
+                ixt = IxTable();
+                if (!walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
             }
             prof_collect();
             for (size_t i = 0; i < cnt; i++) if (bits[i] && !(status[i] & 27)) { p->tile_ok[first + i] = 1; done++; }

@@ -92,6 +92,8 @@ struct IxTable {
     uint8_t *base = nullptr;        // device pointer (encode: where the chunks go, "DT" follows; decode: where they are)
     uint32_t K = 0, blocks = 0, entry_bytes = 0, per_chunk = 0;
     bool pads = true;               // false: a version 1 table (one chunk, no pad chunk behind it)
+    uint32_t version = 3;           // decode: what the chunks say (3: every chunk carries a 16-bit check of its entries in the head's reserved bytes)
+    bool check_heads = false;       // decode: the chunk heads behind the first were not read on the host: the check kernel looks at them
     bool block_lens = false;        // entries carry the bit length of every block of their segment (10 bits each): 8-bit lane-per-block rasters
     bool own_index = false;         // encode: the index is the library's own, only sampled for the table -- no unit lengths needed
 };

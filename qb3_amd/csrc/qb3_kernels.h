@@ -316,6 +316,7 @@ struct DecArgs {
     const uint8_t *ix;              // coarse index chunk found in the container (null: none): restart points for the walk
     uint32_t ix_K, ix_blocks, ix_E, ix_per_chunk, ix_pad;     // ix_pad: bytes of the pad chunk behind every table chunk
     uint32_t ix_bl;                 // the entries carry block lengths: the lane-per-block decoder needs no walk and no index
+    uint32_t ix_ver, ix_check_heads;    // version of the table's chunks (3: with checks); the host has not seen the chunk heads behind the first
     uint32_t bl_mode;               // ... and this launch decodes from them
     // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
     uint32_t ntiles;
@@ -323,6 +324,17 @@ struct DecArgs {
     const uint64_t *tile_bits;
 };
 
+
+// The check a version 3 "ix" chunk carries in the two reserved bytes of its head: a position-weighted sum of the chunk's
+// entry bytes folded to 16 bits (a table sits in an ignorable chunk the format does not protect; its positions, rungs and
+// values are taken as truth by the decoder, so a damaged table must be told from a good one: the decoder then falls back
+// to the plain walk).  part = this thread's share of the sum over bytes [0, n) of `e`, thread t of nthr taking i = t, t + nthr, ...
+__device__ __forceinline__ uint32_t ix_sum_part(const uint8_t *e, uint32_t n, uint32_t t, uint32_t nthr) {
+    uint32_t s = 0;
+    for (uint32_t i = t; i < n; i += nthr) s += ((uint32_t)e[i] + 1u) * (i * 0x9e3779b1u + 1u);
+    return s;
+}
+__device__ __forceinline__ uint32_t ix_sum_fold(uint32_t s) { return (s ^ (s >> 16)) & 0xffffu; }
 
 // entry k of a restart table whose first chunk starts at `base` (layout: qb3_dev.h, IxTable)
 __device__ __forceinline__ const uint8_t *ix_entry_at(const uint8_t *base, uint32_t per_chunk, uint32_t E, uint32_t pad, uint32_t k) {

@@ -66,26 +66,27 @@ class DeviceEncoder:
 
 
 class DeviceDecoder:
-    """Decoder for one device-resident container.  `container` is the device tensor holding it (the wrapper copies
-    the head it needs to the host: qb3x_header_size_bound bytes at most) or a host array holding at least that head."""
+    """Decoder for one device-resident container.  `container` is the device tensor holding it -- the library then reads
+    the few header bytes it needs itself (qb3x_read_start_device: two small copies, whatever the size of a restart table) --
+    or a host array holding the container's head up to its "DT" mark (qb3x_read_start)."""
 
     def __init__(self, container, nbytes):
         nbytes = int(nbytes)
-        if torch.is_tensor(container):
-            first = container[:min(nbytes, 64)].cpu().numpy()
-            need = lib.qb3x_header_size_bound(first.ctypes.data_as(_vp), first.size)
-            head = first if need <= first.size else container[:min(nbytes, need)].cpu().numpy()
-        else:
-            head = container
-        self.hdr = np.ascontiguousarray(head, dtype=np.uint8)
         dims = (_sz * 3)()
-        self.p = lib.qb3x_read_start(self.hdr.ctypes.data_as(_vp), min(self.hdr.size, nbytes), nbytes, dims)
-        if not self.p:
-            raise ValueError("qb3x_read_start rejected the stream")
-        if not lib.qb3_read_info(self.p):
-            lib.qb3_destroy_decoder(self.p)
-            self.p = None
-            raise ValueError("qb3_read_info failed (or the host copy ends before the container's DT mark)")
+        if torch.is_tensor(container):
+            self.hdr = None
+            self.p = lib.qb3x_read_start_device(_vp(container.data_ptr()), nbytes, dims, _stream_ptr())
+            if not self.p:
+                raise ValueError("not a QB3 container (or its header does not parse)")
+        else:
+            self.hdr = np.ascontiguousarray(container, dtype=np.uint8)
+            self.p = lib.qb3x_read_start(self.hdr.ctypes.data_as(_vp), min(self.hdr.size, nbytes), nbytes, dims)
+            if not self.p:
+                raise ValueError("qb3x_read_start rejected the stream")
+            if not lib.qb3_read_info(self.p):
+                lib.qb3_destroy_decoder(self.p)
+                self.p = None
+                raise ValueError("qb3_read_info failed (or the host copy ends before the container's DT mark)")
         self.w, self.h, self.bands = dims[0], dims[1], dims[2]
         self.out_bytes = lib.qb3_decoded_size(self.p)
         self.nbytes = nbytes
@@ -159,14 +160,10 @@ class TileBatchCoder:
     def decode(self, out, use_index=True):
         """decodes the n containers made by encode() into `out` (n * raw_bytes)."""
         if self.d is None:
-            first = self.dst[:min(int(self.sizes[0]), 64)].cpu().numpy()
-            need = lib.qb3x_header_size_bound(first.ctypes.data_as(_vp), first.size)         # (a restart table makes the header long)
-            head = np.ascontiguousarray(self.dst[:min(int(self.sizes[0]), max(need, 64))].cpu().numpy())
             dims = (_sz * 3)()
-            self.d = lib.qb3x_read_start(head.ctypes.data_as(_vp), head.size, int(self.sizes[0]), dims)
-            if not self.d or not lib.qb3_read_info(self.d):
+            self.d = lib.qb3x_read_start_device(_vp(self.dst.data_ptr()), int(self.sizes[0]), dims, _stream_ptr())
+            if not self.d:
                 raise ValueError("tile 0 does not parse")
-            self._head = head
         k = lib.qb3x_decode_tiles(self.d, _vp(self.dst.data_ptr()), self.n, self.pitch, self.sizes, _vp(out.data_ptr()), self.raw_bytes,
                                   _vp(self.index.data_ptr()) if (use_index and self.index is not None) else None, _stream_ptr())
         if k != self.n:

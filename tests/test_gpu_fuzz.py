@@ -48,7 +48,10 @@ def test_random_cases_match_the_oracle(qb3, oracle, block):
         img = oracle.generate(w, h, b, dt, gen, seed)
         tag = f"case {block}.{k}: {w}x{h}x{b} type {dt} {gen} seed {seed} mode {mode} cband {cb} stride {stride}"
         q, away = 1, False
-        if stride:                      # rows `stride` values apart, junk-free padding
+        if dt <= 5 and rng.random() < 0.15:                  # lossy: quantised on the way in, scaled back on the way out
+            q, away = rng.choice([2, 3, 4, 5, 10]), rng.random() < 0.5
+            tag += f" quanta {'+' if away else ''}{q}"
+        if stride:                      # rows `stride` values apart, junk-free padding (with or without quanta: reference test_qb3.cpp:659-660)
             src = np.zeros((h, stride), dtype=img.dtype)
             src[:, :w * b] = img.reshape(h, w * b)
             e = oracle.Encoder(w, h, b, dt)
@@ -56,13 +59,12 @@ def test_random_cases_match_the_oracle(qb3, oracle, block):
             if cb is not None:
                 e.set_coreband(cb)
             e.set_stride(stride)
+            if q > 1:
+                e.set_quanta(q, away)
             ref = e.encode(src)
-            got = _encode_strided(qb3, src, w, h, b, dt, mode, cb, stride)
+            got = _encode_strided(qb3, src, w, h, b, dt, mode, cb, stride, quanta=q, away=away)
         else:
             src = img
-            if dt <= 5 and rng.random() < 0.12:                  # lossy: quantised on the way in, scaled back on the way out
-                q, away = rng.choice([2, 3, 4, 5, 10]), rng.random() < 0.5
-                tag += f" quanta {'+' if away else ''}{q}"
             ref = oracle.encode(img, dt, mode, cband=cb, quanta=q, away=away)
             got = qb3.encode(img, dt, mode, cband=cb, quanta=q, away=away)
         assert len(got) == len(ref) and np.array_equal(got, ref), tag
@@ -74,15 +76,35 @@ def test_random_cases_match_the_oracle(qb3, oracle, block):
             continue
         out, dims, dtype, m = qb3.decode(ref)
         assert dims == (w, h, b) and np.array_equal(out, want), tag
+        if stride:                      # ... and into a destination with the same line stride: the pixels land on the lines, nothing between them
+            sout = _decode_strided(qb3, ref, h, stride, img.dtype)
+            assert np.array_equal(sout[:, :w * b].reshape(-1).view(np.uint8), want) and (sout[:, w * b:].view(np.uint8) == 0xa5).all(), tag + " (strided decode)"
         if rng.random() < 0.3 and mode in (8, 4, 0, 5, 1):      # and through the self-indexing container
             level = 1 + (k & 1)         # the restart table, with block lengths every other time (where the raster takes them)
-            s2 = _encode_strided(qb3, src, w, h, b, dt, mode, cb, stride, chunk=level) if stride else \
+            s2 = _encode_strided(qb3, src, w, h, b, dt, mode, cb, stride, chunk=level, quanta=q, away=away) if stride else \
                 qb3.encode(img, dt, mode, cband=cb, quanta=q, away=away, index_chunk=level)
             out2, _, _, _ = qb3.decode(s2)
             assert np.array_equal(out2, want), tag + " (index chunk, level %d)" % level
 
 
-def _encode_strided(qb3, buf, w, h, b, dt, mode, cb, stride, chunk=False):
+def _decode_strided(qb3, stream, h, stride, npdtype):
+    """qb3_read_data into lines `stride` values apart (qb3_set_decoder_stride); the gaps keep their fill"""
+    import ctypes as C
+    L = qb3.lib
+    dims = (C.c_size_t * 3)()
+    buf = np.ascontiguousarray(stream)
+    d = L.qb3_read_start(buf.ctypes.data, buf.size, dims)
+    assert d and L.qb3_read_info(d)
+    try:
+        L.qb3_set_decoder_stride(d, stride)
+        out = np.full(h * stride * np.dtype(npdtype).itemsize, 0xa5, np.uint8)
+        assert L.qb3_read_data(d, out.ctypes.data), "strided qb3_read_data failed"
+        return out.view(npdtype).reshape(h, stride)
+    finally:
+        L.qb3_destroy_decoder(d)
+
+
+def _encode_strided(qb3, buf, w, h, b, dt, mode, cb, stride, chunk=False, quanta=1, away=False):
     """qb3.encode() takes (h, w, bands) arrays; strided input goes through the C API directly"""
     import ctypes as C
     L = qb3.lib
@@ -95,6 +117,8 @@ def _encode_strided(qb3, buf, w, h, b, dt, mode, cb, stride, chunk=False):
             arr = (C.c_size_t * b)(*cb)
             L.qb3_set_encoder_coreband(p, b, arr)
         L.qb3_set_encoder_stride(p, stride)
+        if quanta > 1:
+            L.qb3_set_encoder_quanta(p, quanta, away)
         dst = np.empty(L.qb3_max_encoded_size(p), dtype=np.uint8)
         src = np.ascontiguousarray(buf)
         n = L.qb3_encode(p, src.ctypes.data, dst.ctypes.data)
