@@ -116,8 +116,11 @@ static void parallel_memcpy(uint8_t *dst, const uint8_t *src, size_t n) {
     const size_t part = ((n + T - 1) / T + 4095) & ~(size_t)4095;
     std::thread th[8];
     unsigned started = 0;
-    for (unsigned t = 1; t < T && t * part < n; t++, started++)
-        th[started] = std::thread([=] { memcpy(dst + t * part, src + t * part, std::min(part, n - t * part)); });
+    for (unsigned t = 1; t < T && t * part < n; t++) {
+        // (a thread that cannot be had -- a pids or RLIMIT_NPROC limit -- must not send an exception across the C ABI: its part is copied here)
+        try { th[started] = std::thread([=] { memcpy(dst + t * part, src + t * part, std::min(part, n - t * part)); }); started++; }
+        catch (...) { memcpy(dst + t * part, src + t * part, std::min(part, n - t * part)); }
+    }
     memcpy(dst, src, std::min(part, n));
     for (unsigned t = 0; t < started; t++) th[t].join();
 }
@@ -306,10 +309,15 @@ static bool is_rle_mode(int m) { return m == QB3M_RLE || m == QB3M_CF_RLE || m =
 // bytes the restart-table chunks add to a container of this handle (0: none would be written)
 static size_t ix_room(const encs *p) {
     if (!p->ix_chunk || p->xsize < 4 || p->ysize < 4 || p->xsize * p->ysize <= 16 || p->mode == QB3M_STORED) return 0;
-    // (an RLE0 mode codes the stream of its base mode; the table stays when the RLE0 pass does not win)
-    const int m = is_rle_mode(p->mode) ? (int)p->mode - 2 : (int)p->mode;
-    const Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, m, p->cband, nullptr);
-    return ix_total_bytes(ix_layout(g, p->ix_chunk));
+    // The bound must not depend on the mode: the reference's callers size the buffer right after qb3_create_encoder and BEFORE
+    // qb3_set_encoder_mode (reference cqb3.cpp:405-464, test_qb3.cpp:84-102).  The largest table any mode would write for this
+    // raster: FTL and BASE streams share a layout, the common-factor modes have another.
+    size_t room = 0;
+    for (int m : {(int)QB3M_FTL, (int)QB3M_CF_H}) {
+        const Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, p->stride, p->order, m, p->cband, nullptr);
+        room = std::max(room, ix_total_bytes(ix_layout(g, p->ix_chunk)));
+    }
+    return room;
 }
 QB3_API size_t qb3_max_encoded_size(const encsp p) { return max_encoded_size_ref(p) + ix_room(p); }
 
