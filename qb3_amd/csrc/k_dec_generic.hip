@@ -279,7 +279,7 @@ __global__ void dec3_kernel(const DecArgs a0) {
             cprev[tid] = v;
             crung[tid] = ent[6 + tid] & UMASK;
         } else {
-            cprev[tid] = (uint64_t)((const T *)a.idx.prev)[seg * bands + tid];
+            cprev[tid] = a.totals_only ? 0ull : (uint64_t)((const T *)a.idx.prev)[seg * bands + tid];       // (totals_only: the segment's sums, not pixels)
             crung[tid] = a.idx.rung[seg * bands + tid];
         }
     }
@@ -369,6 +369,10 @@ __global__ void dec3_kernel(const DecArgs a0) {
         __syncthreads();
     }
     if (bad) atomicOr(a.status, 1u);
+    if (a.totals_only) {        // a plain stream, first pass: leave the segment's per-band sums where the entering values go (prev_scan_kernel turns them into those)
+        if (tid < bands) ((T *)a.idx.prev)[seg * bands + tid] = (T)cprev[tid];
+        return;
+    }
     if (tid == 0 && seg == a.g.nseg - 1) {      // reference: more than 7 unused bits at the end is a failure
         const uint64_t used = (uint64_t)cpos + 32 * w0 - a.in_bit0;
         if (used > a.in_bits) atomicOr(a.status, 4u);

@@ -115,23 +115,24 @@ __global__ void __launch_bounds__(64) dec_walk_kernel(const DecArgs a0) {
 template <typename T>
 __global__ void __launch_bounds__(1024) prev_scan_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
-    __shared__ uint32_t part[1024];
+    typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type S;
+    __shared__ S part[1024];
     const uint32_t tid = threadIdx.x, B = a.g.bands, c = blockIdx.y;       // one workgroup per tile and band
     const uint64_t nseg = a.g.nseg, per = (nseg + 1023) / 1024;
     const uint64_t s0 = (uint64_t)tid * per, s1 = (s0 + per < nseg) ? s0 + per : nseg;
     T *prev = (T *)a.idx.prev;
-    uint32_t sum = 0;
+    S sum = 0;
     for (uint64_t s = s0; s < s1; s++) sum += prev[s * B + c];
     part[tid] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {               // inclusive scan of the partial sums
-        const uint32_t y = tid >= d ? part[tid - d] : 0u;
+        const S y = tid >= d ? part[tid - d] : (S)0;
         __syncthreads();
         part[tid] += y;
         __syncthreads();
     }
-    uint32_t run = part[tid] - sum;
-    for (uint64_t s = s0; s < s1; s++) { const uint32_t t = prev[s * B + c]; prev[s * B + c] = (T)run; run += t; }
+    S run = part[tid] - sum;
+    for (uint64_t s = s0; s < s1; s++) { const S t = prev[s * B + c]; prev[s * B + c] = (T)run; run += t; }
 }
 
 // ---- the same walk from the container's restart table: ONE LANE per restart point ---------------------------
@@ -933,6 +934,301 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
     }
 }
 
+// ---- the same for plain 32- and 64-bit streams (FTL / BASE) -----------------------------------------------------------
+// Thirty-two or sixty-four rungs would make a row 64-128 bytes and a window a few units long.  But the rungs a stream
+// visits keep to a narrow band (a band's rung moves with the local range of the data): the table is built for SIXTEEN
+// CONSECUTIVE RUNGS [R0, R0 + 16), in the 16-bit layout (a row of sixteen 16-bit entries per position, rungs relative to
+// R0), and an entry whose unit leaves the band carries the stop bit -- the walk then gives up on the table and the
+// call falls back to the one-lane parser (a stream that ranges over more than sixteen rungs: rare, and no worse off than
+// before).  R0 comes from the stream's first index segment, which walk_probe_kernel parses outright (one lane; the
+// stream starts at rung 0, outside any band that fits real data): it leaves the walk's entry state behind that segment.
+// Code lengths: a code at rung r takes r, r + 1 or r + 2 bits by its two low bits whatever r is, so the table workgroup
+// keeps the EXTRA bits of 2, 4 and 8 codes (at most 16: a byte) per rung and position and adds the multiples of r.
+constexpr uint32_t WIDE_THREADS = 64 * (1 + 3 * 4 + 1);      // the walker, four loader groups of three waves, the writer
+template <uint32_t UB, uint32_t NR_> struct chainW {         // NR_: rungs in the band, 8 or 16 (a row is 16 or 32 bytes: what the walk costs is the table bytes one CU can stream)
+    static constexpr uint32_t NRUNG = 1u << UB, NR = NR_, ROWB = 2 * NR_, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;
+    // a window of the walk: as many positions as the 16-bit entries can address ((CW + MAXU) * ROWB < 65536), a multiple of 96 (the
+    // loaders' 192 sixteen-byte pieces a turn) and of TCW, the positions ONE table workgroup tabulates (its LDS holds 32 bytes a position)
+    static constexpr uint32_t CW = NR_ == 8 ? 2880 : (UB == 5 ? 1440 : 960), WIN_BYTES = CW * ROWB, WIN_U4 = WIN_BYTES / 16, TCW = 480;
+    static constexpr uint32_t NP = (TCW + UB + 2 + 15 * MAXC + 2 + 31) & ~31u;     // positions a table workgroup looks at
+    static constexpr uint32_t NG = 4, WAVES = WIDE_THREADS / 64;                      // loader groups of three waves (a window's load takes longer than its walk: four in flight); the walker, the writer
+    static constexpr uint32_t TR_BYTES = ((CW / 2 + 8) * 2 + 15) & ~15u;
+    static constexpr uint32_t TR0 = 2 * WIN_BYTES, RS0 = TR0 + 2 * TR_BYTES, WR0 = RS0 + 64, META = WR0 + 64, LDS_BYTES = META + 128;
+    static constexpr uint32_t F_READY = META, F_TRAILED = META + 32, F_NUNITS = META + 40, F_O0 = META + 48, F_WALKED = META + 56, F_STOP = META + 60, F_U0 = META + 64;
+    static_assert((CW + MAXU) * ROWB < 65536 && WIN_U4 % 192 == 0 && CW % TCW == 0 && (UB == 5 || UB == 6) && (NR_ == 8 || NR_ == 16), "window layout of the wide types");
+};
+
+// The first index segment of every tile, parsed outright by one lane: unit lengths, the segment's entry, the band of rungs
+// [R0, R0 + 16) for the table (WalkState16::pad) and the walk's entry state behind the segment.
+template <typename T>
+__global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkState16 *states, uint32_t nr) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    constexpr uint32_t NRUNG = 1u << UBits<T>::v;
+    if (threadIdx.x) return;
+    const uint32_t B = a.g.bands, NB = a.g.seg_blocks;
+    const uint64_t nblocks = a.g.nblocks, nb = nblocks < NB ? nblocks : NB;
+    Reader rd;
+    rd.init(a.in32, a.in_bit0, a.in_bit0 + a.in_bits);
+    uint32_t rung[MAXBANDS], minr = NRUNG, maxr = 0;
+    bool ok = true;
+    a.idx.bitpos[0] = 0;
+    for (uint32_t c = 0; c < B; c++) { rung[c] = 0; a.idx.rung[c] = 0; }
+    T g[16], pcf = 0;
+    for (uint64_t gb = 0; gb < nb && ok; gb++)
+        for (uint32_t c = 0; c < B; c++) {
+            const uint64_t u0 = rd.position();
+            ok = parse_unit<T, CM_FTL>(rd, rung[c], pcf, g) && ok;      // (lengths and rungs are the same with and without the step)
+            ((uint16_t *)a.idx.ulen)[gb * B + c] = (uint16_t)(rd.position() - u0);
+            minr = rung[c] < minr ? rung[c] : minr; maxr = rung[c] > maxr ? rung[c] : maxr;
+        }
+    WalkState16 *S = states + blockIdx.x;
+    // the band: nr rungs around what the first segment saw (its smallest rung at least one above the band's floor when there is room)
+    uint32_t R0 = (minr + maxr + 1) / 2 >= nr / 2 ? (minr + maxr + 1) / 2 - nr / 2 : 0;
+    if (R0 > NRUNG - nr) R0 = NRUNG - nr;
+    ok = ok && minr >= R0 && maxr - R0 < nr;
+    uint64_t rel = 0;
+    for (uint32_t c = 0; c < B; c++) { const uint32_t d = rung[c] - R0; ok = ok && d < nr; rel |= (uint64_t)(d & 15u) << (4 * c); }
+    S->P = rd.position() - a.in_bit0; S->unit = nb * B; S->rungs = rel; S->pad = R0; S->bad = ok ? 0u : 1u;
+    if (!ok) atomicOr(a.status, 1u);
+}
+
+template <uint32_t UB, uint32_t NRB>
+__global__ void __launch_bounds__(256) walk_tableW_kernel(const DecArgs a0, uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch, const WalkState16 *states) {
+    typedef chainW<UB, NRB> W;
+    constexpr uint32_t NP = W::NP, CW = W::CW, TCW = W::TCW, NR = W::NR, MAXC = W::MAXC, ROWB = W::ROWB, NRUNG = W::NRUNG;
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    const uint64_t p0 = slab0 + (uint64_t)blockIdx.x * TCW;                // blockIdx.x: a piece of TCW positions; CW / TCW pieces a window
+    const uint32_t ow = (uint32_t)(((uint64_t)blockIdx.x * TCW) % CW);     // the piece's place in its window: entries count positions from the window's start
+    if (p0 >= a.in_bits + 2 * CW || states[blockIdx.y].bad) return;        // (uniform) far beyond the stream, or no walk will come
+    const uint32_t R0 = states[blockIdx.y].pad;
+    __shared__ uint32_t words[NP / 32 + 3];
+    __shared__ uint8_t t1[NP], eA[NR][NP], eB[NR][NP];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t q0 = a.in_bit0 + p0, w0 = q0 >> 5, endw = (a.in_bit0 + a.in_bits + 31) >> 5;
+    const uint32_t sh = (uint32_t)q0 & 31;
+    for (uint32_t i = tid; i < NP / 32 + 3; i += 256) words[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
+    __syncthreads();
+    auto bits = [&](uint32_t i) { const uint32_t b = sh + i, k = b >> 5; return __builtin_amdgcn_alignbit(words[k + 1], words[k], b & 31); };
+    for (uint32_t i = tid; i < NP; i += 256) { const uint32_t x = bits(i); t1[i] = (uint8_t)((x & 1) + ((x & 3) == 3)); }   // a code's extra bits
+    __syncthreads();
+    uint32_t valid = NP - MAXC;
+    for (uint32_t b = 0; b < NR; b++) {                                     // two codes
+        const uint32_t r = R0 + b;
+        if (r) for (uint32_t i = tid; i < valid; i += 256) { const uint32_t e = t1[i]; eA[b][i] = (uint8_t)(e + t1[i + r + e]); }
+    }
+    __syncthreads();
+    uint8_t (*src)[NP] = eA, (*dst)[NP] = eB;
+#pragma unroll 1
+    for (uint32_t lvl = 1; lvl < 3; lvl++) {                                // four, eight codes: extras add, positions move by k * r + extras
+        valid -= MAXC << lvl;
+        for (uint32_t b = 0; b < NR; b++) {
+            const uint32_t r = R0 + b, kr = r << lvl;
+            if (r) for (uint32_t i = tid; i < valid; i += 256) { const uint32_t e = src[b][i]; dst[b][i] = (uint8_t)(e + src[b][i + kr + e]); }
+        }
+        __syncthreads();
+        uint8_t (*t)[NP] = src; src = dst; dst = t;
+    }
+    // src = the extras of eight codes; sixteen = eight + eight, formed here
+    uint4 *out = tab + ((uint64_t)blockIdx.y * tab_pitch + (uint64_t)blockIdx.x * (ROWB / 16 * TCW));      // (rows are consecutive: ROWB / 16 sixteen-byte pieces a position)
+    for (uint32_t o = tid; o < TCW; o += 256) {
+        const uint32_t x = bits(o);
+        uint32_t delta = 0; bool sig = false;
+        const uint32_t cs = walk_switch<UB>(x, delta, sig);                 // from rung 0: the step itself
+        const uint32_t len0 = cs + (((bits(o + cs)) & 1) ? 17 : 1);         // rung 0: one flag, then 16 raw bits
+        uint32_t e[NR];
+#pragma unroll
+        for (uint32_t bin = 0; bin < NR; bin++) {
+            const uint32_t r = (R0 + bin + delta) & (NRUNG - 1), rb = r - R0;
+            const bool out_of_band = rb >= NR;
+            const uint32_t bb = out_of_band ? 0u : rb;
+            uint32_t u = len0;
+            if (r && !out_of_band) { const uint32_t n8 = 8 * r + src[bb][o + cs]; u = cs + n8 + 8 * r + src[bb][o + cs + n8]; }
+            e[bin] = ((ow + o + (out_of_band ? 1u : u)) * ROWB) | (bb << 1) | ((sig || out_of_band) ? 1u : 0u);
+        }
+        if (NR == 16) {
+            out[2 * o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+            out[2 * o + 1] = make_uint4(e[8 % NR] | e[9 % NR] << 16, e[10 % NR] | e[11 % NR] << 16, e[12 % NR] | e[13 % NR] << 16, e[14 % NR] | e[15 % NR] << 16);
+        } else out[o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+    }
+}
+
+// The walk: walk_chain16_kernel's organisation (a lane chases, six waves load windows, one writes the index) with the
+// wide types' window size; rungs are relative to the band's R0 on the way, absolute in the index.
+template <uint32_t UB, uint32_t NRB>
+__global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs a0, const uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch, WalkState16 *states) {
+    typedef chainW<UB, NRB> W;
+    constexpr uint32_t CW = W::CW, ROWB = W::ROWB, NR = W::NR, WIN_BYTES = W::WIN_BYTES, WIN_U4 = W::WIN_U4, TR0 = W::TR0, TR_BYTES = W::TR_BYTES, RS0 = W::RS0, WR0 = W::WR0,
+                       META = W::META, F_READY = W::F_READY, F_TRAILED = W::F_TRAILED, F_NUNITS = W::F_NUNITS, F_O0 = W::F_O0, F_WALKED = W::F_WALKED, F_STOP = W::F_STOP, F_U0 = W::F_U0;
+    using chain::flag_get; using chain::flag_set; using chain::SPIN_MAX;
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t B = a.g.bands, NB = a.g.seg_blocks;
+    const uint64_t nunits = a.g.nblocks * B;
+    WalkState16 *S = states + blockIdx.x;
+    const uint64_t P0 = S->P, U_in = S->unit, R_in = S->rungs;
+    const uint32_t R0 = S->pad;
+    const uint64_t slab_end = slab0 + (uint64_t)nwin * CW;
+    if (S->bad || P0 < slab0 || P0 >= slab_end || P0 >= a.in_bits || U_in >= nunits) return;  // (uniform) nothing of this tile in this slab
+    const uint32_t k0 = (uint32_t)((P0 - slab0) / CW);                      // the window the walk starts in
+    volatile uint32_t *rs = (volatile uint32_t *)(smem + RS0), *wr = (volatile uint32_t *)(smem + WR0);     // rung * 2 per band: the walk's, the writer's
+    if (tid < 32) {     // (the first two windows find their trail slots free)
+        uint32_t v = tid == (F_STOP - META) / 4 ? 0xffffffffu : 0u;
+        if (tid == (k0 & 1) * 4 + 3) v = k0 + 1;
+        if (tid == ((k0 + 1) & 1) * 4 + 3) v = k0 + 2;
+        ((uint32_t *)(smem + META))[tid] = v;
+    }
+    if (tid < 16) { const uint32_t r2 = (uint32_t)((R_in >> (4 * tid)) & 15u) << 1; rs[tid] = r2; wr[tid] = r2; }
+    __syncthreads();
+    const uint4 *wt = tab + (uint64_t)blockIdx.x * tab_pitch;
+    auto ready = [&](uint32_t slot, uint32_t want) {
+        const chain::u32x4_t f = *(volatile __attribute__((address_space(3))) chain::u32x4_t *)(uintptr_t)(F_READY + 16 * slot);
+        return f.x == want && f.y == want && f.z == want && f.w == want;
+    };
+
+    if (wave == 0) {
+        if (lane) return;
+        uint32_t bad = 0, k = k0, o = (uint32_t)((P0 - slab0) % CW);
+        uint64_t U = U_in, Pn = P0;
+        uint32_t c = (uint32_t)(U % B);
+        bool stuck = false;
+        while (true) {
+            const uint32_t s = k & 1;
+            uint32_t spin = 0;
+            while (!ready(s, k + 1) && ++spin < SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+            if (spin >= SPIN_MAX) { stuck = true; break; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint32_t A = o * ROWB + rs[c], n = 0;
+            const uint64_t left64 = nunits - U;
+            uint32_t left = left64 > 0xffffffffull ? 0xffffffffu : (uint32_t)left64;
+            typedef const __attribute__((address_space(3))) uint16_t *LdsHalf;
+            typedef __attribute__((address_space(3))) uint16_t *LdsHalfW;
+            typedef __attribute__((address_space(3))) uint32_t *LdsWordW;
+            const uint32_t wbase = s * WIN_BYTES;
+            LdsHalfW trw = (LdsHalfW)(uintptr_t)(TR0 + s * TR_BYTES);
+            LdsWordW rsw = (LdsWordW)(uintptr_t)RS0;
+            constexpr uint32_t M = 0xffffu & ~(ROWB - 1), RM = (NR - 1) << 1;
+            // a unit per turn, until one starts beyond the window or an entry carries the stop bit (a unit that leaves the band of
+            // rungs, or the signal code): ONE dependent LDS read a unit
+#ifdef PXW_EXP_NOWALK
+            if (true) { A = CW * ROWB + (rs[c] & RM); }
+            else
+#endif
+            if (B == 1) {
+                while (A < CW * ROWB && left && !(bad & 1u)) {
+                    const uint32_t e = *(LdsHalf)(uintptr_t)(wbase + A);
+                    trw[n++] = (uint16_t)e; bad |= e;
+                    A = e & (M | RM);
+                    left--;
+                }
+                rsw[0] = A & RM;
+            } else {
+                uint32_t cn = c + 1 == B ? 0 : c + 1;
+                uint32_t rn = rsw[cn];
+                while (A < CW * ROWB && left && !(bad & 1u)) {
+                    const uint32_t cn2 = cn + 1 == B ? 0 : cn + 1;
+                    const uint32_t e = *(LdsHalf)(uintptr_t)(wbase + A);
+                    const uint32_t r2 = B > 2 ? rsw[cn2] : 0u;
+                    trw[n++] = (uint16_t)e; bad |= e;
+                    rsw[c] = e & RM;
+                    A = (e & M) | rn;
+                    if (B == 2) rn = e & RM; else rn = r2;                  // (two bands: this band comes again after the next unit)
+                    c = cn; cn = cn2; left--;
+                }
+            }
+            *(volatile uint64_t *)(smem + F_U0 + 8 * s) = U;
+            flag_set(F_NUNITS + 4 * s, n);
+            flag_set(F_O0 + 4 * s, o);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            flag_set(F_TRAILED + 4 * s, k + 1);
+            U += n;
+            const uint32_t oe = A / ROWB;
+            Pn = slab0 + (uint64_t)k * CW + oe;
+            k++;
+            flag_set(F_WALKED, k - k0);
+            if (U >= nunits || (bad & 1u)) break;                           // the units ran out, or the table does not carry this stream
+            o = oe - CW;                                                    // (the walk left the window: oe >= CW)
+            if (k >= nwin || Pn >= a.in_bits) break;                        // the slab ends here, or the stream does (a damaged one)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        flag_set(F_STOP, k);
+        uint64_t Rn = 0;
+        for (uint32_t i = 0; i < B; i++) Rn |= (uint64_t)((rs[i] >> 1) & 15u) << (4 * i);
+        S->P = stuck ? ~0ull : Pn; S->unit = U; S->rungs = Rn; S->bad = (bad & 1u) | (stuck ? 1u : 0u);
+        if ((bad & 1u) || stuck) atomicOr(a.status, 1u);
+        return;
+    }
+    if (wave <= 3 * W::NG) {
+        constexpr uint32_t NG = W::NG;
+        const uint32_t g = (wave - 1) / 3, part = (wave - 1) % 3;
+#ifdef PXW_EXP_HALFLOAD
+        constexpr uint32_t NV = WIN_U4 / 192 / 2;
+#else
+        constexpr uint32_t NV = WIN_U4 / 192;                               // sixteen-byte pieces a lane moves per window
+#endif
+        for (uint32_t k = k0 + ((g + NG - k0 % NG) % NG); k < nwin; k += NG) {
+            const uint4 *src = wt + (uint64_t)k * WIN_U4;
+            uint4 v[NV];
+#pragma unroll
+            for (uint32_t i = 0; i < NV; i++) v[i] = src[lane + 64 * (part + 3 * i)];
+            uint32_t spin = 0;
+            bool stop = false;
+            while (true) {                                                  // the slot is free when the window two back has been walked
+                if (flag_get(F_STOP) != 0xffffffffu) { stop = true; break; }
+                if (flag_get(F_WALKED) + 2 > k - k0) break;
+                if (++spin >= SPIN_MAX) { stop = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (stop) break;
+            uint4 *slot = (uint4 *)(smem + (k & 1) * WIN_BYTES);
+#pragma unroll
+            for (uint32_t i = 0; i < NV; i++) slot[lane + 64 * (part + 3 * i)] = v[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) flag_set(F_READY + 16 * (k & 1) + 4 * part, k + 1);
+        }
+        return;
+    }
+    // writer: entry j of the trail = (position the unit ENDS at | rung of its band after it): lengths by difference
+    for (uint32_t k = k0;; k++) {
+        const uint32_t s = k & 1;
+        uint32_t spin = 0;
+        bool stop = false;
+        while (flag_get(F_TRAILED + 4 * s) != k + 1) {
+            const uint32_t st = flag_get(F_STOP);
+            if ((st != 0xffffffffu && k >= st) || ++spin >= SPIN_MAX) { stop = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (stop) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint64_t U0 = *(volatile uint64_t *)(smem + F_U0 + 8 * s);
+        const uint32_t n = flag_get(F_NUNITS + 4 * s), o_first = flag_get(F_O0 + 4 * s);
+        const uint16_t *tr = (const uint16_t *)(smem + TR0 + s * TR_BYTES);
+        const uint64_t wpos = slab0 + (uint64_t)k * CW;
+        uint16_t *ul = (uint16_t *)a.idx.ulen + U0;
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint32_t o0 = j ? tr[j - 1] / ROWB : o_first, o1 = tr[j] / ROWB;
+            ul[j] = (uint16_t)(o1 - o0);
+            const uint64_t Uj = U0 + j;
+            if (Uj % B == 0 && (Uj / B) % NB == 0) {        // a segment starts here: position, and every band's rung as the block finds it
+                const uint64_t seg = Uj / B / NB;
+                a.idx.bitpos[seg] = wpos + o0;
+                for (uint32_t cc = 0; cc < B; cc++) {       // band cc's unit before this one: B - cc units back
+                    const int32_t jj = (int32_t)j - (int32_t)(B - cc);
+                    a.idx.rung[seg * B + cc] = (uint8_t)(R0 + (((jj >= 0 ? (uint32_t)tr[jj] : wr[cc]) >> 1) & (NR - 1)));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < B) {     // the rung every band has after this window: the last unit of each band in it
+            const uint32_t cl = (uint32_t)((U0 + n - 1) % B);
+            const uint32_t back = (cl + B - lane) % B;
+            if (n > back) wr[lane] = tr[n - 1 - back] & ((NR - 1) << 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) flag_set(F_READY + 16 * s + 12, k + 3);              // the trail slot is free for the window that takes it next
+    }
+}
+
 // Slabs of the streams are tabulated by the whole chip, then walked by a workgroup per tile, slab after slab; the
 // table of the next slab is built (on a stream of its own, in the other half of the memory) while this one is walked.
 // tab: [walk state per tile][windows of table rows per tile] x 2; max_bits: the longest stream of the call.
@@ -982,6 +1278,7 @@ static void walk_in_slabs(const DecArgs &a, hipStream_t st, void *tab, size_t ta
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (aux) (void)hipStreamDestroy(aux);
 }
+template <uint32_t U, uint32_t N> struct WideTag { static constexpr uint32_t UB_ = U, NR_ = N; };
 void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
     static const bool lds_ok = [] {
         bool ok = true;
@@ -989,10 +1286,33 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
         ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chain16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, chain16::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 8>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 8>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 16>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 16>::LDS_BYTES) == hipSuccess;
         return ok;
     }();
     (void)lds_ok;
     const uint32_t nt = a.ntiles;
+    if (a.g.tsz >= 4) {         // 32/64-bit FTL/BASE: the first segment parsed outright (band of rungs, entry state), then table + chain
+        WalkState16 *states = (WalkState16 *)tab;
+        const uint32_t nr = a.wide_band == 8 ? 8u : 16u;
+        { ProfScope ps("dec_index_serial", st);
+          if (a.g.tsz == 4) hipLaunchKernelGGL(walk_probe_kernel<uint32_t>, dim3(nt), dim3(64), 0, st, a, states, nr);
+          else hipLaunchKernelGGL(walk_probe_kernel<uint64_t>, dim3(nt), dim3(64), 0, st, a, states, nr); }
+        auto run = [&](auto tag) {
+            constexpr uint32_t UB = decltype(tag)::UB_, NRB = decltype(tag)::NR_;
+            typedef chainW<UB, NRB> W;
+            walk_in_slabs(a, st, tab, tab_bytes, max_bits, W::CW, W::WIN_U4, sizeof(WalkState16),
+                [&](hipStream_t s, uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch) {
+                    hipLaunchKernelGGL((walk_tableW_kernel<UB, NRB>), dim3(nwin * (W::CW / W::TCW), nt), dim3(256), 0, s, a, rows, s0, nwin, pitch, (const WalkState16 *)states); },
+                [&](hipStream_t s, const uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch, uint8_t *sts, uint32_t) {
+                    hipLaunchKernelGGL((walk_chainW_kernel<UB, NRB>), dim3(nt), dim3(64 * W::WAVES), W::LDS_BYTES, s, a, rows, s0, nwin, pitch, (WalkState16 *)sts); });
+        };
+        if (a.g.tsz == 4) { if (nr == 16) run(WideTag<5, 16>()); else run(WideTag<5, 8>()); }
+        else { if (nr == 16) run(WideTag<6, 16>()); else run(WideTag<6, 8>()); }
+        return;
+    }
     if (a.g.tsz == 2) {
         walk_in_slabs(a, st, tab, tab_bytes, max_bits, chain16::CW, chain16::WIN_U4, sizeof(WalkState16),
             [&](hipStream_t s, uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch) {
@@ -1012,12 +1332,14 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
             else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first); });
 }
 // bytes of table memory that take `max_bits` of every stream in one round (16-bit data: 32 bytes a stream bit)
+// (32/64-bit data: sized for the table of sixteen rungs, 32 bytes a stream bit in windows of 1440 / 960 positions; the table of eight is half of it)
+static uint32_t walk_cw(uint32_t tsz) { return tsz == 2 ? chain16::CW : tsz == 4 ? chainW<5, 16>::CW : tsz == 8 ? chainW<6, 16>::CW : chain::CW; }
 size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits, uint32_t tsz) {
-    const uint32_t cw = tsz == 2 ? chain16::CW : chain::CW, win_bytes = tsz == 2 ? chain16::WIN_BYTES : chain::WIN_BYTES;
+    const uint32_t cw = walk_cw(tsz), win_bytes = tsz == 1 ? chain::WIN_BYTES : cw * 32;
     const uint64_t need = (max_bits + cw - 1) / cw;
     return (((size_t)ntiles * sizeof(WalkState16) + 255) & ~(size_t)255) + (size_t)win_bytes * ntiles * need + 4096;
 }
-size_t walk_table_min_bytes(uint32_t ntiles, uint32_t tsz) { return walk_table_bytes(ntiles, 2 * 16 * (tsz == 2 ? chain16::CW : chain::CW), tsz); }
+size_t walk_table_min_bytes(uint32_t ntiles, uint32_t tsz) { return walk_table_bytes(ntiles, 2 * 16 * walk_cw(tsz), tsz); }
 
 void launch_dec_walk(const DecArgs &a, hipStream_t st) {
     if (a.ix) {                             // the containers' own restart tables: a lane per entry
@@ -1042,6 +1364,8 @@ void launch_dec_walk(const DecArgs &a, hipStream_t st) {
 }
 void launch_prev_scan(const DecArgs &a, hipStream_t st) {
     if (a.g.tsz == 1) hipLaunchKernelGGL(prev_scan_kernel<uint8_t>, dim3(a.ntiles, a.g.bands), dim3(1024), 0, st, a);
+    else if (a.g.tsz == 4) hipLaunchKernelGGL(prev_scan_kernel<uint32_t>, dim3(a.ntiles, a.g.bands), dim3(1024), 0, st, a);
+    else if (a.g.tsz == 8) hipLaunchKernelGGL(prev_scan_kernel<uint64_t>, dim3(a.ntiles, a.g.bands), dim3(1024), 0, st, a);
     else hipLaunchKernelGGL(prev_scan_kernel<uint16_t>, dim3(a.ntiles, a.g.bands), dim3(1024), 0, st, a);
 }
 

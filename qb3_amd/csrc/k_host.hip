@@ -20,6 +20,7 @@ const Tuning &tuning() {
         const char *cap = getenv("QB3_WALK_TAB_KB"); // plain 8-bit streams: bytes of table memory (a small one means many rounds)
         v.walk_tab_kb = cap ? (size_t)strtoull(cap, nullptr, 10) : 0;
         v.slow_index = on("QB3_SLOW_INDEX");         // index-less streams: the one-lane index rebuild instead of the walkers
+        { const char *e = getenv("QB3_WIDE_BAND"); v.wide_band = e && e[0] ? atoi(e) : 0; }      // plain 32/64-bit streams: rungs in the table's band (test hook)
         v.no_bl = on("QB3_NO_BLOCK_LENGTHS");        // containers whose table carries block lengths: walk them like the others
         return v;
     }();
@@ -402,7 +403,8 @@ DecPlan plan_decode(const Geometry &g) {
 
 size_t walk_table_cap() { return tuning().walk_tab_kb ? tuning().walk_tab_kb << 10 : (size_t)1 << 30; }
 bool walk_table_applies(const Geometry &g, const DecPlan &plan) {
-    return ((plan.px && g.tsz == 1) || (plan.px16 && g.tsz == 2)) && g.mode != CM_BEST && !tuning().slow_walk && !tuning().slow_index;
+    // 8- and 16-bit rasters the lane-per-block decoders take; 32/64-bit rasters the unit-parallel decoder takes (a band of sixteen rungs)
+    return ((plan.px && g.tsz == 1) || (plan.px16 && g.tsz == 2) || (g.tsz >= 4 && plan.fast)) && g.mode != CM_BEST && !tuning().slow_walk && !tuning().slow_index;
 }
 
 // A restart table is untrusted input that the decoder takes positions, rungs and values from: before any of it is used the
@@ -463,19 +465,21 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         HIPCHK(hipGetLastError());
         return 0;
     }
-    if (rebuild && (use_px || use_px16 || wide_walk) && !tuning().slow_index) {
+    // plain 32/64-bit FTL/BASE streams: unit lengths through the table of a band of rungs, when the caller brought memory for it
+    const bool wide_plain = rebuild && !a.ix && unit_parallel && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk;
+    if (rebuild && (use_px || use_px16 || wide_walk || wide_plain) && !tuning().slow_index) {
         // index-less stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
         // produce the values entering the segments (totals pass + scan)
         // plain 8-bit stream: through the table of unit lengths by position when the caller brought memory for it
         const bool has_ix = a.ix != nullptr;
-        if ((use_px || use_px16) && !has_ix && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk) launch_dec_walk_table(a, st, walk_tab, walk_tab_bytes, max_bits);
+        if ((use_px || use_px16 || wide_plain) && !has_ix && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk) launch_dec_walk_table(a, st, walk_tab, walk_tab_bytes, max_bits);
         else { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
         if (!(a.ix && a.ix_blocks == a.g.seg_blocks) && !wide_walk) {         // (an entry per segment: the walk copied the entering values)
           {
             ProfScope ps("dec_index_prev", st);
             DecArgs t = a;
             t.totals_only = 1;
-            if (use_px) launch_dec_px(t, plan, st); else launch_dec_px16(t, plan, st);
+            if (use_px) launch_dec_px(t, plan, st); else if (use_px16) launch_dec_px16(t, plan, st); else launch_dec_generic(t, plan, st);
           }
           ProfScope ps("dec_index_scan", st);
           launch_prev_scan(a, st);
@@ -494,7 +498,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
 
 int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
                   void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb,
-                  const uint64_t *tile_bits, const IxTable &ix, void *walk_tab, size_t walk_tab_bytes, bool full_staging) {
+                  const uint64_t *tile_bits, const IxTable &ix, void *walk_tab, size_t walk_tab_bytes, bool full_staging, uint32_t wide_band) {
     hipStream_t st = (hipStream_t)stream;
     DecArgs a;
     // 16-bit lane-per-block decoder: a wave stages its segment in LDS, and four worst-case segments (278 bits a unit) keep
@@ -547,6 +551,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.totals_only = 0;
     a.bl_mode = 0;
+    a.wide_band = tuning().wide_band ? (uint32_t)tuning().wide_band : wide_band;
     a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.dst_pitch & 3);
     a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;

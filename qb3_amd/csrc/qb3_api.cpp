@@ -928,10 +928,13 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
     if (!d_index && !ix.base && !walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
     uint32_t status = 0;
     IxTable table = ix;
-    for (int turn = 0; turn < 2; turn++) {
+    // (32/64-bit plain streams: the table of a band of sixteen rungs; a stream that leaves the band goes to the one-lane parser)
+    bool walk_tab_ok = true;
+    const uint32_t wide_band = 16;
+    for (int turn = 0; turn < 3; turn++) {
         for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the stream's average)
             if (launch_decode(g, plan, in32, (uint32_t)(8 * (off & 3)), (uint64_t)nbytes * 8, d_img, d_index, p->d_ws.p, &d_status, st, TileBatch(), nullptr, table,
-                              p->d_tab.p, p->d_tab.cap, full != 0))
+                              walk_tab_ok ? p->d_tab.p : nullptr, walk_tab_ok ? p->d_tab.cap : 0, full != 0, wide_band))
                 return false;
             const hipError_t e = fetch_small(&status, d_status, 4, st);
             if (e != hipSuccess) { set_error("decode kernels", (int)e); return false; }
@@ -940,9 +943,12 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
         // The container's restart table is a convenience the format does not protect: when its check fails (bit 5) or the
         // decode that relied on it does, the stream is decoded again WITHOUT it -- the plain walk, what the reference does
         // with such a container -- so a damaged table costs time, never pixels.
-        if (!(status & (27 | 32)) || d_index || !table.base) break;
-        table = IxTable();
-        if (!walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
+        if (!(status & (27 | 32)) || d_index) break;
+        if (table.base) {
+            table = IxTable();
+            if (!walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
+        } else if (walk_tab_ok && g.tsz >= 4 && p->d_tab.p && walk_table_applies(g, plan)) walk_tab_ok = false;
+        else break;
     }
     prof_collect();
     // bit 0: corrupt unit, bit 1: more than 7 unused bits at the end (reference QB3decode.h:411,569,740).
@@ -1160,11 +1166,13 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
             if (!d_index && !use_ix && !walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
             const uint8_t *src0 = (const uint8_t *)d_src + first * src_pitch;
             uint32_t *d_status = nullptr;
-            for (int turn = 0; turn < 2; turn++) {
+            bool walk_tab_ok = true;
+            const uint32_t wide_band = 16;
+            for (int turn = 0; turn < 3; turn++) {
                 for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the streams' average)
                     if (launch_decode(g, plan, (const uint32_t *)(src0 + (hdr & ~(size_t)3)), (uint32_t)(8 * (hdr & 3)), 0, (uint8_t *)d_dst + first * dst_pitch,
                                       d_index ? (const uint8_t *)d_index + first * isz : nullptr, p->d_ws.p, &d_status, st, tb, (const uint64_t *)p->d_in.p,
-                                      ixt, p->d_tab.p, p->d_tab.cap, full != 0)) { p->error = QB3E_LIBERR; return done; }
+                                      ixt, walk_tab_ok ? p->d_tab.p : nullptr, walk_tab_ok ? p->d_tab.cap : 0, full != 0, wide_band)) { p->error = QB3E_LIBERR; return done; }
                     e = hipMemcpyAsync(status.data(), d_status, 4 * cnt, hipMemcpyDeviceToHost, st);
                     if (e == hipSuccess) e = hipStreamSynchronize(st);
                     if (e != hipSuccess) { set_error("decode kernels (tiles)", (int)e); p->error = QB3E_LIBERR; return done; }
@@ -1175,9 +1183,12 @@ QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t sr
                 // a tile whose table fails its check, or whose decode from the table fails: the batch again without the tables
                 bool table_trouble = false;
                 for (size_t i = 0; i < cnt; i++) table_trouble = table_trouble || (bits[i] && (status[i] & (27 | 32)));
-                if (!table_trouble || !ixt.base) break;
-                ixt = IxTable();
-                if (!walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
+                if (!table_trouble || d_index) break;
+                if (ixt.base) {
+                    ixt = IxTable();
+                    if (!walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
+                } else if (walk_tab_ok && g.tsz >= 4 && p->d_tab.p && walk_table_applies(g, plan)) walk_tab_ok = false;   // a stream left the band of rungs: the one-lane parser
+                else break;
             }
             prof_collect();
             for (size_t i = 0; i < cnt; i++) if (bits[i] && !(status[i] & 27)) { p->tile_ok[first + i] = 1; done++; }

@@ -318,6 +318,7 @@ struct DecArgs {
     uint32_t ix_bl;                 // the entries carry block lengths: the lane-per-block decoder needs no walk and no index
     uint32_t ix_ver, ix_check_heads;    // version of the table's chunks (3: with checks); the host has not seen the chunk heads behind the first
     uint32_t bl_mode;               // ... and this launch decodes from them
+    uint32_t wide_band;             // plain 32/64-bit streams: rungs in the band the walk's table covers (16; 8: QB3_WIDE_BAND, a test hook)
     // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
     uint32_t ntiles;
     uint64_t ts_in, ts_img, ts_idx;
@@ -543,7 +544,7 @@ struct ProfScope {
 };
 
 // process-wide debugging switches, read once from the environment (k_host.hip)
-struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool no_bl; size_t walk_tab_kb; };
+struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool no_bl; size_t walk_tab_kb; int wide_band; };
 const Tuning &tuning();
 
 uint32_t magic_div(uint32_t d);

@@ -1491,3 +1491,38 @@ def test_a_damaged_restart_table_costs_time_not_pixels(qb3, oracle, case):
     if cb is not None:
         qb3.lib.qb3x_set_decoder_compat(dec.p, 0)
     assert torch.equal(dec.decode(dbad, index=None), torch.from_numpy(raw).cuda()), "device flavour"
+
+
+@pytest.mark.parametrize("case", [(256, 256, 1, 5, "DEM", FTL), (300, 200, 1, 7, "DEM", BASE), (260, 132, 3, 4, "NOISY3", BASE), (128, 128, 1, 5, "TERRACE", FTL),
+                                  (128, 128, 1, 7, "FEW", FTL), (64, 64, 1, 6, "RUNG63", FTL), (256, 128, 5, 4, "RANDOM", FTL), (1024, 1024, 1, 5, "DEM", FTL),
+                                  (1024, 768, 2, 7, "DEM", BASE), (509, 259, 1, 5, "DEM", FTL), (640, 480, 16, 4, "DEM", FTL), (2048, 2048, 1, 5, "LANDSAT16", BASE)],
+                         ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % c)
+def test_plain_wide_streams_through_the_band_table(qb3, oracle, case):
+    """plain (reference-made: no index, no restart table) 32/64-bit FTL/BASE streams: the first index segment is parsed
+    outright, the rest walked through a table of unit ends by position for a band of sixteen rungs (walk_tableW_kernel,
+    walk_chainW_kernel), the entering values come from a totals pass of the unit-parallel decoder; a stream that leaves the
+    band (FEW / RANDOM data ranges over all rungs) falls back to the one-lane parser.  Pixels exact either way; and the
+    table path is the one taken where the data allows it (reference QB3decode.h:293-412)."""
+    import ctypes as C
+    import torch
+    from qb3_amd import device as qdev
+    w, h, b, dt, gen, mode = case
+    img = oracle.generate(w, h, b, dt, gen, 4)
+    cb = None if b in (1, 3, 4) else list(range(b))
+    ref = oracle.encode(img, dt, mode, cband=cb)
+    d = torch.from_numpy(ref).cuda()
+    dec = qdev.DeviceDecoder(d, len(ref))
+    if cb is not None:
+        qb3.lib.qb3x_set_decoder_compat(dec.p, 0)
+    L = qb3.lib
+    L.qb3x_profile_enable(1); L.qb3x_profile_reset()
+    out = dec.decode(d, index=None)
+    torch.cuda.synchronize()
+    names = C.create_string_buffer(1024)
+    L.qb3x_profile_names(names, 1024)
+    L.qb3x_profile_enable(0)
+    assert np.array_equal(out.cpu().numpy(), img.view(np.uint8).ravel())
+    if gen in ("DEM", "LANDSAT16", "NOISY3") and ref[10] != 255:
+        assert b"dec_index_table" in names.value, names.value          # the band table carried the stream
+    got, dims, _, _ = qb3.decode(ref)                                       # ... and through the host-pointer API
+    assert dims == (w, h, b) and np.array_equal(got, img.view(np.uint8).ravel())
