@@ -222,6 +222,7 @@ __device__ __forceinline__ bool best_two_pass(const EncArgs &a) {
 template <typename T, bool FIRST>
 __global__ void __launch_bounds__(256) enc_best_kernel(const EncArgs a0) {      // (256 = the plan's largest block: without the bound the compiler budgets for 1024 threads and the recode loop spills)
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    enc_scan_counter_reset(a);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const bool two_pass = best_two_pass(a);
     if (FIRST) { best_chunk<T, true>(a, a0, smem, blockIdx.x, two_pass); return; }

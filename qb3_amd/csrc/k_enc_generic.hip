@@ -6,6 +6,7 @@ namespace qb3dev {
 template <typename T, bool STEP>
 __global__ void enc_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    enc_scan_counter_reset(a);
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
@@ -103,7 +104,7 @@ __global__ void enc_kernel(const EncArgs a0) {
             if (seg * a.g.seg_blocks == gblk) {
                 ((T *)a.idx.prev)[(uint64_t)seg * bands + c] = pv;
                 a.idx.rung[(uint64_t)seg * bands + c] = (uint8_t)prung;
-                if (c == 0) a.idx.bitpos[seg] = ((uint64_t)chunk << 32) | pos;     // chunk-relative; fixed up by enc_seam_kernel
+                if (c == 0) a.idx.bitpos[seg] = ((uint64_t)chunk << 32) | pos;     // chunk-relative; fixed up by enc_finish_kernel
             }
         }
     }

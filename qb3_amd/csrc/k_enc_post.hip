@@ -3,12 +3,18 @@
 
 namespace qb3dev {
 
-// Exclusive scan of the chunk bit counts, one workgroup per SCAN_GROUP chunks (4 per thread); the per-group sums
-// are folded in by the consumers.  64-bit offsets: a 16384^2 x 3 stream exceeds 2^32 bits.
-__global__ void enc_scan_kernel(const EncArgs a0) {
+// Exclusive scan of the chunk bit counts in ONE launch: a workgroup per SCAN_GROUP chunks (4 per thread) leaves its chunks'
+// offsets inside the group and the group's sum; the workgroup that finishes LAST (a counter behind the group sums, zeroed
+// by the coding kernel of the same call) scans the group sums in place -- entry [ngroups] gets the total.  64-bit offsets:
+// a 16384^2 x 3 stream exceeds 2^32 bits.  The consumers add group offset and chunk offset (chunk_start).
+__global__ void __launch_bounds__(SCAN_GROUP / 4) enc_scan_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     __shared__ uint32_t wsum[16];
+    __shared__ uint64_t wsum64[16];
+    __shared__ uint64_t carry;
+    __shared__ uint32_t is_last;
     const uint32_t tid = threadIdx.x, i0 = blockIdx.x * SCAN_GROUP + 4 * tid;
+    const uint32_t ngroups = (a.nchunks + SCAN_GROUP - 1) / SCAN_GROUP;
     uint32_t v[4], sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { v[k] = (i0 + k < a.nchunks) ? a.chunk_bits[i0 + k] : 0; sum += v[k]; }
@@ -16,28 +22,26 @@ __global__ void enc_scan_kernel(const EncArgs a0) {
     uint64_t off = block_exscan(sum, wsum, &total);
 #pragma unroll
     for (int k = 0; k < 4; k++) if (i0 + k < a.nchunks) { a.chunk_off[i0 + k] = off; off += v[k]; }
-    if (tid == 0) a.group_sum[blockIdx.x] = total;
-}
-
-// Second level: exclusive scan of the group sums in place (one workgroup); entry [ngroups] gets the total.
-__global__ void enc_scan2_kernel(const EncArgs a0) {
-    const EncArgs a = enc_for_tile(a0, blockIdx.y);
-    __shared__ uint64_t wsum64[16];
-    __shared__ uint64_t carry;
-    const uint32_t ngroups = (a.nchunks + SCAN_GROUP - 1) / SCAN_GROUP;
-    if (threadIdx.x == 0) carry = 0;
+    if (tid == 0) {
+        a.group_sum[blockIdx.x] = total;
+        __threadfence();                                    // the sum is out before the count says so (agent scope: the XCDs' L2s)
+        is_last = atomicAdd((uint32_t *)&a.group_sum[ngroups + 1], 1u) == gridDim.x - 1;
+        carry = 0;
+    }
     __syncthreads();
+    if (!is_last) return;                                   // (uniform)
+    __threadfence();
     for (uint32_t base = 0; base < ngroups; base += blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
-        const uint64_t v = i < ngroups ? a.group_sum[i] : 0ull;
-        const uint64_t ex = block_exscan_v<uint64_t>(v, wsum64);
+        const uint32_t i = base + tid;
+        const uint64_t g = i < ngroups ? __hip_atomic_load(&a.group_sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        const uint64_t ex = block_exscan_v<uint64_t>(g, wsum64);
         const uint64_t c0 = carry;
         if (i < ngroups) a.group_sum[i] = c0 + ex;
         __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) carry = c0 + ex + v;
+        if (tid == blockDim.x - 1) carry = c0 + ex + g;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { a.group_sum[ngroups] = carry; a.res->zero_run = 0; }      // (enc_concat_kernel raises it)
+    if (tid == 0) { a.group_sum[ngroups] = carry; a.res->zero_run = 0; }      // (enc_concat_kernel raises zero_run)
 }
 
 // start of chunk k in the stream, in bits (k == nchunks: the stream length)
@@ -149,16 +153,59 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     if (a.zrun_probe && __any(zrun) && lane == 0) atomicOr(&a.res->zero_run, 1u);
 }
 
-// One thread per chunk boundary: a dword that holds the end of one chunk and the start of the next is the OR of
-// their edge dwords; the thread of the FIRST boundary inside a dword assembles it.  The same launch turns the
-// chunk-relative index positions into stream positions and publishes the stream length.
-__global__ void enc_seam_kernel(const EncArgs a0) {
+// What is left to do once the chunks stand in the stream, in ONE launch:
+// * a thread per chunk boundary: a dword that holds the end of one chunk and the start of the next is the OR of their edge
+//   dwords; the thread of the FIRST boundary inside a dword assembles it (the stream's first dword, when the header ends
+//   inside it, is written byte by byte from the stream's first byte on: the bytes in front belong to whoever writes the header);
+// * the stream length;
+// * the chunk-relative index positions become stream positions, and the thread that does that for a segment also writes
+//   the segment's entry of the restart table -- every ix_spe-th segment entry of the index, packed little endian, in
+//   chunks of ix_per_chunk entries, each a lower-case (ignorable) "ix" chunk followed by a 4-byte "zz" pad chunk, then "DT".
+//   Chunk head: "ix", length (the whole chunk: the reference skips unknown chunks by that many bytes from the chunk
+//   start, QB3decode.cpp:254-255), version 3, flags (bit 0: entries carry the common factors, bit 1: block lengths),
+//   the chunk's check (ix_seal_kernel), blocks per entry.  The pad makes the container parse the same if a reader adds the 4
+//   head bytes to the length.  (Entries with block lengths: their fill kernel writes the fixed fields too.);
+// * the container header in front of the stream (device flavour).
+__global__ void __launch_bounds__(256) enc_finish_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    const uint32_t B = a.g.bands, tsz = a.g.tsz;
+    if (blockIdx.x == 0 && a.hdr_len) {                     // the stream starts at out32 + out_bit0 / 8; the prepared header bytes end hdr_back before
+        uint8_t *start = (uint8_t *)a.out32 + (a.out_bit0 >> 3) - a.hdr_back;
+        for (uint32_t i = threadIdx.x; i < a.hdr_len; i += blockDim.x) start[i] = a0.hdr[i];
+    }
     if (a.have_idx)
         for (uint64_t sgi = k; sgi < a.g.nseg; sgi += nthreads) {
             const uint64_t v = a.idx.bitpos[sgi];
-            a.idx.bitpos[sgi] = chunk_start(a, (uint32_t)(v >> 32)) + (v & 0xffffffffu);
+            const uint64_t bp = chunk_start(a, (uint32_t)(v >> 32)) + (v & 0xffffffffu);
+            a.idx.bitpos[sgi] = bp;
+            if (!a.ix_dst || sgi % a.ix_spe) continue;
+            const uint32_t ke = (uint32_t)(sgi / a.ix_spe);        // the segment's entry of the restart table
+            const uint32_t c = ke / a.ix_per_chunk, j = ke - c * a.ix_per_chunk;
+            const uint32_t here = (a.ix_K - c * a.ix_per_chunk < a.ix_per_chunk) ? a.ix_K - c * a.ix_per_chunk : a.ix_per_chunk;   // entries of this chunk
+            uint8_t *chunk = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E);
+            if (j == 0) {
+                const uint32_t len = IX_HEAD + here * a.ix_E;
+                chunk[0] = 'i'; chunk[1] = 'x'; chunk[2] = (uint8_t)len; chunk[3] = (uint8_t)(len >> 8);
+                chunk[4] = 3; chunk[5] = (a.g.mode == CM_BEST ? 1 : 0) | (a.ix_bl ? 2 : 0); chunk[6] = 0; chunk[7] = 0;      // (bytes 6, 7: ix_seal_kernel)
+                for (uint32_t i = 0; i < 4; i++) chunk[8 + i] = (uint8_t)(a.ix_blocks >> (8 * i));
+                uint8_t *pad = chunk + len;
+                pad[0] = 'z'; pad[1] = 'z'; pad[2] = 4; pad[3] = 0;
+                if (c * a.ix_per_chunk + here == a.ix_K) { pad[4] = 'D'; pad[5] = 'T'; }
+            }
+            if (a.ix_bl) continue;              // (entries with block lengths: their fill kernel writes the fixed fields too)
+            uint8_t *e = chunk + IX_HEAD + (uint64_t)j * a.ix_E;
+            for (uint32_t i = 0; i < 6; i++) e[i] = (uint8_t)(bp >> (8 * i));
+            e += 6;
+            for (uint32_t c2 = 0; c2 < B; c2++) e[c2] = a.idx.rung[sgi * B + c2];
+            e += B;
+            const uint8_t *pv = (const uint8_t *)a.idx.prev + sgi * B * tsz;
+            for (uint32_t i = 0; i < B * tsz; i++) e[i] = pv[i];
+            if (a.g.mode == CM_BEST) {
+                e += B * tsz;
+                const uint8_t *cf = (const uint8_t *)a.idx.cf + sgi * B * tsz;
+                for (uint32_t i = 0; i < B * tsz; i++) e[i] = cf[i];
+            }
         }
     if (k > a.nchunks) return;
     const uint64_t Ek = (uint64_t)a.out_bit0 + chunk_start(a, k);
@@ -172,54 +219,10 @@ __global__ void enc_seam_kernel(const EncArgs a0) {
         const uint64_t En = (uint64_t)a.out_bit0 + chunk_start(a, j + 1);
         if ((En >> 5) != d || (En & 31) == 0) break;       // chunk j reaches the end of the dword
     }
-    a.out32[d] = v;
-}
-
-// Writes the container header in front of every tile's stream (after enc_seam_kernel, which owns the first dword).
-__global__ void write_header_kernel(const EncArgs a0) {
-    const EncArgs a = enc_for_tile(a0, blockIdx.y);
-    // the stream starts at out32 + out_bit0/8; the header ends there
-    // (with a coarse index chunk the prepared bytes are followed by its entries and "DT": hdr_back > hdr_len)
-    uint8_t *start = (uint8_t *)a.out32 + (a.out_bit0 >> 3) - a.hdr_back;
-    for (uint32_t i = threadIdx.x; i < a.hdr_len; i += blockDim.x) start[i] = a0.hdr[i];
-}
-
-// The restart table: every ix_spe-th segment entry of the (finished) index, packed little endian, in chunks of
-// ix_per_chunk entries -- each a lower-case (ignorable) "ix" chunk followed by a 4-byte "zz" pad chunk -- then "DT".
-// Chunk head: "ix", length (the whole chunk: the reference skips unknown chunks by that many bytes from the chunk
-// start, QB3decode.cpp:254-255), version 2, flags (bit 0: entries carry the common factors), 2 reserved bytes,
-// blocks per entry.  The pad makes the container parse the same if a reader adds the 4 head bytes to the length.
-__global__ void ix_fill_kernel(const EncArgs a0) {
-    const EncArgs a = enc_for_tile(a0, blockIdx.y);
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, B = a.g.bands, tsz = a.g.tsz;
-    if (k >= a.ix_K) return;
-    const uint32_t c = k / a.ix_per_chunk, j = k - c * a.ix_per_chunk;
-    const uint32_t here = (a.ix_K - c * a.ix_per_chunk < a.ix_per_chunk) ? a.ix_K - c * a.ix_per_chunk : a.ix_per_chunk;   // entries of this chunk
-    uint8_t *chunk = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E);
-    if (j == 0) {
-        const uint32_t len = IX_HEAD + here * a.ix_E;
-        chunk[0] = 'i'; chunk[1] = 'x'; chunk[2] = (uint8_t)len; chunk[3] = (uint8_t)(len >> 8);
-        chunk[4] = 3; chunk[5] = (a.g.mode == CM_BEST ? 1 : 0) | (a.ix_bl ? 2 : 0); chunk[6] = 0; chunk[7] = 0;      // (bytes 6, 7: ix_seal_kernel)
-        for (uint32_t i = 0; i < 4; i++) chunk[8 + i] = (uint8_t)(a.ix_blocks >> (8 * i));
-        uint8_t *pad = chunk + len;
-        pad[0] = 'z'; pad[1] = 'z'; pad[2] = 4; pad[3] = 0;
-        if (c * a.ix_per_chunk + here == a.ix_K) { pad[4] = 'D'; pad[5] = 'T'; }
-    }
-    if (a.ix_bl) return;                    // (entries with block lengths: ix_bl_fill_kernel writes their fixed fields too)
-    const uint64_t s = (uint64_t)k * a.ix_spe;
-    uint8_t *e = chunk + IX_HEAD + (uint64_t)j * a.ix_E;
-    const uint64_t bp = a.idx.bitpos[s];
-    for (uint32_t i = 0; i < 6; i++) e[i] = (uint8_t)(bp >> (8 * i));
-    e += 6;
-    for (uint32_t c2 = 0; c2 < B; c2++) e[c2] = a.idx.rung[s * B + c2];
-    e += B;
-    const uint8_t *pv = (const uint8_t *)a.idx.prev + s * B * tsz;
-    for (uint32_t i = 0; i < B * tsz; i++) e[i] = pv[i];
-    if (a.g.mode == CM_BEST) {
-        e += B * tsz;
-        const uint8_t *cf = (const uint8_t *)a.idx.cf + s * B * tsz;
-        for (uint32_t i = 0; i < B * tsz; i++) e[i] = cf[i];
-    }
+    if (k == 0 && a.out_bit0) {                             // the dword the header ends in: the stream's bytes only
+        uint8_t *p8 = (uint8_t *)(a.out32 + d);
+        for (uint32_t i = a.out_bit0 >> 3; i < 4; i++) p8[i] = (uint8_t)(v >> (8 * i));
+    } else a.out32[d] = v;
 }
 
 // Block lengths behind the entries' fixed fields (tables of level 2).  A block's bit length is the sum of its units'
@@ -391,16 +394,16 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     {
         ProfScope ps("enc_scan", st);
         hipLaunchKernelGGL(enc_scan_kernel, dim3((plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP, nt), dim3(SCAN_GROUP / 4), 0, st, a);
-        hipLaunchKernelGGL(enc_scan2_kernel, dim3(1, nt), dim3(1024), 0, st, a);
     }
     {
         ProfScope ps("enc_concat", st);
         hipLaunchKernelGGL(enc_concat_kernel, dim3((plan.nchunks + 3) / 4, nt), dim3(256), 0, st, a);
     }
     ProfScope ps("enc_seams", st);
-    hipLaunchKernelGGL(enc_seam_kernel, dim3((plan.nchunks + 1 + 255) / 256, nt), dim3(256), 0, st, a);
-    if (a.hdr_len) hipLaunchKernelGGL(write_header_kernel, dim3(1, nt), dim3(64), 0, st, a);
-    if (a.ix_dst && a.have_idx) hipLaunchKernelGGL(ix_fill_kernel, dim3((a.ix_K + 255) / 256, nt), dim3(256), 0, st, a);
+    {       // boundaries, stream length, index positions, the restart table's entries and chunk heads, the header: one launch
+        const uint64_t want = std::max<uint64_t>(plan.nchunks + 1, a.have_idx ? std::min<uint64_t>(a.g.nseg, (uint64_t)1 << 20) : 0);
+        hipLaunchKernelGGL(enc_finish_kernel, dim3((uint32_t)((want + 255) / 256), nt), dim3(256), 0, st, a);
+    }
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1 && a.g.mode == CM_BEST) hipLaunchKernelGGL(ix_bl_best_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
     else if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz >= 4) {

@@ -68,6 +68,7 @@ __device__ __forceinline__ void px_code_chunk(const EncArgs &a, const EncArgs &a
 template <int B, bool RGB, uint64_t ORDER, bool STEP>
 __global__ void __launch_bounds__(256, 4) enc_px_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    enc_scan_counter_reset(a);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t nblocks = (uint32_t)a.g.nblocks;

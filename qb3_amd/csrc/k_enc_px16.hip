@@ -25,6 +25,7 @@ __device__ __forceinline__ uint32_t gather_pair16(const uint32_t (&w)[4][2 * BG]
 template <int BG, bool RGB, uint64_t ORDER, bool STEP>
 __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    enc_scan_counter_reset(a);
     constexpr uint32_t UB = 4, UMASK = 15;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -182,10 +183,10 @@ __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
                         for (int i = first[k + 1] - 1; i >= first[k]; i--) {
                             const uint32_t m = (g8[i >> 1] >> (16 * (i & 1))) & 0xffffu;
                             const uint32_t e = *lds_at((m << 2) + tb);
-                            acc = (acc << (e & 31u)) | (e >> 8);
+                            acc = __builtin_amdgcn_alignbit(acc, e, e);      // (acc << length) | code (qb3_px.h, PxEncTab)
                             s += e;
                         }
-                        s &= 0xffu;
+                        s = 32u * (uint32_t)(first[k + 1] - first[k]) - (s & 0xffu);
                         uint64_t a64 = acc;
                         if (k == 0) { a64 = (a64 << csl) | csc; s += csl; }
                         pc[c][k] = a64; pl[c][k] = s; lsum += s;

@@ -570,6 +570,7 @@ __global__ void __launch_bounds__(256) enc_px_best_sample_kernel(const EncArgs a
 template <int B, bool RGB, uint64_t ORDER, bool FIRST>
 __global__ void __launch_bounds__(256) enc_px_best_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    enc_scan_counter_reset(a);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const bool two_pass = pxb_two_pass(a);
     if (FIRST) { px_best_chunk<B, RGB, ORDER, true>(a, a0, smem, blockIdx.x, two_pass); return; }

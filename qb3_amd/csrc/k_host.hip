@@ -211,7 +211,7 @@ static EncWs enc_ws_layout(const Geometry &g, uint32_t nchunks, uint32_t nbp, ui
     size_t o = 0;
     w.bits = o; o += align8(4 * (size_t)nchunks);
     w.off = o; o += 8 * (size_t)nchunks;
-    w.gsum = o; o += 8 * ((size_t)w.ngroups + 1);
+    w.gsum = o; o += 8 * ((size_t)w.ngroups + 2);          // (+ the total, + enc_scan_kernel's count of finished workgroups)
     w.seams = o; o += 8 * (size_t)nchunks;
     o = (o + 15) & ~(size_t)15;
     w.scratch = o; o += align8(4 * (size_t)nchunks * w.slot_dw);

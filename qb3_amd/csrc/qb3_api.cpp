@@ -502,7 +502,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     if (ixroom && !narrow) {
         ixt = ix_layout(g, p->ix_chunk);
         hdr_stamp = write_headers(p, hdrbuf, false);
-        hdr = hdr_stamp + ix_total_bytes(ixt) + 2;        // chunks, then "DT": both written by ix_fill_kernel
+        hdr = hdr_stamp + ix_total_bytes(ixt) + 2;        // chunks, then "DT": both written by enc_finish_kernel
         ixt.base = out_dev + hdr_stamp;
         if (!d_index) {                                   // the table is a sample of the index: make one
             if (!p->d_idx.ensure(index_bytes(g))) { p->error = QB3E_LIBERR; return 0; }
@@ -551,7 +551,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
         if (on_host) {
             memcpy(host_dst, hdrbuf, hdr_stamp);
             if (!download(p->stager, (uint8_t *)host_dst + hdr_stamp, out_dev + hdr_stamp, len - hdr_stamp, st)) { p->error = QB3E_LIBERR; return 0; }
-        }       // device flavour: the header was written by write_header_kernel, in stream order
+        }       // device flavour: the header was written by enc_finish_kernel, in stream order
         return len;
     }
     // not worth it: raw bypass (reference QB3encode.cpp:571-573), which leaves the handle's mode at STORED
@@ -631,7 +631,7 @@ QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t sr
         ixt = ix_layout(g, p->ix_chunk);
         hdr_stamp = write_headers(p, hdrbuf, false);
         ix_bytes = ix_total_bytes(ixt);
-        hdr = hdr_stamp + ix_bytes + 2;                   // chunks, then "DT": both written by ix_fill_kernel
+        hdr = hdr_stamp + ix_bytes + 2;                   // chunks, then "DT": both written by enc_finish_kernel
         if (!index_all) {                                 // the table is a sample of the index: make one per tile of a batch
             isz_all = (index_bytes(g) + 7) & ~(size_t)7;
             if (!p->d_idx.ensure(batch * isz_all)) { p->error = QB3E_LIBERR; return 0; }
@@ -1034,7 +1034,7 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
         ixt.version = p->ix_ver; ixt.check_heads = p->ix_heads_unchecked;
         if (on_host) {
             const size_t bytes = ix_total_bytes(ixt);
-            if (!p->d_ix.ensure(bytes)) { p->error = QB3E_LIBERR; return 0; }
+            if (!p->d_ix.ensure(bytes + 16)) { p->error = QB3E_LIBERR; return 0; }       // (+16: the check kernel reads whole sixteen-byte groups)
             HIPOK(hipMemcpyAsync(p->d_ix.p, p->s_start + p->ix_off, bytes, hipMemcpyHostToDevice, st));
             ixt.base = (uint8_t *)p->d_ix.p;
         } else ixt.base = (uint8_t *)d_src + p->ix_off;

@@ -13,7 +13,7 @@
 //   The chunk's bits go to a private slot in the workspace, a two-level scan of the chunk totals gives the offsets,
 //   enc_concat_kernel funnel-shifts every slot into place (single-pass variants with a decoupled look-back were built
 //   and measured slower on this part).  Dwords shared by two chunks are assembled by
-//   enc_seam_kernel from a two-entry-per-chunk seam table: no memset of the output, no global atomics on it.
+//   enc_finish_kernel from a two-entry-per-chunk seam table: no memset of the output, no global atomics on it.
 //   8-bit grey/RGB/RGBA and 16-bit rasters use lane-per-block kernels that keep the block in registers
 //   (k_enc_px.hip, k_enc_px16.hip); everything else the unit-per-lane kernels (k_enc_generic.hip, k_enc_best.hip).
 //
@@ -207,7 +207,7 @@ struct EncArgs {
     uint32_t *recode_need, *recode_list, *recode_n;    //   ... chunks to code again: flag per chunk, list, count
     uint32_t ntiles;
     uint64_t ts_img, ts_out, ts_ws, ts_idx;     // batched tiles: byte strides from tile to tile (blockIdx.y = tile)
-    uint32_t hdr_len;       // container header bytes to put in front of the stream (write_header_kernel)
+    uint32_t hdr_len;       // container header bytes to put in front of the stream (enc_finish_kernel)
     uint32_t hdr_back;      // distance from the container start to the stream start (= hdr_len without an index chunk)
     uint8_t hdr[80];        // at most 11 + 20 (CB) + 12 (QV) + 12 (SC) + 12 (ix head) bytes
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups per block (lanes per block), magic of it
@@ -281,6 +281,10 @@ template <typename T> __device__ __forceinline__ void put_value(LdsWriter &w, T 
 }
 
 constexpr uint32_t SCAN_GROUP = 4096;      // chunks per workgroup of enc_scan_kernel
+// every coding kernel's first workgroup: the counter by which enc_scan_kernel's last workgroup knows itself (behind the group sums)
+__device__ __forceinline__ void enc_scan_counter_reset(const EncArgs &a) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.group_sum[(a.nchunks + SCAN_GROUP - 1) / SCAN_GROUP + 1] = 0;
+}
 
 // step transform in place (QB3encode.h:169-176)
 template <typename T> __device__ __forceinline__ void apply_step(T (&v)[16], uint32_t rung) {
@@ -331,8 +335,22 @@ struct DecArgs {
 // values are taken as truth by the decoder, so a damaged table must be told from a good one: the decoder then falls back
 // to the plain walk).  part = this thread's share of the sum over bytes [0, n) of `e`, thread t of nthr taking i = t, t + nthr, ...
 __device__ __forceinline__ uint32_t ix_sum_part(const uint8_t *e, uint32_t n, uint32_t t, uint32_t nthr) {
+    // sum over i in [0, n) of (e[i] + 1) * (i * K + 1), K = 0x9e3779b1 (mod 2^32).  The bytes are read sixteen at a time from
+    // the aligned address at or below e (a table starts wherever the header ends); bytes outside [0, n) do not count.
+    const uint32_t off = (uint32_t)((uintptr_t)e & 15);
+    const uint4 *base = (const uint4 *)(e - off);
+    const uint32_t nvec = (off + n + 15) >> 4;
     uint32_t s = 0;
-    for (uint32_t i = t; i < n; i += nthr) s += ((uint32_t)e[i] + 1u) * (i * 0x9e3779b1u + 1u);
+    for (uint32_t v = t; v < nvec; v += nthr) {
+        const uint4 q = base[v];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t i = 16 * v + k - off;            // (wraps for the bytes in front of e: then i >= n)
+            const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            s += i < n ? (b + 1u) * (i * 0x9e3779b1u + 1u) : 0u;
+        }
+    }
     return s;
 }
 __device__ __forceinline__ uint32_t ix_sum_fold(uint32_t s) { return (s ^ (s >> 16)) & 0xffffu; }

@@ -26,9 +26,9 @@ __device__ __forceinline__ uint32_t pk_mags16(uint32_t d) {       // (d << 1) ^ 
 //     dword that holds the previous block's last visited pixel;
 //   * band count and curve are template parameters: v_perm_b32 gathers each band's bytes in curve order, four to
 //     a register, and band difference, running delta and mag-sign are byte-parallel (SWAR) on those registers;
-//   * the code table is a compile-time constant (code << 8 | length) copied from L2; a unit's bit string is six
-//     pieces of at most 27 bits, each built BACKWARDS with one v_lshl_or_b32 per value (the shift count is the
-//     entry itself: the hardware uses its low five bits) and its length is the low byte of the sum of the entries;
+//   * the code table is a compile-time constant copied from L2; a unit's bit string is six pieces of at most 27 bits,
+//     each built BACKWARDS with one v_alignbit_b32 per value (the entry holds the code left-aligned and the shift count
+//     in its low five bits) and its length comes from the low byte of the sum of the entries;
 //   * rungs of the neighbouring block come from the neighbouring lane (DPP wave shift, LDS only across waves);
 //     lane 0 of the workgroup is the halo block (computes rungs only), so a chunk is 255 blocks;
 //   * one workgroup scan per chunk (block bit lengths, DPP), one 32-bit LDS bit writer per lane.
@@ -36,8 +36,11 @@ constexpr uint32_t order_nib(uint64_t order, int i) { return (uint32_t)(order >>
 // core band of band c under the default map: R-G, G, B-G (, A)   (reference QB3encode.cpp:41-45)
 template <int B, bool RGB> constexpr int core_of(int c) { return (RGB && (c == 0 || c == 2)) ? 1 : c; }
 
-// Encode table of the px kernel, built at compile time: rung r (1..7) at entries [2<<r, 4<<r), indexed by the
-// mag-sign value; entry = code << 8 | length, middle swap applied (reference QB3encode.h:30-33, 132-141)
+// Encode table of the px kernels, built at compile time: rung r (1..7) at entries [2<<r, 4<<r), indexed by the mag-sign
+// value, middle swap applied (reference QB3encode.h:30-33, 132-141).  An entry is made for ONE instruction per value: the
+// code left-aligned in the dword, and in the low five bits 32 - length -- v_alignbit_b32(acc, e, e) shifts (acc : e) right
+// by 32 - length, which is (acc << length) | code (a unit's bit string is built backwards, last value first); the sum of
+// the entries' low bytes gives the piece's length: 32 * values - sum (a code is 1 to 9 bits, a piece at most three values).
 struct PxEncTab { alignas(16) uint32_t e[512]; };
 constexpr PxEncTab make_px_enc_tab() {
     PxEncTab t{};
@@ -47,7 +50,8 @@ constexpr PxEncTab make_px_enc_tab() {
             uint32_t v = m;
             if (v == top || v == top - 1) v ^= 2 * top - 1;
             const uint32_t code = (v < half) ? (v << 1) : (v < top) ? (((v - half) << 2) | 1) : (((v - top) << 2) | 3);
-            t.e[(2u << r) + m] = (code << 8) | (r + (v >= half) + (v >= top));
+            const uint32_t len = r + (v >= half) + (v >= top);
+            t.e[(2u << r) + m] = (code << (32 - len)) | (32 - len);
         }
     }
     return t;

@@ -144,11 +144,12 @@ __device__ __forceinline__ uint32_t px_unit_pieces(const uint32_t (&gq)[4], uint
         for (int i = first[k + 1] - 1; i >= first[k]; i--) {
             const uint32_t m = (g4[i >> 2] >> (8 * (i & 3))) & 0xffu;
             const uint32_t e = *lds_at((m << 2) + tb);
-            acc = (acc << (e & 31u)) | (e >> 8);
+            acc = __builtin_amdgcn_alignbit(acc, e, e);      // (acc << length) | code: the entry's low five bits are 32 - length
             s += e;
         }
-        if (k == 0) { acc = (acc << csl) | csc; s += csl; }
-        pc[k] = acc; pl[k] = s & 0xffu; lsum += s & 0xffu;
+        uint32_t len = 32u * (uint32_t)(first[k + 1] - first[k]) - (s & 0xffu);
+        if (k == 0) { acc = (acc << csl) | csc; len += csl; }
+        pc[k] = acc; pl[k] = len; lsum += len;
     }
     return lsum;
 }
