@@ -944,17 +944,24 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
 // stream starts at rung 0, outside any band that fits real data): it leaves the walk's entry state behind that segment.
 // Code lengths: a code at rung r takes r, r + 1 or r + 2 bits by its two low bits whatever r is, so the table workgroup
 // keeps the EXTRA bits of 2, 4 and 8 codes (at most 16: a byte) per rung and position and adds the multiples of r.
-constexpr uint32_t WIDE_THREADS = 64 * (1 + 3 * 4 + 1);      // the walker, four loader groups of three waves, the writer
+constexpr uint32_t WIDE_NG = 4, WIDE_NWR = 3, WIDE_NT = 8;   // loader groups of three waves, writer waves, trail slots
+constexpr uint32_t WIDE_THREADS = 64 * (1 + 3 * WIDE_NG + WIDE_NWR);
 template <uint32_t UB, uint32_t NR_> struct chainW {         // NR_: rungs in the band, 8 or 16 (a row is 16 or 32 bytes: what the walk costs is the table bytes one CU can stream)
     static constexpr uint32_t NRUNG = 1u << UB, NR = NR_, ROWB = 2 * NR_, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;
     // a window of the walk: as many positions as the 16-bit entries can address ((CW + MAXU) * ROWB < 65536), a multiple of 96 (the
     // loaders' 192 sixteen-byte pieces a turn) and of TCW, the positions ONE table workgroup tabulates (its LDS holds 32 bytes a position)
     static constexpr uint32_t CW = NR_ == 8 ? 2880 : (UB == 5 ? 1440 : 960), WIN_BYTES = CW * ROWB, WIN_U4 = WIN_BYTES / 16, TCW = 480;
     static constexpr uint32_t NP = (TCW + UB + 2 + 15 * MAXC + 2 + 31) & ~31u;     // positions a table workgroup looks at
-    static constexpr uint32_t NG = 4, WAVES = WIDE_THREADS / 64;                      // loader groups of three waves (a window's load takes longer than its walk: four in flight); the walker, the writer
+    // One lane walks; what it waits for must never be one memory round trip per window.  A window's load takes about three
+    // times as long as its walk: four loader groups (three waves each) keep four windows in flight for the two slots.  A
+    // writer wave ends its turn waiting for its index stores (the compiler drains the store counter before the next spin
+    // loop): about as long again -- so three writers take the windows in turn, and the trails wait for them in a ring of
+    // eight slots, each with the walk's state at the window's start (units done, every band's rung).
+    static constexpr uint32_t NG = WIDE_NG, NWR = WIDE_NWR, NT = WIDE_NT;
     static constexpr uint32_t TR_BYTES = ((CW / 2 + 8) * 2 + 15) & ~15u;
-    static constexpr uint32_t TR0 = 2 * WIN_BYTES, RS0 = TR0 + 2 * TR_BYTES, WR0 = RS0 + 64, META = WR0 + 64, LDS_BYTES = META + 128;
-    static constexpr uint32_t F_READY = META, F_TRAILED = META + 32, F_NUNITS = META + 40, F_O0 = META + 48, F_WALKED = META + 56, F_STOP = META + 60, F_U0 = META + 64;
+    static constexpr uint32_t TR0 = 2 * WIN_BYTES, TM0 = TR0 + NT * TR_BYTES /* [NT] x 32 bytes: units done (u64), rungs (u64), units, first position */,
+                              RS0 = TM0 + NT * 32, META = RS0 + 64, LDS_BYTES = META + 128;
+    static constexpr uint32_t F_READY = META /* [2][4] */, F_TRAILED = META + 32 /* [NT] */, F_TFREE = META + 64 /* [NT] */, F_WALKED = META + 96, F_STOP = META + 100;
     static_assert((CW + MAXU) * ROWB < 65536 && WIN_U4 % 192 == 0 && CW % TCW == 0 && (UB == 5 || UB == 6) && (NR_ == 8 || NR_ == 16), "window layout of the wide types");
 };
 
@@ -1057,8 +1064,9 @@ __global__ void __launch_bounds__(256) walk_tableW_kernel(const DecArgs a0, uint
 template <uint32_t UB, uint32_t NRB>
 __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs a0, const uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch, WalkState16 *states) {
     typedef chainW<UB, NRB> W;
-    constexpr uint32_t CW = W::CW, ROWB = W::ROWB, NR = W::NR, WIN_BYTES = W::WIN_BYTES, WIN_U4 = W::WIN_U4, TR0 = W::TR0, TR_BYTES = W::TR_BYTES, RS0 = W::RS0, WR0 = W::WR0,
-                       META = W::META, F_READY = W::F_READY, F_TRAILED = W::F_TRAILED, F_NUNITS = W::F_NUNITS, F_O0 = W::F_O0, F_WALKED = W::F_WALKED, F_STOP = W::F_STOP, F_U0 = W::F_U0;
+    constexpr uint32_t CW = W::CW, ROWB = W::ROWB, NR = W::NR, WIN_BYTES = W::WIN_BYTES, WIN_U4 = W::WIN_U4, TR0 = W::TR0, TR_BYTES = W::TR_BYTES, TM0 = W::TM0, RS0 = W::RS0,
+                       META = W::META, F_READY = W::F_READY, F_TRAILED = W::F_TRAILED, F_TFREE = W::F_TFREE, F_WALKED = W::F_WALKED, F_STOP = W::F_STOP,
+                       NG = W::NG, NWR = W::NWR, NT = W::NT;
     using chain::flag_get; using chain::flag_set; using chain::SPIN_MAX;
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1071,20 +1079,11 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
     const uint64_t slab_end = slab0 + (uint64_t)nwin * CW;
     if (S->bad || P0 < slab0 || P0 >= slab_end || P0 >= a.in_bits || U_in >= nunits) return;  // (uniform) nothing of this tile in this slab
     const uint32_t k0 = (uint32_t)((P0 - slab0) / CW);                      // the window the walk starts in
-    volatile uint32_t *rs = (volatile uint32_t *)(smem + RS0), *wr = (volatile uint32_t *)(smem + WR0);     // rung * 2 per band: the walk's, the writer's
-    if (tid < 32) {     // (the first two windows find their trail slots free)
-        uint32_t v = tid == (F_STOP - META) / 4 ? 0xffffffffu : 0u;
-        if (tid == (k0 & 1) * 4 + 3) v = k0 + 1;
-        if (tid == ((k0 + 1) & 1) * 4 + 3) v = k0 + 2;
-        ((uint32_t *)(smem + META))[tid] = v;
-    }
-    if (tid < 16) { const uint32_t r2 = (uint32_t)((R_in >> (4 * tid)) & 15u) << 1; rs[tid] = r2; wr[tid] = r2; }
+    volatile uint32_t *rs = (volatile uint32_t *)(smem + RS0);             // rung * 2 per band: the walk's
+    if (tid < 32) ((uint32_t *)(smem + META))[tid] = tid == (F_STOP - META) / 4 ? 0xffffffffu : 0u;
+    if (tid < 16) rs[tid] = (uint32_t)((R_in >> (4 * tid)) & 15u) << 1;
     __syncthreads();
     const uint4 *wt = tab + (uint64_t)blockIdx.x * tab_pitch;
-    auto ready = [&](uint32_t slot, uint32_t want) {
-        const chain::u32x4_t f = *(volatile __attribute__((address_space(3))) chain::u32x4_t *)(uintptr_t)(F_READY + 16 * slot);
-        return f.x == want && f.y == want && f.z == want && f.w == want;
-    };
 
     if (wave == 0) {
         if (lane) return;
@@ -1093,11 +1092,21 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
         uint32_t c = (uint32_t)(U % B);
         bool stuck = false;
         while (true) {
-            const uint32_t s = k & 1;
+            const uint32_t s = k & 1, ts = k % NT;
             uint32_t spin = 0;
-            while (!ready(s, k + 1) && ++spin < SPIN_MAX) __builtin_amdgcn_s_sleep(1);
-            if (spin >= SPIN_MAX) { stuck = true; break; }
+            while (true) {      // the window's three parts are in LDS, and the trail slot has been read out (it held window k - NT)
+                const bool here = flag_get(F_READY + 16 * s) == k + 1 && flag_get(F_READY + 16 * s + 4) == k + 1 && flag_get(F_READY + 16 * s + 8) == k + 1;
+                const bool slot = k - k0 < NT || flag_get(F_TFREE + 4 * ts) == k - NT + 1;
+                if (here && slot) break;
+                if (++spin >= SPIN_MAX) { stuck = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (stuck) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint64_t Rw = 0;                                                // every band's rung as the window finds it
+            for (uint32_t i = 0; i < B; i++) Rw |= (uint64_t)((rs[i] >> 1) & 15u) << (4 * i);
+            volatile uint64_t *tm = (volatile uint64_t *)(smem + TM0 + 32 * ts);
+            tm[0] = U; tm[1] = Rw;
             uint32_t A = o * ROWB + rs[c], n = 0;
             const uint64_t left64 = nunits - U;
             uint32_t left = left64 > 0xffffffffull ? 0xffffffffu : (uint32_t)left64;
@@ -1105,15 +1114,11 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
             typedef __attribute__((address_space(3))) uint16_t *LdsHalfW;
             typedef __attribute__((address_space(3))) uint32_t *LdsWordW;
             const uint32_t wbase = s * WIN_BYTES;
-            LdsHalfW trw = (LdsHalfW)(uintptr_t)(TR0 + s * TR_BYTES);
+            LdsHalfW trw = (LdsHalfW)(uintptr_t)(TR0 + ts * TR_BYTES);
             LdsWordW rsw = (LdsWordW)(uintptr_t)RS0;
             constexpr uint32_t M = 0xffffu & ~(ROWB - 1), RM = (NR - 1) << 1;
             // a unit per turn, until one starts beyond the window or an entry carries the stop bit (a unit that leaves the band of
             // rungs, or the signal code): ONE dependent LDS read a unit
-#ifdef PXW_EXP_NOWALK
-            if (true) { A = CW * ROWB + (rs[c] & RM); }
-            else
-#endif
             if (B == 1) {
                 while (A < CW * ROWB && left && !(bad & 1u)) {
                     const uint32_t e = *(LdsHalf)(uintptr_t)(wbase + A);
@@ -1136,11 +1141,9 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
                     c = cn; cn = cn2; left--;
                 }
             }
-            *(volatile uint64_t *)(smem + F_U0 + 8 * s) = U;
-            flag_set(F_NUNITS + 4 * s, n);
-            flag_set(F_O0 + 4 * s, o);
+            ((volatile uint32_t *)tm)[4] = n; ((volatile uint32_t *)tm)[5] = o;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            flag_set(F_TRAILED + 4 * s, k + 1);
+            flag_set(F_TRAILED + 4 * ts, k + 1);
             U += n;
             const uint32_t oe = A / ROWB;
             Pn = slab0 + (uint64_t)k * CW + oe;
@@ -1158,14 +1161,9 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
         if ((bad & 1u) || stuck) atomicOr(a.status, 1u);
         return;
     }
-    if (wave <= 3 * W::NG) {
-        constexpr uint32_t NG = W::NG;
+    if (wave <= 3 * NG) {
         const uint32_t g = (wave - 1) / 3, part = (wave - 1) % 3;
-#ifdef PXW_EXP_HALFLOAD
-        constexpr uint32_t NV = WIN_U4 / 192 / 2;
-#else
         constexpr uint32_t NV = WIN_U4 / 192;                               // sixteen-byte pieces a lane moves per window
-#endif
         for (uint32_t k = k0 + ((g + NG - k0 % NG) % NG); k < nwin; k += NG) {
             const uint4 *src = wt + (uint64_t)k * WIN_U4;
             uint4 v[NV];
@@ -1188,21 +1186,23 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
         }
         return;
     }
-    // writer: entry j of the trail = (position the unit ENDS at | rung of its band after it): lengths by difference
-    for (uint32_t k = k0;; k++) {
-        const uint32_t s = k & 1;
+    // writers: entry j of a window's trail = (position the unit ENDS at | rung of its band after it): lengths by difference
+    const uint32_t wtr = wave - 1 - 3 * NG;
+    for (uint32_t k = k0 + wtr;; k += NWR) {
+        const uint32_t ts = k % NT;
         uint32_t spin = 0;
         bool stop = false;
-        while (flag_get(F_TRAILED + 4 * s) != k + 1) {
+        while (flag_get(F_TRAILED + 4 * ts) != k + 1) {
             const uint32_t st = flag_get(F_STOP);
             if ((st != 0xffffffffu && k >= st) || ++spin >= SPIN_MAX) { stop = true; break; }
             __builtin_amdgcn_s_sleep(2);
         }
         if (stop) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint64_t U0 = *(volatile uint64_t *)(smem + F_U0 + 8 * s);
-        const uint32_t n = flag_get(F_NUNITS + 4 * s), o_first = flag_get(F_O0 + 4 * s);
-        const uint16_t *tr = (const uint16_t *)(smem + TR0 + s * TR_BYTES);
+        const volatile uint64_t *tm = (const volatile uint64_t *)(smem + TM0 + 32 * ts);
+        const uint64_t U0 = tm[0], Rw = tm[1];
+        const uint32_t n = ((const volatile uint32_t *)tm)[4], o_first = ((const volatile uint32_t *)tm)[5];
+        const uint16_t *tr = (const uint16_t *)(smem + TR0 + ts * TR_BYTES);
         const uint64_t wpos = slab0 + (uint64_t)k * CW;
         uint16_t *ul = (uint16_t *)a.idx.ulen + U0;
         for (uint32_t j = lane; j < n; j += 64) {
@@ -1212,20 +1212,15 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
             if (Uj % B == 0 && (Uj / B) % NB == 0) {        // a segment starts here: position, and every band's rung as the block finds it
                 const uint64_t seg = Uj / B / NB;
                 a.idx.bitpos[seg] = wpos + o0;
-                for (uint32_t cc = 0; cc < B; cc++) {       // band cc's unit before this one: B - cc units back
+                for (uint32_t cc = 0; cc < B; cc++) {       // band cc's unit before this one: B - cc units back, or the window's entering state
                     const int32_t jj = (int32_t)j - (int32_t)(B - cc);
-                    a.idx.rung[seg * B + cc] = (uint8_t)(R0 + (((jj >= 0 ? (uint32_t)tr[jj] : wr[cc]) >> 1) & (NR - 1)));
+                    const uint32_t rb = jj >= 0 ? ((uint32_t)tr[jj] >> 1) & (NR - 1) : (uint32_t)(Rw >> (4 * cc)) & 15u;
+                    a.idx.rung[seg * B + cc] = (uint8_t)(R0 + rb);
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < B) {     // the rung every band has after this window: the last unit of each band in it
-            const uint32_t cl = (uint32_t)((U0 + n - 1) % B);
-            const uint32_t back = (cl + B - lane) % B;
-            if (n > back) wr[lane] = tr[n - 1 - back] & ((NR - 1) << 1);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) flag_set(F_READY + 16 * s + 12, k + 3);              // the trail slot is free for the window that takes it next
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the trail has been READ: LDS operations of a wave are in order; the index stores may still be on their way)
+        if (lane == 0) flag_set(F_TFREE + 4 * ts, k + 1);
     }
 }
 
@@ -1307,7 +1302,7 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
                 [&](hipStream_t s, uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch) {
                     hipLaunchKernelGGL((walk_tableW_kernel<UB, NRB>), dim3(nwin * (W::CW / W::TCW), nt), dim3(256), 0, s, a, rows, s0, nwin, pitch, (const WalkState16 *)states); },
                 [&](hipStream_t s, const uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch, uint8_t *sts, uint32_t) {
-                    hipLaunchKernelGGL((walk_chainW_kernel<UB, NRB>), dim3(nt), dim3(64 * W::WAVES), W::LDS_BYTES, s, a, rows, s0, nwin, pitch, (WalkState16 *)sts); });
+                    hipLaunchKernelGGL((walk_chainW_kernel<UB, NRB>), dim3(nt), dim3(WIDE_THREADS), W::LDS_BYTES, s, a, rows, s0, nwin, pitch, (WalkState16 *)sts); });
         };
         if (a.g.tsz == 4) { if (nr == 16) run(WideTag<5, 16>()); else run(WideTag<5, 8>()); }
         else { if (nr == 16) run(WideTag<6, 16>()); else run(WideTag<6, 8>()); }

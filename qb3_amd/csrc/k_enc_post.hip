@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) ix_bl16_fill_kernel(const EncArgs a0) {
     static_assert(IX_BL_BITS == 10, "groups of four fields are five bytes");
     const uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // fields 4 * grp .. 4 * grp + 3 of entry grp / 32
     // (a single band: one field per lane -- the unit's length -- 64 fields an entry, 16 threads)
-    const uint32_t B = a.g.bands, BG = B <= 4 ? B : (B % 4 == 0 ? 4 : 2), FPL = B == 1 ? 1 : 2, NG = B / BG, NB = 64 / NG, tpe = 16 * FPL;
+    const uint32_t B = a.g.bands, BG = a.px16_bg, FPL = B == 1 ? 1 : 2, NG = B / BG, NB = 64 / NG, tpe = 16 * FPL;
     const uint64_t k = grp / tpe;
     if (k >= a.ix_K) return;
     const uint32_t t = (uint32_t)(grp - k * tpe);

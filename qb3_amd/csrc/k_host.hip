@@ -101,10 +101,16 @@ static void fast_geometry(uint32_t bands, uint32_t tsz, uint32_t *threads, uint3
 // Blocks per index segment.  A function of stream-intrinsic properties only (bands, value size, mode): encoder
 // and decoder must agree on it whatever their strides, band maps or buffer alignments are.
 // 16-bit lane-per-block kernels: bands = ng x bg, bg <= 4 bands per lane (0: no such split)
-static void px16_split(uint32_t B, uint32_t *bg, uint32_t *ng) {
+// 16-bit lane-per-block kernels: bands = ng x bg, bg <= 4 bands per lane (0: no such split).  (Measured, round 3: two bands a
+// lane for rasters of four and eight bands -- 65-99 registers instead of 124, 5-7 waves a SIMD instead of 4 -- made
+// config 3 SLOWER: decode 0.72 ms against 0.58, encode 0.43 against 0.41: twice the lanes pay the per-lane overheads
+// -- index loads, scans, the store address arithmetic -- and the stores turn from 32-byte pieces into 4-byte ones.)
+static void px16_split(const Geometry &g, uint32_t *bg, uint32_t *ng) {
+    const uint32_t B = g.bands;
     *bg = B <= 4 ? B : (B % 4 == 0) ? 4 : (B % 2 == 0) ? 2 : 0;
     *ng = *bg ? B / *bg : 0;
 }
+uint32_t px16_bands_per_lane(const Geometry &g) { uint32_t bg, ng; px16_split(g, &bg, &ng); return bg; }
 
 uint32_t seg_blocks_for(const Geometry &g) {
     if (g.mode != CM_BEST) {      // one segment = the blocks of one decoder workgroup, at most 256
@@ -113,7 +119,7 @@ uint32_t seg_blocks_for(const Geometry &g) {
         if (g.tsz == 1 && (g.bands == 1 || g.bands == 3 || g.bands == 4)) return 64;
         if (g.tsz == 2) {       // 16-bit: a wave = 64 lanes of (block, band group)
             uint32_t bg, ng;
-            px16_split(g.bands, &bg, &ng);
+            px16_split(g, &bg, &ng);
             if (bg) return 64 / ng;
         }
         uint32_t threads, bpp, passes;
@@ -148,7 +154,7 @@ bool ix_block_lens_ok(const Geometry &g) {
     // 16-bit data the lane-per-block decoder takes, up to eight bands: a lane owns up to four bands (a single band: one unit, one field)
     if (g.tsz != 2 || g.bands > 8) return false;
     uint32_t bg = 0, ng = 0;
-    px16_split(g.bands, &bg, &ng);
+    px16_split(g, &bg, &ng);
     return bg != 0 && g.seg_blocks == 64 / ng;
 }
 // One entry per index segment for FTL/BASE streams (a lane then walks one segment, lengths only, and the segment's
@@ -251,7 +257,7 @@ static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *
     if (g.w < 4 || g.h < 4) return false;                  // any width and stride: rows are read and written at halfword alignment
     if (g.order != HILBERT && g.order != ZCURVE) return false;
     const uint32_t B = g.bands;
-    px16_split(B, bg, ng);
+    px16_split(g, bg, ng);
     if (!*bg) return false;
     // identity, or R-G, G, B-G on the first three bands (they must sit in one lane: 3 or 4 bands per group)
     bool ident = true, def = *bg >= 3;
@@ -336,6 +342,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.cw_used = w + L.cwused; a.seg_from_entry = w + L.segfe; a.recode_need = (uint32_t *)(w + L.rneed); a.recode_list = (uint32_t *)(w + L.rlist);
     a.slot_dw = L.slot_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
+    a.px16_bg = g.tsz == 2 ? px16_bands_per_lane(g) : 0;
     a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.src_pitch & 3);
     a.res = (EncResult *)(w + L.res);
     a.st = st_in;

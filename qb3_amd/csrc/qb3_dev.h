@@ -100,6 +100,7 @@ struct IxTable {
 uint32_t ix_entry_bytes(const Geometry &g, bool block_lens = false);
 bool ix_block_lens_ok(const Geometry &g);         // can a table for this geometry carry block lengths
 uint32_t ix_bl_fields(const Geometry &g);         // ... how many fields an entry then ends with
+uint32_t px16_bands_per_lane(const Geometry &g);  // 16-bit lane-per-block kernels: bands a lane owns (0: the split does not apply)
 inline uint32_t ix_bl_bits(uint32_t tsz) { return tsz >= 4 ? IX_BL_BITS_WIDE : IX_BL_BITS; }
 constexpr uint32_t IX_BL_BEST_BYTES = 3;  // ... of a block's field in a table of 8-bit common-factor data: the block's bits (12) | the rungs its units are entered with (3 bits a band) << 12
 // bytes of the fields behind the fixed part of an entry that covers `blocks` blocks (cf: the stream is a common-factor one)

@@ -211,6 +211,7 @@ struct EncArgs {
     uint32_t hdr_back;      // distance from the container start to the stream start (= hdr_len without an index chunk)
     uint8_t hdr[80];        // at most 11 + 20 (CB) + 12 (QV) + 12 (SC) + 12 (ix head) bytes
     uint32_t px_ng, px_magic_ng;    // 16-bit lane-per-block kernel: band groups per block (lanes per block), magic of it
+    uint32_t px16_bg;               // ... bands a lane owns (what the table's fields are counted by, whichever kernel codes)
     uint32_t px_aligned;            // lane-per-block kernels: every row of every block is dword aligned (plain dword loads)
     uint8_t *ix_dst;                // restart table: where its first chunk goes (null: none), "DT" right after the last
     uint32_t ix_K, ix_spe, ix_E;    //   ... entries, fine segments per entry, bytes per entry
