@@ -946,11 +946,19 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
 // keeps the EXTRA bits of 2, 4 and 8 codes (at most 16: a byte) per rung and position and adds the multiples of r.
 constexpr uint32_t WIDE_NG = 4, WIDE_NWR = 3, WIDE_NT = 8;   // loader groups of three waves, writer waves, trail slots
 constexpr uint32_t WIDE_THREADS = 64 * (1 + 3 * WIDE_NG + WIDE_NWR);
-template <uint32_t UB, uint32_t NR_> struct chainW {         // NR_: rungs in the band, 8 or 16 (a row is 16 or 32 bytes: what the walk costs is the table bytes one CU can stream)
-    static constexpr uint32_t NRUNG = 1u << UB, NR = NR_, ROWB = 2 * NR_, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;
+// NR_: rungs in the band.  8 or 16: a row of 16-bit entries (16 or 32 bytes a position), entry = (position the unit ends at) *
+// ROWB | 2 * rung | stop -- one dependent read a unit.  14: BYTE entries, a row of sixteen bytes -- what the walk costs is the
+// table bytes ONE CU can stream (15.8 GB/s measured, whatever the slab size or the number of loader waves: a CU keeps about
+// 128 cache lines in flight), so half the bytes is half the time: bytes 0 .. 13 hold, per rung of the band, the EXTRA bits of
+// the sixteen codes that start behind the switch (0 .. 32; rung 0: 1 or 17, the flag and the raw bits), bytes 14, 15 the
+// switch (bits 0-3 its length, 4-9 the rung step, 10 the signal).  Two dependent reads a unit: the switch, then the extras
+// of the rung it leads to; unit length = switch + 16 * rung + extras.
+template <uint32_t UB, uint32_t NR_> struct chainW {
+    static constexpr bool BYTE = NR_ == 14;
+    static constexpr uint32_t NRUNG = 1u << UB, NR = NR_, ROWB = BYTE ? 16 : 2 * NR_, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;
     // a window of the walk: as many positions as the 16-bit entries can address ((CW + MAXU) * ROWB < 65536), a multiple of 96 (the
     // loaders' 192 sixteen-byte pieces a turn) and of TCW, the positions ONE table workgroup tabulates (its LDS holds 32 bytes a position)
-    static constexpr uint32_t CW = NR_ == 8 ? 2880 : (UB == 5 ? 1440 : 960), WIN_BYTES = CW * ROWB, WIN_U4 = WIN_BYTES / 16, TCW = 480;
+    static constexpr uint32_t CW = ROWB == 16 ? 2880 : (UB == 5 ? 1440 : 960), WIN_BYTES = CW * ROWB, WIN_U4 = WIN_BYTES / 16, TCW = 480;
     static constexpr uint32_t NP = (TCW + UB + 2 + 15 * MAXC + 2 + 31) & ~31u;     // positions a table workgroup looks at
     // One lane walks; what it waits for must never be one memory round trip per window.  A window's load takes about three
     // times as long as its walk: four loader groups (three waves each) keep four windows in flight for the two slots.  A
@@ -962,7 +970,7 @@ template <uint32_t UB, uint32_t NR_> struct chainW {         // NR_: rungs in th
     static constexpr uint32_t TR0 = 2 * WIN_BYTES, TM0 = TR0 + NT * TR_BYTES /* [NT] x 32 bytes: units done (u64), rungs (u64), units, first position */,
                               RS0 = TM0 + NT * 32, META = RS0 + 64, LDS_BYTES = META + 128;
     static constexpr uint32_t F_READY = META /* [2][4] */, F_TRAILED = META + 32 /* [NT] */, F_TFREE = META + 64 /* [NT] */, F_WALKED = META + 96, F_STOP = META + 100;
-    static_assert((CW + MAXU) * ROWB < 65536 && WIN_U4 % 192 == 0 && CW % TCW == 0 && (UB == 5 || UB == 6) && (NR_ == 8 || NR_ == 16), "window layout of the wide types");
+    static_assert(((CW + MAXU) * ROWB < 65536 || (BYTE && CW + MAXU < 4096)) && WIN_U4 % 192 == 0 && CW % TCW == 0 && (UB == 5 || UB == 6) && (NR_ == 8 || NR_ == 14 || NR_ == 16), "window layout of the wide types");
 };
 
 // The first index segment of every tile, parsed outright by one lane: unit lengths, the segment's entry, the band of rungs
@@ -986,13 +994,14 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
             const uint64_t u0 = rd.position();
             ok = parse_unit<T, CM_FTL>(rd, rung[c], pcf, g) && ok;      // (lengths and rungs are the same with and without the step)
             ((uint16_t *)a.idx.ulen)[gb * B + c] = (uint16_t)(rd.position() - u0);
-            minr = rung[c] < minr ? rung[c] : minr; maxr = rung[c] > maxr ? rung[c] : maxr;
+            if (gb || nb == 1) { minr = rung[c] < minr ? rung[c] : minr; maxr = rung[c] > maxr ? rung[c] : maxr; }
         }
     WalkState16 *S = states + blockIdx.x;
-    // the band: nr rungs around what the first segment saw (its smallest rung at least one above the band's floor when there is room)
-    uint32_t R0 = (minr + maxr + 1) / 2 >= nr / 2 ? (minr + maxr + 1) / 2 - nr / 2 : 0;
+    // the band: nr rungs from a little below the smallest rung the first segment saw.  What lies ABOVE the typical rung matters
+    // more than what lies below: the first unit of every block row is entered from the far end of the row before and sits
+    // log2(row length) rungs above its neighbours.  (The stream's very first units, entered from zero, are not looked at.)
+    uint32_t R0 = minr >= 3 ? minr - 3 : 0;
     if (R0 > NRUNG - nr) R0 = NRUNG - nr;
-    ok = ok && minr >= R0 && maxr - R0 < nr;
     uint64_t rel = 0;
     for (uint32_t c = 0; c < B; c++) { const uint32_t d = rung[c] - R0; ok = ok && d < nr; rel |= (uint64_t)(d & 15u) << (4 * c); }
     S->P = rd.position() - a.in_bit0; S->unit = nb * B; S->rungs = rel; S->pad = R0; S->bad = ok ? 0u : 1u;
@@ -1042,20 +1051,33 @@ __global__ void __launch_bounds__(256) walk_tableW_kernel(const DecArgs a0, uint
         uint32_t delta = 0; bool sig = false;
         const uint32_t cs = walk_switch<UB>(x, delta, sig);                 // from rung 0: the step itself
         const uint32_t len0 = cs + (((bits(o + cs)) & 1) ? 17 : 1);         // rung 0: one flag, then 16 raw bits
-        uint32_t e[NR];
+        if constexpr (W::BYTE) {
+            uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (uint32_t bin = 0; bin < NR; bin++) {
-            const uint32_t r = (R0 + bin + delta) & (NRUNG - 1), rb = r - R0;
-            const bool out_of_band = rb >= NR;
-            const uint32_t bb = out_of_band ? 0u : rb;
-            uint32_t u = len0;
-            if (r && !out_of_band) { const uint32_t n8 = 8 * r + src[bb][o + cs]; u = cs + n8 + 8 * r + src[bb][o + cs + n8]; }
-            e[bin] = ((ow + o + (out_of_band ? 1u : u)) * ROWB) | (bb << 1) | ((sig || out_of_band) ? 1u : 0u);
+            for (uint32_t b = 0; b < NR; b++) {                             // the rung the switch LEADS to: the extras of the sixteen codes behind it
+                const uint32_t r = R0 + b;
+                uint32_t ex = len0 - cs;
+                if (r) { const uint32_t e8 = src[b][o + cs]; ex = e8 + src[b][o + cs + 8 * r + e8]; }
+                w[b >> 2] |= ex << (8 * (b & 3));
+            }
+            w[3] |= (cs | (delta << 4) | ((sig ? 1u : 0u) << 10)) << 16;
+            out[o] = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            uint32_t e[NR];
+#pragma unroll
+            for (uint32_t bin = 0; bin < NR; bin++) {
+                const uint32_t r = (R0 + bin + delta) & (NRUNG - 1), rb = r - R0;
+                const bool out_of_band = rb >= NR;
+                const uint32_t bb = out_of_band ? 0u : rb;
+                uint32_t u = len0;
+                if (r && !out_of_band) { const uint32_t n8 = 8 * r + src[bb][o + cs]; u = cs + n8 + 8 * r + src[bb][o + cs + n8]; }
+                e[bin] = ((ow + o + (out_of_band ? 1u : u)) * ROWB) | (bb << 1) | ((sig || out_of_band) ? 1u : 0u);
+            }
+            if (NR == 16) {
+                out[2 * o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+                out[2 * o + 1] = make_uint4(e[8 % NR] | e[9 % NR] << 16, e[10 % NR] | e[11 % NR] << 16, e[12 % NR] | e[13 % NR] << 16, e[14 % NR] | e[15 % NR] << 16);
+            } else out[o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
         }
-        if (NR == 16) {
-            out[2 * o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
-            out[2 * o + 1] = make_uint4(e[8 % NR] | e[9 % NR] << 16, e[10 % NR] | e[11 % NR] << 16, e[12 % NR] | e[13 % NR] << 16, e[14 % NR] | e[15 % NR] << 16);
-        } else out[o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
     }
 }
 
@@ -1079,9 +1101,10 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
     const uint64_t slab_end = slab0 + (uint64_t)nwin * CW;
     if (S->bad || P0 < slab0 || P0 >= slab_end || P0 >= a.in_bits || U_in >= nunits) return;  // (uniform) nothing of this tile in this slab
     const uint32_t k0 = (uint32_t)((P0 - slab0) / CW);                      // the window the walk starts in
-    volatile uint32_t *rs = (volatile uint32_t *)(smem + RS0);             // rung * 2 per band: the walk's
+    constexpr uint32_t RSH = W::BYTE ? 0 : 1;                               // rs[]: the bands' rungs (relative to R0), times two for the entry tables
+    volatile uint32_t *rs = (volatile uint32_t *)(smem + RS0);
     if (tid < 32) ((uint32_t *)(smem + META))[tid] = tid == (F_STOP - META) / 4 ? 0xffffffffu : 0u;
-    if (tid < 16) rs[tid] = (uint32_t)((R_in >> (4 * tid)) & 15u) << 1;
+    if (tid < 16) rs[tid] = (uint32_t)((R_in >> (4 * tid)) & 15u) << RSH;
     __syncthreads();
     const uint4 *wt = tab + (uint64_t)blockIdx.x * tab_pitch;
 
@@ -1104,10 +1127,10 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
             if (stuck) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             uint64_t Rw = 0;                                                // every band's rung as the window finds it
-            for (uint32_t i = 0; i < B; i++) Rw |= (uint64_t)((rs[i] >> 1) & 15u) << (4 * i);
+            for (uint32_t i = 0; i < B; i++) Rw |= (uint64_t)((rs[i] >> RSH) & 15u) << (4 * i);
             volatile uint64_t *tm = (volatile uint64_t *)(smem + TM0 + 32 * ts);
             tm[0] = U; tm[1] = Rw;
-            uint32_t A = o * ROWB + rs[c], n = 0;
+            uint32_t A = o * ROWB + (W::BYTE ? 0u : rs[c]), n = 0;
             const uint64_t left64 = nunits - U;
             uint32_t left = left64 > 0xffffffffull ? 0xffffffffu : (uint32_t)left64;
             typedef const __attribute__((address_space(3))) uint16_t *LdsHalf;
@@ -1118,8 +1141,24 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
             LdsWordW rsw = (LdsWordW)(uintptr_t)RS0;
             constexpr uint32_t M = 0xffffu & ~(ROWB - 1), RM = (NR - 1) << 1;
             // a unit per turn, until one starts beyond the window or an entry carries the stop bit (a unit that leaves the band of
-            // rungs, or the signal code): ONE dependent LDS read a unit
-            if (B == 1) {
+            // rungs, or the signal code): ONE dependent LDS read a unit (byte tables: two)
+            if constexpr (W::BYTE) {
+                typedef const __attribute__((address_space(3))) uint8_t *LdsByte;
+                uint32_t rb = rsw[c];                                       // the band's rung, relative to R0
+                while (A < CW * ROWB && left && !(bad & 1u)) {              // (A: the row of the unit's first bit)
+                    const uint32_t sw = *(LdsHalf)(uintptr_t)(wbase + A + 14);
+                    const uint32_t rabs = (R0 + rb + ((sw >> 4) & 63u)) & (W::NRUNG - 1), rnew = rabs - R0;
+                    const bool stop = ((sw >> 10) & 1u) || rnew >= NR;
+                    const uint32_t ex = *(LdsByte)(uintptr_t)(wbase + A + (stop ? 0u : rnew));
+                    const uint32_t oe = (A >> 4) + (sw & 15u) + 16 * rabs + ex;         // where the unit ends: the next one's first bit
+                    trw[n++] = (uint16_t)((oe << 4) | (rnew & 15u)); bad |= stop ? 1u : 0u;
+                    rsw[c] = rnew;
+                    A = oe << 4;
+                    c = c + 1 == B ? 0 : c + 1;
+                    rb = B == 1 ? rnew : rsw[c];
+                    left--;
+                }
+            } else if (B == 1) {
                 while (A < CW * ROWB && left && !(bad & 1u)) {
                     const uint32_t e = *(LdsHalf)(uintptr_t)(wbase + A);
                     trw[n++] = (uint16_t)e; bad |= e;
@@ -1156,7 +1195,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         flag_set(F_STOP, k);
         uint64_t Rn = 0;
-        for (uint32_t i = 0; i < B; i++) Rn |= (uint64_t)((rs[i] >> 1) & 15u) << (4 * i);
+        for (uint32_t i = 0; i < B; i++) Rn |= (uint64_t)((rs[i] >> RSH) & 15u) << (4 * i);
         S->P = stuck ? ~0ull : Pn; S->unit = U; S->rungs = Rn; S->bad = (bad & 1u) | (stuck ? 1u : 0u);
         if ((bad & 1u) || stuck) atomicOr(a.status, 1u);
         return;
@@ -1206,7 +1245,8 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
         const uint64_t wpos = slab0 + (uint64_t)k * CW;
         uint16_t *ul = (uint16_t *)a.idx.ulen + U0;
         for (uint32_t j = lane; j < n; j += 64) {
-            const uint32_t o0 = j ? tr[j - 1] / ROWB : o_first, o1 = tr[j] / ROWB;
+            constexpr uint32_t PSH = W::BYTE ? 4 : 0, PDIV = W::BYTE ? 1 : ROWB, RMASK = W::BYTE ? 15u : NR - 1;      // a trail entry: position << 4 | rung (byte tables), position * ROWB | rung << 1
+            const uint32_t o0 = j ? (tr[j - 1] >> PSH) / PDIV : o_first, o1 = (tr[j] >> PSH) / PDIV;
             ul[j] = (uint16_t)(o1 - o0);
             const uint64_t Uj = U0 + j;
             if (Uj % B == 0 && (Uj / B) % NB == 0) {        // a segment starts here: position, and every band's rung as the block finds it
@@ -1214,7 +1254,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
                 a.idx.bitpos[seg] = wpos + o0;
                 for (uint32_t cc = 0; cc < B; cc++) {       // band cc's unit before this one: B - cc units back, or the window's entering state
                     const int32_t jj = (int32_t)j - (int32_t)(B - cc);
-                    const uint32_t rb = jj >= 0 ? ((uint32_t)tr[jj] >> 1) & (NR - 1) : (uint32_t)(Rw >> (4 * cc)) & 15u;
+                    const uint32_t rb = jj >= 0 ? ((uint32_t)tr[jj] >> RSH) & RMASK : (uint32_t)(Rw >> (4 * cc)) & 15u;
                     a.idx.rung[seg * B + cc] = (uint8_t)(R0 + rb);
                 }
             }
@@ -1283,6 +1323,8 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
         ok = ok && hipFuncSetAttribute((const void *)walk_chain16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, chain16::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 8>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 8>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 14>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 14>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 16>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 16>::LDS_BYTES) == hipSuccess;
         return ok;
@@ -1291,7 +1333,7 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
     const uint32_t nt = a.ntiles;
     if (a.g.tsz >= 4) {         // 32/64-bit FTL/BASE: the first segment parsed outright (band of rungs, entry state), then table + chain
         WalkState16 *states = (WalkState16 *)tab;
-        const uint32_t nr = a.wide_band == 8 ? 8u : 16u;
+        const uint32_t nr = a.wide_band == 8 ? 8u : a.wide_band == 14 ? 14u : 16u;
         { ProfScope ps("dec_index_serial", st);
           if (a.g.tsz == 4) hipLaunchKernelGGL(walk_probe_kernel<uint32_t>, dim3(nt), dim3(64), 0, st, a, states, nr);
           else hipLaunchKernelGGL(walk_probe_kernel<uint64_t>, dim3(nt), dim3(64), 0, st, a, states, nr); }
@@ -1304,8 +1346,8 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
                 [&](hipStream_t s, const uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch, uint8_t *sts, uint32_t) {
                     hipLaunchKernelGGL((walk_chainW_kernel<UB, NRB>), dim3(nt), dim3(WIDE_THREADS), W::LDS_BYTES, s, a, rows, s0, nwin, pitch, (WalkState16 *)sts); });
         };
-        if (a.g.tsz == 4) { if (nr == 16) run(WideTag<5, 16>()); else run(WideTag<5, 8>()); }
-        else { if (nr == 16) run(WideTag<6, 16>()); else run(WideTag<6, 8>()); }
+        if (a.g.tsz == 4) { if (nr == 16) run(WideTag<5, 16>()); else if (nr == 8) run(WideTag<5, 8>()); else run(WideTag<5, 14>()); }
+        else { if (nr == 16) run(WideTag<6, 16>()); else if (nr == 8) run(WideTag<6, 8>()); else run(WideTag<6, 14>()); }
         return;
     }
     if (a.g.tsz == 2) {

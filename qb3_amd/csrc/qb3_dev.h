@@ -169,7 +169,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
                   const IxTable &ix = IxTable(),
                   void *walk_tab = nullptr, size_t walk_tab_bytes = 0,     // table memory for plain 8-bit streams (null: the one-wave walk)
                   bool full_staging = false,    // 16-bit data: worst-case LDS staging (after a call that ended with status bit 4)
-                  uint32_t wide_band = 16);     // plain 32/64-bit streams: rungs the walk's table covers (16; 8 halves the table -- and the time -- but the first
+                  uint32_t wide_band = 16);     // plain 32/64-bit streams: rungs the walk's table covers (16; 14: byte entries, 8: half rows -- QB3_WIDE_BAND, test hooks; the first
                                                 // unit of a block row, entered from the far end of the row before, sits many rungs above its neighbours)
 
 // The RLE0 byte pass of the *_RLE modes on device buffers (k_rle0.hip; reference QB3encode.cpp:271-332, QB3decode.cpp:267-307).
