@@ -1033,7 +1033,7 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
         ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads; ixt.block_lens = p->ix_bl;
         ixt.version = p->ix_ver; ixt.check_heads = p->ix_heads_unchecked;
         if (on_host) {
-            const size_t bytes = ix_total_bytes(ixt);
+            const size_t bytes = ix_total_bytes(ixt) + 2;        // (+2: the "DT" behind the last chunk, which the check kernel looks at)
             if (!p->d_ix.ensure(bytes + 16)) { p->error = QB3E_LIBERR; return 0; }       // (+16: the check kernel reads whole sixteen-byte groups)
             HIPOK(hipMemcpyAsync(p->d_ix.p, p->s_start + p->ix_off, bytes, hipMemcpyHostToDevice, st));
             ixt.base = (uint8_t *)p->d_ix.p;

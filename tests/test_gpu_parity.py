@@ -1039,8 +1039,14 @@ def test_restart_table_with_block_lengths(qb3, oracle, case, tmp_path):
         assert sum(c[2] - 12 for c in mine if c[0] == b"ix") == ((nblocks + per_seg - 1) // per_seg) * entry
     out, _, _, _ = oracle.decode(host, identity=True)
     assert out is not None and np.array_equal(out, raw.cpu().numpy()), "the reference decoder must step over the chunks"
+    L = qb3.lib
+    L.qb3x_profile_enable(1); L.qb3x_profile_reset()
     out, _, _, _ = qb3.decode(host)
+    hbuf = C.create_string_buffer(1024)
+    L.qb3x_profile_names(hbuf, 1024)
+    L.qb3x_profile_enable(0)
     assert np.array_equal(out, raw.cpu().numpy())
+    assert hbuf.value == b"dec_units", hbuf.value        # qb3_read_data on host buffers: the table was used (its check passed), no walk
     got = qb3.encode(himg, dt, mode, cband=cb, index_chunk=2)
     assert np.array_equal(got, host), "host and device flavour write the same container"
     L = qb3.lib
