@@ -83,8 +83,14 @@ size_t qb3x_header_size_bound(const void *container, size_t avail);
  * index segment of an FTL/BASE stream (64 blocks of 8-bit grey/RGB/RGBA: 12 bytes, 0.7 % of a typical stream), at about
  * every 64th unit of a common-factor stream (every 32nd for 32/64-bit data; 1.5-6 %) -- into the container in front of "DT", as ignorable (lower-case)
  * chunks: "ix" chunks of at most 64 KB, each followed by a 4-byte pad chunk "zz".
- * An "ix" chunk: 'i' 'x', u16 length of the whole chunk, u8 version (2), u8 flags (bit 0: entries carry common factors),
- * u16 reserved, u32 blocks per entry, then the entries (flag bit 1: they end with block lengths, see below); an entry: 6-byte little-endian bit position of its first unit
+ * An "ix" chunk: 'i' 'x', u16 length of the whole chunk, u8 version (3), u8 flags (bit 0: entries carry common factors),
+ * u16 check of the chunk's entries (version 3; reserved and zero in versions 1 and 2, which are still read), u32 blocks per
+ * entry, then the entries (flag bit 1: they end with block lengths, see below).  The check: the sum over the n entry bytes
+ * b[i] of (b[i] + 1) * (i * 0x9e3779b1 + 1) modulo 2^32, folded to 16 bits (low half XOR high half).  The table sits in a
+ * chunk the format does not protect, and the decoder takes positions, rungs, entering values and lengths from it: before
+ * using it the decoder verifies every chunk's head and check ON THE DEVICE, and on a mismatch -- or when the decode that
+ * relied on the table fails -- decodes the stream WITHOUT the table (the plain walk: what the reference, which skips the
+ * chunk, does).  A damaged table costs time, never pixels.  An entry: 6-byte little-endian bit position of its first unit
  * (from the first stream bit), a rung byte per band, the value entering each band (the type's width, little-endian),
  * and with flag bit 0 the common factor entering each band likewise.  Entry k starts at block k * (blocks per entry);
  * every chunk but the last holds the same number of entries.  The reference's decoder steps over them
@@ -93,8 +99,10 @@ size_t qb3x_header_size_bound(const void *container, size_t avail);
  * that adds the 4 head bytes to it.  This library's decoder uses the table when no out-of-band index is given:
  * qb3_read_data / qb3x_decode_device(d_index = NULL) then walk (FTL/BASE) or decode (common-factor modes) the stream
  * from every entry at once, one lane each, instead of serially.  qb3_max_encoded_size() grows by the table's size while the switch is on.  Not written for
- * RLE0 modes, narrow images and STORED output.  A decoder handle for the device flavour needs a host copy of the
- * container up to its "DT" mark: qb3x_header_size_bound() bytes always suffice (qb3x_read_start).
+ * RLE0 modes, narrow images and STORED output.  A decoder handle for a container in device memory: qb3x_read_start_device
+ * (two small copies whatever the table's size); or, from a host copy of the container up to its "DT" mark,
+ * qb3x_read_start (qb3x_header_size_bound() bytes always suffice).  qb3_max_encoded_size() does not depend on the mode:
+ * it is the room of the largest table any mode writes for the raster (callers size their buffer before setting the mode).
  * Callers that only know the reference API (LD_PRELOAD, relinked tools) can set QB3X_INDEX_CHUNK=1 (or 2) in the
  * environment: it is read when an encoder handle is created.
  * on = 2 -- entries with BLOCK LENGTHS: for the rasters the 8-bit lane-per-block decoder takes (uint8, 1/3/4 bands, FTL/BASE,
@@ -107,10 +115,16 @@ size_t qb3x_header_size_bound(const void *container, size_t avail);
  * a field per block (its unit's length), 80 bytes an entry.  32/64-bit rasters
  * (FTL/BASE, where the unit-parallel decoder applies): an entry ends with a twelve-bit length per UNIT of its segment
  * (band-minor, little endian) -- about 10 % of a stream of small units (4096 x 4096 int32: 0.06 ms instead of 0.40).
- * Common-factor streams have no length table at any level (a unit's form depends on the factor in force); their level 2
- * table has the entries closer together -- about 24 units (12 for 32/64-bit data) instead of 64 (32): 7-12 % of the stream,
- * and the decode from the container alone takes what it takes with the out-of-band index (4096 x 4096 int32 CF: 0.14 ms
- * instead of 0.38; 16384 x 16384 x 3 CF: 2.4 ms instead of 3.3).  For any other raster (8-bit data of 2 or 5+ bands,
+ * Common-factor streams of 16/32/64-bit data have no length table at any level (a unit's form depends on the factor in
+ * force); their level 2 table has the entries closer together -- about 24 units (12 for 32/64-bit data) instead of 64 (32):
+ * 7-12 % of the stream, and the decode from the container alone takes what it takes with the out-of-band index (4096 x 4096
+ * int32 CF: 0.14 ms instead of 0.38).  8-bit common-factor streams of 1, 3 or 4 bands (round 3): at EITHER level an entry
+ * per 64-block segment -- position, rungs, entering values, factors in force -- that ends with a three-byte field per
+ * block: the block's bits (12) | the rungs its units are entered with (3 bits a band) << 12, little endian; 6 + 3 * bands +
+ * 192 bytes an entry, about 12 % of a typical stream.  It is what the lane-per-block decoder of those streams works from
+ * (a common-factor unit leaves its band at the rung of the MULTIPLIED values, so rungs cannot be scanned from the switch
+ * codes; the factor in force is found by a ballot of the units that bring their own): 16384 x 16384 x 3 in QB3M_BEST
+ * decodes from the container alone in 0.47 ms (round 2: 2.4 ms).  For any other raster (8-bit data of 2 or 5+ bands,
  * 16-bit data of other band counts) level 2 writes the level 1 table. */
 void qb3x_set_encoder_index_chunk(encsp p, int on);
 

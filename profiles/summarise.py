@@ -32,7 +32,7 @@ KEYS = [("enc_px_best_sample_kernel", "enc_best_sample"), ("enc_best_sample_kern
         ("enc_best_kernel<unsigned char, false>", "enc_best_recode"), ("enc_best_kernel<unsigned short, false>", "enc_best_recode"),
         ("enc_best_kernel<unsigned int, false>", "enc_best_recode"), ("enc_best_kernel<unsigned long, false>", "enc_best_recode"),
         ("enc_best_kernel", "enc_best_units"), ("best_scan", "enc_best_scan"),
-        ("enc_scan2", "enc_scan2"), ("enc_scan", "enc_scan"), ("enc_concat", "enc_concat"), ("enc_seam", "enc_seams"), ("enc_finish", "enc_seams"), ("ix_seal", "ix_seal"),
+        ("enc_scan2", "enc_scan2"), ("enc_scan", "enc_scan"), ("enc_concat", "enc_concat"), ("enc_seam", "enc_seams"), ("enc_finish", "enc_finish"), ("ix_seal", "ix_seal"), ("ix_check", "ix_check"),
         ("write_header", "write_header"), ("ix_bl_fill", "ix_bl_fill"), ("ix_fill", "ix_fill"), ("dec_px_kernel", "dec_units"), ("dec_px16_kernel", "dec_units"), ("dec3_kernel", "dec_units"),
         ("dec_walk_lanes", "dec_index_serial"), ("dec_walk_kernel", "dec_index_serial"), ("prev_scan", "dec_index_scan"),
         ("walk_table_kernel", "dec_index_table"), ("walk_chain_kernel", "dec_index_serial"),
