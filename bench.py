@@ -44,7 +44,7 @@ ANCHORS = {                 # reference containers, SURVEY.md Appendix C: (size,
     "c4_i32_best": (16413700, "cd51ae557cfbb14f"), "c4_i64_best": (16426177, "62e44ea20713d272"),
     "c5_tile1000": (27171401, "8e91222e70136a30"), "c5_tile1001": (27171735, "4e40f05b13367ea8"),
 }
-ENC_KERNELS = ("enc_units", "enc_best_units", "enc_best_scan", "enc_best_recode", "enc_scan", "enc_concat", "enc_seams")
+ENC_KERNELS = ("enc_units", "enc_best_units", "enc_best_scan", "enc_best_recode", "enc_scan", "enc_concat", "enc_seams", "rle0_size", "rle0_write")
 DEC_KERNELS = ("dec_index_table", "dec_index_serial", "dec_index_prev", "dec_index_scan", "dec_segments", "dec_units")
 
 
@@ -157,14 +157,18 @@ def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen
     res = {"workload": label, "stream_bytes": stream_bytes, "ratio": round(stream_bytes / raw_bytes, 4), "container_bytes": int(n),
            "header_mode": hdr_mode, "bit_identical_to_reference": None if ok is None else bool(ok), "fnv1a64": fnv}
     prof.start()
+    t0 = time.perf_counter()
     for _ in range(steps):
         enc.encode(img)
     torch.cuda.synchronize()
+    enc_wall = (time.perf_counter() - t0) * 1e3 / steps         # (with the library's event records and its one host wait per call)
     e = prof.stop()
     prof.start()
+    t0 = time.perf_counter()
     for _ in range(steps):
         dec.decode(dst, out=out, index=None)
     torch.cuda.synchronize()
+    dec_wall = (time.perf_counter() - t0) * 1e3 / steps
     d_ix = prof.stop()
     prof.start()
     for _ in range(steps):
@@ -177,6 +181,7 @@ def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen
     px = w * h
     res.update({
         "encode_ms_kernels": round(enc_ms, 4), "encode_MPixel_s": round(px / enc_ms / 1e3, 1),
+        "encode_ms_wall": round(enc_wall, 4), "decode_from_container_ms_wall": round(dec_wall, 4),
         "decode_from_container_ms_kernels": round(ix_ms, 4), "decode_from_container_MPixel_s": round(px / ix_ms / 1e3, 1),
         "decode_out_of_band_index_ms_kernels": round(oob_ms, 4), "decode_out_of_band_index_MPixel_s": round(px / oob_ms / 1e3, 1),
         "kernels": {"encode": kernel_table(e, algo), "decode_from_container": kernel_table(d_ix, algo), "decode_out_of_band_index": kernel_table(d_oob, algo)},

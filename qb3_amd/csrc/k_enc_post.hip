@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(SCAN_GROUP / 4) enc_scan_kernel(const EncArgs 
         if (tid == blockDim.x - 1) carry = c0 + ex + g;
         __syncthreads();
     }
-    if (tid == 0) { a.group_sum[ngroups] = carry; a.res->zero_run = 0; }      // (enc_concat_kernel raises zero_run)
+    if (tid == 0) { a.group_sum[ngroups] = carry; a.res->zero_run = 0; a.res->ff_pairs = 0; }      // (enc_concat_kernel counts into them)
 }
 
 // start of chunk k in the stream, in bits (k == nchunks: the stream length)
@@ -50,19 +50,26 @@ __device__ __forceinline__ uint64_t chunk_start(const EncArgs &a, uint32_t k) {
     return a.group_sum[k / SCAN_GROUP] + a.chunk_off[k];
 }
 
-// do two consecutive stream dwords hold four zero bytes in a row that start in the first
-__device__ __forceinline__ bool zero_run_in(uint32_t cur, uint32_t nxt) {
-    return cur == 0 || __builtin_amdgcn_alignbit(nxt, cur, 8) == 0 || __builtin_amdgcn_alignbit(nxt, cur, 16) == 0 ||
-           __builtin_amdgcn_alignbit(nxt, cur, 24) == 0;
+// at how many bytes of cur do four zero bytes in a row start (nxt: the stream dword behind cur)
+__device__ __forceinline__ uint32_t zero_runs_in(uint32_t cur, uint32_t nxt) {
+    return (uint32_t)(cur == 0) + (uint32_t)(__builtin_amdgcn_alignbit(nxt, cur, 8) == 0) +
+           (uint32_t)(__builtin_amdgcn_alignbit(nxt, cur, 16) == 0) + (uint32_t)(__builtin_amdgcn_alignbit(nxt, cur, 24) == 0);
+}
+// how many bytes of v are 0xff and followed, inside v, by another 0xff
+__device__ __forceinline__ uint32_t ff_pairs_in(uint32_t v) {
+    const uint32_t t = v & (v >> 8) & 0x00ffffffu;                     // a byte of t is 0xff where the pair stands
+    return (uint32_t)__popc(((t & 0x7f7f7fu) + 0x010101u) & t & 0x808080u);
 }
 
 // Concatenate: one WAVE per chunk reads the chunk's slot, funnel-shifts it to its bit position and stores the
 // dwords that lie wholly inside the chunk; the first and last shifted dword go to the seam table.
-// With zrun_probe (the RLE0 modes) the wave also looks for four zero bytes in a row among the dwords it moves -- RLE0
-// (reference QB3encode.cpp:536-565) can only shorten a stream that has such a run, and looking here spares a pass over the
-// finished stream.  A dword shared with a neighbouring chunk is tested as this chunk sees it (the neighbour's bits zero) and
-// so is the stream's last dword: the answer can be a false yes (the RLE0 pass then runs and decides), never a false no --
-// a run that touches a shared dword has zeros in both chunks' bits of it, and each chunk tests it against its own side.
+// With zrun_probe (the RLE0 modes) the wave also counts, among the dwords it moves, the positions at which four zero bytes
+// in a row start and the 0xff bytes followed by another in the same dword -- RLE0 (reference QB3encode.cpp:536-565) can only
+// shorten a stream whose zero runs outweigh its pairs of 0xff (rle0_may_win, qb3_dev.h), and counting here spares the byte
+// pass over the finished stream whenever the counts decide.  A dword shared with a neighbouring chunk is tested as this
+// chunk sees it (the neighbour's bits zero) and so is the stream's last dword: zero runs can be counted too often (a run that
+// touches a shared dword has zeros in both chunks' bits of it, and each chunk tests it against its own side), pairs of 0xff
+// too rarely (never across dwords, never in bits another chunk owns) -- both on the side of running the pass.
 __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -78,7 +85,7 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     // is what this copy needs.  Output dword d = source dwords d-1, d funnel-shifted by the chunk's bit phase.
     const uint32_t ng = (nd + 3) >> 2, sh = (32 - phase) & 31;
     constexpr int NQ = 4;                                               // 16-byte loads in flight per lane
-    bool zrun = false;
+    uint32_t zrun = 0, ffp = 0;
     for (uint32_t gb = 0; gb < ng; gb += 64 * NQ) {
         uint4 cur[NQ];
         uint32_t before[NQ];                                            // lane 0: the dword before its group
@@ -126,8 +133,10 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
             }
             if (a.zrun_probe) {         // (wave uniform) runs that start in dwords 0 .. 2 of the group; dwords behind the chunk count as non-zero
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (d + k >= nd) v[k] = 0xffffffffu;
-                zrun = zrun || zero_run_in(v[0], v[1]) || zero_run_in(v[1], v[2]) || zero_run_in(v[2], v[3]);
+                for (int k = 0; k < 4; k++) {
+                    if (d + k >= nd) v[k] = 0xffffffffu; else ffp += ff_pairs_in(v[k]);
+                }
+                zrun += zero_runs_in(v[0], v[1]) + zero_runs_in(v[1], v[2]) + zero_runs_in(v[2], v[3]);
                 first[q] = v[0]; last[q] = v[3];
             }
         }
@@ -146,11 +155,16 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
                         }
                     }
                 }
-                zrun = zrun || zero_run_in(last[q], nxt);
+                zrun += zero_runs_in(last[q], nxt);
             }
         }
     }
-    if (a.zrun_probe && __any(zrun) && lane == 0) atomicOr(&a.res->zero_run, 1u);
+    if (a.zrun_probe) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { zrun += (uint32_t)__shfl_xor((int)zrun, o, 64); ffp += (uint32_t)__shfl_xor((int)ffp, o, 64); }
+        if (lane == 0 && zrun) atomicAdd((unsigned long long *)&a.res->zero_run, (unsigned long long)zrun);
+        if (lane == 0 && ffp) atomicAdd((unsigned long long *)&a.res->ff_pairs, (unsigned long long)ffp);
+    }
 }
 
 // What is left to do once the chunks stand in the stream, in ONE launch:
@@ -209,7 +223,7 @@ __global__ void __launch_bounds__(256) enc_finish_kernel(const EncArgs a0) {
         }
     if (k > a.nchunks) return;
     const uint64_t Ek = (uint64_t)a.out_bit0 + chunk_start(a, k);
-    if (k == a.nchunks) { a.res->total_bits = Ek - a.out_bit0; a.res->error = 0u; }
+    if (k == a.nchunks) { a.res->total_bits = Ek - a.out_bit0; }
     if ((Ek & 31) == 0) return;
     const uint64_t d = Ek >> 5;
     if (k > 0) { const uint64_t Ep = (uint64_t)a.out_bit0 + chunk_start(a, k - 1); if ((Ep >> 5) == d && (Ep & 31)) return; }

@@ -13,14 +13,52 @@ namespace qb3dev {
 // Long runs are skipped a 4 KB chunk at a time through a table that says which chunks hold one byte value only.
 constexpr uint32_t RLE_CHUNK = 4096, RLE_THREADS = 256, RLE_PER_THREAD = RLE_CHUNK / RLE_THREADS;
 
-__global__ void __launch_bounds__(256) rle0_uniform_kernel(const uint8_t *s, uint64_t n, uint16_t *uniform) {
+// sixteen bytes of s from p on as four dwords, the byte before them and the byte behind them, through aligned dword loads
+// (p > 0 and p + 17 <= n: every dword read holds at least one byte of s)
+struct Rle16 { uint32_t w[4], prev, next; };
+__device__ __forceinline__ Rle16 rle_load16(const uint8_t *s, uint64_t p) {
+    const uintptr_t A = (uintptr_t)(s + p);
+    const uint32_t *d = (const uint32_t *)(A & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(A & 3) * 8;
+    uint32_t v[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k + 1] = d[k];
+    v[0] = sh ? v[1] : d[-1];                               // (the byte before p is in d[0] unless p is dword aligned)
+    Rle16 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.w[k] = sh ? __builtin_amdgcn_alignbit(v[k + 2], v[k + 1], sh) : v[k + 1];
+    r.next = (sh ? __builtin_amdgcn_alignbit(0u, v[5], sh) : v[5]) & 0xffu;
+    r.prev = sh ? (v[1] >> (sh - 8)) & 0xffu : v[0] >> 24;
+    return r;
+}
+// 0x80 in every byte of v that is 00 or ff
+__device__ __forceinline__ uint32_t rle_special4(uint32_t v) {
+    const uint32_t a = ((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v, n = ~v, b = ((n & 0x7f7f7f7fu) + 0x7f7f7f7fu) | n;
+    return ~(a & b) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t rle_ff4(uint32_t v) {
+    const uint32_t n = ~v, b = ((n & 0x7f7f7f7fu) + 0x7f7f7f7fu) | n;
+    return ~b & 0x80808080u;
+}
+
+// which 4 KB chunks hold one byte value only (and starts the size pass's total at n)
+__global__ void __launch_bounds__(256) rle0_uniform_kernel(const uint8_t *s, uint64_t n, uint16_t *uniform, uint64_t *total) {
     const uint64_t c0 = (uint64_t)blockIdx.x * RLE_CHUNK;
     __shared__ uint32_t differs;
     if (threadIdx.x == 0) differs = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) total[0] = n;
     __syncthreads();
     const uint8_t v = s[c0];
     bool d = c0 + RLE_CHUNK > n;                            // a short last chunk never counts as uniform
-    for (uint32_t i = threadIdx.x; i < RLE_CHUNK && c0 + i < n; i += 256) d = d || s[c0 + i] != v;
+    const uint64_t p = c0 + (uint64_t)threadIdx.x * RLE_PER_THREAD;
+    if (!d) {
+        if (p > 0 && p + RLE_PER_THREAD + 1 <= n) {
+            const Rle16 r = rle_load16(s, p);
+            const uint32_t sv = (uint32_t)v * 0x01010101u;
+            d = r.w[0] != sv || r.w[1] != sv || r.w[2] != sv || r.w[3] != sv;
+        } else
+            for (uint32_t i = 0; i < RLE_PER_THREAD; i++) d = d || s[p + i] != v;
+    }
     if (d) differs = 1;
     __syncthreads();
     if (threadIdx.x == 0) uniform[blockIdx.x] = differs ? (uint16_t)0x100 : (uint16_t)v;
@@ -99,7 +137,7 @@ __device__ __forceinline__ bool rle_special(uint8_t c) { return c == 0 || c == 0
 
 // MODE 0: bytes per chunk; MODE 1: write (chunk_off known)
 template <int MODE, bool DECODE>
-__global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64_t n, const uint16_t *uniform, uint32_t *chunk_out, const uint64_t *chunk_off, uint8_t *dst);
+__global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64_t n, const uint16_t *uniform, uint32_t *chunk_out, const uint64_t *chunk_off, uint8_t *dst, uint64_t *total);
 
 // ---- decoding (reference QB3decode.cpp:267-291): ff ff x is a code wherever it STARTS at a code boundary, and a maximal
 // run of ff bytes always starts at one (the byte before it is a copied byte or the count of a zero code).  Of a run of L
@@ -124,7 +162,7 @@ __device__ uint64_t derle0_run(const uint8_t *s, uint64_t n, uint64_t a, const u
 }
 
 template <int MODE, bool DECODE>
-__global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64_t n, const uint16_t *uniform, uint32_t *chunk_out, const uint64_t *chunk_off, uint8_t *dst) {
+__global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64_t n, const uint16_t *uniform, uint32_t *chunk_out, const uint64_t *chunk_off, uint8_t *dst, uint64_t *total) {
     __shared__ uint32_t part[256];
     const uint32_t tid = threadIdx.x;
     const uint64_t p0 = (uint64_t)blockIdx.x * RLE_CHUNK + (uint64_t)tid * RLE_PER_THREAD;
@@ -150,12 +188,35 @@ __global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64
         }
         return o;
     };
-    const uint64_t mine = walk(nullptr);
+    // Most threads need no walk: a byte that is 00 or ff with no such byte next to it is copied like any other (a region of
+    // one byte: no pair, no run of four), so sixteen bytes without two special bytes in a row -- the bytes before and behind
+    // them included -- are sixteen bytes out; expanding, sixteen bytes with no ff among them or just before them are.  The
+    // stream's first bytes and its end (no code starts in the last two bytes) take the walk.
+    bool quick = false;
+    if (p0 > 0 && p0 + RLE_PER_THREAD + 3 <= n) {
+        const Rle16 r = rle_load16(s, p0);
+        if (!DECODE) {
+            uint32_t f[5];
+#pragma unroll
+            for (int k = 0; k < 4; k++) f[k] = rle_special4(r.w[k]);
+            f[4] = rle_special4(r.next | 0x01010100u);
+            uint32_t adj = rle_special4(r.prev | 0x01010100u) & f[0] & 0x80u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) adj |= f[k] & __builtin_amdgcn_alignbit(f[k + 1], f[k], 8);
+            quick = adj == 0;
+        } else
+            quick = (rle_ff4(r.w[0]) | rle_ff4(r.w[1]) | rle_ff4(r.w[2]) | rle_ff4(r.w[3]) | rle_ff4(r.prev | 0x01010100u)) == 0;
+    }
+    const uint64_t mine = quick ? RLE_PER_THREAD : walk(nullptr);
     part[tid] = (uint32_t)mine;                             // (a thread's share is below 2^32: the output of one region is at most 3/2 of its bytes + 258 per code)
     __syncthreads();
     if (MODE == 0) {
         for (uint32_t d = 128; d > 0; d >>= 1) { if (tid < d) part[tid] += part[tid + d]; __syncthreads(); }
-        if (tid == 0) chunk_out[blockIdx.x] = part[0];
+        if (tid == 0) {     // total = n + what the chunks' sizes differ from their byte counts by: most chunks add nothing
+            chunk_out[blockIdx.x] = part[0];
+            const uint64_t c0 = (uint64_t)blockIdx.x * RLE_CHUNK, in = n - c0 < RLE_CHUNK ? n - c0 : RLE_CHUNK;
+            if (part[0] != in) atomicAdd((unsigned long long *)total, (unsigned long long)part[0] - (unsigned long long)in);   // (wraps: two's complement)
+        }
         return;
     }
     for (uint32_t d = 1; d < 256; d <<= 1) {                // inclusive scan
@@ -164,10 +225,10 @@ __global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64
         part[tid] += y;
         __syncthreads();
     }
-    if (mine) walk(dst + chunk_off[blockIdx.x] + (part[tid] - (uint32_t)mine));
+    if (mine) walk(dst + chunk_off[blockIdx.x] + (part[tid] - (uint32_t)mine));     // (a quick thread's sixteen bytes are copied by the walk)
 }
 
-// chunk_off = exclusive prefix of chunk_out (one workgroup); total[0] = the sum
+// chunk_off = exclusive prefix of chunk_out (one workgroup; only the write pass needs it); total[0] = the sum again
 __global__ void __launch_bounds__(1024) rle0_scan_kernel(const uint32_t *chunk_out, uint64_t *chunk_off, uint64_t nchunks, uint64_t *total) {
     __shared__ uint64_t part[1024];
     const uint32_t tid = threadIdx.x;
@@ -209,10 +270,12 @@ int rle0_device_size(const void *d_src, uint64_t n, void *ws, bool decode, uint6
     if (n == 0) { *total = 0; return 0; }
     const RleWs w = rle_ws(ws, n);
     const uint8_t *s = (const uint8_t *)d_src;
-    hipLaunchKernelGGL(rle0_uniform_kernel, dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform);
-    if (decode) hipLaunchKernelGGL((rle0_pass_kernel<0, true>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr);
-    else hipLaunchKernelGGL((rle0_pass_kernel<0, false>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr);
-    hipLaunchKernelGGL(rle0_scan_kernel, dim3(1), dim3(1024), 0, st, w.out, w.off, w.nchunks, w.total);
+    {
+    ProfScope ps(decode ? "rle0_expand_size" : "rle0_size", st);
+    hipLaunchKernelGGL(rle0_uniform_kernel, dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.total);
+    if (decode) hipLaunchKernelGGL((rle0_pass_kernel<0, true>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr, w.total);
+    else hipLaunchKernelGGL((rle0_pass_kernel<0, false>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr, w.total);
+    }
     HIPCHK(hipMemcpyAsync(total, w.total, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
@@ -223,8 +286,10 @@ int rle0_device_write(const void *d_src, uint64_t n, void *ws, bool decode, void
     if (n == 0) return 0;
     const RleWs w = rle_ws(ws, n);
     const uint8_t *s = (const uint8_t *)d_src;
-    if (decode) hipLaunchKernelGGL((rle0_pass_kernel<1, true>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)d_dst);
-    else hipLaunchKernelGGL((rle0_pass_kernel<1, false>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)d_dst);
+    ProfScope ps(decode ? "rle0_expand" : "rle0_write", st);
+    hipLaunchKernelGGL(rle0_scan_kernel, dim3(1), dim3(1024), 0, st, w.out, w.off, w.nchunks, w.total + 1);      // (the size pass left the chunk sums)
+    if (decode) hipLaunchKernelGGL((rle0_pass_kernel<1, true>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)d_dst, w.total + 1);
+    else hipLaunchKernelGGL((rle0_pass_kernel<1, false>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)d_dst, w.total + 1);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <chrono>
+#include <new>
 #include <vector>
 #include <limits>
 #include <thread>
@@ -248,10 +249,20 @@ static size_t write_headers(const encs *p, uint8_t *dst, bool with_dt = true) {
 static size_t raw_size(const encs *p) { return p->xsize * p->ysize * p->nbands * szof(p->type); }
 
 // ---------------------------------------------------------------- encoder handle
+// No C++ exception crosses the C ABI: a failed allocation (std::vector, std::thread) inside a call is an error return with
+// a message for qb3x_last_error, not std::terminate in the caller's process
+template <class R, class F> static R abi_guard(R fail, F &&f) noexcept {
+    try { return f(); }
+    catch (const std::exception &e) { set_error(e.what(), -1); }
+    catch (...) { set_error("C++ exception inside the library", -1); }
+    return fail;
+}
+
 QB3_API encsp qb3_create_encoder(size_t w, size_t h, size_t b, qb3_dtype dt) {
     if (w == 0 || w > 0x10000 || h == 0 || h > 0x10000 || b == 0 || b > QB3_MAXBANDS || (int)dt < 0 || (int)dt > (int)QB3_I64)
         return nullptr;
-    encs *p = new encs();
+    encs *p = new (std::nothrow) encs();
+    if (!p) return nullptr;
     p->xsize = w; p->ysize = h; p->nbands = b; p->type = dt;
     p->stride = 0; p->order = 0; p->quanta = 1; p->away = false; p->mode = QB3M_DEFAULT; p->error = 0;
     { const char *e = getenv("QB3X_INDEX_CHUNK"); p->ix_chunk = e ? (atoi(e) >= 2 ? 2 : atoi(e) != 0) : 0; }
@@ -408,7 +419,7 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
     prof_collect();
     *bits = res.total_bits;
-    if (zero_run) *zero_run = (int)res.zero_run;
+    if (zero_run) *zero_run = rle0_may_win(res) ? 1 : 0;
     if (carry)
         for (size_t c = 0; c < p->nbands; c++) {
             p->band[c].prev = (size_t)res.prev[c]; p->band[c].runbits = res.rung[c]; p->band[c].cf = (size_t)res.cf[c];
@@ -511,7 +522,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
         }
     }
     uint64_t bits = 0;
-    int has_run = 1;        // (RLE0 modes: the concatenation pass looks for four zero bytes in a row, without which RLE0 cannot win)
+    int has_run = 1;        // (RLE0 modes: the concatenation pass counts zero runs and pairs of 0xff; rle0_may_win, qb3_dev.h)
     if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits, hdrbuf, hdr_stamp, ixt, rle ? &has_run : nullptr)) {   // the index describes the block stream, RLE0 wrapped or not
         p->error = QB3E_LIBERR; return 0;
     }
@@ -522,7 +533,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     if (rle) {
         // the RLE0 post pass (reference QB3encode.cpp:536-565)
         p->mode = mode;
-        // ... which can only win when the stream has a run of four zero bytes at all (has_run: the encoder kernels looked)
+        // ... which can only win when the stream's zero runs outweigh its pairs of 0xff (has_run: the encoder kernels counted)
         if (len_ref <= maxsz / 2 && has_run) {
             // the byte pass on the device (k_rle0.hip): its size first, the bytes only when it wins -- into a buffer of its
             // own (the passes run in parallel: not in place), then behind the RLE mode's header
@@ -567,12 +578,12 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
 
 QB3_API size_t qb3_encode(encsp p, void *source, void *destination) {
     if (!p || !source || !destination) return 0;
-    return encode_common(p, source, destination, nullptr, nullptr, nullptr, nullptr);
+    return abi_guard<size_t>(0, [&] { return encode_common(p, source, destination, nullptr, nullptr, nullptr, nullptr); });
 }
 
 QB3_API size_t qb3x_encode_device(encsp p, const void *d_src, void *d_dst, void *d_index, void *stream) {
     if (!p || !d_src || !d_dst || ((uintptr_t)d_dst & 3)) { if (p) p->error = QB3E_EINV; return 0; }
-    return encode_common(p, nullptr, nullptr, d_src, d_dst, d_index, (hipStream_t)stream);
+    return abi_guard<size_t>(0, [&] { return encode_common(p, nullptr, nullptr, d_src, d_dst, d_index, (hipStream_t)stream); });
 }
 
 QB3_API void qb3x_set_encoder_index_chunk(encsp p, int on) { if (p) p->ix_chunk = on >= 2 ? 2 : on != 0; }
@@ -597,8 +608,14 @@ static size_t encode_tiles_loop(encsp p, const void *d_src, size_t first, size_t
     return done;
 }
 
+static size_t encode_tiles_body(encsp p, const void *d_src, size_t n, size_t src_pitch, void *d_dst, size_t dst_pitch,
+                                void *d_index, size_t *sizes, void *stream);
 QB3_API size_t qb3x_encode_tiles(encsp p, const void *d_src, size_t n, size_t src_pitch, void *d_dst, size_t dst_pitch,
                                  void *d_index, size_t *sizes, void *stream) {
+    return abi_guard<size_t>(0, [&] { return encode_tiles_body(p, d_src, n, src_pitch, d_dst, dst_pitch, d_index, sizes, stream); });
+}
+static size_t encode_tiles_body(encsp p, const void *d_src, size_t n, size_t src_pitch, void *d_dst, size_t dst_pitch,
+                                void *d_index, size_t *sizes, void *stream) {
     if (!p || !d_src || !d_dst || !sizes || (dst_pitch & 3) || ((uintptr_t)d_dst & 3)) return 0;
     const size_t isz = d_index ? qb3x_index_size(p) : 0;
     const qb3_mode mode = p->mode;
@@ -720,10 +737,10 @@ static decsp read_start_impl(void *source, size_t hdr_avail, size_t source_size,
     return p;
 }
 QB3_API decsp qb3_read_start(void *source, size_t source_size, size_t *image_size) {
-    return read_start_impl(source, source_size, source_size, image_size);
+    return abi_guard<decsp>(nullptr, [&] { return read_start_impl(source, source_size, source_size, image_size); });
 }
 QB3_API decsp qb3x_read_start(void *header, size_t header_size, size_t stream_size, size_t *image_size) {
-    return read_start_impl(header, header_size, stream_size, image_size);
+    return abi_guard<decsp>(nullptr, [&] { return read_start_impl(header, header_size, stream_size, image_size); });
 }
 // Upper bound of the bytes in front of the block stream of a container that starts with these (at least 11) bytes:
 // the fixed header, the reference's chunks and this library's restart-table chunks for the worst mode.
@@ -863,7 +880,11 @@ QB3_API bool qb3_read_info(decsp p) {
 // table ends -- two small copies instead of the whole table (24 MB for a 16384 x 16384 x 3 raster at level 2), whose
 // chunk heads and checks the device verifies before the table is used (ix_check_kernel).  A table that is not regular
 // is read whole.  Returns a handle in the state qb3_read_info leaves, or NULL.
+static decsp read_start_device_body(const void *d_container, size_t nbytes, size_t *image_size, void *stream);
 QB3_API decsp qb3x_read_start_device(const void *d_container, size_t nbytes, size_t *image_size, void *stream) {
+    return abi_guard<decsp>(nullptr, [&] { return read_start_device_body(d_container, nbytes, image_size, stream); });
+}
+static decsp read_start_device_body(const void *d_container, size_t nbytes, size_t *image_size, void *stream) {
     if (!d_container || nbytes < 15 || !image_size || !device_ok()) return nullptr;
     hipStream_t st = (hipStream_t)stream;
     auto fetch = [&](std::vector<uint8_t> &dst, size_t off, size_t n) -> bool {
@@ -1071,12 +1092,12 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
 
 QB3_API size_t qb3_read_data(decsp p, void *dst) {
     if (!p || !dst) return 0;
-    return decode_common(p, dst, nullptr, nullptr, nullptr, nullptr);
+    return abi_guard<size_t>(0, [&] { return decode_common(p, dst, nullptr, nullptr, nullptr, nullptr); });
 }
 
 QB3_API size_t qb3x_decode_device(decsp p, const void *d_src, void *d_dst, const void *d_index, void *stream) {
     if (!p || !d_src || !d_dst || ((uintptr_t)d_src & 3)) { if (p) p->error = QB3E_EINV; return 0; }
-    return decode_common(p, nullptr, d_src, d_dst, d_index, (hipStream_t)stream);
+    return abi_guard<size_t>(0, [&] { return decode_common(p, nullptr, d_src, d_dst, d_index, (hipStream_t)stream); });
 }
 
 // One tile through its own header: a host copy of its head is parsed into a handle of its own (a batch may hold
@@ -1094,8 +1115,14 @@ static bool decode_tile_alone(decsp ref, const uint8_t *d_tile, size_t size, voi
     return ok;
 }
 
+static size_t decode_tiles_body(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
+                                void *d_dst, size_t dst_pitch, const void *d_index, void *stream);
 QB3_API size_t qb3x_decode_tiles(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
                                  void *d_dst, size_t dst_pitch, const void *d_index, void *stream) {
+    return abi_guard<size_t>(0, [&] { return decode_tiles_body(p, d_src, n, src_pitch, sizes, d_dst, dst_pitch, d_index, stream); });
+}
+static size_t decode_tiles_body(decsp p, const void *d_src, size_t n, size_t src_pitch, const size_t *sizes,
+                                void *d_dst, size_t dst_pitch, const void *d_index, void *stream) {
     if (!p || !d_src || !d_dst || !sizes || (src_pitch & 3) || ((uintptr_t)d_src & 3)) return 0;
     if (p->stage != 2 || p->error != QB3E_OK) return 0;
     const size_t hdr = (size_t)(p->s_in - p->s_start);

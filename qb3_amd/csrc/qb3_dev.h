@@ -60,9 +60,16 @@ struct EncResult {
     uint64_t prev[MAXBANDS];
     uint64_t cf[MAXBANDS];
     uint32_t rung[MAXBANDS];
-    uint32_t error;             // reserved
-    uint32_t zero_run;          // the stream holds four zero bytes in a row, or might (asked for with launch_encode's zrun_probe: RLE0 can only win then)
+    // asked for with launch_encode's zrun_probe (the RLE0 modes), counted while the chunks are concatenated:
+    uint64_t zero_run;          // byte positions at which four zero bytes in a row start -- at least as many as there are
+    uint64_t ff_pairs;          // 0xff bytes followed by another 0xff -- at most as many as there are (rle0_may_win)
 };
+
+// RLE0 (reference QB3encode.cpp:271-332) writes three bytes for every PAIR of 0xff bytes (a run of L of them holds L / 2
+// pairs, at least (L - 1) / 2; the stream's last two bytes are copied) and three bytes for 4 + r zero bytes, which saves
+// at most one byte per position at which four zero bytes start.  So its output is at least n + ff_pairs / 2 - 1 - zero_run
+// bytes, and it can only be shorter than n when that is below n: for most streams the counts decide without the byte pass.
+inline bool rle0_may_win(const EncResult &r) { return r.zero_run > 0 && 2 * r.zero_run + 2 > r.ff_pairs; }
 
 // Workspace sizes
 struct EncPlan {
@@ -138,7 +145,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
                   const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb = TileBatch(),
                   const uint8_t *hdr = nullptr, uint32_t hdr_len = 0,      // hdr: container header stamped before each stream
                   const IxTable &ix = IxTable(),
-                  bool zrun_probe = false);     // look for four zero bytes in a row while concatenating (EncResult::zero_run)
+                  bool zrun_probe = false);     // count runs of zero bytes and pairs of 0xff while concatenating (EncResult::zero_run, ff_pairs)
 
 struct DecPlan {
     uint32_t threads;       // lanes per workgroup, one index segment per lane
