@@ -1264,6 +1264,240 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
     }
 }
 
+// ---- Single-band 32/64-bit plain streams: EXITS instead of a chain through the table.
+// The chain above reads the whole table through one CU (32 bytes a stream bit at 15.8 GB/s).  With ONE band the state of the
+// walk is (position, rung) and nothing else, so a function "state entering a stretch of the stream -> state leaving it" can be
+// tabulated and functions of consecutive stretches composed -- the serial part then takes one step per STRETCH, not per unit.
+// walk_exitW_kernel: a workgroup per super-window of K windows of W positions.  Per window it builds the table T[position][rung
+// in] -> (position the unit ends at, rung behind its switch) in LDS, the way walk_tableW_kernel does (one target rung at a time:
+// extras of 2, 4, 8 codes by doubling), and moves every state of X -- all (position < MAXU, rung) a walk can enter the
+// super-window with -- through T until it leaves the window; after K windows X holds, per entering state, the state the walk
+// leaves the super-window with and the units it took: 4 bytes x MAXU x 16 per 32768 stream bits, about a byte a bit.
+// walk_exit_chain_kernel: one lane hops from super-window to super-window (one dependent load each) and notes where each is
+// entered.  walk_exit_units_kernel: a lane per super-window parses its units from there: unit lengths, segment entries.
+// A unit that leaves the band of rungs or carries the signal code stops the walk: status bit 0, and the caller falls back.
+template <uint32_t UB> struct exitW {
+    static constexpr uint32_t NRUNG = 1u << UB, NR = 16, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;
+    static constexpr uint32_t W = UB == 5 ? 2048 : 1024, K = 32768 / W, SW = W * K, THREADS = 1024;
+    // A walk leaves a window at the first unit that starts behind it AND is entered with a rung of the band: units entered
+    // out of the band (the one behind a unit whose switch jumped out: the first unit of a block row of a wide raster) are
+    // walked on the spot from the code lengths, so a window can be entered up to PE bits in.
+    static constexpr uint32_t PE = MAXU + 512, NX = PE * NR;                               // states a window can be entered with
+    static constexpr uint32_t NPT = (W + UB + 2 + 15 * MAXC + 2 + 31) & ~31u;               // positions the table of a window looks at
+    static constexpr uint32_t NPS = W + PE, NP1 = (NPS + MAXU + 2 + 31) & ~31u;             // positions with a switch entry; with a code length
+    static constexpr uint32_t X_STOP = 0x7fffu;                                             // X: (position - W) * 16 + rung (15 bits: the entering state of the next window) | units << 15; stop: the low 15 bits all set
+    static constexpr uint32_t T0 = 0, X0 = T0 + W * NR * 2, S0 = X0 + NX * 4, E1 = S0 + ((NPS * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT,
+                              LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
+    static_assert(W + MAXU < 4095 && PE * NR + NR <= 0x7fff && K * W / 2 < (1u << 17) && (UB == 5 || UB == 6) && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk");
+};
+
+template <uint32_t UB>
+__global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint32_t *xg, uint32_t s_begin, uint32_t s_count, const WalkState16 *states) {
+    typedef exitW<UB> E;
+    constexpr uint32_t W = E::W, NR = E::NR, NPT = E::NPT, NP1 = E::NP1, NPS = E::NPS, MAXC = E::MAXC, NRUNG = E::NRUNG, NX = E::NX, NT = E::THREADS;
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    const WalkState16 &S = states[blockIdx.y];
+    if (S.bad) return;
+    const uint32_t R0 = S.pad;
+    const uint64_t base = S.P + (uint64_t)(s_begin + blockIdx.x) * E::SW;                   // the super-window's first bit (the walk enters the first one at its bit 0)
+    if (base >= a.in_bits) return;                                                          // (uniform) no walk comes here
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *T = (uint16_t *)(smem + E::T0), *sw = (uint16_t *)(smem + E::S0);
+    uint32_t *M = (uint32_t *)(smem + E::X0), *words = (uint32_t *)(smem + E::WORDS);
+    uint32_t *out = xg + ((uint64_t)blockIdx.y * s_count + blockIdx.x) * NX;          // X: the super-window's exits, entering state by entering state
+    constexpr uint32_t M_EMPTY = 0xffffffffu, M_NEED = 0xfffffffeu;
+    uint8_t *t1 = smem + E::E1, *eA = smem + E::EA, *eB = smem + E::EB;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t endw = (a.in_bit0 + a.in_bits + 31) >> 5;
+#pragma unroll 1
+    for (uint32_t k = 0; k < E::K; k++) {
+        const uint64_t q0 = a.in_bit0 + base + (uint64_t)k * W, w0 = q0 >> 5;
+        const uint32_t sh = (uint32_t)q0 & 31;
+        for (uint32_t i = tid; i < NP1 / 32 + 3; i += NT) words[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
+        __syncthreads();
+        auto bits = [&](uint32_t i) { const uint32_t b = sh + i, j = b >> 5; return __builtin_amdgcn_alignbit(words[j + 1], words[j], b & 31); };
+        for (uint32_t i = tid; i < NP1; i += NT) { const uint32_t x = bits(i); t1[i] = (uint8_t)((x & 1) + ((x & 3) == 3)); }   // a code's extra bits
+        for (uint32_t o = tid; o < NPS; o += NT) {                                          // the switch in front of a unit that starts at o
+            uint32_t delta = 0; bool sig = false;
+            const uint32_t cs = walk_switch<UB>(bits(o), delta, sig);
+            sw[o] = (uint16_t)(cs | (delta << 4) | ((sig ? 1u : 0u) << 10) | ((bits(o + cs) & 1u) << 11));
+        }
+        for (uint32_t i = tid; i < W * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;  // (an entry no target rung fills: the unit leaves the band, or is the signal)
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t rb = 0; rb < NR; rb++) {                                              // the rung the switch leads to
+            const uint32_t r = R0 + rb;
+#ifdef EXIT_EXP_NOTAB
+            if (r && rb == 0) {
+#else
+            if (r) {                                                                        // extras of two, four, eight codes at rung r
+#endif
+                for (uint32_t i = tid; i < NPT - MAXC; i += NT) { const uint32_t e = t1[i]; eA[i] = (uint8_t)(e + t1[i + r + e]); }
+                __syncthreads();
+                for (uint32_t i = tid; i < NPT - 3 * MAXC; i += NT) { const uint32_t e = eA[i]; eB[i] = (uint8_t)(e + eA[i + 2 * r + e]); }
+                __syncthreads();
+                for (uint32_t i = tid; i < NPT - 7 * MAXC; i += NT) { const uint32_t e = eB[i]; eA[i] = (uint8_t)(e + eB[i + 4 * r + e]); }
+                __syncthreads();
+            }
+            for (uint32_t o = tid; o < W; o += NT) {
+                const uint32_t s = sw[o], cs = s & 15u, delta = (s >> 4) & 63u;
+                const uint32_t bin = ((r - delta) & (NRUNG - 1)) - R0;                      // the rung the unit is entered with, in the band
+                if (bin >= NR || ((s >> 10) & 1u)) continue;
+                uint32_t u = cs + (((s >> 11) & 1u) ? 17u : 1u);                            // rung 0: one flag, then 16 raw bits
+                if (r) { const uint32_t n8 = 8 * r + eA[o + cs]; u = cs + n8 + 8 * r + eA[o + cs + n8]; }
+                T[o * NR + bin] = (uint16_t)((o + u) | (rb << 12));
+            }
+            __syncthreads();
+        }
+        // Every entering state of the super-window through this window.  Walks merge: behind the first window the thousands of
+        // states stand at a few hundred distinct (position, rung), so the states say which they need (M), those are walked once,
+        // and every state takes its answer from there.  X stays in global memory (read and written once a window, coalesced).
+        for (uint32_t i = tid; i < NX; i += NT) M[i] = k ? M_EMPTY : M_NEED;
+        __syncthreads();
+        if (k) {
+            for (uint32_t idx = tid; idx < NX; idx += NT) { const uint32_t x = out[idx]; if ((x & E::X_STOP) != E::X_STOP) M[x & 0x7fffu] = M_NEED; }
+            __syncthreads();
+        }
+        for (uint32_t key = tid; key < NX; key += NT) {
+            if (M[key] != M_NEED) continue;
+            uint32_t pos = key / NR, r = key % NR, cnt = 0;                                 // (a state's low 15 bits: position | rung << 11 = position * 16 + rung: the key itself)
+            bool stop = false;
+#ifdef EXIT_EXP_NOWALK
+            pos = W + (pos & 255);
+#endif
+            while (true) {
+                if (r < NR) {
+                    if (pos >= W) break;                                                    // behind the window, in the band: the next window's
+                    const uint32_t e = T[pos * NR + r];
+                    if (e != 0xffffu) { pos = e & 0xfffu; r = e >> 12; cnt++; continue; }
+                }
+                // a unit the table does not hold (it leaves the band, or is entered from outside it): by the code lengths
+                if (pos >= NPS) { stop = true; break; }
+                const uint32_t s = sw[pos], cs = s & 15u;
+                if ((s >> 10) & 1u) { stop = true; break; }                                 // the signal code: not a stream for this walk
+                const uint32_t rabs = (R0 + r + ((s >> 4) & 63u)) & (NRUNG - 1);
+                uint32_t q = pos + cs;
+                if (rabs) { for (uint32_t i = 0; i < 16; i++) q += rabs + t1[q]; }
+                else q += ((s >> 11) & 1u) ? 17u : 1u;
+                pos = q; r = (rabs - R0) & (NRUNG - 1); cnt++;
+            }
+            if (pos - W >= E::PE) stop = true;                                              // (only behind a unit entered out of the band)
+            M[key] = stop ? (E::X_STOP | (cnt << 15)) : ((pos - W) * NR + r) | (cnt << 15);
+        }
+        __syncthreads();
+        for (uint32_t idx = tid; idx < NX; idx += NT) {
+            if (!k) { out[idx] = M[idx]; continue; }
+            const uint32_t x = out[idx];
+            if ((x & E::X_STOP) == E::X_STOP) continue;
+            const uint32_t m = M[x & 0x7fffu];
+            out[idx] = (m & 0x7fffu) | (((x >> 15) + (m >> 15)) << 15);
+        }
+        __syncthreads();
+    }
+}
+
+// entries: per tile nsuper + 2 of {position lo, hi, unit, rung in the band}: where the walk enters super-window s; the last one is
+// {the super-window the walk stands in front of, 1 when every unit has been found}.  The stream is taken s_count super-windows at
+// a time (the memory for their exits is reused): a call takes up where the one before stopped.
+template <uint32_t UB>
+__global__ void __launch_bounds__(64) walk_exit_chain_kernel(const DecArgs a0, const uint32_t *xg, uint32_t nsuper, uint32_t s_begin, uint32_t s_count, WalkState16 *states, uint4 *entries) {
+    typedef exitW<UB> E;
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    if (threadIdx.x) return;
+    WalkState16 *S = states + blockIdx.x;
+    if (S->bad) return;
+    const uint64_t nunits = a.g.nblocks, P0 = S->P;
+    uint4 *en = entries + (uint64_t)blockIdx.x * (nsuper + 2), *hd = en + nsuper + 1;
+    uint64_t P = P0, U = S->unit;
+    uint32_t r = (uint32_t)S->rungs & 15u, s = 0;
+    bool bad = false, done = false;
+    if (s_begin) {
+        const uint4 h = *hd;
+        if (h.y) return;                                                                    // all units found in an earlier call
+        const uint4 e = en[s_begin];
+        P = (uint64_t)e.x | (uint64_t)e.y << 32; U = e.z; r = e.w; s = s_begin;
+        bad = h.x != s_begin;
+    }
+    const uint32_t s_end = s_begin + s_count < nsuper ? s_begin + s_count : nsuper;
+    const uint32_t *x0 = xg + (uint64_t)blockIdx.x * s_count * E::NX;
+    while (!bad) {
+        en[s] = make_uint4((uint32_t)P, (uint32_t)(P >> 32), (uint32_t)U, r);
+        if (U >= nunits) { done = true; break; }
+        if (s >= s_end) { bad = s >= nsuper; break; }                                       // the next call's; or units left and no stream (a damaged one)
+        if (P >= a.in_bits) { bad = true; break; }
+        const uint32_t x = x0[(uint64_t)(s - s_begin) * E::NX + (uint32_t)(P - (P0 + (uint64_t)s * E::SW)) * E::NR + r];
+        U += x >> 15;
+        s++;
+        if ((x & E::X_STOP) == E::X_STOP) {                                                 // fine if the stream's units end before the stop
+            bad = U < nunits; done = !bad;
+            en[s] = make_uint4(0u, 0u, (uint32_t)(U < nunits ? U : nunits), 0u);
+            break;
+        }
+        r = x & 15u;
+        P = P0 + (uint64_t)s * E::SW + ((x & 0x7fffu) >> 4);
+    }
+    *hd = make_uint4(s, done ? 1u : 0u, 0u, 0u);                                            // done: super-windows 0 .. s - 1 have units to parse, entries 0 .. s stand
+    if (bad) { S->bad = 1u; atomicOr(a.status, 1u); }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, const WalkState16 *states, const uint4 *entries, uint32_t nsuper) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    const WalkState16 &S = states[blockIdx.y];
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    const uint4 *en = entries + (uint64_t)blockIdx.y * (nsuper + 2);
+    const uint4 hd = en[nsuper + 1];
+    if (S.bad || !hd.y || s >= hd.x) return;
+    const uint4 e = en[s];
+    const uint64_t nunits = a.g.nblocks, NB = a.g.seg_blocks;
+    uint64_t U = e.z, Uend = en[s + 1].z;
+    if (Uend > nunits) Uend = nunits;
+    uint32_t rung = S.pad + e.w;
+    Reader rd;
+    rd.init(a.in32, a.in_bit0 + ((uint64_t)e.x | (uint64_t)e.y << 32), a.in_bit0 + a.in_bits);
+    T g[16], pcf = 0;
+    bool ok = true;
+    uint16_t *ul = (uint16_t *)a.idx.ulen;
+    for (; U < Uend; U++) {
+        const uint64_t u0 = rd.position();
+        if (U % NB == 0) { const uint64_t seg = U / NB; a.idx.bitpos[seg] = u0 - a.in_bit0; a.idx.rung[seg] = (uint8_t)rung; }
+        ok = parse_unit<T, CM_FTL>(rd, rung, pcf, g) && ok;                                 // (lengths and rungs are the same with and without the step)
+        ul[U] = (uint16_t)(rd.position() - u0);
+    }
+    if (!ok) atomicOr(a.status, 1u);
+}
+// memory of the exit walk: states, entries, and the exits of as many super-windows as fit (at least one a tile)
+template <uint32_t UB> static bool walk_exit_layout(uint32_t nt, uint64_t max_bits, size_t tab_bytes, uint32_t *nsuper, uint32_t *slab, size_t *x_off) {
+    typedef exitW<UB> E;
+    const uint64_t ns = (max_bits + E::SW - 1) / E::SW;
+    const size_t fixed = (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255) + (((size_t)nt * (ns + 2) * 16 + 255) & ~(size_t)255);
+    if (ns == 0 || ns > 0x7fffffffu || tab_bytes < fixed + (size_t)nt * E::NX * 4) return false;
+    const uint64_t fit = (tab_bytes - fixed) / ((size_t)nt * E::NX * 4);
+    *nsuper = (uint32_t)ns; *slab = (uint32_t)(fit < ns ? fit : ns); *x_off = fixed;
+    return true;
+}
+template <uint32_t UB, typename T>
+static bool launch_walk_exit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+    typedef exitW<UB> E;
+    uint32_t nsuper = 0, slab = 0;
+    size_t x_off = 0;
+    const uint32_t nt = a.ntiles;
+    if (!walk_exit_layout<UB>(nt, max_bits, tab_bytes, &nsuper, &slab, &x_off)) return false;
+    WalkState16 *states = (WalkState16 *)tab;
+    uint4 *entries = (uint4 *)((uint8_t *)tab + (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255));
+    uint32_t *xg = (uint32_t *)((uint8_t *)tab + x_off);
+    for (uint32_t s0 = 0; s0 < nsuper; s0 += slab) {
+        const uint32_t cnt = nsuper - s0 < slab ? nsuper - s0 : slab;
+        { ProfScope ps("dec_index_table", st);
+          hipLaunchKernelGGL(walk_exitW_kernel<UB>, dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states); }
+        ProfScope ps("dec_index_serial", st);
+        hipLaunchKernelGGL(walk_exit_chain_kernel<UB>, dim3(nt), dim3(64), 0, st, a, (const uint32_t *)xg, nsuper, s0, cnt, states, entries);
+    }
+    ProfScope ps("dec_index_serial", st);
+    hipLaunchKernelGGL(walk_exit_units_kernel<T>, dim3((nsuper + 63) / 64, nt), dim3(64), 0, st, a, (const WalkState16 *)states, (const uint4 *)entries, nsuper);
+    return true;
+}
+
 // Slabs of the streams are tabulated by the whole chip, then walked by a workgroup per tile, slab after slab; the
 // table of the next slab is built (on a stream of its own, in the other half of the memory) while this one is walked.
 // tab: [walk state per tile][windows of table rows per tile] x 2; max_bits: the longest stream of the call.
@@ -1327,6 +1561,8 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 14>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 16>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 16>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<6>::LDS_BYTES) == hipSuccess;
         return ok;
     }();
     (void)lds_ok;
@@ -1337,6 +1573,9 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
         { ProfScope ps("dec_index_serial", st);
           if (a.g.tsz == 4) hipLaunchKernelGGL(walk_probe_kernel<uint32_t>, dim3(nt), dim3(64), 0, st, a, states, nr);
           else hipLaunchKernelGGL(walk_probe_kernel<uint64_t>, dim3(nt), dim3(64), 0, st, a, states, nr); }
+        if (a.g.bands == 1 && a.wide_band == 16 && lds_ok) {    // one band: exits of super-windows composed, a hop per 32768 bits (wide_band 17: the chain, a test hook)
+            if (a.g.tsz == 4 ? launch_walk_exit<5, uint32_t>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<6, uint64_t>(a, st, tab, tab_bytes, max_bits)) return;
+        }
         auto run = [&](auto tag) {
             constexpr uint32_t UB = decltype(tag)::UB_, NRB = decltype(tag)::NR_;
             typedef chainW<UB, NRB> W;
