@@ -702,7 +702,7 @@ constexpr uint32_t TR0 = 2 * WIN_BYTES, RS0 = TR0 + 2 * TR_BYTES, WR0 = RS0 + 64
 constexpr uint32_t F_READY = META /* [2][4] */, F_TRAILED = META + 32, F_NUNITS = META + 40, F_O0 = META + 48,
                    F_WALKED = META + 56, F_STOP = META + 60, F_U0 = META + 64 /* u64[2] */;
 }  // namespace chain16
-struct WalkState16 { uint64_t P, unit, rungs; uint32_t bad, pad; };        // a tile's walk between two slabs (rungs: 4 bits a band)
+struct WalkState16 { uint64_t P, unit, rungs; uint32_t bad, pad; uint64_t cf; };   // a tile's walk between two slabs (rungs: 4 bits a band; cf: the exit walk of common-factor streams, the factor in force behind the first segment)
 
 __global__ void __launch_bounds__(256) walk_table16_kernel(const DecArgs a0, uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch) {
     using namespace chain16;
@@ -975,7 +975,7 @@ template <uint32_t UB, uint32_t NR_> struct chainW {
 
 // The first index segment of every tile, parsed outright by one lane: unit lengths, the segment's entry, the band of rungs
 // [R0, R0 + 16) for the table (WalkState16::pad) and the walk's entry state behind the segment.
-template <typename T>
+template <typename T, int MODE>
 __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkState16 *states, uint32_t nr) {
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     constexpr uint32_t NRUNG = 1u << UBits<T>::v;
@@ -988,14 +988,17 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
     bool ok = true;
     a.idx.bitpos[0] = 0;
     for (uint32_t c = 0; c < B; c++) { rung[c] = 0; a.idx.rung[c] = 0; }
-    T g[16], pcf = 0;
+    T g[16], pcf[MAXBANDS], tot[MAXBANDS];
+    for (uint32_t c = 0; c < B; c++) { pcf[c] = 0; tot[c] = 0; if (MODE == CM_BEST) ((T *)a.idx.cf)[c] = 0; }
     for (uint64_t gb = 0; gb < nb && ok; gb++)
         for (uint32_t c = 0; c < B; c++) {
             const uint64_t u0 = rd.position();
-            ok = parse_unit<T, CM_FTL>(rd, rung[c], pcf, g) && ok;      // (lengths and rungs are the same with and without the step)
-            ((uint16_t *)a.idx.ulen)[gb * B + c] = (uint16_t)(rd.position() - u0);
+            ok = parse_unit<T, MODE>(rd, rung[c], pcf[c], g) && ok;     // (FTL / BASE: lengths and rungs are the same with and without the step)
+            if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[gb * B + c] = (uint16_t)(rd.position() - u0);
+            if (MODE == CM_BEST) for (uint32_t i = 0; i < 16; i++) tot[c] = (T)(tot[c] + smag_t<T>(g[i]));   // (common-factor streams: the segment's sum, for the scan that gives every segment its entering value)
             if (gb || nb == 1) { minr = rung[c] < minr ? rung[c] : minr; maxr = rung[c] > maxr ? rung[c] : maxr; }
         }
+    if (MODE == CM_BEST) for (uint32_t c = 0; c < B; c++) ((T *)a.idx.prev)[c] = tot[c];
     WalkState16 *S = states + blockIdx.x;
     // the band: nr rungs from a little below the smallest rung the first segment saw.  What lies ABOVE the typical rung matters
     // more than what lies below: the first unit of every block row is entered from the far end of the row before and sits
@@ -1004,7 +1007,7 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
     if (R0 > NRUNG - nr) R0 = NRUNG - nr;
     uint64_t rel = 0;
     for (uint32_t c = 0; c < B; c++) { const uint32_t d = rung[c] - R0; ok = ok && d < nr; rel |= (uint64_t)(d & 15u) << (4 * c); }
-    S->P = rd.position() - a.in_bit0; S->unit = nb * B; S->rungs = rel; S->pad = R0; S->bad = ok ? 0u : 1u;
+    S->P = rd.position() - a.in_bit0; S->unit = nb * B; S->rungs = rel; S->pad = R0; S->bad = ok ? 0u : 1u; S->cf = (uint64_t)pcf[0];
     if (!ok) atomicOr(a.status, 1u);
 }
 
@@ -1285,13 +1288,14 @@ template <uint32_t UB> struct exitW {
     static constexpr uint32_t PE = MAXU + 512, NX = PE * NR;                               // states a window can be entered with
     static constexpr uint32_t NPT = (W + UB + 2 + 15 * MAXC + 2 + 31) & ~31u;               // positions the table of a window looks at
     static constexpr uint32_t NPS = W + PE, NP1 = (NPS + MAXU + 2 + 31) & ~31u;             // positions with a switch entry; with a code length
+    static constexpr uint32_t X_DEP = 1u << 30, X_SLOW = 1u << 31, X_CNT = 0x7fffu;          // (common-factor streams) a unit took the factor in force when the super-window was entered; a unit brought its own
     static constexpr uint32_t X_STOP = 0x7fffu;                                             // X: (position - W) * 16 + rung (15 bits: the entering state of the next window) | units << 15; stop: the low 15 bits all set
     static constexpr uint32_t T0 = 0, X0 = T0 + W * NR * 2, S0 = X0 + NX * 4, E1 = S0 + ((NPS * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT,
                               LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
     static_assert(W + MAXU < 4095 && PE * NR + NR <= 0x7fff && K * W / 2 < (1u << 17) && (UB == 5 || UB == 6) && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk");
 };
 
-template <uint32_t UB>
+template <uint32_t UB, bool CF>
 __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint32_t *xg, uint32_t s_begin, uint32_t s_count, const WalkState16 *states) {
     typedef exitW<UB> E;
     constexpr uint32_t W = E::W, NR = E::NR, NPT = E::NPT, NP1 = E::NP1, NPS = E::NPS, MAXC = E::MAXC, NRUNG = E::NRUNG, NX = E::NX, NT = E::THREADS;
@@ -1360,8 +1364,10 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
         }
         for (uint32_t key = tid; key < NX; key += NT) {
             if (M[key] != M_NEED) continue;
-            uint32_t pos = key / NR, r = key % NR, cnt = 0;                                 // (a state's low 15 bits: position | rung << 11 = position * 16 + rung: the key itself)
+            uint32_t pos = key / NR, r = key % NR, cnt = 0;                                 // (a state's low 15 bits: position * 16 + rung: the key itself)
             bool stop = false;
+            typedef typename std::conditional<UB == 5, uint32_t, uint64_t>::type TT;
+            TT cfv = (TT)S.cf; uint32_t xfl = 0;                                            // (common-factor streams) the factor in force: the one behind the first segment until a unit brings its own
 #ifdef EXIT_EXP_NOWALK
             pos = W + (pos & 255);
 #endif
@@ -1374,7 +1380,23 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
                 // a unit the table does not hold (it leaves the band, or is entered from outside it): by the code lengths
                 if (pos >= NPS) { stop = true; break; }
                 const uint32_t s = sw[pos], cs = s & 15u;
-                if ((s >> 10) & 1u) { stop = true; break; }                                 // the signal code: not a stream for this walk
+                if ((s >> 10) & 1u) {                                                       // the signal code
+                    if (!CF) { stop = true; break; }                                        // ... in a stream that should have none
+                    // a common-factor or index unit: parsed outright (its values decide the rung it leaves).  The factor in force
+                    // is not part of the state: a unit that takes it is walked with the factor the stream had behind its first
+                    // segment and says so (X_DEP: right as long as no unit in between brought another, which the hop checks); a
+                    // unit that brings its own marks the walk X_SLOW: the hop parses that super-window outright.
+                    ReaderT<LdsWords> rd;
+                    rd.init((LdsWords)words, sh + pos, 32ull * (NP1 / 32 + 3));
+                    uint32_t rg = (R0 + r) & (NRUNG - 1), fl = 0;
+                    TT pc = cfv, g[16];
+                    const bool ok = parse_unit<TT, CM_BEST>(rd, rg, pc, g, &fl);
+                    if (!ok) { stop = true; break; }
+                    if ((fl & 1u) && !(xfl & E::X_SLOW)) xfl |= E::X_DEP;
+                    if (fl & 2u) { xfl |= E::X_SLOW; cfv = pc; }
+                    pos = (uint32_t)rd.position() - sh; r = (rg - R0) & (NRUNG - 1); cnt++;
+                    continue;
+                }
                 const uint32_t rabs = (R0 + r + ((s >> 4) & 63u)) & (NRUNG - 1);
                 uint32_t q = pos + cs;
                 if (rabs) { for (uint32_t i = 0; i < 16; i++) q += rabs + t1[q]; }
@@ -1382,87 +1404,131 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
                 pos = q; r = (rabs - R0) & (NRUNG - 1); cnt++;
             }
             if (pos - W >= E::PE) stop = true;                                              // (only behind a unit entered out of the band)
-            M[key] = stop ? (E::X_STOP | (cnt << 15)) : ((pos - W) * NR + r) | (cnt << 15);
+            M[key] = (stop ? (E::X_STOP | (cnt << 15)) : ((pos - W) * NR + r) | (cnt << 15)) | xfl;
         }
         __syncthreads();
         for (uint32_t idx = tid; idx < NX; idx += NT) {
             if (!k) { out[idx] = M[idx]; continue; }
             const uint32_t x = out[idx];
             if ((x & E::X_STOP) == E::X_STOP) continue;
-            const uint32_t m = M[x & 0x7fffu];
-            out[idx] = (m & 0x7fffu) | (((x >> 15) + (m >> 15)) << 15);
+            const uint32_t m = M[x & 0x7fffu];          // (flags add up: a factor brought anywhere, a factor taken before one was brought -- or after: X_SLOW then)
+            out[idx] = (m & 0x7fffu) | (((((x >> 15) & E::X_CNT) + ((m >> 15) & E::X_CNT)) & E::X_CNT) << 15) | ((x | m) & (E::X_DEP | E::X_SLOW));
         }
         __syncthreads();
     }
 }
 
-// entries: per tile nsuper + 2 of {position lo, hi, unit, rung in the band}: where the walk enters super-window s; the last one is
-// {the super-window the walk stands in front of, 1 when every unit has been found}.  The stream is taken s_count super-windows at
-// a time (the memory for their exits is reused): a call takes up where the one before stopped.
-template <uint32_t UB>
+// entries: per tile nsuper + 2 pairs of {position lo, hi, unit, rung in the band} {factor in force lo, hi}: where and how the walk
+// enters super-window s; the last pair is {the super-window the walk stands in front of, 1 when every unit has been found}.  The
+// stream is taken s_count super-windows at a time (the memory for their exits is reused): a call takes up where the one before
+// stopped.  A super-window whose exit cannot be taken from the table -- a unit in it brought a common factor of its own, or took
+// the one in force when that is no longer the one the table was made with, or the walk stopped -- is parsed outright by this
+// lane (about 260 units): the stream still decodes, at the one-lane parser's pace for that stretch.
+template <uint32_t UB, int MODE>
 __global__ void __launch_bounds__(64) walk_exit_chain_kernel(const DecArgs a0, const uint32_t *xg, uint32_t nsuper, uint32_t s_begin, uint32_t s_count, WalkState16 *states, uint4 *entries) {
     typedef exitW<UB> E;
+    typedef typename std::conditional<UB == 5, uint32_t, uint64_t>::type T;
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     if (threadIdx.x) return;
     WalkState16 *S = states + blockIdx.x;
     if (S->bad) return;
-    const uint64_t nunits = a.g.nblocks, P0 = S->P;
-    uint4 *en = entries + (uint64_t)blockIdx.x * (nsuper + 2), *hd = en + nsuper + 1;
-    uint64_t P = P0, U = S->unit;
+    const uint64_t nunits = a.g.nblocks, P0 = S->P, spec = S->cf;
+    const uint32_t R0 = S->pad;
+    uint4 *en = entries + (uint64_t)blockIdx.x * 2 * (nsuper + 2), *hd = en + 2 * (nsuper + 1);
+    uint64_t P = P0, U = S->unit, cf = spec;
     uint32_t r = (uint32_t)S->rungs & 15u, s = 0;
     bool bad = false, done = false;
     if (s_begin) {
         const uint4 h = *hd;
         if (h.y) return;                                                                    // all units found in an earlier call
-        const uint4 e = en[s_begin];
-        P = (uint64_t)e.x | (uint64_t)e.y << 32; U = e.z; r = e.w; s = s_begin;
+        const uint4 e = en[2 * s_begin], f = en[2 * s_begin + 1];
+        P = (uint64_t)e.x | (uint64_t)e.y << 32; U = e.z; r = e.w; s = s_begin; cf = (uint64_t)f.x | (uint64_t)f.y << 32;
         bad = h.x != s_begin;
     }
     const uint32_t s_end = s_begin + s_count < nsuper ? s_begin + s_count : nsuper;
     const uint32_t *x0 = xg + (uint64_t)blockIdx.x * s_count * E::NX;
     while (!bad) {
-        en[s] = make_uint4((uint32_t)P, (uint32_t)(P >> 32), (uint32_t)U, r);
+        en[2 * s] = make_uint4((uint32_t)P, (uint32_t)(P >> 32), (uint32_t)U, r);
+        en[2 * s + 1] = make_uint4((uint32_t)cf, (uint32_t)(cf >> 32), 0u, 0u);
         if (U >= nunits) { done = true; break; }
         if (s >= s_end) { bad = s >= nsuper; break; }                                       // the next call's; or units left and no stream (a damaged one)
         if (P >= a.in_bits) { bad = true; break; }
-        const uint32_t x = x0[(uint64_t)(s - s_begin) * E::NX + (uint32_t)(P - (P0 + (uint64_t)s * E::SW)) * E::NR + r];
-        U += x >> 15;
+        const uint64_t base = P0 + (uint64_t)s * E::SW;
+        const uint32_t x = x0[(uint64_t)(s - s_begin) * E::NX + (uint32_t)(P - base) * E::NR + r];
+        const bool stopped = (x & E::X_STOP) == E::X_STOP;
+        const bool slow = stopped || (MODE == CM_BEST && ((x & E::X_SLOW) || ((x & E::X_DEP) && cf != spec)));
         s++;
-        if ((x & E::X_STOP) == E::X_STOP) {                                                 // fine if the stream's units end before the stop
-            bad = U < nunits; done = !bad;
-            en[s] = make_uint4(0u, 0u, (uint32_t)(U < nunits ? U : nunits), 0u);
+        if (!slow) {
+            U += (x >> 15) & E::X_CNT;
+            r = x & 15u;
+            P = base + E::SW + ((x & 0x7fffu) >> 4);
+            continue;
+        }
+        if (stopped && U + ((x >> 15) & E::X_CNT) >= nunits) {                              // the stream's units end before the stop
+            done = true;
+            en[2 * s] = make_uint4(0u, 0u, (uint32_t)nunits, 0u); en[2 * s + 1] = make_uint4(0u, 0u, 0u, 0u);
             break;
         }
-        r = x & 15u;
-        P = P0 + (uint64_t)s * E::SW + ((x & 0x7fffu) >> 4);
+        // this super-window by the units themselves: up to the first unit that starts behind it and is entered with a rung of the band
+        Reader rd;
+        rd.init(a.in32, a.in_bit0 + P, a.in_bit0 + a.in_bits);
+        uint32_t rung = R0 + r;
+        T pc = (T)cf, g[16];
+        bool ok = true;
+        const uint64_t end = base + E::SW;
+        while (ok && U < nunits) {
+            const uint64_t pos = rd.position() - a.in_bit0;
+            if (pos >= a.in_bits || (pos >= end && ((rung - R0) & (E::NRUNG - 1)) < E::NR)) break;
+            ok = parse_unit<T, MODE>(rd, rung, pc, g);
+            U++;
+        }
+        P = rd.position() - a.in_bit0; r = (rung - R0) & (E::NRUNG - 1); cf = (uint64_t)pc;
+        if (!ok || (U < nunits && (P < end || P - end >= E::PE || r >= E::NR))) { bad = true; break; }
     }
     *hd = make_uint4(s, done ? 1u : 0u, 0u, 0u);                                            // done: super-windows 0 .. s - 1 have units to parse, entries 0 .. s stand
     if (bad) { S->bad = 1u; atomicOr(a.status, 1u); }
 }
 
+// idx.prev = 0 behind the first segment: the sums of the segments' values are added up there by the lanes that parse them
 template <typename T>
+__global__ void __launch_bounds__(256) walk_exit_zero_kernel(const DecArgs a0) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    const uint64_t seg = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (seg && seg < a.g.nseg) ((T *)a.idx.prev)[seg] = 0;
+}
+template <typename T, int MODE>
 __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, const WalkState16 *states, const uint4 *entries, uint32_t nsuper) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     const WalkState16 &S = states[blockIdx.y];
     const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    const uint4 *en = entries + (uint64_t)blockIdx.y * (nsuper + 2);
-    const uint4 hd = en[nsuper + 1];
+    const uint4 *en = entries + (uint64_t)blockIdx.y * 2 * (nsuper + 2);
+    const uint4 hd = en[2 * (nsuper + 1)];
     if (S.bad || !hd.y || s >= hd.x) return;
-    const uint4 e = en[s];
+    const uint4 e = en[2 * s], f = en[2 * s + 1];
     const uint64_t nunits = a.g.nblocks, NB = a.g.seg_blocks;
-    uint64_t U = e.z, Uend = en[s + 1].z;
+    uint64_t U = e.z, Uend = en[2 * s + 2].z;
     if (Uend > nunits) Uend = nunits;
     uint32_t rung = S.pad + e.w;
     Reader rd;
     rd.init(a.in32, a.in_bit0 + ((uint64_t)e.x | (uint64_t)e.y << 32), a.in_bit0 + a.in_bits);
-    T g[16], pcf = 0;
+    T g[16], pcf = (T)((uint64_t)f.x | (uint64_t)f.y << 32), tot = 0;                    // (the factor in force where the super-window is entered)
     bool ok = true;
     uint16_t *ul = (uint16_t *)a.idx.ulen;
+    typedef typename std::conditional<sizeof(T) == 4, unsigned int, unsigned long long>::type AT;
     for (; U < Uend; U++) {
         const uint64_t u0 = rd.position();
-        if (U % NB == 0) { const uint64_t seg = U / NB; a.idx.bitpos[seg] = u0 - a.in_bit0; a.idx.rung[seg] = (uint8_t)rung; }
-        ok = parse_unit<T, CM_FTL>(rd, rung, pcf, g) && ok;                                 // (lengths and rungs are the same with and without the step)
-        ul[U] = (uint16_t)(rd.position() - u0);
+        if (U % NB == 0) {
+            const uint64_t seg = U / NB;
+            a.idx.bitpos[seg] = u0 - a.in_bit0; a.idx.rung[seg] = (uint8_t)rung;
+            if (MODE == CM_BEST) ((T *)a.idx.cf)[seg] = pcf;
+        }
+        ok = parse_unit<T, MODE>(rd, rung, pcf, g) && ok;                                   // (FTL / BASE: lengths and rungs are the same with and without the step)
+        if (MODE != CM_BEST) ul[U] = (uint16_t)(rd.position() - u0);
+        else {                                                                              // the segment's sum of values: the scan makes entering values of them
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) tot = (T)(tot + smag_t<T>(g[i]));
+            if ((U + 1) % NB == 0 || U + 1 == Uend) { atomicAdd((AT *)a.idx.prev + U / NB, (AT)tot); tot = 0; }
+        }
     }
     if (!ok) atomicOr(a.status, 1u);
 }
@@ -1470,13 +1536,13 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
 template <uint32_t UB> static bool walk_exit_layout(uint32_t nt, uint64_t max_bits, size_t tab_bytes, uint32_t *nsuper, uint32_t *slab, size_t *x_off) {
     typedef exitW<UB> E;
     const uint64_t ns = (max_bits + E::SW - 1) / E::SW;
-    const size_t fixed = (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255) + (((size_t)nt * (ns + 2) * 16 + 255) & ~(size_t)255);
+    const size_t fixed = (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255) + (((size_t)nt * (ns + 2) * 32 + 255) & ~(size_t)255);
     if (ns == 0 || ns > 0x7fffffffu || tab_bytes < fixed + (size_t)nt * E::NX * 4) return false;
     const uint64_t fit = (tab_bytes - fixed) / ((size_t)nt * E::NX * 4);
     *nsuper = (uint32_t)ns; *slab = (uint32_t)(fit < ns ? fit : ns); *x_off = fixed;
     return true;
 }
-template <uint32_t UB, typename T>
+template <uint32_t UB, typename T, int MODE>
 static bool launch_walk_exit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
     typedef exitW<UB> E;
     uint32_t nsuper = 0, slab = 0;
@@ -1489,12 +1555,12 @@ static bool launch_walk_exit(const DecArgs &a, hipStream_t st, void *tab, size_t
     for (uint32_t s0 = 0; s0 < nsuper; s0 += slab) {
         const uint32_t cnt = nsuper - s0 < slab ? nsuper - s0 : slab;
         { ProfScope ps("dec_index_table", st);
-          hipLaunchKernelGGL(walk_exitW_kernel<UB>, dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states); }
+          hipLaunchKernelGGL((walk_exitW_kernel<UB, MODE == CM_BEST>), dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states); }
         ProfScope ps("dec_index_serial", st);
-        hipLaunchKernelGGL(walk_exit_chain_kernel<UB>, dim3(nt), dim3(64), 0, st, a, (const uint32_t *)xg, nsuper, s0, cnt, states, entries);
+        hipLaunchKernelGGL((walk_exit_chain_kernel<UB, MODE>), dim3(nt), dim3(64), 0, st, a, (const uint32_t *)xg, nsuper, s0, cnt, states, entries);
     }
     ProfScope ps("dec_index_serial", st);
-    hipLaunchKernelGGL(walk_exit_units_kernel<T>, dim3((nsuper + 63) / 64, nt), dim3(64), 0, st, a, (const WalkState16 *)states, (const uint4 *)entries, nsuper);
+    hipLaunchKernelGGL((walk_exit_units_kernel<T, MODE>), dim3((nsuper + 63) / 64, nt), dim3(64), 0, st, a, (const WalkState16 *)states, (const uint4 *)entries, nsuper);
     return true;
 }
 
@@ -1547,8 +1613,23 @@ static void walk_in_slabs(const DecArgs &a, hipStream_t st, void *tab, size_t ta
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (aux) (void)hipStreamDestroy(aux);
 }
+// Plain single-band 32/64-bit COMMON-FACTOR streams through the same exits (units with the signal code are parsed outright
+// inside the walk).  False: not taken (no memory for it) -- the caller parses the stream with one lane.
+static bool walk_exit_lds_ok();
+bool launch_dec_walk_best(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+    if (a.g.bands != 1 || a.g.tsz < 4 || a.g.mode != CM_BEST || !walk_exit_lds_ok()) return false;
+    uint32_t ns = 0, slab = 0; size_t xo = 0;
+    if (!(a.g.tsz == 4 ? walk_exit_layout<5>(a.ntiles, max_bits, tab_bytes, &ns, &slab, &xo) : walk_exit_layout<6>(a.ntiles, max_bits, tab_bytes, &ns, &slab, &xo))) return false;
+    WalkState16 *states = (WalkState16 *)tab;
+    const uint32_t nt = a.ntiles;
+    { ProfScope ps("dec_index_serial", st);
+      const dim3 zg((uint32_t)((a.g.nseg + 255) / 256), nt);
+      if (a.g.tsz == 4) { hipLaunchKernelGGL(walk_exit_zero_kernel<uint32_t>, zg, dim3(256), 0, st, a); hipLaunchKernelGGL((walk_probe_kernel<uint32_t, CM_BEST>), dim3(nt), dim3(64), 0, st, a, states, 16u); }
+      else { hipLaunchKernelGGL(walk_exit_zero_kernel<uint64_t>, zg, dim3(256), 0, st, a); hipLaunchKernelGGL((walk_probe_kernel<uint64_t, CM_BEST>), dim3(nt), dim3(64), 0, st, a, states, 16u); } }
+    return a.g.tsz == 4 ? launch_walk_exit<5, uint32_t, CM_BEST>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<6, uint64_t, CM_BEST>(a, st, tab, tab_bytes, max_bits);
+}
 template <uint32_t U, uint32_t N> struct WideTag { static constexpr uint32_t UB_ = U, NR_ = N; };
-void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+static bool walk_lds_attributes() {
     static const bool lds_ok = [] {
         bool ok = true;
         ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
@@ -1561,20 +1642,26 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 14>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 16>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 16>::LDS_BYTES) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<6>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<6>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<6>::LDS_BYTES) == hipSuccess;
         return ok;
     }();
-    (void)lds_ok;
+    return lds_ok;
+}
+static bool walk_exit_lds_ok() { return walk_lds_attributes(); }
+void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+    const bool lds_ok = walk_lds_attributes();
     const uint32_t nt = a.ntiles;
     if (a.g.tsz >= 4) {         // 32/64-bit FTL/BASE: the first segment parsed outright (band of rungs, entry state), then table + chain
         WalkState16 *states = (WalkState16 *)tab;
         const uint32_t nr = a.wide_band == 8 ? 8u : a.wide_band == 14 ? 14u : 16u;
         { ProfScope ps("dec_index_serial", st);
-          if (a.g.tsz == 4) hipLaunchKernelGGL(walk_probe_kernel<uint32_t>, dim3(nt), dim3(64), 0, st, a, states, nr);
-          else hipLaunchKernelGGL(walk_probe_kernel<uint64_t>, dim3(nt), dim3(64), 0, st, a, states, nr); }
+          if (a.g.tsz == 4) hipLaunchKernelGGL((walk_probe_kernel<uint32_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, nr);
+          else hipLaunchKernelGGL((walk_probe_kernel<uint64_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, nr); }
         if (a.g.bands == 1 && a.wide_band == 16 && lds_ok) {    // one band: exits of super-windows composed, a hop per 32768 bits (wide_band 17: the chain, a test hook)
-            if (a.g.tsz == 4 ? launch_walk_exit<5, uint32_t>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<6, uint64_t>(a, st, tab, tab_bytes, max_bits)) return;
+            if (a.g.tsz == 4 ? launch_walk_exit<5, uint32_t, CM_FTL>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<6, uint64_t, CM_FTL>(a, st, tab, tab_bytes, max_bits)) return;
         }
         auto run = [&](auto tag) {
             constexpr uint32_t UB = decltype(tag)::UB_, NRB = decltype(tag)::NR_;

@@ -473,7 +473,9 @@ template <typename T, bool STEP, typename RD> __device__ __forceinline__ void ge
 // Parse one unit.  rung / pcf are the running state of this band.  Returns false on a corrupt stream.
 // MODE: CM_FTL (no step, signal is an ordinary "no change"), CM_BASE / CM_BEST (step; signal opens the
 // common-factor and index forms, reference QB3decode.h:619-716).
-template <typename T, int MODE, typename RD> __device__ __forceinline__ bool parse_unit(RD &rd, uint32_t &rung, T &pcf, T (&g)[16]) {
+// flags (optional; the plain-stream walks of k_dec_walk.hip): bit 0 = a common-factor unit that takes the factor of the band's
+// last such unit (pcf as handed in), bit 1 = one that brings its own (pcf is that factor afterwards)
+template <typename T, int MODE, typename RD> __device__ __forceinline__ bool parse_unit(RD &rd, uint32_t &rung, T &pcf, T (&g)[16], uint32_t *flags = nullptr) {
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     bool signal = false;
     uint32_t delta = 0;
@@ -499,7 +501,8 @@ template <typename T, int MODE, typename RD> __device__ __forceinline__ bool par
             if (vr == 0) v = rd.get(1);
             else { T t = get_value<T, RD>(rd, vr); v = (uint64_t)((vr >= 3) ? unswap<T>(t, vr) : t); }   // cf values: rungs 1,2 unswapped (QB3encode.h:144-150)
             pcf = cf = (T)(v + ((uint64_t)own << cfrung));
-        }
+            if (flags) *flags |= 2u;
+        } else if (flags) *flags |= 1u;
         cf = (T)(cf + 2);
         if (r) {
             get_group<T, true, RD>(rd, r, g);
@@ -583,6 +586,7 @@ void launch_dec_px16(const DecArgs &a, const DecPlan &plan, hipStream_t st);    
 void launch_dec_px_best(const DecArgs &a, const DecPlan &plan, hipStream_t st);    // k_dec_px_best.hip
 void launch_dec_walk(const DecArgs &a, hipStream_t st);                            // k_dec_walk.hip: unit lengths of an index-less 8/16-bit stream
 void launch_prev_scan(const DecArgs &a, hipStream_t st);                           // k_dec_walk.hip
+bool launch_dec_walk_best(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);    // k_dec_walk.hip: plain single-band 32/64-bit common-factor streams
 void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);   // k_dec_walk.hip: plain 8- and 16-bit streams
 
 }  // namespace qb3dev

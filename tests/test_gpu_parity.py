@@ -1499,6 +1499,87 @@ def test_a_damaged_restart_table_costs_time_not_pixels(qb3, oracle, case):
     assert torch.equal(dec.decode(dbad, index=None), torch.from_numpy(raw).cuda()), "device flavour"
 
 
+@pytest.mark.parametrize("switch", ["", "QB3_WALK_TAB_KB=6144", "QB3_WIDE_BAND=17"], ids=["default", "exits-in-many-rounds", "chain-through-the-table"])
+def test_plain_single_band_wide_streams_by_exits(qb3, oracle, switch):
+    """plain single-band 32/64-bit streams: the walk by exits of super-windows (walk_exitW_kernel, walk_exit_chain_kernel,
+    walk_exit_units_kernel) -- rasters wide enough that the first unit of a block row leaves the band of sixteen rungs (walked
+    from the code lengths inside the kernel), data over all rungs, a truncated stream, a batch of tiles; with so little table
+    memory that the exits are taken in many rounds; and the chain through the table of round 3's first form, which stays for
+    rasters of more than one band.  Pixels exact in every case (reference QB3decode.h:293-412).  A child process each: the
+    switches are read once."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np, torch, ctypes as C
+sys.path.insert(0, %r)
+import qb3_amd
+from qb3_amd import device as qdev
+from oracle import pyoracle as o
+L = qb3_amd.lib
+for (w, h, dt, gen, mode, want_table) in [(2048, 1024, 5, "DEM", 8, True), (4100, 260, 5, "DEM", 4, True), (1500, 700, 7, "DEM", 8, True), (8192, 64, 5, "DEM", 8, True),
+                                          (512, 512, 5, "LANDSAT16", 4, True), (256, 256, 7, "FEW", 8, False), (128, 256, 5, "RANDOM", 8, False), (64, 64, 6, "RUNG63", 8, False),
+                                          (640, 480, 4, "TERRACE", 8, False),
+                                          # common-factor streams (QB3M_CF_H = 5, QB3M_BEST = 7): units with the signal code parsed inside the walk, super-windows
+                                          # in which a unit brings a factor of its own parsed outright by the hopping lane (QB3decode.h:619-716)
+                                          (2048, 1024, 5, "DEM", 5, True), (1500, 700, 7, "DEM", 7, True), (1024, 512, 5, "TERRACE", 5, True), (512, 512, 7, "FEW", 7, False),
+                                          (1024, 1024, 5, "SCALED", 5, True), (768, 512, 4, "LANDSAT16", 7, True)]:
+    if gen == "SCALED":                         # every value a multiple of ten: every unit takes the factor the first ones brought
+        img = (o.generate(w, h, 1, dt, "DEM", 11).astype(np.int64) // 16 * 10).astype(np.int32)
+    else:
+        img = o.generate(w, h, 1, dt, gen, 11)
+    ref = o.encode(img, dt, mode)
+    d = torch.from_numpy(ref).cuda()
+    dec = qdev.DeviceDecoder(d, len(ref))
+    L.qb3x_profile_enable(1); L.qb3x_profile_reset()
+    out = dec.decode(d, index=None)
+    torch.cuda.synchronize()
+    names = C.create_string_buffer(1024)
+    L.qb3x_profile_names(names, 1024)
+    L.qb3x_profile_enable(0)
+    assert np.array_equal(out.cpu().numpy(), img.view(np.uint8).ravel()), (w, h, dt, gen)
+    if want_table and ref[10] != 255:
+        assert b"dec_index_table" in names.value, (w, h, dt, gen, names.value)
+# the same stream cut short: an error or clamped pixels as the reference's reader gives, never a hang or a fault
+img = o.generate(1024, 1024, 1, 5, "DEM", 12)
+ref = o.encode(img, 5, 8)
+for cut in (len(ref) // 2, len(ref) - 1000):
+    d = torch.from_numpy(np.ascontiguousarray(ref[:cut])).cuda()
+    dims = (C.c_size_t * 3)()
+    q = L.qb3x_read_start_device(d.data_ptr(), cut, dims, None)
+    if q:
+        out = torch.zeros(img.nbytes, dtype=torch.uint8, device="cuda")
+        L.qb3x_decode_device(q, d.data_ptr(), out.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        L.qb3_destroy_decoder(q)
+# a batch of plain tiles
+w, h, n = 512, 384, 5
+imgs = [o.generate(w, h, 1, 5, "DEM", 40 + t) for t in range(n)]
+refs = [o.encode(im, 5, 8) for im in imgs]
+pitch = (max(len(r) for r in refs) + 3) // 4 * 4
+buf = np.zeros(n * pitch, dtype=np.uint8)
+sizes = (C.c_size_t * n)()
+for t, r in enumerate(refs):
+    buf[t * pitch:t * pitch + len(r)] = r; sizes[t] = len(r)
+dst = torch.from_numpy(buf).cuda()
+dims = (C.c_size_t * 3)()
+hdr = buf[:64].copy()
+q = L.qb3_read_start(hdr.ctypes.data, sizes[0], dims)
+assert L.qb3_read_info(q)
+out = torch.zeros(n * w * h * 4, dtype=torch.uint8, device="cuda")
+assert L.qb3x_decode_tiles(q, dst.data_ptr(), n, pitch, sizes, out.data_ptr(), w * h * 4, None, None) == n
+got = out.cpu().numpy()
+for t in range(n):
+    assert np.array_equal(got[t * w * h * 4:(t + 1) * w * h * 4], imgs[t].view(np.uint8).ravel()), t
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if switch:
+        name, _, value = switch.partition("=")
+        env[name] = value
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("case", [(256, 256, 1, 5, "DEM", FTL), (300, 200, 1, 7, "DEM", BASE), (260, 132, 3, 4, "NOISY3", BASE), (128, 128, 1, 5, "TERRACE", FTL),
                                   (128, 128, 1, 7, "FEW", FTL), (64, 64, 1, 6, "RUNG63", FTL), (256, 128, 5, 4, "RANDOM", FTL), (1024, 1024, 1, 5, "DEM", FTL),
                                   (1024, 768, 2, 7, "DEM", BASE), (509, 259, 1, 5, "DEM", FTL), (640, 480, 16, 4, "DEM", FTL), (2048, 2048, 1, 5, "LANDSAT16", BASE)],
