@@ -995,6 +995,7 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
             const uint64_t u0 = rd.position();
             ok = parse_unit<T, MODE>(rd, rung[c], pcf[c], g) && ok;     // (FTL / BASE: lengths and rungs are the same with and without the step)
             if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[gb * B + c] = (uint16_t)(rd.position() - u0);
+            else if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[gb * B + c] = (uint8_t)(rd.position() - u0);
             if (MODE == CM_BEST) for (uint32_t i = 0; i < 16; i++) tot[c] = (T)(tot[c] + smag_t<T>(g[i]));   // (common-factor streams: the segment's sum, for the scan that gives every segment its entering value)
             if (gb || nb == 1) { minr = rung[c] < minr ? rung[c] : minr; maxr = rung[c] > maxr ? rung[c] : maxr; }
         }
@@ -1279,20 +1280,22 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
 // walk_exit_chain_kernel: one lane hops from super-window to super-window (one dependent load each) and notes where each is
 // entered.  walk_exit_units_kernel: a lane per super-window parses its units from there: unit lengths, segment entries.
 // A unit that leaves the band of rungs or carries the signal code stops the walk: status bit 0, and the caller falls back.
+template <uint32_t UB> struct WalkValue { typedef typename std::conditional<UB == 3, uint8_t, typename std::conditional<UB == 4, uint16_t, typename std::conditional<UB == 5, uint32_t, uint64_t>::type>::type>::type type; };
 template <uint32_t UB> struct exitW {
-    static constexpr uint32_t NRUNG = 1u << UB, NR = 16, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;
-    static constexpr uint32_t W = UB == 5 ? 2048 : 1024, K = 32768 / W, SW = W * K, THREADS = 1024;
+    static constexpr uint32_t NRUNG = 1u << UB, NR = 16, NRB = NRUNG < NR ? NRUNG : NR, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;
+    static constexpr uint32_t W = UB == 6 ? 1024 : 2048, K = 32768 / W, SW = W * K, THREADS = 1024;
     // A walk leaves a window at the first unit that starts behind it AND is entered with a rung of the band: units entered
     // out of the band (the one behind a unit whose switch jumped out: the first unit of a block row of a wide raster) are
-    // walked on the spot from the code lengths, so a window can be entered up to PE bits in.
-    static constexpr uint32_t PE = MAXU + 512, NX = PE * NR;                               // states a window can be entered with
+    // walked on the spot from the code lengths, so a window can be entered up to PE bits in.  (8- and 16-bit data: the band
+    // is all the rungs there are.)
+    static constexpr uint32_t PE = MAXU + (UB >= 5 ? 512 : 0), NX = PE * NR;                // states a window can be entered with
     static constexpr uint32_t NPT = (W + UB + 2 + 15 * MAXC + 2 + 31) & ~31u;               // positions the table of a window looks at
     static constexpr uint32_t NPS = W + PE, NP1 = (NPS + MAXU + 2 + 31) & ~31u;             // positions with a switch entry; with a code length
     static constexpr uint32_t X_DEP = 1u << 30, X_SLOW = 1u << 31, X_CNT = 0x7fffu;          // (common-factor streams) a unit took the factor in force when the super-window was entered; a unit brought its own
     static constexpr uint32_t X_STOP = 0x7fffu;                                             // X: (position - W) * 16 + rung (15 bits: the entering state of the next window) | units << 15; stop: the low 15 bits all set
     static constexpr uint32_t T0 = 0, X0 = T0 + W * NR * 2, S0 = X0 + NX * 4, E1 = S0 + ((NPS * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT,
                               LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
-    static_assert(W + MAXU < 4095 && PE * NR + NR <= 0x7fff && K * W / 2 < (1u << 17) && (UB == 5 || UB == 6) && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk");
+    static_assert(W + MAXU < 4095 && PE * NR + NR <= 0x7fff && K * W / 2 < (1u << 15) + 1 && UB >= 3 && UB <= 6 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk");
 };
 
 template <uint32_t UB, bool CF>
@@ -1329,7 +1332,7 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
         for (uint32_t i = tid; i < W * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;  // (an entry no target rung fills: the unit leaves the band, or is the signal)
         __syncthreads();
 #pragma unroll 1
-        for (uint32_t rb = 0; rb < NR; rb++) {                                              // the rung the switch leads to
+        for (uint32_t rb = 0; rb < E::NRB; rb++) {                                          // the rung the switch leads to
             const uint32_t r = R0 + rb;
 #ifdef EXIT_EXP_NOTAB
             if (r && rb == 0) {
@@ -1366,7 +1369,7 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
             if (M[key] != M_NEED) continue;
             uint32_t pos = key / NR, r = key % NR, cnt = 0;                                 // (a state's low 15 bits: position * 16 + rung: the key itself)
             bool stop = false;
-            typedef typename std::conditional<UB == 5, uint32_t, uint64_t>::type TT;
+            typedef typename WalkValue<UB>::type TT;
             TT cfv = (TT)S.cf; uint32_t xfl = 0;                                            // (common-factor streams) the factor in force: the one behind the first segment until a unit brings its own
 #ifdef EXIT_EXP_NOWALK
             pos = W + (pos & 255);
@@ -1427,7 +1430,7 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
 template <uint32_t UB, int MODE>
 __global__ void __launch_bounds__(64) walk_exit_chain_kernel(const DecArgs a0, const uint32_t *xg, uint32_t nsuper, uint32_t s_begin, uint32_t s_count, WalkState16 *states, uint4 *entries) {
     typedef exitW<UB> E;
-    typedef typename std::conditional<UB == 5, uint32_t, uint64_t>::type T;
+    typedef typename WalkValue<UB>::type T;
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     if (threadIdx.x) return;
     WalkState16 *S = states + blockIdx.x;
@@ -1514,7 +1517,7 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
     T g[16], pcf = (T)((uint64_t)f.x | (uint64_t)f.y << 32), tot = 0;                    // (the factor in force where the super-window is entered)
     bool ok = true;
     uint16_t *ul = (uint16_t *)a.idx.ulen;
-    typedef typename std::conditional<sizeof(T) == 4, unsigned int, unsigned long long>::type AT;
+    typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned int>::type AT;    // (sums are added up for 32/64-bit common-factor streams only)
     for (; U < Uend; U++) {
         const uint64_t u0 = rd.position();
         if (U % NB == 0) {
@@ -1523,11 +1526,11 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
             if (MODE == CM_BEST) ((T *)a.idx.cf)[seg] = pcf;
         }
         ok = parse_unit<T, MODE>(rd, rung, pcf, g) && ok;                                   // (FTL / BASE: lengths and rungs are the same with and without the step)
-        if (MODE != CM_BEST) ul[U] = (uint16_t)(rd.position() - u0);
+        if (MODE != CM_BEST) { if (sizeof(T) == 1) ((uint8_t *)ul)[U] = (uint8_t)(rd.position() - u0); else ul[U] = (uint16_t)(rd.position() - u0); }
         else {                                                                              // the segment's sum of values: the scan makes entering values of them
 #pragma unroll
             for (uint32_t i = 0; i < 16; i++) tot = (T)(tot + smag_t<T>(g[i]));
-            if ((U + 1) % NB == 0 || U + 1 == Uend) { atomicAdd((AT *)a.idx.prev + U / NB, (AT)tot); tot = 0; }
+            if ((U + 1) % NB == 0 || U + 1 == Uend) { if (sizeof(T) >= 4) atomicAdd((AT *)a.idx.prev + U / NB, (AT)tot); tot = 0; }
         }
     }
     if (!ok) atomicOr(a.status, 1u);
@@ -1642,6 +1645,8 @@ static bool walk_lds_attributes() {
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 14>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 16>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 16>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<3>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<4>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<6>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
@@ -1654,6 +1659,13 @@ static bool walk_exit_lds_ok() { return walk_lds_attributes(); }
 void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
     const bool lds_ok = walk_lds_attributes();
     const uint32_t nt = a.ntiles;
+    if (a.g.tsz <= 2 && a.g.bands == 1 && a.wide_band == 16 && lds_ok) {       // one band of 8- or 16-bit data: the exits too (the band is all the rungs)
+        WalkState16 *states = (WalkState16 *)tab;
+        { ProfScope ps("dec_index_serial", st);
+          if (a.g.tsz == 1) hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 8u);
+          else hipLaunchKernelGGL((walk_probe_kernel<uint16_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 16u); }
+        if (a.g.tsz == 1 ? launch_walk_exit<3, uint8_t, CM_FTL>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<4, uint16_t, CM_FTL>(a, st, tab, tab_bytes, max_bits)) return;
+    }
     if (a.g.tsz >= 4) {         // 32/64-bit FTL/BASE: the first segment parsed outright (band of rungs, entry state), then table + chain
         WalkState16 *states = (WalkState16 *)tab;
         const uint32_t nr = a.wide_band == 8 ? 8u : a.wide_band == 14 ? 14u : 16u;
