@@ -458,7 +458,25 @@ def main():
             pdec.decode(pdst, out=pout, index=None)
             torch.cuda.synchronize()
             pdt = time.perf_counter() - p0
-            return {"ms_wall": round(pdt * 1e3, 2), "MPixel_s": round(pw * pw / pdt / 1e6, 1), "exact": bool(torch.equal(pout, pimg.reshape(-1).view(torch.uint8)))}
+            res = {"ms_wall": round(pdt * 1e3, 2), "MPixel_s": round(pw * pw / pdt / 1e6, 1), "exact": bool(torch.equal(pout, pimg.reshape(-1).view(torch.uint8)))}
+            if pb == 1:         # ... and through the reference's own entry point on host buffers (qb3_read_data: upload and download included)
+                import ctypes as C
+                L = qb3_amd.lib
+                hsrc = pdst[:int(pn)].cpu().numpy().copy()
+                hout = np.zeros(pout.numel(), dtype=np.uint8)
+                dims = (C.c_size_t * 3)()
+                hp = L.qb3_read_start(hsrc.ctypes.data, hsrc.size, dims)
+                if hp and L.qb3_read_info(hp):
+                    L.qb3_read_data(hp, hout.ctypes.data)       # (first call: device buffers, the table)
+                    h0 = time.perf_counter()
+                    got = L.qb3_read_data(hp, hout.ctypes.data)
+                    hdt = time.perf_counter() - h0
+                    res["qb3_read_data_ms_wall"] = round(hdt * 1e3, 2)
+                    res["qb3_read_data_MPixel_s"] = round(pw * pw / hdt / 1e6, 1)
+                    res["qb3_read_data_exact"] = bool(got == hout.size and np.array_equal(hout, pimg.reshape(-1).view(torch.uint8).cpu().numpy()))
+                if hp:
+                    L.qb3_destroy_decoder(hp)
+            return res
         pimg = synth.generate(4096, 4096, 3, dtype, "NOISY3", 1000, device=dev)
         plain = {"workload": "4096x4096x3 uint8 NOISY3 seed 1000, plain container, index = NULL"}
         plain.update(plain_decode(pimg, 4096))
@@ -466,12 +484,15 @@ def main():
         if args.size == 16384:
             plain["config2"] = {"workload": "the 16384x16384x3 raster of the headline, plain container, index = NULL"}
             plain["config2"].update(plain_decode(img, 16384))
-        # 32-bit data (config 4's raster): FTL through the table of a band of sixteen rungs; the common-factor stream still goes
-        # to the one-lane parser (a position table cannot be keyed by the factor in force)
-        for ptag, pmode, pname in (("int32_ftl", qb3_amd.QB3M_FTL, "QB3M_FTL"), ("int32_best", qb3_amd.QB3M_BEST, "QB3M_BEST")):
-            pimg = synth.generate(4096, 4096, 1, qb3_amd.QB3_I32, "DEM", 4, device=dev)
-            plain[ptag] = {"workload": f"4096x4096x1 int32 DEM seed 4, {pname}, plain container, index = NULL"}
-            plain[ptag].update(plain_decode(pimg, 4096, 1, qb3_amd.QB3_I32, pmode))
+        # one band (elevation rasters; config 4's): the walk by exits of super-windows (k_dec_walk.hip), also for common-factor streams
+        for ptag, pdt_, pgen, pmode, pname in (("int32_ftl", qb3_amd.QB3_I32, "DEM", qb3_amd.QB3M_FTL, "int32 DEM seed 4, QB3M_FTL"),
+                                               ("int32_best", qb3_amd.QB3_I32, "DEM", qb3_amd.QB3M_BEST, "int32 DEM seed 4, QB3M_BEST"),
+                                               ("int64_ftl", qb3_amd.QB3_I64, "DEM", qb3_amd.QB3M_FTL, "int64 DEM seed 4, QB3M_FTL"),
+                                               ("int16_base", qb3_amd.QB3_I16, "DEM", qb3_amd.QB3M_BASE, "int16 DEM seed 4, QB3M_BASE"),
+                                               ("uint8_grey", qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_FTL, "uint8 NOISY3 seed 4, QB3M_FTL")):
+            pimg = synth.generate(4096, 4096, 1, pdt_, pgen, 4, device=dev)
+            plain[ptag] = {"workload": f"4096x4096x1 {pname}, plain container, index = NULL"}
+            plain[ptag].update(plain_decode(pimg, 4096, 1, pdt_, pmode))
             del pimg
         torch.cuda.empty_cache()
 
