@@ -265,14 +265,20 @@ static RleWs rle_ws(void *ws, uint64_t n) {
     return w;
 }
 // size of the coded (decode = false) or expanded (decode = true) form of the n bytes at d_src; synchronises the stream
-int rle0_device_size(const void *d_src, uint64_t n, void *ws, bool decode, uint64_t *total, void *stream) {
+__global__ void __launch_bounds__(256) rle0_no_uniform_kernel(uint16_t *uniform, uint64_t nchunks, uint64_t n, uint64_t *total) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nchunks) uniform[i] = (uint16_t)0x100;
+    if (i == 0) total[0] = n;
+}
+int rle0_device_size(const void *d_src, uint64_t n, void *ws, bool decode, uint64_t *total, void *stream, bool no_uniform_chunk) {
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) { *total = 0; return 0; }
     const RleWs w = rle_ws(ws, n);
     const uint8_t *s = (const uint8_t *)d_src;
     {
     ProfScope ps(decode ? "rle0_expand_size" : "rle0_size", st);
-    hipLaunchKernelGGL(rle0_uniform_kernel, dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.total);
+    if (no_uniform_chunk) hipLaunchKernelGGL(rle0_no_uniform_kernel, dim3((uint32_t)((w.nchunks + 255) / 256)), dim3(256), 0, st, w.uniform, w.nchunks, n, w.total);
+    else hipLaunchKernelGGL(rle0_uniform_kernel, dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.total);
     if (decode) hipLaunchKernelGGL((rle0_pass_kernel<0, true>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr, w.total);
     else hipLaunchKernelGGL((rle0_pass_kernel<0, false>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr, w.total);
     }

@@ -419,7 +419,7 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
     prof_collect();
     *bits = res.total_bits;
-    if (zero_run) *zero_run = rle0_may_win(res) ? 1 : 0;
+    if (zero_run) *zero_run = rle0_may_win(res) ? (rle0_no_uniform_chunk(res) ? 2 : 1) : 0;      // (2: and no 4 KB of the stream hold one byte value only)
     if (carry)
         for (size_t c = 0; c < p->nbands; c++) {
             p->band[c].prev = (size_t)res.prev[c]; p->band[c].runbits = res.rung[c]; p->band[c].cf = (size_t)res.cf[c];
@@ -539,7 +539,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
             // own (the passes run in parallel: not in place), then behind the RLE mode's header
             const size_t n = len - hdr;
             uint64_t rsz64 = 0;
-            if (!p->d_rle.ensure(rle0_ws_bytes(n)) || rle0_device_size(out_dev + hdr, n, p->d_rle.p, false, &rsz64, st)) { p->error = QB3E_LIBERR; return 0; }
+            if (!p->d_rle.ensure(rle0_ws_bytes(n)) || rle0_device_size(out_dev + hdr, n, p->d_rle.p, false, &rsz64, st, has_run == 2)) { p->error = QB3E_LIBERR; return 0; }
             const size_t rsz = (size_t)rsz64;
             if (rsz <= maxsz - len_ref && rsz < n) {
                 uint8_t hdr2[80];

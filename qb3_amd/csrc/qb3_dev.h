@@ -70,6 +70,9 @@ struct EncResult {
 // at most one byte per position at which four zero bytes start.  So its output is at least n + ff_pairs / 2 - 1 - zero_run
 // bytes, and it can only be shorter than n when that is below n: for most streams the counts decide without the byte pass.
 inline bool rle0_may_win(const EncResult &r) { return r.zero_run > 0 && 2 * r.zero_run + 2 > r.ff_pairs; }
+// 4 KB of zero bytes hold 4093 such positions, 4 KB of 0xff 3072 such pairs inside dwords (fewer where chunks of the stream meet: a
+// dword shared by two chunks is not looked at): below both, the table of one-valued 4 KB chunks the byte pass skips long runs by is all "no"
+inline bool rle0_no_uniform_chunk(const EncResult &r) { return r.zero_run < 4000 && r.ff_pairs < 1024; }
 
 // Workspace sizes
 struct EncPlan {
@@ -184,7 +187,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
 // expanded (decode = true) form and synchronises the stream; rle0_device_write, called next with the same arguments,
 // writes it (does not synchronise).
 size_t rle0_ws_bytes(uint64_t n);
-int rle0_device_size(const void *d_src, uint64_t n, void *ws, bool decode, uint64_t *total, void *stream);
+int rle0_device_size(const void *d_src, uint64_t n, void *ws, bool decode, uint64_t *total, void *stream, bool no_uniform_chunk = false);     // no_uniform_chunk: the caller knows that no 4 KB of the bytes hold one value only
 int rle0_device_write(const void *d_src, uint64_t n, void *ws, bool decode, void *d_dst, void *stream);
 
 
