@@ -1535,6 +1535,276 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
     }
     if (!ok) atomicOr(a.status, 1u);
 }
+// ---- The same for 8-bit rasters of THREE bands (RGB).  The walk's state at a block boundary is (position, a rung per band):
+// 447 positions x 512 rung combinations = 228 864 states a super-window can be entered with -- too many to carry through every
+// window, but rungs aside the walks merge within one window (positions do, rung offsets never: about ten positions survive per
+// combination).  So the first window is walked by every state (its exit and block count go to global memory, G), the distinct
+// exits are ranked through a bitmap (D, a few thousand), only those are carried through the other windows of the super-window
+// (Xd, LDS), and at the end every state composes its first-window exit with what became of it.  One hop per super-window of
+// 65 536 bits as before; 915 KB of exits per super-window, so the stream is taken in rounds of what the table memory holds.
+template <uint32_t B> struct exitB {
+    static constexpr uint32_t UB = 3, NRUNG = 8, NR = 8, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;        // 149
+    static constexpr uint32_t W = 2048, K = 32, SW = W * K, THREADS = 1024;
+    static constexpr uint32_t PE = B * MAXU, NC = 1u << (3 * B), NKEY = PE * NC;                             // entering positions, rung combinations, states
+    static constexpr uint32_t TP = W + (B - 1) * MAXU;                                                        // positions with a table row: the later units of a block that starts in the window
+    static constexpr uint32_t NPT = (TP + UB + 2 + 15 * MAXC + 2 + 31) & ~31u, NP1 = (TP + MAXU + 2 + 63) & ~31u;
+    static constexpr uint32_t KEYB = 18, KEYM = (1u << KEYB) - 1, X_STOP = KEYM, DCAP = 8192;                 // X: state | blocks << 18; stop: the state field all set
+    static constexpr uint32_t BMW = (NKEY + 31) / 32;                                                         // words of the bitmap of first-window exits
+    static constexpr uint32_t T0 = 0, BM0 = T0 + ((TP * NR * 2 + 15) & ~15u), PF0 = BM0 + BMW * 4, XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
+                              E1 = S0 + ((TP * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
+    static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && SW / (2 * B) < (1u << (32 - KEYB)) && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
+};
+
+template <uint32_t B>
+__global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint32_t *xg, uint32_t s_begin, uint32_t s_count, const WalkState16 *states) {
+    typedef exitB<B> E;
+    constexpr uint32_t W = E::W, NR = E::NR, NPT = E::NPT, NP1 = E::NP1, TP = E::TP, MAXC = E::MAXC, NRUNG = E::NRUNG, NKEY = E::NKEY, NT = E::THREADS, UB = E::UB;
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    const WalkState16 &S = states[blockIdx.y];
+    if (S.bad) return;
+    const uint64_t base = S.P + (uint64_t)(s_begin + blockIdx.x) * E::SW;
+    if (base >= a.in_bits) return;                                                          // (uniform) no walk comes here
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *T = (uint16_t *)(smem + E::T0), *sw = (uint16_t *)(smem + E::S0), *pf = (uint16_t *)(smem + E::PF0);
+    uint32_t *bm = (uint32_t *)(smem + E::BM0), *Xd = (uint32_t *)(smem + E::XD0), *words = (uint32_t *)(smem + E::WORDS);
+    uint8_t *t1 = smem + E::E1, *eA = smem + E::EA, *eB = smem + E::EB;
+    uint32_t *G = xg + ((uint64_t)blockIdx.y * s_count + blockIdx.x) * NKEY;               // the super-window's exits, entering state by entering state
+    __shared__ uint32_t s_D;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t endw = (a.in_bit0 + a.in_bits + 31) >> 5;
+    // a state through the window: whole blocks until one starts behind it.  Returns the state behind | blocks << 18, or the stop.
+    auto walk = [&](uint32_t key) -> uint32_t {
+        uint32_t pos = key >> (3 * B), r[B], cnt = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < B; c++) r[c] = (key >> (3 * c)) & 7u;
+        while (pos < W) {
+#pragma unroll
+            for (uint32_t c = 0; c < B; c++) {
+                const uint32_t e = T[pos * NR + r[c]];
+                if (e == 0xffffu) return E::X_STOP;                                         // the signal code: not a stream for this walk
+                pos = e & 0xfffu; r[c] = e >> 12;
+            }
+            cnt++;
+        }
+        uint32_t k2 = (pos - W) << (3 * B);
+#pragma unroll
+        for (uint32_t c = 0; c < B; c++) k2 |= r[c] << (3 * c);
+        return k2 | (cnt << E::KEYB);
+    };
+    uint32_t D = 0;
+#pragma unroll 1
+    for (uint32_t k = 0; k < E::K; k++) {
+        const uint64_t q0 = a.in_bit0 + base + (uint64_t)k * W, w0 = q0 >> 5;
+        const uint32_t sh = (uint32_t)q0 & 31;
+        for (uint32_t i = tid; i < NP1 / 32 + 3; i += NT) words[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
+        __syncthreads();
+        auto bits = [&](uint32_t i) { const uint32_t b = sh + i, j = b >> 5; return __builtin_amdgcn_alignbit(words[j + 1], words[j], b & 31); };
+        for (uint32_t i = tid; i < NP1; i += NT) { const uint32_t x = bits(i); t1[i] = (uint8_t)((x & 1) + ((x & 3) == 3)); }
+        for (uint32_t o = tid; o < TP; o += NT) {
+            uint32_t delta = 0; bool sig = false;
+            const uint32_t cs = walk_switch<UB>(bits(o), delta, sig);
+            sw[o] = (uint16_t)(cs | (delta << 4) | ((sig ? 1u : 0u) << 10) | ((bits(o + cs) & 1u) << 11));
+        }
+        for (uint32_t i = tid; i < TP * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t r = 0; r < NRUNG; r++) {                                              // the rung the switch leads to
+            if (r) {
+                for (uint32_t i = tid; i < NPT - MAXC; i += NT) { const uint32_t e = t1[i]; eA[i] = (uint8_t)(e + t1[i + r + e]); }
+                __syncthreads();
+                for (uint32_t i = tid; i < NPT - 3 * MAXC; i += NT) { const uint32_t e = eA[i]; eB[i] = (uint8_t)(e + eA[i + 2 * r + e]); }
+                __syncthreads();
+                for (uint32_t i = tid; i < NPT - 7 * MAXC; i += NT) { const uint32_t e = eB[i]; eA[i] = (uint8_t)(e + eB[i + 4 * r + e]); }
+                __syncthreads();
+            }
+            for (uint32_t o = tid; o < TP; o += NT) {
+                const uint32_t s = sw[o], cs = s & 15u, delta = (s >> 4) & 63u;
+                if ((s >> 10) & 1u) continue;
+                const uint32_t bin = (r - delta) & (NRUNG - 1);
+                uint32_t u = cs + (((s >> 11) & 1u) ? 17u : 1u);
+                if (r) { const uint32_t n8 = 8 * r + eA[o + cs]; u = cs + n8 + 8 * r + eA[o + cs + n8]; }
+                T[o * NR + bin] = (uint16_t)((o + u) | (r << 12));
+            }
+            __syncthreads();
+        }
+        if (k == 0) {
+            for (uint32_t i = tid; i < E::BMW; i += NT) bm[i] = 0;
+            __syncthreads();
+            for (uint32_t key = tid; key < NKEY; key += NT) {                               // every state through the first window
+                const uint32_t x = walk(key);
+                G[key] = x;
+                if ((x & E::KEYM) != E::X_STOP) atomicOr(&bm[(x & E::KEYM) >> 5], 1u << (x & 31u));
+            }
+            __syncthreads();
+            // rank of every distinct exit: exclusive prefix of the bitmap words' bit counts (the scan's scratch: Xd, not yet in use)
+            constexpr uint32_t PER = (E::BMW + NT - 1) / NT;
+            uint32_t mine = 0;
+            for (uint32_t i = 0; i < PER; i++) { const uint32_t w = tid * PER + i; if (w < E::BMW) mine += __popc(bm[w]); }
+            Xd[tid] = mine;
+            __syncthreads();
+            for (uint32_t d = 1; d < NT; d <<= 1) {
+                const uint32_t y = tid >= d ? Xd[tid - d] : 0u;
+                __syncthreads();
+                Xd[tid] += y;
+                __syncthreads();
+            }
+            uint32_t run = Xd[tid] - mine;
+            if (tid == NT - 1) s_D = Xd[tid];
+            __syncthreads();
+            D = s_D;
+            if (D > E::DCAP) {                                                              // (uniform) more distinct exits than are carried: the hop parses this super-window outright
+                for (uint32_t key = tid; key < NKEY; key += NT) G[key] = E::X_STOP;
+                return;
+            }
+            for (uint32_t i = 0; i < PER; i++) { const uint32_t w = tid * PER + i; if (w < E::BMW) { pf[w] = (uint16_t)run; run += __popc(bm[w]); } }
+            __syncthreads();
+            for (uint32_t w = tid; w < E::BMW; w += NT) {                                   // the distinct exits, in rank order
+                uint32_t m = bm[w], j = pf[w];
+                while (m) { const uint32_t b = __ffs(m) - 1; Xd[j++] = w * 32 + b; m &= m - 1; }
+            }
+            __syncthreads();
+        } else {
+            for (uint32_t j = tid; j < D; j += NT) {                                        // the distinct walks through this window
+                const uint32_t x = Xd[j];
+                if ((x & E::KEYM) == E::X_STOP) continue;
+                const uint32_t y = walk(x & E::KEYM);
+                Xd[j] = (y & E::KEYM) == E::X_STOP ? E::X_STOP : (y & E::KEYM) | (((x >> E::KEYB) + (y >> E::KEYB)) << E::KEYB);
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t key = tid; key < NKEY; key += NT) {                                       // every state: its first-window exit, then what became of that
+        const uint32_t e = G[key];
+        if ((e & E::KEYM) == E::X_STOP) continue;
+        const uint32_t k1 = e & E::KEYM, w = k1 >> 5;
+        const uint32_t x = Xd[pf[w] + __popc(bm[w] & ((1u << (k1 & 31u)) - 1u))];
+        G[key] = (x & E::KEYM) == E::X_STOP ? E::X_STOP : (x & E::KEYM) | (((e >> E::KEYB) + (x >> E::KEYB)) << E::KEYB);
+    }
+}
+
+// the hop for rasters of B bands: entries {position lo, hi, block, rungs (4 bits a band)}
+template <uint32_t B>
+__global__ void __launch_bounds__(64) walk_exitB_chain_kernel(const DecArgs a0, const uint32_t *xg, uint32_t nsuper, uint32_t s_begin, uint32_t s_count, WalkState16 *states, uint4 *entries) {
+    typedef exitB<B> E;
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    if (threadIdx.x) return;
+    WalkState16 *S = states + blockIdx.x;
+    if (S->bad) return;
+    const uint64_t nblocks = a.g.nblocks, P0 = S->P;
+    uint4 *en = entries + (uint64_t)blockIdx.x * 2 * (nsuper + 2), *hd = en + 2 * (nsuper + 1);
+    uint64_t P = P0, U = S->unit / B;
+    uint32_t rr = (uint32_t)S->rungs & ((1u << (4 * B)) - 1), s = 0;
+    bool bad = false, done = false;
+    if (s_begin) {
+        const uint4 h = *hd;
+        if (h.y) return;
+        const uint4 e = en[2 * s_begin];
+        P = (uint64_t)e.x | (uint64_t)e.y << 32; U = e.z; rr = e.w; s = s_begin;
+        bad = h.x != s_begin;
+    }
+    const uint32_t s_end = s_begin + s_count < nsuper ? s_begin + s_count : nsuper;
+    const uint32_t *x0 = xg + (uint64_t)blockIdx.x * s_count * E::NKEY;
+    while (!bad) {
+        en[2 * s] = make_uint4((uint32_t)P, (uint32_t)(P >> 32), (uint32_t)U, rr);
+        en[2 * s + 1] = make_uint4(0u, 0u, 0u, 0u);
+        if (U >= nblocks) { done = true; break; }
+        if (s >= s_end) { bad = s >= nsuper; break; }
+        if (P >= a.in_bits) { bad = true; break; }
+        const uint64_t base = P0 + (uint64_t)s * E::SW;
+        uint32_t key = (uint32_t)(P - base) << (3 * B);
+        for (uint32_t c = 0; c < B; c++) key |= ((rr >> (4 * c)) & 7u) << (3 * c);
+        const uint32_t x = x0[(uint64_t)(s - s_begin) * E::NKEY + key];
+        s++;
+        if ((x & E::KEYM) != E::X_STOP) {
+            U += x >> E::KEYB;
+            const uint32_t k2 = x & E::KEYM;
+            P = base + E::SW + (k2 >> (3 * B));
+            rr = 0;
+            for (uint32_t c = 0; c < B; c++) rr |= ((k2 >> (3 * c)) & 7u) << (4 * c);
+            continue;
+        }
+        // this super-window by the units themselves: whole blocks up to the first that starts behind it
+        Reader rd;
+        rd.init(a.in32, a.in_bit0 + P, a.in_bit0 + a.in_bits);
+        uint32_t rung[B];
+        for (uint32_t c = 0; c < B; c++) rung[c] = (rr >> (4 * c)) & 15u;
+        uint8_t pc = 0, g[16];
+        bool ok = true;
+        const uint64_t end = base + E::SW;
+        while (ok && U < nblocks) {
+            const uint64_t pos = rd.position() - a.in_bit0;
+            if (pos >= a.in_bits || pos >= end) break;
+            for (uint32_t c = 0; c < B; c++) ok = parse_unit<uint8_t, CM_FTL>(rd, rung[c], pc, g) && ok;
+            U++;
+        }
+        P = rd.position() - a.in_bit0;
+        rr = 0;
+        for (uint32_t c = 0; c < B; c++) rr |= rung[c] << (4 * c);
+        if (!ok || (U < nblocks && (P < end || P - end >= E::PE))) { bad = true; break; }
+    }
+    *hd = make_uint4(s, done ? 1u : 0u, 0u, 0u);
+    if (bad) { S->bad = 1u; atomicOr(a.status, 1u); }
+}
+
+// a lane per super-window parses its blocks: unit lengths, segment entries (rasters of several bands)
+template <typename T>
+__global__ void __launch_bounds__(64) walk_exit_blocks_kernel(const DecArgs a0, const WalkState16 *states, const uint4 *entries, uint32_t nsuper) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.y);
+    const WalkState16 &S = states[blockIdx.y];
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    const uint4 *en = entries + (uint64_t)blockIdx.y * 2 * (nsuper + 2);
+    const uint4 hd = en[2 * (nsuper + 1)];
+    if (S.bad || !hd.y || s >= hd.x) return;
+    const uint4 e = en[2 * s];
+    const uint32_t B = a.g.bands;
+    const uint64_t nblocks = a.g.nblocks, NB = a.g.seg_blocks;
+    uint64_t U = e.z, Uend = en[2 * s + 2].z;
+    if (Uend > nblocks) Uend = nblocks;
+    uint32_t rung[4];
+    for (uint32_t c = 0; c < 4; c++) rung[c] = (e.w >> (4 * c)) & 15u;
+    Reader rd;
+    rd.init(a.in32, a.in_bit0 + ((uint64_t)e.x | (uint64_t)e.y << 32), a.in_bit0 + a.in_bits);
+    T g[16], pcf = 0;
+    bool ok = true;
+    for (; U < Uend; U++) {
+        if (U % NB == 0) {
+            const uint64_t seg = U / NB;
+            a.idx.bitpos[seg] = rd.position() - a.in_bit0;
+            for (uint32_t c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)rung[c];
+        }
+        for (uint32_t c = 0; c < B; c++) {
+            const uint64_t u0 = rd.position();
+            ok = parse_unit<T, CM_FTL>(rd, rung[c], pcf, g) && ok;
+            if (sizeof(T) == 1) ((uint8_t *)a.idx.ulen)[U * B + c] = (uint8_t)(rd.position() - u0); else ((uint16_t *)a.idx.ulen)[U * B + c] = (uint16_t)(rd.position() - u0);
+        }
+    }
+    if (!ok) atomicOr(a.status, 1u);
+}
+
+template <uint32_t B>
+static bool launch_walk_exitB(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+    typedef exitB<B> E;
+    const uint32_t nt = a.ntiles;
+    const uint64_t ns = (max_bits + E::SW - 1) / E::SW;
+    const size_t fixed = (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255) + (((size_t)nt * (ns + 2) * 32 + 255) & ~(size_t)255);
+    if (ns == 0 || ns > 0x7fffffffu || tab_bytes < fixed + (size_t)nt * E::NKEY * 4) return false;
+    const uint64_t fit = (tab_bytes - fixed) / ((size_t)nt * E::NKEY * 4);
+    const uint32_t nsuper = (uint32_t)ns, slab = (uint32_t)(fit < ns ? fit : ns);
+    WalkState16 *states = (WalkState16 *)tab;
+    uint4 *entries = (uint4 *)((uint8_t *)tab + (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255));
+    uint32_t *xg = (uint32_t *)((uint8_t *)tab + fixed);
+    for (uint32_t s0 = 0; s0 < nsuper; s0 += slab) {
+        const uint32_t cnt = nsuper - s0 < slab ? nsuper - s0 : slab;
+        { ProfScope ps("dec_index_table", st);
+          hipLaunchKernelGGL(walk_exitB_kernel<B>, dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states); }
+        ProfScope ps("dec_index_serial", st);
+        hipLaunchKernelGGL(walk_exitB_chain_kernel<B>, dim3(nt), dim3(64), 0, st, a, (const uint32_t *)xg, nsuper, s0, cnt, states, entries);
+    }
+    ProfScope ps("dec_index_serial", st);
+    hipLaunchKernelGGL(walk_exit_blocks_kernel<uint8_t>, dim3((nsuper + 63) / 64, nt), dim3(64), 0, st, a, (const WalkState16 *)states, (const uint4 *)entries, nsuper);
+    return true;
+}
+
 // memory of the exit walk: states, entries, and the exits of as many super-windows as fit (at least one a tile)
 template <uint32_t UB> static bool walk_exit_layout(uint32_t nt, uint64_t max_bits, size_t tab_bytes, uint32_t *nsuper, uint32_t *slab, size_t *x_off) {
     typedef exitW<UB> E;
@@ -1645,6 +1915,7 @@ static bool walk_lds_attributes() {
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 14>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 16>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 16>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<3>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<3>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<4>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
@@ -1665,6 +1936,12 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
           if (a.g.tsz == 1) hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 8u);
           else hipLaunchKernelGGL((walk_probe_kernel<uint16_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 16u); }
         if (a.g.tsz == 1 ? launch_walk_exit<3, uint8_t, CM_FTL>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<4, uint16_t, CM_FTL>(a, st, tab, tab_bytes, max_bits)) return;
+    }
+    if (a.g.tsz == 1 && a.g.bands == 3 && a.wide_band == 16 && lds_ok) {        // 8-bit RGB: exits with the rung of every band in the state
+        WalkState16 *states = (WalkState16 *)tab;
+        { ProfScope ps("dec_index_serial", st);
+          hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 8u); }
+        if (launch_walk_exitB<3>(a, st, tab, tab_bytes, max_bits)) return;
     }
     if (a.g.tsz >= 4) {         // 32/64-bit FTL/BASE: the first segment parsed outright (band of rungs, entry state), then table + chain
         WalkState16 *states = (WalkState16 *)tab;
