@@ -1556,7 +1556,7 @@ template <uint32_t B> struct exitB {
 };
 
 template <uint32_t B>
-__global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint32_t *xg, uint32_t s_begin, uint32_t s_count, const WalkState16 *states) {
+__global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint32_t *xg, uint32_t s_begin, uint32_t s_count, const WalkState16 *states, uint32_t dcap) {
     typedef exitB<B> E;
     constexpr uint32_t W = E::W, NR = E::NR, NPT = E::NPT, NP1 = E::NP1, TP = E::TP, MAXC = E::MAXC, NRUNG = E::NRUNG, NKEY = E::NKEY, NT = E::THREADS, UB = E::UB;
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
@@ -1652,7 +1652,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
             if (tid == NT - 1) s_D = Xd[tid];
             __syncthreads();
             D = s_D;
-            if (D > E::DCAP) {                                                              // (uniform) more distinct exits than are carried: the hop parses this super-window outright
+            if (D > dcap) {                                                                 // (uniform) more distinct exits than are carried (dcap <= DCAP; less: a test hook): the hop parses this super-window outright
                 for (uint32_t key = tid; key < NKEY; key += NT) G[key] = E::X_STOP;
                 return;
             }
@@ -1796,7 +1796,7 @@ static bool launch_walk_exitB(const DecArgs &a, hipStream_t st, void *tab, size_
     for (uint32_t s0 = 0; s0 < nsuper; s0 += slab) {
         const uint32_t cnt = nsuper - s0 < slab ? nsuper - s0 : slab;
         { ProfScope ps("dec_index_table", st);
-          hipLaunchKernelGGL(walk_exitB_kernel<B>, dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states); }
+          hipLaunchKernelGGL(walk_exitB_kernel<B>, dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states, a.wide_band == 18 ? 64u : E::DCAP); }
         ProfScope ps("dec_index_serial", st);
         hipLaunchKernelGGL(walk_exitB_chain_kernel<B>, dim3(nt), dim3(64), 0, st, a, (const uint32_t *)xg, nsuper, s0, cnt, states, entries);
     }
@@ -1937,7 +1937,7 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
           else hipLaunchKernelGGL((walk_probe_kernel<uint16_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 16u); }
         if (a.g.tsz == 1 ? launch_walk_exit<3, uint8_t, CM_FTL>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<4, uint16_t, CM_FTL>(a, st, tab, tab_bytes, max_bits)) return;
     }
-    if (a.g.tsz == 1 && a.g.bands == 3 && a.wide_band == 16 && lds_ok) {        // 8-bit RGB: exits with the rung of every band in the state
+    if (a.g.tsz == 1 && a.g.bands == 3 && (a.wide_band == 16 || a.wide_band == 18) && lds_ok) {    // 8-bit RGB: exits with the rung of every band in the state (18: a test hook, see dcap)
         WalkState16 *states = (WalkState16 *)tab;
         { ProfScope ps("dec_index_serial", st);
           hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 8u); }

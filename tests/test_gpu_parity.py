@@ -1499,6 +1499,72 @@ def test_a_damaged_restart_table_costs_time_not_pixels(qb3, oracle, case):
     assert torch.equal(dec.decode(dbad, index=None), torch.from_numpy(raw).cuda()), "device flavour"
 
 
+@pytest.mark.parametrize("switch", ["", "QB3_WALK_TAB_KB=4096", "QB3_WIDE_BAND=18", "QB3_WIDE_BAND=17"],
+                         ids=["default", "exits-in-many-rounds", "super-windows-parsed-by-the-hopping-lane", "chain-through-the-table"])
+def test_plain_rgb_streams_by_exits(qb3, oracle, switch):
+    """plain 8-bit RGB streams: the walk by exits with a rung per band in the state (walk_exitB_kernel, walk_exitB_chain_kernel,
+    walk_exit_blocks_kernel) -- odd sizes, FTL and BASE, data of every kind, a truncated stream, a batch of tiles; with table
+    memory for four super-windows a round; with the cap on distinct exits set so low that every super-window is parsed by
+    the hopping lane; and the chain through the table, which other band counts still take.  Pixels exact in every case."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np, torch, ctypes as C
+sys.path.insert(0, %r)
+import qb3_amd
+from qb3_amd import device as qdev
+from oracle import pyoracle as o
+L = qb3_amd.lib
+for (w, h, gen, mode) in [(1024, 1024, "NOISY3", 8), (1100, 700, "NOISY3", 4), (509, 259, "GRAD", 8), (2048, 300, "PALETTE", 8), (640, 480, "RANDOM", 8),
+                          (768, 512, "FEW", 4), (256, 256, "CONST", 8), (4096, 64, "NOISY3", 0)]:
+    img = o.generate(w, h, 3, 0, gen, 21)
+    ref = o.encode(img, 0, mode)
+    d = torch.from_numpy(ref).cuda()
+    dec = qdev.DeviceDecoder(d, len(ref))
+    out = dec.decode(d, index=None)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), img.view(np.uint8).ravel()), (w, h, gen, mode)
+    got, dims, _, _ = qb3_amd.decode(ref)
+    assert np.array_equal(got, img.view(np.uint8).ravel()), (w, h, gen, mode, "host")
+img = o.generate(1024, 1024, 3, 0, "NOISY3", 22)
+ref = o.encode(img, 0, 8)
+for cut in (len(ref) // 2, len(ref) - 1000):         # cut short: an error or clamped pixels, never a hang or a fault
+    d = torch.from_numpy(np.ascontiguousarray(ref[:cut])).cuda()
+    dims = (C.c_size_t * 3)()
+    q = L.qb3x_read_start_device(d.data_ptr(), cut, dims, None)
+    if q:
+        out = torch.zeros(img.nbytes, dtype=torch.uint8, device="cuda")
+        L.qb3x_decode_device(q, d.data_ptr(), out.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        L.qb3_destroy_decoder(q)
+w, h, n = 512, 384, 5
+imgs = [o.generate(w, h, 3, 0, "NOISY3", 60 + t) for t in range(n)]
+refs = [o.encode(im, 0, 8) for im in imgs]
+pitch = (max(len(r) for r in refs) + 3) // 4 * 4
+buf = np.zeros(n * pitch, dtype=np.uint8)
+sizes = (C.c_size_t * n)()
+for t, r in enumerate(refs):
+    buf[t * pitch:t * pitch + len(r)] = r; sizes[t] = len(r)
+dst = torch.from_numpy(buf).cuda()
+dims = (C.c_size_t * 3)()
+hdr = buf[:64].copy()
+q = L.qb3_read_start(hdr.ctypes.data, sizes[0], dims)
+assert L.qb3_read_info(q)
+out = torch.zeros(n * w * h * 3, dtype=torch.uint8, device="cuda")
+assert L.qb3x_decode_tiles(q, dst.data_ptr(), n, pitch, sizes, out.data_ptr(), w * h * 3, None, None) == n
+got = out.cpu().numpy()
+for t in range(n):
+    assert np.array_equal(got[t * w * h * 3:(t + 1) * w * h * 3], imgs[t].view(np.uint8).ravel()), t
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if switch:
+        name, _, value = switch.partition("=")
+        env[name] = value
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("switch", ["", "QB3_WALK_TAB_KB=6144", "QB3_WIDE_BAND=17"], ids=["default", "exits-in-many-rounds", "chain-through-the-table"])
 def test_plain_single_band_wide_streams_by_exits(qb3, oracle, switch):
     """plain single-band 32/64-bit streams: the walk by exits of super-windows (walk_exitW_kernel, walk_exit_chain_kernel,
