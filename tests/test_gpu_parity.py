@@ -1537,7 +1537,7 @@ for cut in (len(ref) // 2, len(ref) - 1000):         # cut short: an error or cl
         L.qb3x_decode_device(q, d.data_ptr(), out.data_ptr(), None, None)
         torch.cuda.synchronize()
         L.qb3_destroy_decoder(q)
-w, h, n = 512, 384, 5
+w, h, n = 512, 384, 3            # (up to four tiles a call go by exits, larger batches by a chain a tile)
 imgs = [o.generate(w, h, 3, 0, "NOISY3", 60 + t) for t in range(n)]
 refs = [o.encode(im, 0, 8) for im in imgs]
 pitch = (max(len(r) for r in refs) + 3) // 4 * 4
