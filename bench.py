@@ -260,6 +260,10 @@ def measure_tiles(torch, qb3_amd, synth, qdev, dev, ntiles, steps, seed0=1000):
                             "encode_MPixel_s": round(px / (t_enc_i / steps) / 1e6, 1), "decode_from_containers_MPixel_s": round(px / (t_dec_i / steps) / 1e6, 1),
                             "restart_table_bytes": table_bytes_all},
            "kernels": kernel_table(avg, algo), "roofline": roofline_of(avg, algo, ENC_KERNELS + DEC_KERNELS)}
+    if res["roofline"] is not None:
+        res["roofline"]["traffic"], valu = pmc_traffic(res["roofline"]["kernel"], "c5_one_rank")
+        if valu:
+            res["roofline"]["valu"] = valu
     return res, tc, imgs, out
 
 
@@ -595,27 +599,33 @@ def run_other(wl, args, torch, qb3_amd, synth, qdev, dev):
     """configs 3, 4 and 5 on one GPU, a few steps each"""
     steps = max(3, min(args.steps, 5))
     out = {}
-    if wl == "plain":       # a plain container (what the reference writes) decoded from the stream alone: the serial walk
+    if wl == "plain":       # plain containers (what the reference writes) decoded from the stream alone: the walks of k_dec_walk.hip
         w = 4096
-        img = synth.generate(w, w, 3, qb3_amd.QB3_U8, "NOISY3", 1000, device=dev)
-        enc = qdev.DeviceEncoder(w, w, 3, qb3_amd.QB3_U8, mode=qb3_amd.QB3M_FTL)
-        dst, n, _ = enc.encode(img)
-        dec = qdev.DeviceDecoder(dst, n)
-        res = torch.empty(w * w * 3, dtype=torch.uint8, device=dev)
-        dec.decode(dst, out=res, index=None)
-        prof = Prof(qdev)
-        prof.start()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        for tag, bands, dt_, gen, seed, mode, name in (("plain", 3, qb3_amd.QB3_U8, "NOISY3", 1000, qb3_amd.QB3M_FTL, "x3 uint8 NOISY3 seed 1000, QB3M_FTL"),
+                                                       ("plain_int32_ftl", 1, qb3_amd.QB3_I32, "DEM", 4, qb3_amd.QB3M_FTL, "x1 int32 DEM seed 4, QB3M_FTL"),
+                                                       ("plain_int32_best", 1, qb3_amd.QB3_I32, "DEM", 4, qb3_amd.QB3M_BEST, "x1 int32 DEM seed 4, QB3M_BEST"),
+                                                       ("plain_int16_base", 1, qb3_amd.QB3_I16, "DEM", 4, qb3_amd.QB3M_BASE, "x1 int16 DEM seed 4, QB3M_BASE")):
+            img = synth.generate(w, w, bands, dt_, gen, seed, device=dev)
+            enc = qdev.DeviceEncoder(w, w, bands, dt_, mode=mode)
+            dst, n, _ = enc.encode(img)
+            dec = qdev.DeviceDecoder(dst, n)
+            res = torch.empty(img.numel() * img.element_size(), dtype=torch.uint8, device=dev)
             dec.decode(dst, out=res, index=None)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        avg = prof.stop()
-        # (the table and the chain run once per slab of the stream: launches > steps; ms per decode = avg_ms * launches / steps)
-        out["plain"] = {"workload": "4096x4096x3 uint8 NOISY3 seed 1000, QB3M_FTL, plain container, qb3x_decode_device with index = NULL",
-                        "stream_bytes": int(n), "ms_wall": round(dt * 1e3, 2), "MPixel_s": round(w * w / dt / 1e6, 1), "exact": bool(torch.equal(res, img.reshape(-1))),
+            prof = Prof(qdev)
+            prof.start()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                dec.decode(dst, out=res, index=None)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            avg = prof.stop()
+            # (exits and hops run once per round of the stream: launches >= steps; ms per decode = avg_ms * launches / steps)
+            out[tag] = {"workload": f"4096x4096{name}, plain container, qb3x_decode_device with index = NULL",
+                        "stream_bytes": int(n), "ms_wall": round(dt * 1e3, 2), "MPixel_s": round(w * w / dt / 1e6, 1), "exact": bool(torch.equal(res, img.reshape(-1).view(torch.uint8))),
                         "kernels": {k: {"avg_ms": round(v[0], 4), "launches": v[1], "ms_per_decode": round(v[0] * v[1] / steps, 3)} for k, v in sorted(avg.items())}}
+            del img, enc, dec, dst, res
+            torch.cuda.empty_cache()
     elif wl == "c2best":    # not a BASELINE configuration: the raster of configs[1] in QB3M_BEST (common factor + index coding)
         out["c2_best"] = measure_image(torch, qb3_amd, synth, qdev, dev, "c2_best", 16384, 16384, 3, qb3_amd.QB3_U8, "NOISY3", 2, qb3_amd.QB3M_BEST, steps,
                                        "16384x16384x3 uint8 NOISY3 seed 2, QB3M_BEST")

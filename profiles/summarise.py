@@ -27,7 +27,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # library profile names (qb3x_profile_names) by a substring of the kernel symbol
-KEYS = [("enc_px_best_sample_kernel", "enc_best_sample"), ("enc_best_sample_kernel", "enc_best_sample"),
+KEYS = [("walk_exitW_kernel", "dec_index_table"), ("walk_exitB_kernel", "dec_index_table"), ("walk_exitB_chain", "dec_index_serial"), ("walk_exit_", "dec_index_serial"),
+        ("walk_probe", "dec_index_serial"), ("walk_tableW", "dec_index_table"), ("walk_chainW", "dec_index_serial"), ("walk_table16", "dec_index_table"), ("walk_chain16", "dec_index_serial"),
+        ("enc_px_best_sample_kernel", "enc_best_sample"), ("enc_best_sample_kernel", "enc_best_sample"),
         ("enc_px_best_kernel", "enc_best_units"), ("dec_px_best_kernel", "dec_units"), ("ix_bl_best_fill", "ix_bl_fill"),
         ("best_idx_fix", "enc_best_idx_fix"), ("ix_bl16_fill", "ix_bl_fill"), ("ix_blw_fill", "ix_bl_fill"), ("rle0_", "rle0"), ("enc_px_kernel", "enc_units"), ("enc_px16_kernel", "enc_units"), ("enc_kernel", "enc_units"),
         ("enc_best_kernel<unsigned char, false>", "enc_best_recode"), ("enc_best_kernel<unsigned short, false>", "enc_best_recode"),
