@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(SCAN_GROUP / 4) enc_scan_kernel(const EncArgs 
         if (tid == blockDim.x - 1) carry = c0 + ex + g;
         __syncthreads();
     }
-    if (tid == 0) { a.group_sum[ngroups] = carry; a.res->zero_run = 0; a.res->ff_pairs = 0; }      // (enc_concat_kernel counts into them)
+    if (tid == 0) { a.group_sum[ngroups] = carry; a.res->zero_run = 0; a.res->ff_pairs = 0; a.res->zero_dwords = 0; }      // (enc_concat_kernel counts into them)
 }
 
 // start of chunk k in the stream, in bits (k == nchunks: the stream length)
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     // is what this copy needs.  Output dword d = source dwords d-1, d funnel-shifted by the chunk's bit phase.
     const uint32_t ng = (nd + 3) >> 2, sh = (32 - phase) & 31;
     constexpr int NQ = 4;                                               // 16-byte loads in flight per lane
-    uint32_t zrun = 0, ffp = 0;
+    uint32_t zrun = 0, ffp = 0, zdw = 0;
     for (uint32_t gb = 0; gb < ng; gb += 64 * NQ) {
         uint4 cur[NQ];
         uint32_t before[NQ];                                            // lane 0: the dword before its group
@@ -134,7 +134,12 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
             if (a.zrun_probe) {         // (wave uniform) runs that start in dwords 0 .. 2 of the group; dwords behind the chunk count as non-zero
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (d + k >= nd) v[k] = 0xffffffffu; else ffp += ff_pairs_in(v[k]);
+                    if (d + k >= nd) v[k] = 0xffffffffu;
+                    else {
+                        ffp += ff_pairs_in(v[k]);
+                        const bool shared = (d + k == 0 && phase) || (d + k == nd - 1 && tailbits);
+                        zdw += (uint32_t)(v[k] == 0 && !shared);            // (all-zero dwords that are this chunk's alone: 4 KB of zeros hold hundreds)
+                    }
                 }
                 zrun += zero_runs_in(v[0], v[1]) + zero_runs_in(v[1], v[2]) + zero_runs_in(v[2], v[3]);
                 first[q] = v[0]; last[q] = v[3];
@@ -161,7 +166,8 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     }
     if (a.zrun_probe) {
 #pragma unroll
-        for (int o = 32; o; o >>= 1) { zrun += (uint32_t)__shfl_xor((int)zrun, o, 64); ffp += (uint32_t)__shfl_xor((int)ffp, o, 64); }
+        for (int o = 32; o; o >>= 1) { zrun += (uint32_t)__shfl_xor((int)zrun, o, 64); ffp += (uint32_t)__shfl_xor((int)ffp, o, 64); zdw += (uint32_t)__shfl_xor((int)zdw, o, 64); }
+        if (lane == 0 && zdw) atomicAdd((unsigned long long *)&a.res->zero_dwords, (unsigned long long)zdw);
         if (lane == 0 && zrun) atomicAdd((unsigned long long *)&a.res->zero_run, (unsigned long long)zrun);
         if (lane == 0 && ffp) atomicAdd((unsigned long long *)&a.res->ff_pairs, (unsigned long long)ffp);
     }

@@ -63,6 +63,7 @@ struct EncResult {
     // asked for with launch_encode's zrun_probe (the RLE0 modes), counted while the chunks are concatenated:
     uint64_t zero_run;          // byte positions at which four zero bytes in a row start -- at least as many as there are
     uint64_t ff_pairs;          // 0xff bytes followed by another 0xff -- at most as many as there are (rle0_may_win)
+    uint64_t zero_dwords;       // aligned all-zero dwords that belong to one chunk of the stream alone -- at most as many as there are
 };
 
 // RLE0 (reference QB3encode.cpp:271-332) writes three bytes for every PAIR of 0xff bytes (a run of L of them holds L / 2
@@ -70,9 +71,10 @@ struct EncResult {
 // at most one byte per position at which four zero bytes start.  So its output is at least n + ff_pairs / 2 - 1 - zero_run
 // bytes, and it can only be shorter than n when that is below n: for most streams the counts decide without the byte pass.
 inline bool rle0_may_win(const EncResult &r) { return r.zero_run > 0 && 2 * r.zero_run + 2 > r.ff_pairs; }
-// 4 KB of zero bytes hold 4093 such positions, 4 KB of 0xff 3072 such pairs inside dwords (fewer where chunks of the stream meet: a
-// dword shared by two chunks is not looked at): below both, the table of one-valued 4 KB chunks the byte pass skips long runs by is all "no"
-inline bool rle0_no_uniform_chunk(const EncResult &r) { return r.zero_run < 4000 && r.ff_pairs < 1024; }
+// 4 KB of zero bytes hold at least 1022 aligned all-zero dwords, of which at most two per chunk of the stream are shared with a
+// neighbour (a chunk is at least 64 bytes: 128 of them); 4 KB of 0xff hold three pairs in each of those dwords.  Below both
+// counts the table of one-valued 4 KB chunks the byte pass skips long runs by is all "no" and need not be made.
+inline bool rle0_no_uniform_chunk(const EncResult &r) { return r.zero_dwords < 800 && r.ff_pairs < 1024; }
 
 // Workspace sizes
 struct EncPlan {
