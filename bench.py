@@ -447,6 +447,18 @@ def main():
         sustained_steps += 50
     sustained = time.perf_counter() - s0
 
+    # what a container seen for the first time costs: a handle made from the bytes in device memory (qb3x_read_start_device: a
+    # 64-byte fetch, the chunk heads), the decode from the container alone, the handle destroyed -- the timed step reuses one handle
+    fresh = None
+    if not args.no_workloads:
+        f0 = time.perf_counter()
+        for _ in range(10):
+            fdec = qdev.DeviceDecoder(dst, n)
+            fdec.decode(dst, out=out, index=None)
+            fdec.close()
+        torch.cuda.synchronize()
+        fresh = {"ms_wall": round((time.perf_counter() - f0) * 100, 3), "what": "qb3x_read_start_device + qb3_read_info + qb3x_decode_device (index = NULL) + qb3_destroy_decoder per container"}
+
     # ---- plain containers (what the reference writes: no table inside, no index beside them): the stream is walked
     # serially (a table of unit lengths by bit position, built by the whole chip, then one look-up per unit on one lane)
     plain = None
@@ -545,7 +557,7 @@ def main():
         "decode": {"from_container_ms_kernels": round(dec_ms, 4), "out_of_band_index_ms_kernels": round(oob_ms, 4),
                    "out_of_band_index_MPixel_s_kernels": round(W * H / oob_ms / 1e3, 1) if oob_ms else None,
                    "out_of_band_index_bytes": oob_index_bytes if workloads is None else None, "other_table_level": other,
-                   "plain_container": plain},
+                   "fresh_handle_per_container": fresh, "plain_container": plain},
         "sustained": {"seconds": round(sustained, 2), "steps": sustained_steps, "MPixel_s": round(sustained_steps * W * H / sustained / 1e6, 1)},
         "kernels": kernels,
         "roofline": roofline,

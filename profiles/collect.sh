@@ -2,8 +2,8 @@
 # profiles/collect.sh TAG -- the rocprofv3 runs behind profiles/TAG_* (run on the GPU box from the repo root).
 # Counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa tracing next to --pmc).
 # TAG_*: BASELINE configs[1] alone (bench.py --no-workloads): kernel trace, FETCH_SIZE, WRITE_SIZE and SQ passes.
-# TAG_c2best / TAG_c3 / TAG_c4 / TAG_c5 / TAG_plain: the other configurations (bench.py --workload ...): kernel trace, and -- but for
-# `plain`, whose walk runs for seconds -- the same FETCH_SIZE, WRITE_SIZE and SQ passes (TAG_<wl>_pmc_hbm.csv, TAG_<wl>_sq.csv;
+# TAG_c2best / TAG_c3 / TAG_c4 / TAG_c5 / TAG_plain: the other configurations (bench.py --workload ...): kernel trace and
+# the same FETCH_SIZE, WRITE_SIZE and SQ passes (TAG_<wl>_pmc_hbm.csv, TAG_<wl>_sq.csv;
 # pmc_traffic.json keeps them under the workload's name in bench.py's `workloads`).  WORKLOADS="c2best c3" limits the list.
 set -e
 TAG=${1:-rXX}
@@ -25,7 +25,7 @@ for WL in ${WORKLOADS:-c2best c3 c4 c5 plain}; do
     rocprofv3 --kernel-trace --stats -d $OUT/trace_$WL -o t --output-format csv -- python3 $W > $OUT/${TAG}_${WL}_bench_under_rocprof.json 2> $OUT/trace_$WL.log
     PROFILE_CMD="python3 $W" python3 profiles/summarise.py --stats-only ${TAG}_$WL $OUT/trace_$WL
     cp profiles/${TAG}_${WL}_kernel_stats.csv $OUT/
-    if [ "$WL" != plain ]; then
+    if true; then       # (plain included since round 3: its walks take milliseconds now)
         rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch_$WL -o f --output-format csv -- python3 $W > /dev/null 2> $OUT/fetch_$WL.log
         rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write_$WL -o w --output-format csv -- python3 $W > /dev/null 2> $OUT/write_$WL.log
         rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/sq_$WL -o s --output-format csv -- python3 $W > /dev/null 2> $OUT/sq_$WL.log
