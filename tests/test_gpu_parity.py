@@ -1528,15 +1528,28 @@ for (w, h, gen, mode) in [(1024, 1024, "NOISY3", 8), (1100, 700, "NOISY3", 4), (
     assert np.array_equal(got, img.view(np.uint8).ravel()), (w, h, gen, mode, "host")
 img = o.generate(1024, 1024, 3, 0, "NOISY3", 22)
 ref = o.encode(img, 0, 8)
-for cut in (len(ref) // 2, len(ref) - 1000):         # cut short: an error or clamped pixels, never a hang or a fault
-    d = torch.from_numpy(np.ascontiguousarray(ref[:cut])).cuda()
+import random
+rng = random.Random(5)
+damaged = [np.ascontiguousarray(ref[:cut]) for cut in (len(ref) // 2, len(ref) - 1000)]      # cut short: an error or clamped pixels, never a hang or a fault
+for trial in range(12):                             # ... and smashed: bit flips, runs of one byte value, anywhere behind the header
+    s = ref.copy()
+    if trial & 1:
+        for _ in range(rng.randrange(1, 6)):
+            at = rng.randrange(64, len(s)); s[at] ^= 1 << rng.randrange(8)
+    else:
+        at = rng.randrange(64, len(s)); k = min(len(s) - at, rng.randrange(1, 5000)); s[at:at + k] = rng.choice((0, 255, rng.randrange(256)))
+    damaged.append(s)
+for s in damaged:
+    d = torch.from_numpy(s).cuda()
     dims = (C.c_size_t * 3)()
-    q = L.qb3x_read_start_device(d.data_ptr(), cut, dims, None)
+    q = L.qb3x_read_start_device(d.data_ptr(), len(s), dims, None)
     if q:
         out = torch.zeros(img.nbytes, dtype=torch.uint8, device="cuda")
         L.qb3x_decode_device(q, d.data_ptr(), out.data_ptr(), None, None)
         torch.cuda.synchronize()
         L.qb3_destroy_decoder(q)
+d = torch.from_numpy(ref).cuda()                    # the GPU is still well: the intact stream decodes
+assert np.array_equal(qdev.DeviceDecoder(d, len(ref)).decode(d, index=None).cpu().numpy(), img.view(np.uint8).ravel())
 w, h, n = 512, 384, 3            # (up to four tiles a call go by exits, larger batches by a chain a tile)
 imgs = [o.generate(w, h, 3, 0, "NOISY3", 60 + t) for t in range(n)]
 refs = [o.encode(im, 0, 8) for im in imgs]
@@ -1608,15 +1621,28 @@ for (w, h, dt, gen, mode, want_table) in [(2048, 1024, 5, "DEM", 8, True), (4100
 # the same stream cut short: an error or clamped pixels as the reference's reader gives, never a hang or a fault
 img = o.generate(1024, 1024, 1, 5, "DEM", 12)
 ref = o.encode(img, 5, 8)
-for cut in (len(ref) // 2, len(ref) - 1000):
-    d = torch.from_numpy(np.ascontiguousarray(ref[:cut])).cuda()
+import random
+rng = random.Random(5)
+damaged = [np.ascontiguousarray(ref[:cut]) for cut in (len(ref) // 2, len(ref) - 1000)]      # cut short: an error or clamped pixels, never a hang or a fault
+for trial in range(12):                             # ... and smashed: bit flips, runs of one byte value, anywhere behind the header
+    s = ref.copy()
+    if trial & 1:
+        for _ in range(rng.randrange(1, 6)):
+            at = rng.randrange(64, len(s)); s[at] ^= 1 << rng.randrange(8)
+    else:
+        at = rng.randrange(64, len(s)); k = min(len(s) - at, rng.randrange(1, 5000)); s[at:at + k] = rng.choice((0, 255, rng.randrange(256)))
+    damaged.append(s)
+for s in damaged:
+    d = torch.from_numpy(s).cuda()
     dims = (C.c_size_t * 3)()
-    q = L.qb3x_read_start_device(d.data_ptr(), cut, dims, None)
+    q = L.qb3x_read_start_device(d.data_ptr(), len(s), dims, None)
     if q:
         out = torch.zeros(img.nbytes, dtype=torch.uint8, device="cuda")
         L.qb3x_decode_device(q, d.data_ptr(), out.data_ptr(), None, None)
         torch.cuda.synchronize()
         L.qb3_destroy_decoder(q)
+d = torch.from_numpy(ref).cuda()                    # the GPU is still well: the intact stream decodes
+assert np.array_equal(qdev.DeviceDecoder(d, len(ref)).decode(d, index=None).cpu().numpy(), img.view(np.uint8).ravel())
 # a batch of plain tiles
 w, h, n = 512, 384, 5
 imgs = [o.generate(w, h, 1, 5, "DEM", 40 + t) for t in range(n)]
