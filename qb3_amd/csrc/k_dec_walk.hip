@@ -1293,8 +1293,9 @@ template <uint32_t UB> struct exitW {
     static constexpr uint32_t NPS = W + PE, NP1 = (NPS + MAXU + 2 + 31) & ~31u;             // positions with a switch entry; with a code length
     static constexpr uint32_t X_DEP = 1u << 30, X_SLOW = 1u << 31, X_CNT = 0x7fffu;          // (common-factor streams) a unit took the factor in force when the super-window was entered; a unit brought its own
     static constexpr uint32_t X_STOP = 0x7fffu;                                             // X: (position - W) * 16 + rung (15 bits: the entering state of the next window) | units << 15; stop: the low 15 bits all set
-    static constexpr uint32_t T0 = 0, X0 = T0 + W * NR * 2, S0 = X0 + NX * 4, E1 = S0 + ((NPS * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT,
-                              LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
+    static constexpr uint32_t BMW = (NX + 31) / 32, DCAP = 2048;                               // words of the bitmap of first-window exits; distinct exits carried
+    static constexpr uint32_t T0 = 0, X0 = T0 + W * NR * 2, PF0 = X0 + ((BMW * 4 + 15) & ~15u), XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
+                              E1 = S0 + ((NPS * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
     static_assert(W + MAXU < 4095 && PE * NR + NR <= 0x7fff && K * W / 2 < (1u << 15) + 1 && UB >= 3 && UB <= 6 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk");
 };
 
@@ -1310,12 +1311,19 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
     if (base >= a.in_bits) return;                                                          // (uniform) no walk comes here
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t *T = (uint16_t *)(smem + E::T0), *sw = (uint16_t *)(smem + E::S0);
-    uint32_t *M = (uint32_t *)(smem + E::X0), *words = (uint32_t *)(smem + E::WORDS);
+    uint32_t *bm = (uint32_t *)(smem + E::X0), *Xd = (uint32_t *)(smem + E::XD0), *words = (uint32_t *)(smem + E::WORDS);
+    uint16_t *pf = (uint16_t *)(smem + E::PF0);
     uint32_t *out = xg + ((uint64_t)blockIdx.y * s_count + blockIdx.x) * NX;          // X: the super-window's exits, entering state by entering state
-    constexpr uint32_t M_EMPTY = 0xffffffffu, M_NEED = 0xfffffffeu;
+    __shared__ uint32_t s_D;
+    uint32_t D = 0;
     uint8_t *t1 = smem + E::E1, *eA = smem + E::EA, *eB = smem + E::EB;
     const uint32_t tid = threadIdx.x;
     const uint64_t endw = (a.in_bit0 + a.in_bits + 31) >> 5;
+    // a first-window exit (or a list entry) a, then b: flags add up -- a factor brought anywhere, a factor taken before one was
+    // brought, or after: X_SLOW then
+    auto compose = [](uint32_t a, uint32_t b) -> uint32_t {
+        return (b & 0x7fffu) | (((((a >> 15) & E::X_CNT) + ((b >> 15) & E::X_CNT)) & E::X_CNT) << 15) | ((a | b) & (E::X_DEP | E::X_SLOW));
+    };
 #pragma unroll 1
     for (uint32_t k = 0; k < E::K; k++) {
         const uint64_t q0 = a.in_bit0 + base + (uint64_t)k * W, w0 = q0 >> 5;
@@ -1329,10 +1337,14 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
             const uint32_t cs = walk_switch<UB>(bits(o), delta, sig);
             sw[o] = (uint16_t)(cs | (delta << 4) | ((sig ? 1u : 0u) << 10) | ((bits(o + cs) & 1u) << 11));
         }
-        for (uint32_t i = tid; i < W * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;  // (an entry no target rung fills: the unit leaves the band, or is the signal)
+        // The table is made for the super-window's FIRST window only, where thousands of states walk; behind it a few hundred
+        // distinct states are left, and walking those from the code lengths (sixteen dependent byte reads a unit) costs a
+        // quarter of what tabulating sixteen rungs of the window does.
+        const bool tabled = k == 0;
+        if (tabled) for (uint32_t i = tid; i < W * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;  // (an entry no target rung fills: the unit leaves the band, or is the signal)
         __syncthreads();
 #pragma unroll 1
-        for (uint32_t rb = 0; rb < E::NRB; rb++) {                                          // the rung the switch leads to
+        for (uint32_t rb = 0; tabled && rb < E::NRB; rb++) {                                // the rung the switch leads to
             const uint32_t r = R0 + rb;
 #ifdef EXIT_EXP_NOTAB
             if (r && rb == 0) {
@@ -1356,17 +1368,11 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
             }
             __syncthreads();
         }
-        // Every entering state of the super-window through this window.  Walks merge: behind the first window the thousands of
-        // states stand at a few hundred distinct (position, rung), so the states say which they need (M), those are walked once,
-        // and every state takes its answer from there.  X stays in global memory (read and written once a window, coalesced).
-        for (uint32_t i = tid; i < NX; i += NT) M[i] = k ? M_EMPTY : M_NEED;
-        __syncthreads();
-        if (k) {
-            for (uint32_t idx = tid; idx < NX; idx += NT) { const uint32_t x = out[idx]; if ((x & E::X_STOP) != E::X_STOP) M[x & 0x7fffu] = M_NEED; }
-            __syncthreads();
-        }
-        for (uint32_t key = tid; key < NX; key += NT) {
-            if (M[key] != M_NEED) continue;
+        // Every entering state of the super-window through its first window (exit and unit count to global memory, X); walks merge
+        // -- behind the first window the thousands of states stand at a few hundred distinct (position, rung) -- so the distinct
+        // exits are ranked through a bitmap and only those (Xd, LDS) are carried through the other windows; at the end every
+        // state composes its first-window exit with what became of it.
+        auto walk = [&](uint32_t key) -> uint32_t {
             uint32_t pos = key / NR, r = key % NR, cnt = 0;                                 // (a state's low 15 bits: position * 16 + rung: the key itself)
             bool stop = false;
             typedef typename WalkValue<UB>::type TT;
@@ -1377,10 +1383,12 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
             while (true) {
                 if (r < NR) {
                     if (pos >= W) break;                                                    // behind the window, in the band: the next window's
-                    const uint32_t e = T[pos * NR + r];
-                    if (e != 0xffffu) { pos = e & 0xfffu; r = e >> 12; cnt++; continue; }
+                    if (tabled) {
+                        const uint32_t e = T[pos * NR + r];
+                        if (e != 0xffffu) { pos = e & 0xfffu; r = e >> 12; cnt++; continue; }
+                    }
                 }
-                // a unit the table does not hold (it leaves the band, or is entered from outside it): by the code lengths
+                // a unit the table does not hold (it leaves the band, is entered from outside it, or there is no table): by the code lengths
                 if (pos >= NPS) { stop = true; break; }
                 const uint32_t s = sw[pos], cs = s & 15u;
                 if ((s >> 10) & 1u) {                                                       // the signal code
@@ -1407,17 +1415,54 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
                 pos = q; r = (rabs - R0) & (NRUNG - 1); cnt++;
             }
             if (pos - W >= E::PE) stop = true;                                              // (only behind a unit entered out of the band)
-            M[key] = (stop ? (E::X_STOP | (cnt << 15)) : ((pos - W) * NR + r) | (cnt << 15)) | xfl;
+            return (stop ? (E::X_STOP | (cnt << 15)) : ((pos - W) * NR + r) | (cnt << 15)) | xfl;
+        };
+        if (k == 0) {
+            for (uint32_t i = tid; i < E::BMW; i += NT) bm[i] = 0;
+            __syncthreads();
+            for (uint32_t key = tid; key < NX; key += NT) {
+                const uint32_t x = walk(key);
+                out[key] = x;
+                if ((x & E::X_STOP) != E::X_STOP) atomicOr(&bm[(x & 0x7fffu) >> 5], 1u << (x & 31u));
+            }
+            __syncthreads();
+            if (tid < 64) {                                                                 // rank of every distinct exit: one wave scans the bitmap words' bit counts
+                uint32_t run = 0;
+                for (uint32_t w0 = 0; w0 < E::BMW; w0 += 64) {
+                    const uint32_t w = w0 + tid, c = w < E::BMW ? __popc(bm[w]) : 0u;
+                    uint32_t x = c;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if ((int)tid >= d) x += y; }
+                    if (w < E::BMW) pf[w] = (uint16_t)(run + x - c);
+                    run += __shfl(x, 63, 64);
+                }
+                if (tid == 0) s_D = run;
+            }
+            __syncthreads();
+            D = s_D;
+            if (D > E::DCAP) {                                                              // (uniform) more distinct exits than are carried: the hop parses this super-window outright
+                for (uint32_t key = tid; key < NX; key += NT) out[key] = E::X_STOP;
+                return;
+            }
+            for (uint32_t w = tid; w < E::BMW; w += NT) {                                   // the distinct exits, in rank order
+                uint32_t m = bm[w], j = pf[w];
+                while (m) { const uint32_t b = __ffs(m) - 1; Xd[j++] = w * 32 + b; m &= m - 1; }
+            }
+            __syncthreads();
+        } else {
+            for (uint32_t j = tid; j < D; j += NT) {                                        // the distinct walks through this window
+                const uint32_t x = Xd[j];
+                if ((x & E::X_STOP) == E::X_STOP) continue;
+                Xd[j] = compose(x, walk(x & 0x7fffu));
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (uint32_t idx = tid; idx < NX; idx += NT) {
-            if (!k) { out[idx] = M[idx]; continue; }
-            const uint32_t x = out[idx];
-            if ((x & E::X_STOP) == E::X_STOP) continue;
-            const uint32_t m = M[x & 0x7fffu];          // (flags add up: a factor brought anywhere, a factor taken before one was brought -- or after: X_SLOW then)
-            out[idx] = (m & 0x7fffu) | (((((x >> 15) & E::X_CNT) + ((m >> 15) & E::X_CNT)) & E::X_CNT) << 15) | ((x | m) & (E::X_DEP | E::X_SLOW));
-        }
-        __syncthreads();
+    }
+    for (uint32_t key = tid; key < NX; key += NT) {                                         // every state: its first-window exit, then what became of that
+        const uint32_t e = out[key];
+        if ((e & E::X_STOP) == E::X_STOP) continue;
+        const uint32_t k1 = e & 0x7fffu, w = k1 >> 5;
+        out[key] = compose(e, Xd[pf[w] + __popc(bm[w] & ((1u << (k1 & 31u)) - 1u))]);
     }
 }
 
