@@ -978,28 +978,46 @@ template <uint32_t UB, uint32_t NR_> struct chainW {
 template <typename T, int MODE>
 __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkState16 *states, uint32_t nr) {
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
-    constexpr uint32_t NRUNG = 1u << UBits<T>::v;
-    if (threadIdx.x) return;
-    const uint32_t B = a.g.bands, NB = a.g.seg_blocks;
+    constexpr uint32_t UB = UBits<T>::v, NRUNG = 1u << UB, MAXU = UB + 2 + 16 * (NRUNG + 1), STAGE = 2048;     // (dwords of the stream's head staged in LDS)
+    __shared__ uint32_t stage[STAGE + 4], s_rung[MAXBANDS];
+    __shared__ uint64_t s_pcf[MAXBANDS], s_tot[MAXBANDS];                  // (per-band state: indexed at run time, so not in registers)
+    const uint32_t B = a.g.bands, NB = a.g.seg_blocks, lane = threadIdx.x;
     const uint64_t nblocks = a.g.nblocks, nb = nblocks < NB ? nblocks : NB;
-    Reader rd;
-    rd.init(a.in32, a.in_bit0, a.in_bit0 + a.in_bits);
-    uint32_t rung[MAXBANDS], minr = NRUNG, maxr = 0;
+    // the first segment is parsed from LDS when it is sure to fit (a lane reading global memory waits a round trip per word)
+    const bool staged = nb * B * MAXU + 64 <= 32ull * STAGE;
+    const uint64_t w0 = a.in_bit0 >> 5, endw = (a.in_bit0 + a.in_bits + 31) >> 5;
+    if (staged) for (uint32_t i = lane; i < STAGE + 4; i += 64) stage[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
+    if (lane < MAXBANDS) { s_rung[lane] = 0; s_pcf[lane] = 0; s_tot[lane] = 0; }
+    __syncthreads();
+    if (lane) return;
+    uint32_t minr = NRUNG, maxr = 0;
     bool ok = true;
     a.idx.bitpos[0] = 0;
-    for (uint32_t c = 0; c < B; c++) { rung[c] = 0; a.idx.rung[c] = 0; }
-    T g[16], pcf[MAXBANDS], tot[MAXBANDS];
-    for (uint32_t c = 0; c < B; c++) { pcf[c] = 0; tot[c] = 0; if (MODE == CM_BEST) ((T *)a.idx.cf)[c] = 0; }
-    for (uint64_t gb = 0; gb < nb && ok; gb++)
-        for (uint32_t c = 0; c < B; c++) {
-            const uint64_t u0 = rd.position();
-            ok = parse_unit<T, MODE>(rd, rung[c], pcf[c], g) && ok;     // (FTL / BASE: lengths and rungs are the same with and without the step)
-            if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[gb * B + c] = (uint16_t)(rd.position() - u0);
-            else if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[gb * B + c] = (uint8_t)(rd.position() - u0);
-            if (MODE == CM_BEST) for (uint32_t i = 0; i < 16; i++) tot[c] = (T)(tot[c] + smag_t<T>(g[i]));   // (common-factor streams: the segment's sum, for the scan that gives every segment its entering value)
-            if (gb || nb == 1) { minr = rung[c] < minr ? rung[c] : minr; maxr = rung[c] > maxr ? rung[c] : maxr; }
-        }
-    if (MODE == CM_BEST) for (uint32_t c = 0; c < B; c++) ((T *)a.idx.prev)[c] = tot[c];
+    for (uint32_t c = 0; c < B; c++) { a.idx.rung[c] = 0; if (MODE == CM_BEST) ((T *)a.idx.cf)[c] = 0; }
+    uint64_t P_end = 0;
+    auto run = [&](auto &rd, uint64_t origin) {                            // origin: position() of the stream's first bit
+        T g[16];
+        for (uint64_t gb = 0; gb < nb && ok; gb++)
+            for (uint32_t c = 0; c < B; c++) {
+                const uint64_t u0 = rd.position();
+                uint32_t rg = s_rung[c];
+                T pc = (T)s_pcf[c];
+                ok = parse_unit<T, MODE>(rd, rg, pc, g) && ok;             // (FTL / BASE: lengths and rungs are the same with and without the step)
+                s_rung[c] = rg; s_pcf[c] = (uint64_t)pc;
+                if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[gb * B + c] = (uint16_t)(rd.position() - u0);
+                else if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[gb * B + c] = (uint8_t)(rd.position() - u0);
+                if (MODE == CM_BEST) {                                     // (common-factor streams: the segment's sum, for the scan that gives every segment its entering value)
+                    T t = (T)s_tot[c];
+                    for (uint32_t i = 0; i < 16; i++) t = (T)(t + smag_t<T>(g[i]));
+                    s_tot[c] = (uint64_t)t;
+                }
+                if (gb || nb == 1) { minr = rg < minr ? rg : minr; maxr = rg > maxr ? rg : maxr; }
+            }
+        P_end = rd.position() - origin;
+    };
+    if (staged) { ReaderT<LdsWords> rd; rd.init((LdsWords)stage, a.in_bit0 & 31, 32ull * (STAGE + 4)); run(rd, (uint64_t)(a.in_bit0 & 31)); }
+    else { Reader rd; rd.init(a.in32, a.in_bit0, a.in_bit0 + a.in_bits); run(rd, (uint64_t)a.in_bit0); }
+    if (MODE == CM_BEST) for (uint32_t c = 0; c < B; c++) ((T *)a.idx.prev)[c] = (T)s_tot[c];
     WalkState16 *S = states + blockIdx.x;
     // the band: nr rungs from a little below the smallest rung the first segment saw.  What lies ABOVE the typical rung matters
     // more than what lies below: the first unit of every block row is entered from the far end of the row before and sits
@@ -1007,8 +1025,8 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
     uint32_t R0 = minr >= 3 ? minr - 3 : 0;
     if (R0 > NRUNG - nr) R0 = NRUNG - nr;
     uint64_t rel = 0;
-    for (uint32_t c = 0; c < B; c++) { const uint32_t d = rung[c] - R0; ok = ok && d < nr; rel |= (uint64_t)(d & 15u) << (4 * c); }
-    S->P = rd.position() - a.in_bit0; S->unit = nb * B; S->rungs = rel; S->pad = R0; S->bad = ok ? 0u : 1u; S->cf = (uint64_t)pcf[0];
+    for (uint32_t c = 0; c < B; c++) { const uint32_t d = s_rung[c] - R0; ok = ok && d < nr; rel |= (uint64_t)(d & 15u) << (4 * c); }
+    S->P = P_end; S->unit = nb * B; S->rungs = rel; S->pad = R0; S->bad = ok ? 0u : 1u; S->cf = s_pcf[0];
     if (!ok) atomicOr(a.status, 1u);
 }
 
