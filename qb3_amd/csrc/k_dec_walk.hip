@@ -976,13 +976,14 @@ template <uint32_t UB, uint32_t NR_> struct chainW {
 // The first index segment of every tile, parsed outright by one lane: unit lengths, the segment's entry, the band of rungs
 // [R0, R0 + 16) for the table (WalkState16::pad) and the walk's entry state behind the segment.
 template <typename T, int MODE>
-__global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkState16 *states, uint32_t nr) {
+__global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkState16 *states, uint32_t nr, uint32_t few = 0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     constexpr uint32_t UB = UBits<T>::v, NRUNG = 1u << UB, MAXU = UB + 2 + 16 * (NRUNG + 1), STAGE = 2048;     // (dwords of the stream's head staged in LDS)
     __shared__ uint32_t stage[STAGE + 4], s_rung[MAXBANDS];
     __shared__ uint64_t s_pcf[MAXBANDS], s_tot[MAXBANDS];                  // (per-band state: indexed at run time, so not in registers)
     const uint32_t B = a.g.bands, NB = a.g.seg_blocks, lane = threadIdx.x;
-    const uint64_t nblocks = a.g.nblocks, nb = nblocks < NB ? nblocks : NB;
+    // (few: the exit walks only want the band of rungs and a state to start from -- their unit lanes parse the rest of the segment)
+    const uint64_t nblocks = a.g.nblocks, nb0 = nblocks < NB ? nblocks : NB, nb = few && few < nb0 ? few : nb0;
     // the first segment is parsed from LDS when it is sure to fit (a lane reading global memory waits a round trip per word)
     const bool staged = nb * B * MAXU + 64 <= 32ull * STAGE;
     const uint64_t w0 = a.in_bit0 >> 5, endw = (a.in_bit0 + a.in_bits + 31) >> 5;
@@ -1980,24 +1981,29 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
     if (a.g.tsz <= 2 && a.g.bands == 1 && a.wide_band == 16 && lds_ok && nt <= 16) {       // one band of 8- or 16-bit data: the exits too (the band is all the rungs)
         WalkState16 *states = (WalkState16 *)tab;
         { ProfScope ps("dec_index_serial", st);
-          if (a.g.tsz == 1) hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 8u);
-          else hipLaunchKernelGGL((walk_probe_kernel<uint16_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 16u); }
+          if (a.g.tsz == 1) hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 8u, 16u);
+          else hipLaunchKernelGGL((walk_probe_kernel<uint16_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 16u, 16u); }
         if (a.g.tsz == 1 ? launch_walk_exit<3, uint8_t, CM_FTL>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<4, uint16_t, CM_FTL>(a, st, tab, tab_bytes, max_bits)) return;
     }
     if (a.g.tsz == 1 && a.g.bands == 3 && (a.wide_band == 16 || a.wide_band == 18) && lds_ok && nt <= 4) {    // 8-bit RGB: exits with the rung of every band in the state (18: a test hook, see dcap)
         WalkState16 *states = (WalkState16 *)tab;
         { ProfScope ps("dec_index_serial", st);
-          hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 8u); }
+          hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 8u, 8u); }
         if (launch_walk_exitB<3>(a, st, tab, tab_bytes, max_bits)) return;
     }
     if (a.g.tsz >= 4) {         // 32/64-bit FTL/BASE: the first segment parsed outright (band of rungs, entry state), then table + chain
         WalkState16 *states = (WalkState16 *)tab;
         const uint32_t nr = a.wide_band == 8 ? 8u : a.wide_band == 14 ? 14u : 16u;
-        { ProfScope ps("dec_index_serial", st);
-          if (a.g.tsz == 4) hipLaunchKernelGGL((walk_probe_kernel<uint32_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, nr);
-          else hipLaunchKernelGGL((walk_probe_kernel<uint64_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, nr); }
-        if (a.g.bands == 1 && a.wide_band == 16 && lds_ok && nt <= 16) {    // one band: exits of super-windows composed, a hop per 32768 bits (wide_band 17: the chain, a test hook)
+        const bool exits = a.g.bands == 1 && a.wide_band == 16 && lds_ok && nt <= 16;      // one band: exits of super-windows composed, a hop per 32768 bits (wide_band 17: the chain, a test hook)
+        auto probe = [&](uint32_t few) {
+            ProfScope ps("dec_index_serial", st);
+            if (a.g.tsz == 4) hipLaunchKernelGGL((walk_probe_kernel<uint32_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, nr, few);
+            else hipLaunchKernelGGL((walk_probe_kernel<uint64_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, nr, few);
+        };
+        probe(exits ? 16u : 0u);
+        if (exits) {
             if (a.g.tsz == 4 ? launch_walk_exit<5, uint32_t, CM_FTL>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<6, uint64_t, CM_FTL>(a, st, tab, tab_bytes, max_bits)) return;
+            probe(0u);                                                                      // (no memory for the exits: the chain wants the whole first segment parsed)
         }
         auto run = [&](auto tag) {
             constexpr uint32_t UB = decltype(tag)::UB_, NRB = decltype(tag)::NR_;
