@@ -26,6 +26,17 @@ extern "C" {
 /* Number of usable HIP devices; 0 means the library cannot encode or decode. */
 int qb3x_device_count(void);
 
+/* Device buffers of destroyed handles are kept (at most 24 buffers, 3 GiB) for the next handle of the process, so that a
+ * caller who opens, decodes and closes a container per tile does not pay hipMalloc / hipFree every time; qb3x_trim returns
+ * them to the HIP runtime.  (No counterpart in the reference, which owns no device memory.) */
+void qb3x_trim(void);
+
+/* Diagnostic: the status bits of the decoder handle's last decode call.  Bits 0, 1, 3, 4 are errors (the call returned 0),
+ * bit 2 "the stream ended early" (the reference's reader clamps, QB3decode bitstream.h:36), bit 5 "the container's restart
+ * table failed its check and was not used", bit 6 "a plain stream's walk by exits handed super-windows to its one hopping
+ * lane" (slower, same pixels). */
+unsigned qb3x_last_decode_status(const decsp p);
+
 /* Bytes of device memory an index for this encoder's geometry needs (0 on error). */
 size_t qb3x_index_size(const encsp p);
 /* Same, from a decoder handle (valid after qb3_read_info). */

@@ -59,6 +59,8 @@ _PROTOS = {
     "qb3_get_coreband": (C.c_bool, [_vp, C.POINTER(_sz)]),
     # include/qb3x.h
     "qb3x_device_count": (C.c_int, []),
+    "qb3x_trim": (None, []),
+    "qb3x_last_decode_status": (C.c_uint, [_vp]),
     "qb3x_index_size": (_sz, [_vp]),
     "qb3x_set_encoder_index_chunk": (None, [_vp, C.c_int]),
     "qb3x_decoder_index_size": (_sz, [_vp]),

@@ -1312,7 +1312,7 @@ template <uint32_t UB> struct exitW {
     static constexpr uint32_t NPS = W + PE, NP1 = (NPS + MAXU + 2 + 31) & ~31u;             // positions with a switch entry; with a code length
     static constexpr uint32_t X_DEP = 1u << 30, X_SLOW = 1u << 31, X_CNT = 0x7fffu;          // (common-factor streams) a unit took the factor in force when the super-window was entered; a unit brought its own
     static constexpr uint32_t X_STOP = 0x7fffu;                                             // X: (position - W) * 16 + rung (15 bits: the entering state of the next window) | units << 15; stop: the low 15 bits all set
-    static constexpr uint32_t BMW = (NX + 31) / 32, DCAP = 2048;                               // words of the bitmap of first-window exits; distinct exits carried
+    static constexpr uint32_t BMW = (NX + 31) / 32, DCAP = NX;                                 // words of the bitmap of first-window exits; distinct exits carried: as many as there are (64-bit data, 1024-bit windows: thousands)
     static constexpr uint32_t T0 = 0, X0 = T0 + W * NR * 2, PF0 = X0 + ((BMW * 4 + 15) & ~15u), XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
                               E1 = S0 + ((NPS * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
     static_assert(W + MAXU < 4095 && PE * NR + NR <= 0x7fff && K * W / 2 < (1u << 15) + 1 && UB >= 3 && UB <= 6 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk");
@@ -1356,10 +1356,10 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
             const uint32_t cs = walk_switch<UB>(bits(o), delta, sig);
             sw[o] = (uint16_t)(cs | (delta << 4) | ((sig ? 1u : 0u) << 10) | ((bits(o + cs) & 1u) << 11));
         }
-        // The table is made for the super-window's FIRST window only, where thousands of states walk; behind it a few hundred
-        // distinct states are left, and walking those from the code lengths (sixteen dependent byte reads a unit) costs a
-        // quarter of what tabulating sixteen rungs of the window does.
-        const bool tabled = k == 0;
+        // The table is made for the super-window's FIRST window, where thousands of states walk; behind it a few hundred
+        // distinct states are usually left, and walking those from the code lengths (sixteen dependent byte reads a unit)
+        // costs a quarter of what tabulating sixteen rungs of the window does.
+        const bool tabled = k == 0 || D > 512;                                              // (uniform.  Many distinct states: the table pays in every window)
         if (tabled) for (uint32_t i = tid; i < W * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;  // (an entry no target rung fills: the unit leaves the band, or is the signal)
         __syncthreads();
 #pragma unroll 1
@@ -1537,6 +1537,7 @@ __global__ void __launch_bounds__(64) walk_exit_chain_kernel(const DecArgs a0, c
             break;
         }
         // this super-window by the units themselves: up to the first unit that starts behind it and is entered with a rung of the band
+        atomicOr(a.status, 64u);                                                            // (not an error: says that the walk was handed to this lane)
         Reader rd;
         rd.init(a.in32, a.in_bit0 + P, a.in_bit0 + a.in_bits);
         uint32_t rung = R0 + r;
@@ -1805,6 +1806,7 @@ __global__ void __launch_bounds__(64) walk_exitB_chain_kernel(const DecArgs a0, 
             continue;
         }
         // this super-window by the units themselves: whole blocks up to the first that starts behind it
+        atomicOr(a.status, 64u);                                                            // (not an error: says that the walk was handed to this lane)
         Reader rd;
         rd.init(a.in32, a.in_bit0 + P, a.in_bit0 + a.in_bits);
         uint32_t rung[B];

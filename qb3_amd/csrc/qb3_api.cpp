@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <chrono>
+#include <mutex>
 #include <new>
 #include <vector>
 #include <limits>
@@ -31,19 +32,74 @@ static inline size_t szof(int dt) { return (dt < 0 || dt > QB3_I64) ? 0 : typesi
 static inline unsigned topbit(uint64_t v) { return 63u - (unsigned)__builtin_clzll(v); }
 
 // ---------------------------------------------------------------- device buffers owned by a handle
+// Device buffers of destroyed handles wait in a small per-process pool for the next handle: a caller that opens, decodes and
+// closes a container per tile (the reference's calling pattern) would otherwise pay tens of milliseconds of hipMalloc / hipFree
+// around a fraction of a millisecond of kernels.  Bounded (POOL_ITEMS buffers, POOL_BYTES bytes); qb3x_trim() empties it.
+struct DevPool {
+    struct Item { void *p; size_t cap; int dev; };
+    static constexpr size_t POOL_ITEMS = 24, POOL_BYTES = (size_t)3 << 30;
+    std::mutex mu;
+    std::vector<Item> items;
+    size_t bytes = 0;
+    void *take(size_t n, int dev, size_t *cap) {           // the smallest pooled buffer of this device that holds n and is not more than twice that
+        std::lock_guard<std::mutex> l(mu);
+        size_t best = items.size();
+        for (size_t i = 0; i < items.size(); i++)
+            if (items[i].dev == dev && items[i].cap >= n && items[i].cap / 2 <= n && (best == items.size() || items[i].cap < items[best].cap)) best = i;
+        if (best == items.size()) return nullptr;
+        void *p = items[best].p;
+        *cap = items[best].cap;
+        bytes -= items[best].cap;
+        items.erase(items.begin() + (long)best);
+        return p;
+    }
+    bool give(void *p, size_t cap, int dev) {
+        std::lock_guard<std::mutex> l(mu);
+        if (items.size() >= POOL_ITEMS || bytes + cap > POOL_BYTES) return false;
+        items.push_back({p, cap, dev});
+        bytes += cap;
+        return true;
+    }
+    void trim() {
+        std::vector<Item> out;
+        { std::lock_guard<std::mutex> l(mu); out.swap(items); bytes = 0; }
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto &it : out) { (void)hipSetDevice(it.dev); (void)hipFree(it.p); }
+        (void)hipSetDevice(cur);
+    }
+};
+static DevPool &dev_pool() { static DevPool *g = new DevPool(); return *g; }      // (never destroyed: the HIP runtime may be gone before static destructors run)
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    int dev = 0;
     bool ensure(size_t n) {
         if (n <= cap) return true;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        release();
+        (void)hipGetDevice(&dev);
+        try {
+            if ((p = dev_pool().take(n, dev, &cap)) != nullptr) return true;
+        } catch (...) { p = nullptr; }
         hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) { set_error("hipMalloc", (int)e); p = nullptr; return false; }
+        if (e != hipSuccess) {                              // out of memory with buffers idle in the pool: give them back and try once more
+            (void)hipGetLastError();
+            dev_pool().trim();
+            e = hipMalloc(&p, n);
+        }
+        if (e != hipSuccess) { set_error("hipMalloc", (int)e); p = nullptr; cap = 0; return false; }
         cap = n;
         return true;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() {
+        if (p) {
+            bool kept = false;
+            try { kept = dev_pool().give(p, cap, dev); } catch (...) { kept = false; }
+            if (!kept) (void)hipFree(p);
+        }
+        p = nullptr; cap = 0;
+    }
 };
 
 static bool device_ok() {
@@ -210,6 +266,7 @@ struct decs {
     std::vector<uint8_t> own_head, win2;    // qb3x_read_start_device: the handle's own copy of the container's first bytes, and of a few bytes further on
     size_t win2_off = 0;    // ... at this offset from s_start
     std::vector<uint8_t> tile_ok;   // qb3x_decode_tiles: per tile outcome of the last call
+    uint32_t last_status = 0;       // status bits of the last decode call (qb3x_last_decode_status; tiles: of all tiles together)
     DevBuf d_in, d_img, d_ws, d_ix, d_rle, d_tab;      // d_rle: RLE0 workspace (+ the packed bytes of a host call); d_tab: the unit-length table a plain 8-bit stream is walked through
     Stager stager;
 };
@@ -904,11 +961,12 @@ static decsp read_start_device_body(const void *d_container, size_t nbytes, size
         const size_t need = p->ix_need_off;
         head.swap(p->own_head);
         const bool was_short = p->hdr_short;
+        if (getenv("QB3_DEBUG_RS")) fprintf(stderr, "read_start_device turn %d: need %zu short %d err %d ix_off %zu K %u E %u per %u ver %u\n", turn, need, (int)was_short, p->error, p->ix_off, p->ix_K, p->ix_E, p->ix_per_chunk, p->ix_ver);
         qb3_destroy_decoder(p);
         if (!was_short) return nullptr;
-        if (turn == 0 && need && need + 2 <= nbytes) {  // a regular table: the two bytes behind it
+        if (turn == 0 && need && need + 2 <= nbytes) {  // a regular table: the mark behind it (four bytes: the chunk loop reads a length field behind every tag)
             win_off = need;
-            if (!fetch(win, need, 2)) return nullptr;
+            if (!fetch(win, need, std::min<size_t>(4, nbytes - need))) return nullptr;
         } else if (turn <= 1) {                         // something else: the whole head, as far as a table can reach
             const size_t bound = std::min(nbytes, qb3x_header_size_bound(head.data(), head.size()));
             if (bound <= head.size()) return nullptr;
@@ -972,6 +1030,7 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
         else break;
     }
     prof_collect();
+    p->last_status = status;
     // bit 0: corrupt unit, bit 1: more than 7 unused bits at the end (reference QB3decode.h:411,569,740).
     // bit 2 (ran past the end) is not an error in the reference, whose reader clamps (bitstream.h:36).
     // bit 3: the index handed in does not describe this stream (a segment longer than any valid one).
@@ -1128,6 +1187,7 @@ static size_t decode_tiles_body(decsp p, const void *d_src, size_t n, size_t src
     const size_t hdr = (size_t)(p->s_in - p->s_start);
     hipStream_t st = (hipStream_t)stream;
     p->tile_ok.assign(n, 0);
+    p->last_status = 0;
     if (!n || !device_ok()) return 0;
     // the mode byte of every tile: tiles of tile 0's kind go through one set of launches, the others one by one
     std::vector<uint8_t> modes(n);
@@ -1218,7 +1278,7 @@ static size_t decode_tiles_body(decsp p, const void *d_src, size_t n, size_t src
                 else break;
             }
             prof_collect();
-            for (size_t i = 0; i < cnt; i++) if (bits[i] && !(status[i] & 27)) { p->tile_ok[first + i] = 1; done++; }
+            for (size_t i = 0; i < cnt; i++) { p->last_status |= status[i]; if (bits[i] && !(status[i] & 27)) { p->tile_ok[first + i] = 1; done++; } }
         }
     }
     for (size_t i = 0; i < n; i++) {
@@ -1232,6 +1292,10 @@ static size_t decode_tiles_body(decsp p, const void *d_src, size_t n, size_t src
 QB3_API int qb3x_decode_tile_ok(const decsp p, size_t i) { return (p && i < p->tile_ok.size()) ? p->tile_ok[i] : 0; }
 
 // ---------------------------------------------------------------- misc
+// returns the device buffers that destroyed handles left in the library's pool to the runtime
+QB3_API unsigned qb3x_last_decode_status(const decsp p) { return p ? p->last_status : 0u; }
+QB3_API void qb3x_trim(void) { try { dev_pool().trim(); } catch (...) {} }
+
 QB3_API int qb3x_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;

@@ -1618,6 +1618,8 @@ for (w, h, dt, gen, mode, want_table) in [(2048, 1024, 5, "DEM", 8, True), (4100
     assert np.array_equal(out.cpu().numpy(), img.view(np.uint8).ravel()), (w, h, dt, gen)
     if want_table and ref[10] != 255:
         assert b"dec_index_table" in names.value, (w, h, dt, gen, names.value)
+        if gen == "DEM":        # ... and by hops, not by the hopping lane parsing the super-windows itself (status bit 6)
+            assert not (L.qb3x_last_decode_status(dec.p) & 64), (w, h, dt, gen, mode)
 # the same stream cut short: an error or clamped pixels as the reference's reader gives, never a hang or a fault
 img = o.generate(1024, 1024, 1, 5, "DEM", 12)
 ref = o.encode(img, 5, 8)
