@@ -257,3 +257,11 @@ int main(void) {
         r = subprocess.run([compiler, std, "-Wall", "-Werror", "-I", inc, str(path), "-L", libdir, "-lQB3",
                             "-Wl,-rpath," + libdir, "-o", str(exe)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_pool_and_status_entry_points_without_a_device(qb3):
+    """qb3x_trim and qb3x_last_decode_status (include/qb3x.h, no counterpart in the reference) are harmless without a GPU and
+    with no handle: nothing pooled, nothing to report"""
+    qb3.lib.qb3x_trim()
+    qb3.lib.qb3x_trim()
+    assert qb3.lib.qb3x_last_decode_status(None) == 0
