@@ -1312,7 +1312,7 @@ template <uint32_t UB> struct exitW {
     static constexpr uint32_t NPS = W + PE, NP1 = (NPS + MAXU + 2 + 31) & ~31u;             // positions with a switch entry; with a code length
     static constexpr uint32_t X_DEP = 1u << 30, X_SLOW = 1u << 31, X_CNT = 0x7fffu;          // (common-factor streams) a unit took the factor in force when the super-window was entered; a unit brought its own
     static constexpr uint32_t X_STOP = 0x7fffu;                                             // X: (position - W) * 16 + rung (15 bits: the entering state of the next window) | units << 15; stop: the low 15 bits all set
-    static constexpr uint32_t BMW = (NX + 31) / 32, DCAP = NX;                                 // words of the bitmap of first-window exits; distinct exits carried: as many as there are (64-bit data, 1024-bit windows: thousands)
+    static constexpr uint32_t BMW = (NX + 31) / 32, DCAP = UB == 6 ? NX : (NX < 4096 ? NX : 4096);   // words of the bitmap of first-window exits; distinct exits carried (64-bit data, 1024-bit windows: thousands; else a few hundred)
     static constexpr uint32_t T0 = 0, X0 = T0 + W * NR * 2, PF0 = X0 + ((BMW * 4 + 15) & ~15u), XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
                               E1 = S0 + ((NPS * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
     static_assert(W + MAXU < 4095 && PE * NR + NR <= 0x7fff && K * W / 2 < (1u << 15) + 1 && UB >= 3 && UB <= 6 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk");
@@ -1359,7 +1359,7 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
         // The table is made for the super-window's FIRST window, where thousands of states walk; behind it a few hundred
         // distinct states are usually left, and walking those from the code lengths (sixteen dependent byte reads a unit)
         // costs a quarter of what tabulating sixteen rungs of the window does.
-        const bool tabled = k == 0 || D > 512;                                              // (uniform.  Many distinct states: the table pays in every window)
+        const bool tabled = k == 0 || D > 1024;                                             // (uniform.  Many distinct states: the table pays in every window)
         if (tabled) for (uint32_t i = tid; i < W * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;  // (an entry no target rung fills: the unit leaves the band, or is the signal)
         __syncthreads();
 #pragma unroll 1
@@ -1391,7 +1391,8 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
         // -- behind the first window the thousands of states stand at a few hundred distinct (position, rung) -- so the distinct
         // exits are ranked through a bitmap and only those (Xd, LDS) are carried through the other windows; at the end every
         // state composes its first-window exit with what became of it.
-        auto walk = [&](uint32_t key) -> uint32_t {
+        auto walk = [&](uint32_t key, auto with_table) -> uint32_t {                        // (with_table: a compile-time flag -- the loop without the table look-up is the tighter one)
+            constexpr bool TB = decltype(with_table)::value;
             uint32_t pos = key / NR, r = key % NR, cnt = 0;                                 // (a state's low 15 bits: position * 16 + rung: the key itself)
             bool stop = false;
             typedef typename WalkValue<UB>::type TT;
@@ -1402,7 +1403,7 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
             while (true) {
                 if (r < NR) {
                     if (pos >= W) break;                                                    // behind the window, in the band: the next window's
-                    if (tabled) {
+                    if (TB) {
                         const uint32_t e = T[pos * NR + r];
                         if (e != 0xffffu) { pos = e & 0xfffu; r = e >> 12; cnt++; continue; }
                     }
@@ -1440,7 +1441,7 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
             for (uint32_t i = tid; i < E::BMW; i += NT) bm[i] = 0;
             __syncthreads();
             for (uint32_t key = tid; key < NX; key += NT) {
-                const uint32_t x = walk(key);
+                const uint32_t x = walk(key, std::true_type());
                 out[key] = x;
                 if ((x & E::X_STOP) != E::X_STOP) atomicOr(&bm[(x & 0x7fffu) >> 5], 1u << (x & 31u));
             }
@@ -1472,7 +1473,7 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
             for (uint32_t j = tid; j < D; j += NT) {                                        // the distinct walks through this window
                 const uint32_t x = Xd[j];
                 if ((x & E::X_STOP) == E::X_STOP) continue;
-                Xd[j] = compose(x, walk(x & 0x7fffu));
+                Xd[j] = compose(x, tabled ? walk(x & 0x7fffu, std::true_type()) : walk(x & 0x7fffu, std::false_type()));
             }
             __syncthreads();
         }
