@@ -1707,3 +1707,31 @@ def test_plain_wide_streams_through_the_band_table(qb3, oracle, case):
         assert b"dec_index_table" in names.value, names.value          # the band table carried the stream
     got, dims, _, _ = qb3.decode(ref)                                       # ... and through the host-pointer API
     assert dims == (w, h, b) and np.array_equal(got, img.view(np.uint8).ravel())
+
+
+def test_handles_come_and_go(qb3, oracle):
+    """a container per tile, a handle per container: encoder and decoder handles of changing geometry made, used and destroyed in
+    turn -- their device buffers come from and go back to the library's pool (qb3x_trim empties it in between) -- and every
+    round trip is exact, whatever a buffer held before (reference calling pattern: cqb3.cpp:405-493, one handle per file)"""
+    import torch
+    from qb3_amd import device as qdev
+    L = qb3.lib
+    shapes = [(256, 256, 3, 0, "NOISY3", 8), (1024, 512, 1, 5, "DEM", 8), (64, 64, 3, 0, "GRAD", 4), (512, 512, 8, 2, "LANDSAT16", 4), (256, 256, 3, 0, "NOISY3", 7),
+              (1024, 1024, 3, 0, "PALETTE", 8), (128, 96, 1, 7, "DEM", 5), (256, 256, 3, 0, "NOISY3", 8)]
+    for rnd in range(3):
+        for i, (w, h, b, dt, gen, mode) in enumerate(shapes):
+            img = oracle.generate(w, h, b, dt, gen, 30 + i + 10 * rnd)
+            cb = None if b in (1, 3, 4) else list(range(b))
+            ref = oracle.encode(img, dt, mode, cband=cb)
+            got = qb3.encode(img, dt, mode, cband=cb)                   # a fresh encoder handle
+            assert np.array_equal(got, ref), (rnd, w, h, b, dt, gen, mode)
+            d = torch.from_numpy(ref).cuda()
+            dec = qdev.DeviceDecoder(d, len(ref))                       # a fresh decoder handle on the device copy
+            if cb is not None:
+                L.qb3x_set_decoder_compat(dec.p, 0)
+            out = dec.decode(d, index=None)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), img.view(np.uint8).ravel()), (rnd, w, h, b, dt, gen, mode)
+            dec.close()
+        if rnd == 1:
+            L.qb3x_trim()
