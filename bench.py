@@ -505,6 +505,7 @@ def main():
                                                ("int32_best", qb3_amd.QB3_I32, "DEM", qb3_amd.QB3M_BEST, "int32 DEM seed 4, QB3M_BEST"),
                                                ("int64_ftl", qb3_amd.QB3_I64, "DEM", qb3_amd.QB3M_FTL, "int64 DEM seed 4, QB3M_FTL"),
                                                ("int16_base", qb3_amd.QB3_I16, "DEM", qb3_amd.QB3M_BASE, "int16 DEM seed 4, QB3M_BASE"),
+                                               ("int16_best", qb3_amd.QB3_I16, "DEM", qb3_amd.QB3M_BEST, "int16 DEM seed 4, QB3M_BEST"),
                                                ("uint8_grey", qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_FTL, "uint8 NOISY3 seed 4, QB3M_FTL")):
             pimg = synth.generate(4096, 4096, 1, pdt_, pgen, 4, device=dev)
             plain[ptag] = {"workload": f"4096x4096x1 {pname}, plain container, index = NULL"}

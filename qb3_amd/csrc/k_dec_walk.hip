@@ -1002,11 +1002,13 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
             for (uint32_t c = 0; c < B; c++) {
                 const uint64_t u0 = rd.position();
                 uint32_t rg = s_rung[c];
+                const uint32_t rg_in = rg;
                 T pc = (T)s_pcf[c];
                 ok = parse_unit<T, MODE>(rd, rg, pc, g) && ok;             // (FTL / BASE: lengths and rungs are the same with and without the step)
                 s_rung[c] = rg; s_pcf[c] = (uint64_t)pc;
                 if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[gb * B + c] = (uint16_t)(rd.position() - u0);
                 else if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[gb * B + c] = (uint8_t)(rd.position() - u0);
+                else if (a.g.ulen_sz == 4 && B == 1) ((uint32_t *)a.idx.ulen)[gb] = (uint32_t)((rd.position() - u0) & 0xffffu) | (rg_in & 15u) << 16;   // (block table of the 8-bit common-factor decoder: bits | entering rung)
                 if (MODE == CM_BEST) {                                     // (common-factor streams: the segment's sum, for the scan that gives every segment its entering value)
                     T t = (T)s_tot[c];
                     for (uint32_t i = 0; i < 16; i++) t = (T)(t + smag_t<T>(g[i]));
@@ -1596,7 +1598,7 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
     const uint64_t rel = w0 * 32 - a.in_bit0;                                               // stream position of the stage's first bit
     T g[16], pcf = (T)((uint64_t)f.x | (uint64_t)f.y << 32), tot = 0;                      // (the factor in force where the super-window is entered)
     bool ok = true;
-    typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned int>::type AT;    // (sums are added up for 32/64-bit common-factor streams only)
+    typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned int>::type AT;
     for (; U < Uend; U++) {
         if (U % NB == 0) {
             const uint64_t seg = U / NB;
@@ -1606,13 +1608,30 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
         }
         for (uint32_t c = 0; c < B; c++) {
             const uint64_t u0 = rd.position();
+            const uint32_t rg_in = rung[c];
             ok = parse_unit<T, MODE>(rd, rung[c], pcf, g) && ok;                            // (FTL / BASE: lengths and rungs are the same with and without the step)
             if (MODE != CM_BEST) {
                 if (sizeof(T) == 1) ((uint8_t *)a.idx.ulen)[U * B + c] = (uint8_t)(rd.position() - u0); else ((uint16_t *)a.idx.ulen)[U * B + c] = (uint16_t)(rd.position() - u0);
             } else {                                                                        // the segment's sum of values: the scan makes entering values of them
+                if (sizeof(T) == 1 && a.g.ulen_sz == 4) ((uint32_t *)a.idx.ulen)[U] = (uint32_t)((rd.position() - u0) & 0xffffu) | (rg_in & 15u) << 16;     // (8-bit, one band: the block table of the lane-per-block decoder)
 #pragma unroll
                 for (uint32_t i = 0; i < 16; i++) tot = (T)(tot + smag_t<T>(g[i]));
-                if ((U + 1) % NB == 0 || U + 1 == Uend) { if (sizeof(T) >= 4) atomicAdd((AT *)a.idx.prev + U / NB, (AT)tot); tot = 0; }
+                if ((U + 1) % NB == 0 || U + 1 == Uend) {
+                    const uint64_t seg = U / NB;
+                    if (sizeof(T) >= 4) atomicAdd((AT *)a.idx.prev + seg, (AT)tot);
+                    else {                                                                  // narrow values: the segment's lane of its dword, by compare and swap (the neighbours may be added to meanwhile)
+                        constexpr uint32_t BITS = sizeof(T) < 4 ? 8 * sizeof(T) : 16, PER = sizeof(T) < 4 ? 4 / sizeof(T) : 1, MASK = (1u << BITS) - 1;       // (instantiated, not run, for wide values)
+                        uint32_t *wp = (uint32_t *)a.idx.prev + seg / PER;
+                        const uint32_t sh = (uint32_t)(seg % PER) * BITS;
+                        uint32_t old = *(volatile uint32_t *)wp, assumed;
+                        do {
+                            assumed = old;
+                            const uint32_t nv = (assumed & ~(MASK << sh)) | ((((assumed >> sh) + (uint32_t)tot) & MASK) << sh);
+                            old = atomicCAS(wp, assumed, nv);
+                        } while (old != assumed);
+                    }
+                    tot = 0;
+                }
             }
         }
     }
@@ -1939,16 +1958,19 @@ static void walk_in_slabs(const DecArgs &a, hipStream_t st, void *tab, size_t ta
 // inside the walk).  False: not taken (no memory for it) -- the caller parses the stream with one lane.
 static bool walk_exit_lds_ok();
 bool launch_dec_walk_best(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
-    if (a.g.bands != 1 || a.g.tsz < 4 || a.g.mode != CM_BEST || !walk_exit_lds_ok()) return false;
+    if (a.g.bands != 1 || a.g.mode != CM_BEST || !walk_exit_lds_ok() || (a.g.tsz == 1 && a.g.ulen_sz != 4)) return false;    // (8-bit: the lane-per-block decoder's block table)
     uint32_t ns = 0, slab = 0; size_t xo = 0;
-    if (!(a.g.tsz == 4 ? walk_exit_layout<5>(a.ntiles, max_bits, tab_bytes, &ns, &slab, &xo) : walk_exit_layout<6>(a.ntiles, max_bits, tab_bytes, &ns, &slab, &xo))) return false;
-    WalkState16 *states = (WalkState16 *)tab;
     const uint32_t nt = a.ntiles;
+    if (!(a.g.tsz == 1 ? walk_exit_layout<3>(nt, max_bits, tab_bytes, &ns, &slab, &xo) : a.g.tsz == 2 ? walk_exit_layout<4>(nt, max_bits, tab_bytes, &ns, &slab, &xo) : a.g.tsz == 4 ? walk_exit_layout<5>(nt, max_bits, tab_bytes, &ns, &slab, &xo) : walk_exit_layout<6>(nt, max_bits, tab_bytes, &ns, &slab, &xo))) return false;
+    WalkState16 *states = (WalkState16 *)tab;
     { ProfScope ps("dec_index_serial", st);
       const dim3 zg((uint32_t)((a.g.nseg + 255) / 256), nt);
-      if (a.g.tsz == 4) { hipLaunchKernelGGL(walk_exit_zero_kernel<uint32_t>, zg, dim3(256), 0, st, a); hipLaunchKernelGGL((walk_probe_kernel<uint32_t, CM_BEST>), dim3(nt), dim3(64), 0, st, a, states, 16u); }
+      if (a.g.tsz == 1) { hipLaunchKernelGGL(walk_exit_zero_kernel<uint8_t>, zg, dim3(256), 0, st, a); hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_BEST>), dim3(nt), dim3(64), 0, st, a, states, 8u); }
+      else if (a.g.tsz == 2) { hipLaunchKernelGGL(walk_exit_zero_kernel<uint16_t>, zg, dim3(256), 0, st, a); hipLaunchKernelGGL((walk_probe_kernel<uint16_t, CM_BEST>), dim3(nt), dim3(64), 0, st, a, states, 16u); }
+      else if (a.g.tsz == 4) { hipLaunchKernelGGL(walk_exit_zero_kernel<uint32_t>, zg, dim3(256), 0, st, a); hipLaunchKernelGGL((walk_probe_kernel<uint32_t, CM_BEST>), dim3(nt), dim3(64), 0, st, a, states, 16u); }
       else { hipLaunchKernelGGL(walk_exit_zero_kernel<uint64_t>, zg, dim3(256), 0, st, a); hipLaunchKernelGGL((walk_probe_kernel<uint64_t, CM_BEST>), dim3(nt), dim3(64), 0, st, a, states, 16u); } }
-    return a.g.tsz == 4 ? launch_walk_exit<5, uint32_t, CM_BEST>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<6, uint64_t, CM_BEST>(a, st, tab, tab_bytes, max_bits);
+    return a.g.tsz == 1 ? launch_walk_exit<3, uint8_t, CM_BEST>(a, st, tab, tab_bytes, max_bits) : a.g.tsz == 2 ? launch_walk_exit<4, uint16_t, CM_BEST>(a, st, tab, tab_bytes, max_bits)
+         : a.g.tsz == 4 ? launch_walk_exit<5, uint32_t, CM_BEST>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<6, uint64_t, CM_BEST>(a, st, tab, tab_bytes, max_bits);
 }
 template <uint32_t U, uint32_t N> struct WideTag { static constexpr uint32_t UB_ = U, NR_ = N; };
 static bool walk_lds_attributes() {
@@ -1969,6 +1991,8 @@ static bool walk_lds_attributes() {
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<4>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<6>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<3>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<4>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<6>::LDS_BYTES) == hipSuccess;
         return ok;

@@ -411,8 +411,8 @@ DecPlan plan_decode(const Geometry &g) {
 size_t walk_table_cap() { return tuning().walk_tab_kb ? tuning().walk_tab_kb << 10 : (size_t)1 << 30; }
 bool walk_table_applies(const Geometry &g, const DecPlan &plan) {
     // 8- and 16-bit rasters the lane-per-block decoders take; 32/64-bit rasters the unit-parallel decoder takes (a band of sixteen rungs)
-    // ... and single-band 32/64-bit common-factor streams (the exits of k_dec_walk.hip)
-    if (g.mode == CM_BEST) return g.tsz >= 4 && g.bands == 1 && !tuning().slow_walk && !tuning().slow_index;
+    // ... and single-band common-factor streams of any width (the exits of k_dec_walk.hip)
+    if (g.mode == CM_BEST) return g.bands == 1 && !tuning().slow_walk && !tuning().slow_index;
     return ((plan.px && g.tsz == 1) || (plan.px16 && g.tsz == 2) || (g.tsz >= 4 && plan.fast)) && !tuning().slow_walk && !tuning().slow_index;
 }
 
@@ -494,9 +494,9 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
           launch_prev_scan(a, st);
         }
     } else if (rebuild && !a.from_ix) {
-        // plain single-band 32/64-bit common-factor streams: segment entries by the walk through exits, entering values by a scan
+        // plain single-band common-factor streams: segment entries by the walk through exits, entering values by a scan
         // of the segments' sums; anything else (and that walk when it has no memory): one lane parses the stream
-        const bool best_plain = best && !a.ix && a.g.tsz >= 4 && a.g.bands == 1 && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&
+        const bool best_plain = best && !a.ix && a.g.bands == 1 && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&
                                 !tuning().slow_walk && !tuning().slow_index && launch_dec_walk_best(a, st, walk_tab, walk_tab_bytes, max_bits);
         if (best_plain) { ProfScope ps("dec_index_scan", st); launch_prev_scan(a, st); }
         else { ProfScope ps("dec_index_serial", st); launch_dec_index_serial(a, st); }

@@ -1026,7 +1026,7 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
         if (table.base) {
             table = IxTable();
             if (!walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
-        } else if (walk_tab_ok && g.tsz >= 4 && p->d_tab.p && walk_table_applies(g, plan)) walk_tab_ok = false;
+        } else if (walk_tab_ok && (g.tsz >= 4 || g.mode == CM_BEST) && p->d_tab.p && walk_table_applies(g, plan)) walk_tab_ok = false;
         else break;
     }
     prof_collect();
@@ -1274,7 +1274,7 @@ static size_t decode_tiles_body(decsp p, const void *d_src, size_t n, size_t src
                 if (ixt.base) {
                     ixt = IxTable();
                     if (!walk_table_ready(p, g, plan, tb.n, tb.max_bits)) { p->error = QB3E_LIBERR; return done; }
-                } else if (walk_tab_ok && g.tsz >= 4 && p->d_tab.p && walk_table_applies(g, plan)) walk_tab_ok = false;   // a stream left the band of rungs: the one-lane parser
+                } else if (walk_tab_ok && (g.tsz >= 4 || g.mode == CM_BEST) && p->d_tab.p && walk_table_applies(g, plan)) walk_tab_ok = false;   // a stream left the band of rungs: the one-lane parser
                 else break;
             }
             prof_collect();

@@ -1601,7 +1601,9 @@ for (w, h, dt, gen, mode, want_table) in [(2048, 1024, 5, "DEM", 8, True), (4100
                                           # common-factor streams (QB3M_CF_H = 5, QB3M_BEST = 7): units with the signal code parsed inside the walk, super-windows
                                           # in which a unit brings a factor of its own parsed outright by the hopping lane (QB3decode.h:619-716)
                                           (2048, 1024, 5, "DEM", 5, True), (1500, 700, 7, "DEM", 7, True), (1024, 512, 5, "TERRACE", 5, True), (512, 512, 7, "FEW", 7, False),
-                                          (1024, 1024, 5, "SCALED", 5, True), (768, 512, 4, "LANDSAT16", 7, True)]:
+                                          (1024, 1024, 5, "SCALED", 5, True), (768, 512, 4, "LANDSAT16", 7, True),
+                                          # ... of 16- and 8-bit data too (8-bit: the walk's unit lanes write the block table of the lane-per-block decoder)
+                                          (1024, 1024, 3, "DEM", 7, True), (700, 500, 2, "LANDSAT16", 5, True), (1024, 768, 0, "NOISY3", 5, True), (515, 259, 1, "GRAD", 7, True)]:
     if gen == "SCALED":                         # every value a multiple of ten: every unit takes the factor the first ones brought
         img = (o.generate(w, h, 1, dt, "DEM", 11).astype(np.int64) // 16 * 10).astype(np.int32)
     else:
