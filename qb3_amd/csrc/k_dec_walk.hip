@@ -998,6 +998,8 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
     uint64_t P_end = 0;
     auto run = [&](auto &rd, uint64_t origin) {                            // origin: position() of the stream's first bit
         T g[16];
+        uint32_t bt = 0;
+        uint64_t b0 = 0;
         for (uint64_t gb = 0; gb < nb && ok; gb++)
             for (uint32_t c = 0; c < B; c++) {
                 const uint64_t u0 = rd.position();
@@ -1008,7 +1010,11 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
                 s_rung[c] = rg; s_pcf[c] = (uint64_t)pc;
                 if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[gb * B + c] = (uint16_t)(rd.position() - u0);
                 else if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[gb * B + c] = (uint8_t)(rd.position() - u0);
-                else if (a.g.ulen_sz == 4 && B == 1) ((uint32_t *)a.idx.ulen)[gb] = (uint32_t)((rd.position() - u0) & 0xffffu) | (rg_in & 15u) << 16;   // (block table of the 8-bit common-factor decoder: bits | entering rung)
+                else if (a.g.ulen_sz == 4) {                               // (block table of the 8-bit common-factor decoder: the block's bits | its units' entering rungs)
+                    if (c == 0) { bt = 0; b0 = u0; }
+                    if (c < 4) bt |= (rg_in & 15u) << (16 + 4 * c);
+                    if (c + 1 == B) ((uint32_t *)a.idx.ulen)[gb] = bt | (uint32_t)((rd.position() - b0) & 0xffffu);
+                }
                 if (MODE == CM_BEST) {                                     // (common-factor streams: the segment's sum, for the scan that gives every segment its entering value)
                     T t = (T)s_tot[c];
                     for (uint32_t i = 0; i < 16; i++) t = (T)(t + smag_t<T>(g[i]));
@@ -1029,7 +1035,9 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
     if (R0 > NRUNG - nr) R0 = NRUNG - nr;
     uint64_t rel = 0;
     for (uint32_t c = 0; c < B; c++) { const uint32_t d = s_rung[c] - R0; ok = ok && d < nr; rel |= (uint64_t)(d & 15u) << (4 * c); }
-    S->P = P_end; S->unit = nb * B; S->rungs = rel; S->pad = R0; S->bad = ok ? 0u : 1u; S->cf = s_pcf[0];
+    uint64_t cfs = s_pcf[0];                                               // (several bands, 8-bit data: a byte a band)
+    if (B > 1) { cfs = 0; for (uint32_t c = 0; c < B && c < 8; c++) cfs |= (s_pcf[c] & 0xffull) << (8 * c); }
+    S->P = P_end; S->unit = nb * B; S->rungs = rel; S->pad = R0; S->bad = ok ? 0u : 1u; S->cf = cfs;
     if (!ok) atomicOr(a.status, 1u);
 }
 
@@ -1565,7 +1573,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) walk_exit_zero_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     const uint64_t seg = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (seg && seg < a.g.nseg) ((T *)a.idx.prev)[seg] = 0;
+    if (seg && seg < a.g.nseg) for (uint32_t c = 0; c < a.g.bands; c++) ((T *)a.idx.prev)[seg * a.g.bands + c] = 0;
 }
 // A WAVE per super-window: its stretch of the stream staged in LDS by all lanes (a lane parsing straight from global memory waits
 // a round trip per word: 2.5 ms for 4096^2 int32 against 0.3 staged), then lane 0 parses the units: unit lengths, segment entries,
@@ -1596,44 +1604,50 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
     ReaderT<LdsWords> rd;
     rd.init((LdsWords)stage, (uint32_t)q0 & 31, 32ull * nw);
     const uint64_t rel = w0 * 32 - a.in_bit0;                                               // stream position of the stage's first bit
-    T g[16], pcf = (T)((uint64_t)f.x | (uint64_t)f.y << 32), tot = 0;                      // (the factor in force where the super-window is entered)
+    // (the factors in force where the super-window is entered: one band -- the whole value; several -- a byte a band, 8-bit data)
+    T g[16], pcf[4], tot[4];
+    for (uint32_t c = 0; c < 4; c++) { tot[c] = 0; pcf[c] = B == 1 ? (T)((uint64_t)f.x | (uint64_t)f.y << 32) : (T)(f.x >> (8 * c)); }
     bool ok = true;
     typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned int>::type AT;
     for (; U < Uend; U++) {
         if (U % NB == 0) {
             const uint64_t seg = U / NB;
             a.idx.bitpos[seg] = rel + rd.position();
-            for (uint32_t c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)rung[c];
-            if (MODE == CM_BEST) ((T *)a.idx.cf)[seg] = pcf;
+            for (uint32_t c = 0; c < B; c++) {
+                a.idx.rung[seg * B + c] = (uint8_t)rung[c];
+                if (MODE == CM_BEST) ((T *)a.idx.cf)[seg * B + c] = pcf[c];
+            }
         }
+        const uint64_t b0 = rd.position();
+        uint32_t bt = 0;                                                                    // (8-bit common-factor streams: the block's entry of the lane-per-block decoder's table)
         for (uint32_t c = 0; c < B; c++) {
             const uint64_t u0 = rd.position();
-            const uint32_t rg_in = rung[c];
-            ok = parse_unit<T, MODE>(rd, rung[c], pcf, g) && ok;                            // (FTL / BASE: lengths and rungs are the same with and without the step)
+            if (c < 4) bt |= (rung[c] & 15u) << (16 + 4 * c);
+            ok = parse_unit<T, MODE>(rd, rung[c], pcf[c], g) && ok;                         // (FTL / BASE: lengths and rungs are the same with and without the step)
             if (MODE != CM_BEST) {
                 if (sizeof(T) == 1) ((uint8_t *)a.idx.ulen)[U * B + c] = (uint8_t)(rd.position() - u0); else ((uint16_t *)a.idx.ulen)[U * B + c] = (uint16_t)(rd.position() - u0);
             } else {                                                                        // the segment's sum of values: the scan makes entering values of them
-                if (sizeof(T) == 1 && a.g.ulen_sz == 4) ((uint32_t *)a.idx.ulen)[U] = (uint32_t)((rd.position() - u0) & 0xffffu) | (rg_in & 15u) << 16;     // (8-bit, one band: the block table of the lane-per-block decoder)
 #pragma unroll
-                for (uint32_t i = 0; i < 16; i++) tot = (T)(tot + smag_t<T>(g[i]));
+                for (uint32_t i = 0; i < 16; i++) tot[c] = (T)(tot[c] + smag_t<T>(g[i]));
                 if ((U + 1) % NB == 0 || U + 1 == Uend) {
-                    const uint64_t seg = U / NB;
-                    if (sizeof(T) >= 4) atomicAdd((AT *)a.idx.prev + seg, (AT)tot);
-                    else {                                                                  // narrow values: the segment's lane of its dword, by compare and swap (the neighbours may be added to meanwhile)
+                    const uint64_t slot = (U / NB) * B + c;
+                    if (sizeof(T) >= 4) atomicAdd((AT *)a.idx.prev + slot, (AT)tot[c]);
+                    else {                                                                  // narrow values: the slot's lane of its dword, by compare and swap (the neighbours may be added to meanwhile)
                         constexpr uint32_t BITS = sizeof(T) < 4 ? 8 * sizeof(T) : 16, PER = sizeof(T) < 4 ? 4 / sizeof(T) : 1, MASK = (1u << BITS) - 1;       // (instantiated, not run, for wide values)
-                        uint32_t *wp = (uint32_t *)a.idx.prev + seg / PER;
-                        const uint32_t sh = (uint32_t)(seg % PER) * BITS;
+                        uint32_t *wp = (uint32_t *)a.idx.prev + slot / PER;
+                        const uint32_t sh = (uint32_t)(slot % PER) * BITS;
                         uint32_t old = *(volatile uint32_t *)wp, assumed;
                         do {
                             assumed = old;
-                            const uint32_t nv = (assumed & ~(MASK << sh)) | ((((assumed >> sh) + (uint32_t)tot) & MASK) << sh);
+                            const uint32_t nv = (assumed & ~(MASK << sh)) | ((((assumed >> sh) + (uint32_t)tot[c]) & MASK) << sh);
                             old = atomicCAS(wp, assumed, nv);
                         } while (old != assumed);
                     }
-                    tot = 0;
+                    tot[c] = 0;
                 }
             }
         }
+        if (MODE == CM_BEST && sizeof(T) == 1 && a.g.ulen_sz == 4) ((uint32_t *)a.idx.ulen)[U] = bt | (uint32_t)((rd.position() - b0) & 0xffffu);
     }
     if (!ok) atomicOr(a.status, 1u);
 }
@@ -1644,22 +1658,25 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
 // exits are ranked through a bitmap (D, a few thousand), only those are carried through the other windows of the super-window
 // (Xd, LDS), and at the end every state composes its first-window exit with what became of it.  One hop per super-window of
 // 65 536 bits as before; 915 KB of exits per super-window, so the stream is taken in rounds of what the table memory holds.
-template <uint32_t B> struct exitB {
+template <uint32_t B, bool CF = false> struct exitB {
     static constexpr uint32_t UB = 3, NRUNG = 8, NR = 8, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;        // 149
-    static constexpr uint32_t W = 2048, K = 32, SW = W * K, THREADS = 1024;
+    static constexpr uint32_t W = 2048, K = CF ? 16 : 32, SW = W * K, THREADS = 1024;      // (common-factor streams: a bit of X says "a unit took the factor in force", so a bit less for the count)
     static constexpr uint32_t PE = B * MAXU, NC = 1u << (3 * B), NKEY = PE * NC;                             // entering positions, rung combinations, states
     static constexpr uint32_t TP = W + (B - 1) * MAXU;                                                        // positions with a table row: the later units of a block that starts in the window
     static constexpr uint32_t NPT = (TP + UB + 2 + 15 * MAXC + 2 + 31) & ~31u, NP1 = (TP + MAXU + 2 + 63) & ~31u;
     static constexpr uint32_t KEYB = 18, KEYM = (1u << KEYB) - 1, X_STOP = KEYM, DCAP = 8192;                 // X: state | blocks << 18; stop: the state field all set
+    static constexpr uint32_t X_DEP = CF ? 1u << 31 : 0u, CNTM = CF ? 0x1fffu : 0x3fffu;                       // (common-factor streams) a unit took the factor in force when the super-window was entered
     static constexpr uint32_t BMW = (NKEY + 31) / 32;                                                         // words of the bitmap of first-window exits
+    static constexpr uint32_t NSIG = 128;                                                                     // (common-factor streams) positions of a window whose unit carries the signal code, at most
     static constexpr uint32_t T0 = 0, BM0 = T0 + ((TP * NR * 2 + 15) & ~15u), PF0 = BM0 + BMW * 4, XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
-                              E1 = S0 + ((TP * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
-    static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && SW / (2 * B) < (1u << (32 - KEYB)) && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
+                              E1 = S0 + ((TP * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, SG0 = (WORDS + (NP1 / 32 + 3) * 4 + 15) & ~15u,
+                              SL0 = SG0 + (CF ? NSIG * B * NR * 4 : 0), SP0 = SL0 + (CF ? (TP + 15) & ~15u : 0), LDS_BYTES = SP0 + (CF ? NSIG * 2 + 16 : 0);
+    static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && SW / (2 * B) <= CNTM && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
 };
 
-template <uint32_t B>
+template <uint32_t B, bool CF>
 __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint32_t *xg, uint32_t s_begin, uint32_t s_count, const WalkState16 *states, uint32_t dcap) {
-    typedef exitB<B> E;
+    typedef exitB<B, CF> E;
     constexpr uint32_t W = E::W, NR = E::NR, NPT = E::NPT, NP1 = E::NP1, TP = E::TP, MAXC = E::MAXC, NRUNG = E::NRUNG, NKEY = E::NKEY, NT = E::THREADS, UB = E::UB;
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     const WalkState16 &S = states[blockIdx.y];
@@ -1674,24 +1691,45 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
     __shared__ uint32_t s_D;
     const uint32_t tid = threadIdx.x;
     const uint64_t endw = (a.in_bit0 + a.in_bits + 31) >> 5;
-    // a state through the window: whole blocks until one starts behind it.  Returns the state behind | blocks << 18, or the stop.
+    uint32_t *side = (uint32_t *)(smem + E::SG0);                                           // (common-factor streams: see below)
+    uint8_t *sig_slot = smem + E::SL0;
+    uint16_t *sigpos = (uint16_t *)(smem + E::SP0);
+    __shared__ uint32_t s_nsig;
+    // a state through the window: whole blocks until one starts behind it.  Returns the state behind | blocks << 18 (| X_DEP), or the
+    // stop.  Common-factor streams: the units with the signal code are tabulated apart, per window, by band and entering rung (a
+    // dense pass: every lane parses one -- parsed inside the walks, one lane of a wave at a time, they made the kernel 25 times
+    // slower); one that takes its band's factor in force is parsed with the factor the stream had behind its first segment and
+    // the exit says so (X_DEP); one that brings its own ends the walk -- the hop parses such a super-window itself.
     auto walk = [&](uint32_t key) -> uint32_t {
-        uint32_t pos = key >> (3 * B), r[B], cnt = 0;
+        uint32_t pos = key >> (3 * B), r[B], cnt = 0, dep = 0;
 #pragma unroll
         for (uint32_t c = 0; c < B; c++) r[c] = (key >> (3 * c)) & 7u;
         while (pos < W) {
 #pragma unroll
             for (uint32_t c = 0; c < B; c++) {
                 const uint32_t e = T[pos * NR + r[c]];
-                if (e == 0xffffu) return E::X_STOP;                                         // the signal code: not a stream for this walk
-                pos = e & 0xfffu; r[c] = e >> 12;
+                if (e != 0xffffu) { pos = e & 0xfffu; r[c] = e >> 12; continue; }
+                if (!CF) return E::X_STOP;                                                  // the signal code: not a stream for this walk
+                const uint32_t j = sig_slot[pos];                                           // ... tabulated apart: by band and entering rung
+                if (j == 0xffu) return E::X_STOP;
+                const uint32_t v = side[(j * B + c) * NR + r[c]];
+                if (v & 0x10000u) return E::X_STOP;
+                if (v & 0x8000u) dep = E::X_DEP;
+                pos = v & 0xfffu; r[c] = (v >> 12) & 7u;
+                if (c + 1 < B && pos >= TP) return E::X_STOP;                               // (the block's next unit would start behind the table)
             }
             cnt++;
         }
+        if (pos - W >= E::PE) return E::X_STOP;
         uint32_t k2 = (pos - W) << (3 * B);
 #pragma unroll
         for (uint32_t c = 0; c < B; c++) k2 |= r[c] << (3 * c);
-        return k2 | (cnt << E::KEYB);
+        return k2 | (cnt << E::KEYB) | dep;
+    };
+    // an exit a, then b
+    auto compose = [](uint32_t a, uint32_t b) -> uint32_t {
+        if ((b & E::KEYM) == E::X_STOP) return E::X_STOP;
+        return (b & E::KEYM) | (((((a >> E::KEYB) & E::CNTM) + ((b >> E::KEYB) & E::CNTM)) & E::CNTM) << E::KEYB) | ((a | b) & E::X_DEP);
     };
     uint32_t D = 0;
 #pragma unroll 1
@@ -1726,6 +1764,26 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
                 uint32_t u = cs + (((s >> 11) & 1u) ? 17u : 1u);
                 if (r) { const uint32_t n8 = 8 * r + eA[o + cs]; u = cs + n8 + 8 * r + eA[o + cs + n8]; }
                 T[o * NR + bin] = (uint16_t)((o + u) | (r << 12));
+            }
+            __syncthreads();
+        }
+        if (CF) {       // the units with the signal code: their places, then every (place, band, entering rung) parsed by a lane of its own
+            if (tid == 0) s_nsig = 0;
+            for (uint32_t o = tid; o < TP; o += NT) sig_slot[o] = 0xffu;
+            __syncthreads();
+            for (uint32_t o = tid; o < TP; o += NT)
+                if ((sw[o] >> 10) & 1u) { const uint32_t j = atomicAdd(&s_nsig, 1u); if (j < E::NSIG) { sigpos[j] = (uint16_t)o; sig_slot[o] = (uint8_t)j; } }
+            __syncthreads();
+            const uint32_t nsig = s_nsig < E::NSIG ? s_nsig : E::NSIG;
+            for (uint32_t i = tid; i < nsig * B * NR; i += NT) {
+                const uint32_t j = i / (B * NR), c = (i / NR) % B, rin = i % NR, o = sigpos[j];
+                ReaderT<LdsWords> rd;
+                rd.init((LdsWords)words, sh + o, 32ull * (NP1 / 32 + 3));
+                uint32_t rg = rin, fl = 0;
+                uint8_t pc = (uint8_t)(S.cf >> (8 * c)), g[16];
+                const bool ok = parse_unit<uint8_t, CM_BEST>(rd, rg, pc, g, &fl);
+                const uint32_t end = (uint32_t)rd.position() - sh;
+                side[i] = (!ok || (fl & 2u) || end >= 4096u) ? 0x10000u : end | ((rg & 7u) << 12) | ((fl & 1u) ? 0x8000u : 0u);
             }
             __syncthreads();
         }
@@ -1770,7 +1828,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
                 const uint32_t x = Xd[j];
                 if ((x & E::KEYM) == E::X_STOP) continue;
                 const uint32_t y = walk(x & E::KEYM);
-                Xd[j] = (y & E::KEYM) == E::X_STOP ? E::X_STOP : (y & E::KEYM) | (((x >> E::KEYB) + (y >> E::KEYB)) << E::KEYB);
+                Xd[j] = compose(x, y);
             }
             __syncthreads();
         }
@@ -1780,35 +1838,36 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
         if ((e & E::KEYM) == E::X_STOP) continue;
         const uint32_t k1 = e & E::KEYM, w = k1 >> 5;
         const uint32_t x = Xd[pf[w] + __popc(bm[w] & ((1u << (k1 & 31u)) - 1u))];
-        G[key] = (x & E::KEYM) == E::X_STOP ? E::X_STOP : (x & E::KEYM) | (((e >> E::KEYB) + (x >> E::KEYB)) << E::KEYB);
+        G[key] = compose(e, x);
     }
 }
 
-// the hop for rasters of B bands: entries {position lo, hi, block, rungs (4 bits a band)}
-template <uint32_t B>
+// the hop for rasters of B bands: entries {position lo, hi, block, rungs (4 bits a band)} {factors in force (a byte a band)}
+template <uint32_t B, int MODE>
 __global__ void __launch_bounds__(64) walk_exitB_chain_kernel(const DecArgs a0, const uint32_t *xg, uint32_t nsuper, uint32_t s_begin, uint32_t s_count, WalkState16 *states, uint4 *entries) {
-    typedef exitB<B> E;
+    typedef exitB<B, MODE == CM_BEST> E;
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     if (threadIdx.x) return;
     WalkState16 *S = states + blockIdx.x;
     if (S->bad) return;
     const uint64_t nblocks = a.g.nblocks, P0 = S->P;
+    const uint32_t spec = (uint32_t)S->cf;
     uint4 *en = entries + (uint64_t)blockIdx.x * 2 * (nsuper + 2), *hd = en + 2 * (nsuper + 1);
     uint64_t P = P0, U = S->unit / B;
-    uint32_t rr = (uint32_t)S->rungs & ((1u << (4 * B)) - 1), s = 0;
+    uint32_t rr = (uint32_t)S->rungs & ((1u << (4 * B)) - 1), s = 0, cf = spec;
     bool bad = false, done = false;
     if (s_begin) {
         const uint4 h = *hd;
         if (h.y) return;
         const uint4 e = en[2 * s_begin];
-        P = (uint64_t)e.x | (uint64_t)e.y << 32; U = e.z; rr = e.w; s = s_begin;
+        P = (uint64_t)e.x | (uint64_t)e.y << 32; U = e.z; rr = e.w; s = s_begin; cf = en[2 * s_begin + 1].x;
         bad = h.x != s_begin;
     }
     const uint32_t s_end = s_begin + s_count < nsuper ? s_begin + s_count : nsuper;
     const uint32_t *x0 = xg + (uint64_t)blockIdx.x * s_count * E::NKEY;
     while (!bad) {
         en[2 * s] = make_uint4((uint32_t)P, (uint32_t)(P >> 32), (uint32_t)U, rr);
-        en[2 * s + 1] = make_uint4(0u, 0u, 0u, 0u);
+        en[2 * s + 1] = make_uint4(cf, 0u, 0u, 0u);
         if (U >= nblocks) { done = true; break; }
         if (s >= s_end) { bad = s >= nsuper; break; }
         if (P >= a.in_bits) { bad = true; break; }
@@ -1817,8 +1876,8 @@ __global__ void __launch_bounds__(64) walk_exitB_chain_kernel(const DecArgs a0, 
         for (uint32_t c = 0; c < B; c++) key |= ((rr >> (4 * c)) & 7u) << (3 * c);
         const uint32_t x = x0[(uint64_t)(s - s_begin) * E::NKEY + key];
         s++;
-        if ((x & E::KEYM) != E::X_STOP) {
-            U += x >> E::KEYB;
+        if ((x & E::KEYM) != E::X_STOP && !((x & E::X_DEP) && cf != spec)) {
+            U += (x >> E::KEYB) & E::CNTM;
             const uint32_t k2 = x & E::KEYM;
             P = base + E::SW + (k2 >> (3 * B));
             rr = 0;
@@ -1830,28 +1889,29 @@ __global__ void __launch_bounds__(64) walk_exitB_chain_kernel(const DecArgs a0, 
         Reader rd;
         rd.init(a.in32, a.in_bit0 + P, a.in_bit0 + a.in_bits);
         uint32_t rung[B];
-        for (uint32_t c = 0; c < B; c++) rung[c] = (rr >> (4 * c)) & 15u;
-        uint8_t pc = 0, g[16];
+        uint8_t pc[B], g[16];
+        for (uint32_t c = 0; c < B; c++) { rung[c] = (rr >> (4 * c)) & 15u; pc[c] = (uint8_t)(cf >> (8 * c)); }
         bool ok = true;
         const uint64_t end = base + E::SW;
         while (ok && U < nblocks) {
             const uint64_t pos = rd.position() - a.in_bit0;
             if (pos >= a.in_bits || pos >= end) break;
-            for (uint32_t c = 0; c < B; c++) ok = parse_unit<uint8_t, CM_FTL>(rd, rung[c], pc, g) && ok;
+#pragma unroll
+            for (uint32_t c = 0; c < B; c++) ok = parse_unit<uint8_t, MODE>(rd, rung[c], pc[c], g) && ok;
             U++;
         }
         P = rd.position() - a.in_bit0;
-        rr = 0;
-        for (uint32_t c = 0; c < B; c++) rr |= rung[c] << (4 * c);
+        rr = 0; cf = 0;
+        for (uint32_t c = 0; c < B; c++) { rr |= rung[c] << (4 * c); cf |= (uint32_t)pc[c] << (8 * c); }
         if (!ok || (U < nblocks && (P < end || P - end >= E::PE))) { bad = true; break; }
     }
     *hd = make_uint4(s, done ? 1u : 0u, 0u, 0u);
     if (bad) { S->bad = 1u; atomicOr(a.status, 1u); }
 }
 
-template <uint32_t B>
+template <uint32_t B, int MODE>
 static bool launch_walk_exitB(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
-    typedef exitB<B> E;
+    typedef exitB<B, MODE == CM_BEST> E;
     const uint32_t nt = a.ntiles;
     const uint64_t ns = (max_bits + E::SW - 1) / E::SW;
     const size_t fixed = (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255) + (((size_t)nt * (ns + 2) * 32 + 255) & ~(size_t)255);
@@ -1864,12 +1924,12 @@ static bool launch_walk_exitB(const DecArgs &a, hipStream_t st, void *tab, size_
     for (uint32_t s0 = 0; s0 < nsuper; s0 += slab) {
         const uint32_t cnt = nsuper - s0 < slab ? nsuper - s0 : slab;
         { ProfScope ps("dec_index_table", st);
-          hipLaunchKernelGGL(walk_exitB_kernel<B>, dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states, a.wide_band == 18 ? 64u : E::DCAP); }
+          hipLaunchKernelGGL((walk_exitB_kernel<B, MODE == CM_BEST>), dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states, a.wide_band == 18 ? 64u : E::DCAP); }
         ProfScope ps("dec_index_serial", st);
-        hipLaunchKernelGGL(walk_exitB_chain_kernel<B>, dim3(nt), dim3(64), 0, st, a, (const uint32_t *)xg, nsuper, s0, cnt, states, entries);
+        hipLaunchKernelGGL((walk_exitB_chain_kernel<B, MODE>), dim3(nt), dim3(64), 0, st, a, (const uint32_t *)xg, nsuper, s0, cnt, states, entries);
     }
     ProfScope ps("dec_index_serial", st);
-    hipLaunchKernelGGL((walk_exit_units_kernel<uint8_t, CM_FTL>), dim3(nsuper, nt), dim3(64), ((E::SW + E::PE) / 32 + 4) * 4, st, a, (const WalkState16 *)states, (const uint4 *)entries, nsuper, E::SW, E::PE);
+    hipLaunchKernelGGL((walk_exit_units_kernel<uint8_t, MODE>), dim3(nsuper, nt), dim3(64), ((E::SW + E::PE) / 32 + 4) * 4, st, a, (const WalkState16 *)states, (const uint4 *)entries, nsuper, E::SW, E::PE);
     return true;
 }
 
@@ -1958,7 +2018,15 @@ static void walk_in_slabs(const DecArgs &a, hipStream_t st, void *tab, size_t ta
 // inside the walk).  False: not taken (no memory for it) -- the caller parses the stream with one lane.
 static bool walk_exit_lds_ok();
 bool launch_dec_walk_best(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
-    if (a.g.bands != 1 || a.g.mode != CM_BEST || !walk_exit_lds_ok() || (a.g.tsz == 1 && a.g.ulen_sz != 4)) return false;    // (8-bit: the lane-per-block decoder's block table)
+    if (a.g.mode != CM_BEST || !walk_exit_lds_ok() || (a.g.tsz == 1 && a.g.ulen_sz != 4)) return false;    // (8-bit: the lane-per-block decoder's block table)
+    if (a.g.bands == 3 && a.g.tsz == 1) {          // 8-bit RGB
+        WalkState16 *states = (WalkState16 *)tab;
+        { ProfScope ps("dec_index_serial", st);
+          hipLaunchKernelGGL(walk_exit_zero_kernel<uint8_t>, dim3((uint32_t)((a.g.nseg + 255) / 256), a.ntiles), dim3(256), 0, st, a);
+          hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_BEST>), dim3(a.ntiles), dim3(64), 0, st, a, states, 8u); }
+        return launch_walk_exitB<3, CM_BEST>(a, st, tab, tab_bytes, max_bits);
+    }
+    if (a.g.bands != 1) return false;
     uint32_t ns = 0, slab = 0; size_t xo = 0;
     const uint32_t nt = a.ntiles;
     if (!(a.g.tsz == 1 ? walk_exit_layout<3>(nt, max_bits, tab_bytes, &ns, &slab, &xo) : a.g.tsz == 2 ? walk_exit_layout<4>(nt, max_bits, tab_bytes, &ns, &slab, &xo) : a.g.tsz == 4 ? walk_exit_layout<5>(nt, max_bits, tab_bytes, &ns, &slab, &xo) : walk_exit_layout<6>(nt, max_bits, tab_bytes, &ns, &slab, &xo))) return false;
@@ -1986,7 +2054,8 @@ static bool walk_lds_attributes() {
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 14>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 16>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 16>::LDS_BYTES) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<3>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<3, false>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<3, true>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<3>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<4>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
@@ -2016,7 +2085,7 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
         WalkState16 *states = (WalkState16 *)tab;
         { ProfScope ps("dec_index_serial", st);
           hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(nt), dim3(64), 0, st, a, states, 8u, 8u); }
-        if (launch_walk_exitB<3>(a, st, tab, tab_bytes, max_bits)) return;
+        if (launch_walk_exitB<3, CM_FTL>(a, st, tab, tab_bytes, max_bits)) return;
     }
     if (a.g.tsz >= 4) {         // 32/64-bit FTL/BASE: the first segment parsed outright (band of rungs, entry state), then table + chain
         WalkState16 *states = (WalkState16 *)tab;

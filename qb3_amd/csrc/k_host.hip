@@ -412,7 +412,7 @@ size_t walk_table_cap() { return tuning().walk_tab_kb ? tuning().walk_tab_kb << 
 bool walk_table_applies(const Geometry &g, const DecPlan &plan) {
     // 8- and 16-bit rasters the lane-per-block decoders take; 32/64-bit rasters the unit-parallel decoder takes (a band of sixteen rungs)
     // ... and single-band common-factor streams of any width (the exits of k_dec_walk.hip)
-    if (g.mode == CM_BEST) return g.bands == 1 && !tuning().slow_walk && !tuning().slow_index;
+    if (g.mode == CM_BEST) return (g.bands == 1 || (g.bands == 3 && g.tsz == 1)) && !tuning().slow_walk && !tuning().slow_index;
     return ((plan.px && g.tsz == 1) || (plan.px16 && g.tsz == 2) || (g.tsz >= 4 && plan.fast)) && !tuning().slow_walk && !tuning().slow_index;
 }
 
@@ -496,7 +496,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     } else if (rebuild && !a.from_ix) {
         // plain single-band common-factor streams: segment entries by the walk through exits, entering values by a scan
         // of the segments' sums; anything else (and that walk when it has no memory): one lane parses the stream
-        const bool best_plain = best && !a.ix && a.g.bands == 1 && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&
+        const bool best_plain = best && !a.ix && (a.g.bands == 1 || (a.g.bands == 3 && a.g.tsz == 1)) && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&
                                 !tuning().slow_walk && !tuning().slow_index && launch_dec_walk_best(a, st, walk_tab, walk_tab_bytes, max_bits);
         if (best_plain) { ProfScope ps("dec_index_scan", st); launch_prev_scan(a, st); }
         else { ProfScope ps("dec_index_serial", st); launch_dec_index_serial(a, st); }

@@ -1516,8 +1516,14 @@ from qb3_amd import device as qdev
 from oracle import pyoracle as o
 L = qb3_amd.lib
 for (w, h, gen, mode) in [(1024, 1024, "NOISY3", 8), (1100, 700, "NOISY3", 4), (509, 259, "GRAD", 8), (2048, 300, "PALETTE", 8), (640, 480, "RANDOM", 8),
-                          (768, 512, "FEW", 4), (256, 256, "CONST", 8), (4096, 64, "NOISY3", 0)]:
-    img = o.generate(w, h, 3, 0, gen, 21)
+                          (768, 512, "FEW", 4), (256, 256, "CONST", 8), (4096, 64, "NOISY3", 0),
+                          # common-factor streams (QB3M_CF_H, QB3M_BEST): units with the signal code tabulated apart, super-windows in which a unit
+                          # brings its own factor parsed by the hopping lane, the block table of the lane-per-block decoder written by the unit lanes
+                          (1024, 1024, "NOISY3", 5), (1100, 700, "NOISY3", 7), (509, 259, "GRAD", 5), (768, 512, "PALETTE", 7), (640, 480, "FEW", 5), (512, 512, "SCALED", 5)]:
+    if gen == "SCALED":                         # every value a multiple of three: every unit takes the factor the first ones brought
+        img = (o.generate(w, h, 3, 0, "NOISY3", 21).astype(np.uint16) // 3 * 3).astype(np.uint8)
+    else:
+        img = o.generate(w, h, 3, 0, gen, 21)
     ref = o.encode(img, 0, mode)
     d = torch.from_numpy(ref).cuda()
     dec = qdev.DeviceDecoder(d, len(ref))
