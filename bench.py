@@ -496,6 +496,8 @@ def main():
         pimg = synth.generate(4096, 4096, 3, dtype, "NOISY3", 1000, device=dev)
         plain = {"workload": "4096x4096x3 uint8 NOISY3 seed 1000, plain container, index = NULL"}
         plain.update(plain_decode(pimg, 4096))
+        plain["uint8x3_best"] = {"workload": "the same raster in QB3M_BEST (common factor + index coding), plain container, index = NULL"}
+        plain["uint8x3_best"].update(plain_decode(pimg, 4096, 3, None, qb3_amd.QB3M_BEST))
         del pimg
         if args.size == 16384:
             plain["config2"] = {"workload": "the 16384x16384x3 raster of the headline, plain container, index = NULL"}
