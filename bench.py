@@ -619,7 +619,8 @@ def run_other(wl, args, torch, qb3_amd, synth, qdev, dev):
         for tag, bands, dt_, gen, seed, mode, name in (("plain", 3, qb3_amd.QB3_U8, "NOISY3", 1000, qb3_amd.QB3M_FTL, "x3 uint8 NOISY3 seed 1000, QB3M_FTL"),
                                                        ("plain_int32_ftl", 1, qb3_amd.QB3_I32, "DEM", 4, qb3_amd.QB3M_FTL, "x1 int32 DEM seed 4, QB3M_FTL"),
                                                        ("plain_int32_best", 1, qb3_amd.QB3_I32, "DEM", 4, qb3_amd.QB3M_BEST, "x1 int32 DEM seed 4, QB3M_BEST"),
-                                                       ("plain_int16_base", 1, qb3_amd.QB3_I16, "DEM", 4, qb3_amd.QB3M_BASE, "x1 int16 DEM seed 4, QB3M_BASE")):
+                                                       ("plain_int16_base", 1, qb3_amd.QB3_I16, "DEM", 4, qb3_amd.QB3M_BASE, "x1 int16 DEM seed 4, QB3M_BASE"),
+                                                       ("plain_rgb_best", 3, qb3_amd.QB3_U8, "NOISY3", 1000, qb3_amd.QB3M_BEST, "x3 uint8 NOISY3 seed 1000, QB3M_BEST")):
             img = synth.generate(w, w, bands, dt_, gen, seed, device=dev)
             enc = qdev.DeviceEncoder(w, w, bands, dt_, mode=mode)
             dst, n, _ = enc.encode(img)
