@@ -1775,15 +1775,25 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
                 if ((sw[o] >> 10) & 1u) { const uint32_t j = atomicAdd(&s_nsig, 1u); if (j < E::NSIG) { sigpos[j] = (uint16_t)o; sig_slot[o] = (uint8_t)j; } }
             __syncthreads();
             const uint32_t nsig = s_nsig < E::NSIG ? s_nsig : E::NSIG;
-            for (uint32_t i = tid; i < nsig * B * NR; i += NT) {
-                const uint32_t j = i / (B * NR), c = (i / NR) % B, rin = i % NR, o = sigpos[j];
-                ReaderT<LdsWords> rd;
-                rd.init((LdsWords)words, sh + o, 32ull * (NP1 / 32 + 3));
-                uint32_t rg = rin, fl = 0;
-                uint8_t pc = (uint8_t)(S.cf >> (8 * c)), g[16];
-                const bool ok = parse_unit<uint8_t, CM_BEST>(rd, rg, pc, g, &fl);
-                const uint32_t end = (uint32_t)rd.position() - sh;
-                side[i] = (!ok || (fl & 2u) || end >= 4096u) ? 0x10000u : end | ((rg & 7u) << 12) | ((fl & 1u) ? 0x8000u : 0u);
+            for (uint32_t i = tid; i < nsig * NR; i += NT) {                               // (a lane per place and entering rung: the bands differ only where the unit takes a factor in force, and only if theirs differ)
+                const uint32_t j = i / NR, rin = i % NR, o = sigpos[j];
+                uint32_t first = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < B; c++) {
+                    const uint8_t spec_c = (uint8_t)(S.cf >> (8 * c));
+                    uint32_t v = first;
+                    if (c == 0 || ((first & 0x8000u) && spec_c != (uint8_t)S.cf)) {
+                        ReaderT<LdsWords> rd;
+                        rd.init((LdsWords)words, sh + o, 32ull * (NP1 / 32 + 3));
+                        uint32_t rg = rin, fl = 0;
+                        uint8_t pc = spec_c, g[16];
+                        const bool ok = parse_unit<uint8_t, CM_BEST>(rd, rg, pc, g, &fl);
+                        const uint32_t end = (uint32_t)rd.position() - sh;
+                        v = (!ok || (fl & 2u) || end >= 4096u) ? 0x10000u : end | ((rg & 7u) << 12) | ((fl & 1u) ? 0x8000u : 0u);
+                        if (c == 0) first = v;
+                    }
+                    side[(j * B + c) * NR + rin] = v;
+                }
             }
             __syncthreads();
         }
