@@ -1660,18 +1660,20 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
 // 65 536 bits as before; 915 KB of exits per super-window, so the stream is taken in rounds of what the table memory holds.
 template <uint32_t B, bool CF = false> struct exitB {
     static constexpr uint32_t UB = 3, NRUNG = 8, NR = 8, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;        // 149
-    static constexpr uint32_t W = 2048, K = CF ? 16 : 32, SW = W * K, THREADS = 1024;      // (common-factor streams: a bit of X says "a unit took the factor in force", so a bit less for the count)
+    static constexpr uint32_t W = 2048, K = 32, SW = W * K, THREADS = 1024;
     static constexpr uint32_t PE = B * MAXU, NC = 1u << (3 * B), NKEY = PE * NC;                             // entering positions, rung combinations, states
     static constexpr uint32_t TP = W + (B - 1) * MAXU;                                                        // positions with a table row: the later units of a block that starts in the window
     static constexpr uint32_t NPT = (TP + UB + 2 + 15 * MAXC + 2 + 31) & ~31u, NP1 = (TP + MAXU + 2 + 63) & ~31u;
     static constexpr uint32_t KEYB = 18, KEYM = (1u << KEYB) - 1, X_STOP = KEYM, DCAP = 8192;                 // X: state | blocks << 18; stop: the state field all set
-    static constexpr uint32_t X_DEP = CF ? 1u << 31 : 0u, CNTM = CF ? 0x1fffu : 0x3fffu;                       // (common-factor streams) a unit took the factor in force when the super-window was entered
+    // (common-factor streams) a bit of X says "a unit took the factor in force when the super-window was entered", which leaves 13 bits
+    // for the blocks: a super-window of more than 8191 blocks -- under eight bits a block: flat data -- stops the walk, the hop parses it
+    static constexpr uint32_t X_DEP = CF ? 1u << 31 : 0u, CNTM = CF ? 0x1fffu : 0x3fffu;
     static constexpr uint32_t BMW = (NKEY + 31) / 32;                                                         // words of the bitmap of first-window exits
     static constexpr uint32_t NSIG = 128;                                                                     // (common-factor streams) positions of a window whose unit carries the signal code, at most
     static constexpr uint32_t T0 = 0, BM0 = T0 + ((TP * NR * 2 + 15) & ~15u), PF0 = BM0 + BMW * 4, XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
                               E1 = S0 + ((TP * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, SG0 = (WORDS + (NP1 / 32 + 3) * 4 + 15) & ~15u,
                               SL0 = SG0 + (CF ? NSIG * B * NR * 4 : 0), SP0 = SL0 + (CF ? (TP + 15) & ~15u : 0), LDS_BYTES = SP0 + (CF ? NSIG * 2 + 16 : 0);
-    static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && SW / (2 * B) <= CNTM && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
+    static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && (CF || SW / (2 * B) <= CNTM) && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
 };
 
 template <uint32_t B, bool CF>
@@ -1729,7 +1731,9 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
     // an exit a, then b
     auto compose = [](uint32_t a, uint32_t b) -> uint32_t {
         if ((b & E::KEYM) == E::X_STOP) return E::X_STOP;
-        return (b & E::KEYM) | (((((a >> E::KEYB) & E::CNTM) + ((b >> E::KEYB) & E::CNTM)) & E::CNTM) << E::KEYB) | ((a | b) & E::X_DEP);
+        const uint32_t n = ((a >> E::KEYB) & E::CNTM) + ((b >> E::KEYB) & E::CNTM);
+        if (n > E::CNTM) return E::X_STOP;
+        return (b & E::KEYM) | (n << E::KEYB) | ((a | b) & E::X_DEP);
     };
     uint32_t D = 0;
 #pragma unroll 1
