@@ -1312,7 +1312,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
 template <uint32_t UB> struct WalkValue { typedef typename std::conditional<UB == 3, uint8_t, typename std::conditional<UB == 4, uint16_t, typename std::conditional<UB == 5, uint32_t, uint64_t>::type>::type>::type type; };
 template <uint32_t UB> struct exitW {
     static constexpr uint32_t NRUNG = 1u << UB, NR = 16, NRB = NRUNG < NR ? NRUNG : NR, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;
-    static constexpr uint32_t W = UB == 6 ? 1024 : 2048, K = 32768 / W, SW = W * K, THREADS = 1024;
+    static constexpr uint32_t W = UB == 6 ? 1024 : 2048, K = 65536 / W, SW = W * K, THREADS = 1024;      // (a super-window's cost is its first window's: long ones)
     // A walk leaves a window at the first unit that starts behind it AND is entered with a rung of the band: units entered
     // out of the band (the one behind a unit whose switch jumped out: the first unit of a block row of a wide raster) are
     // walked on the spot from the code lengths, so a window can be entered up to PE bits in.  (8- and 16-bit data: the band
@@ -1325,7 +1325,7 @@ template <uint32_t UB> struct exitW {
     static constexpr uint32_t BMW = (NX + 31) / 32, DCAP = UB == 6 ? NX : (NX < 4096 ? NX : 4096);   // words of the bitmap of first-window exits; distinct exits carried (64-bit data, 1024-bit windows: thousands; else a few hundred)
     static constexpr uint32_t T0 = 0, X0 = T0 + W * NR * 2, PF0 = X0 + ((BMW * 4 + 15) & ~15u), XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
                               E1 = S0 + ((NPS * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, LDS_BYTES = WORDS + (NP1 / 32 + 3) * 4;
-    static_assert(W + MAXU < 4095 && PE * NR + NR <= 0x7fff && K * W / 2 < (1u << 15) + 1 && UB >= 3 && UB <= 6 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk");
+    static_assert(W + MAXU < 4095 && PE * NR + NR <= 0x7fff && UB >= 3 && UB <= 6 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk");
 };
 
 template <uint32_t UB, bool CF>
@@ -1351,7 +1351,8 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
     // a first-window exit (or a list entry) a, then b: flags add up -- a factor brought anywhere, a factor taken before one was
     // brought, or after: X_SLOW then
     auto compose = [](uint32_t a, uint32_t b) -> uint32_t {
-        return (b & 0x7fffu) | (((((a >> 15) & E::X_CNT) + ((b >> 15) & E::X_CNT)) & E::X_CNT) << 15) | ((a | b) & (E::X_DEP | E::X_SLOW));
+        const uint32_t n = ((a >> 15) & E::X_CNT) + ((b >> 15) & E::X_CNT);               // (more units than the field holds -- two bits a unit: flat data -- stop the walk)
+        return (n > E::X_CNT ? E::X_STOP : (b & 0x7fffu)) | ((n & E::X_CNT) << 15) | ((a | b) & (E::X_DEP | E::X_SLOW));
     };
 #pragma unroll 1
     for (uint32_t k = 0; k < E::K; k++) {
@@ -1660,20 +1661,20 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
 // 65 536 bits as before; 915 KB of exits per super-window, so the stream is taken in rounds of what the table memory holds.
 template <uint32_t B, bool CF = false> struct exitB {
     static constexpr uint32_t UB = 3, NRUNG = 8, NR = 8, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;        // 149
-    static constexpr uint32_t W = 2048, K = 32, SW = W * K, THREADS = 1024;
+    static constexpr uint32_t W = 2048, K = 64, SW = W * K, THREADS = 1024;             // (a super-window's cost is its first window's, where every state walks: long ones)
     static constexpr uint32_t PE = B * MAXU, NC = 1u << (3 * B), NKEY = PE * NC;                             // entering positions, rung combinations, states
     static constexpr uint32_t TP = W + (B - 1) * MAXU;                                                        // positions with a table row: the later units of a block that starts in the window
     static constexpr uint32_t NPT = (TP + UB + 2 + 15 * MAXC + 2 + 31) & ~31u, NP1 = (TP + MAXU + 2 + 63) & ~31u;
     static constexpr uint32_t KEYB = 18, KEYM = (1u << KEYB) - 1, X_STOP = KEYM, DCAP = 8192;                 // X: state | blocks << 18; stop: the state field all set
-    // (common-factor streams) a bit of X says "a unit took the factor in force when the super-window was entered", which leaves 13 bits
-    // for the blocks: a super-window of more than 8191 blocks -- under eight bits a block: flat data -- stops the walk, the hop parses it
+    // blocks of a super-window: 14 bits, or 13 beside the bit that says (common-factor streams) "a unit took the factor in force when
+    // the super-window was entered": more blocks than that -- eight or sixteen bits a block: flat data -- stop the walk, the hop parses it
     static constexpr uint32_t X_DEP = CF ? 1u << 31 : 0u, CNTM = CF ? 0x1fffu : 0x3fffu;
     static constexpr uint32_t BMW = (NKEY + 31) / 32;                                                         // words of the bitmap of first-window exits
     static constexpr uint32_t NSIG = 128;                                                                     // (common-factor streams) positions of a window whose unit carries the signal code, at most
     static constexpr uint32_t T0 = 0, BM0 = T0 + ((TP * NR * 2 + 15) & ~15u), PF0 = BM0 + BMW * 4, XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
                               E1 = S0 + ((TP * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, SG0 = (WORDS + (NP1 / 32 + 3) * 4 + 15) & ~15u,
                               SL0 = SG0 + (CF ? NSIG * B * NR * 4 : 0), SP0 = SL0 + (CF ? (TP + 15) & ~15u : 0), LDS_BYTES = SP0 + (CF ? NSIG * 2 + 16 : 0);
-    static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && (CF || SW / (2 * B) <= CNTM) && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
+    static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
 };
 
 template <uint32_t B, bool CF>
