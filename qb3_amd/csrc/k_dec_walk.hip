@@ -1605,6 +1605,8 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
     ReaderT<LdsWords> rd;
     rd.init((LdsWords)stage, (uint32_t)q0 & 31, 32ull * nw);
     const uint64_t rel = w0 * 32 - a.in_bit0;                                               // stream position of the stage's first bit
+    uint32_t lpos = (uint32_t)q0 & 31;                                                      // (FTL / BASE) bit position in the stage
+    const uint32_t lds0 = 8u * (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)stage;    // ... whose first bit is LDS bit lds0
     // (the factors in force where the super-window is entered: one band -- the whole value; several -- a byte a band, 8-bit data)
     T g[16], pcf[4], tot[4];
     for (uint32_t c = 0; c < 4; c++) { tot[c] = 0; pcf[c] = B == 1 ? (T)((uint64_t)f.x | (uint64_t)f.y << 32) : (T)(f.x >> (8 * c)); }
@@ -1613,18 +1615,28 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
     for (; U < Uend; U++) {
         if (U % NB == 0) {
             const uint64_t seg = U / NB;
-            a.idx.bitpos[seg] = rel + rd.position();
+            a.idx.bitpos[seg] = rel + (MODE != CM_BEST ? (uint64_t)lpos : rd.position());
             for (uint32_t c = 0; c < B; c++) {
                 a.idx.rung[seg * B + c] = (uint8_t)rung[c];
                 if (MODE == CM_BEST) ((T *)a.idx.cf)[seg * B + c] = pcf[c];
             }
+        }
+        if (MODE != CM_BEST) {      // FTL / BASE: lengths only, by position in the staged words (walk_unit: three dependent reads an 8-bit unit; a full parse costs ten times that)
+            for (uint32_t c = 0; c < B; c++) {
+                bool bad = false;
+                const uint32_t len = walk_unit<UBits<T>::v>(lds0 + lpos, rung[c], bad);
+                ok = ok && !bad;
+                if (sizeof(T) == 1) ((uint8_t *)a.idx.ulen)[U * B + c] = (uint8_t)len; else ((uint16_t *)a.idx.ulen)[U * B + c] = (uint16_t)len;
+                lpos += len;
+            }
+            continue;
         }
         const uint64_t b0 = rd.position();
         uint32_t bt = 0;                                                                    // (8-bit common-factor streams: the block's entry of the lane-per-block decoder's table)
         for (uint32_t c = 0; c < B; c++) {
             const uint64_t u0 = rd.position();
             if (c < 4) bt |= (rung[c] & 15u) << (16 + 4 * c);
-            ok = parse_unit<T, MODE>(rd, rung[c], pcf[c], g) && ok;                         // (FTL / BASE: lengths and rungs are the same with and without the step)
+            ok = parse_unit<T, MODE>(rd, rung[c], pcf[c], g) && ok;
             if (MODE != CM_BEST) {
                 if (sizeof(T) == 1) ((uint8_t *)a.idx.ulen)[U * B + c] = (uint8_t)(rd.position() - u0); else ((uint16_t *)a.idx.ulen)[U * B + c] = (uint16_t)(rd.position() - u0);
             } else {                                                                        // the segment's sum of values: the scan makes entering values of them
@@ -1661,7 +1673,7 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
 // 65 536 bits as before; 915 KB of exits per super-window, so the stream is taken in rounds of what the table memory holds.
 template <uint32_t B, bool CF = false> struct exitB {
     static constexpr uint32_t UB = 3, NRUNG = 8, NR = 8, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;        // 149
-    static constexpr uint32_t W = 2048, K = 64, SW = W * K, THREADS = 1024;             // (a super-window's cost is its first window's, where every state walks: long ones)
+    static constexpr uint32_t W = 2048, K = 64, SW = W * K, THREADS = 1024;             // (a super-window's cost is its first window's, where every state walks: long ones -- twice this: 4 % more, and the lanes that parse the units become the long pole)
     static constexpr uint32_t PE = B * MAXU, NC = 1u << (3 * B), NKEY = PE * NC;                             // entering positions, rung combinations, states
     static constexpr uint32_t TP = W + (B - 1) * MAXU;                                                        // positions with a table row: the later units of a block that starts in the window
     static constexpr uint32_t NPT = (TP + UB + 2 + 15 * MAXC + 2 + 31) & ~31u, NP1 = (TP + MAXU + 2 + 63) & ~31u;
@@ -1677,6 +1689,15 @@ template <uint32_t B, bool CF = false> struct exitB {
     static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
 };
 
+// diagnostic build (-DEXITB_STAMPS): shader clocks spent per phase, summed over the workgroups of the first launches (scratch/stamps_exitb.py)
+#ifdef EXITB_STAMPS
+__device__ unsigned long long exitb_stamps[16];
+#define XB_T0() unsigned long long xb_t = clock64()
+#define XB_PH(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = clock64(); atomicAdd(&exitb_stamps[k], n_ - xb_t); xb_t = n_; } } while (0)
+#else
+#define XB_T0() do { } while (0)
+#define XB_PH(k) do { } while (0)
+#endif
 template <uint32_t B, bool CF>
 __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint32_t *xg, uint32_t s_begin, uint32_t s_count, const WalkState16 *states, uint32_t dcap) {
     typedef exitB<B, CF> E;
@@ -1736,6 +1757,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
         if (n > E::CNTM) return E::X_STOP;
         return (b & E::KEYM) | (n << E::KEYB) | ((a | b) & E::X_DEP);
     };
+    XB_T0();
     uint32_t D = 0;
 #pragma unroll 1
     for (uint32_t k = 0; k < E::K; k++) {
@@ -1743,6 +1765,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
         const uint32_t sh = (uint32_t)q0 & 31;
         for (uint32_t i = tid; i < NP1 / 32 + 3; i += NT) words[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
         __syncthreads();
+        XB_PH(0);
         auto bits = [&](uint32_t i) { const uint32_t b = sh + i, j = b >> 5; return __builtin_amdgcn_alignbit(words[j + 1], words[j], b & 31); };
         for (uint32_t i = tid; i < NP1; i += NT) { const uint32_t x = bits(i); t1[i] = (uint8_t)((x & 1) + ((x & 3) == 3)); }
         for (uint32_t o = tid; o < TP; o += NT) {
@@ -1752,6 +1775,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
         }
         for (uint32_t i = tid; i < TP * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;
         __syncthreads();
+        XB_PH(1);
 #pragma unroll 1
         for (uint32_t r = 0; r < NRUNG; r++) {                                              // the rung the switch leads to
             if (r) {
@@ -1772,6 +1796,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
             }
             __syncthreads();
         }
+        XB_PH(2);
         if (CF) {       // the units with the signal code: their places, then every (place, band, entering rung) parsed by a lane of its own
             if (tid == 0) s_nsig = 0;
             for (uint32_t o = tid; o < TP; o += NT) sig_slot[o] = 0xffu;
@@ -1802,6 +1827,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
             }
             __syncthreads();
         }
+        XB_PH(3);
         if (k == 0) {
             for (uint32_t i = tid; i < E::BMW; i += NT) bm[i] = 0;
             __syncthreads();
@@ -1811,6 +1837,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
                 if ((x & E::KEYM) != E::X_STOP) atomicOr(&bm[(x & E::KEYM) >> 5], 1u << (x & 31u));
             }
             __syncthreads();
+            XB_PH(4);
             // rank of every distinct exit: exclusive prefix of the bitmap words' bit counts (the scan's scratch: Xd, not yet in use)
             constexpr uint32_t PER = (E::BMW + NT - 1) / NT;
             uint32_t mine = 0;
@@ -1838,6 +1865,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
                 while (m) { const uint32_t b = __ffs(m) - 1; Xd[j++] = w * 32 + b; m &= m - 1; }
             }
             __syncthreads();
+            XB_PH(5);
         } else {
             for (uint32_t j = tid; j < D; j += NT) {                                        // the distinct walks through this window
                 const uint32_t x = Xd[j];
@@ -1846,6 +1874,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
                 Xd[j] = compose(x, y);
             }
             __syncthreads();
+            XB_PH(6);
         }
     }
     for (uint32_t key = tid; key < NKEY; key += NT) {                                       // every state: its first-window exit, then what became of that
@@ -1855,6 +1884,8 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
         const uint32_t x = Xd[pf[w] + __popc(bm[w] & ((1u << (k1 & 31u)) - 1u))];
         G[key] = compose(e, x);
     }
+    __syncthreads();
+    XB_PH(7);
 }
 
 // the hop for rasters of B bands: entries {position lo, hi, block, rungs (4 bits a band)} {factors in force (a byte a band)}
@@ -2186,3 +2217,8 @@ void launch_prev_scan(const DecArgs &a, hipStream_t st) {
 }
 
 }  // namespace qb3dev
+#ifdef EXITB_STAMPS
+extern "C" __attribute__((visibility("default"))) int qb3x_debug_exitb_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qb3dev::exitb_stamps), sizeof(qb3dev::exitb_stamps));
+}
+#endif
