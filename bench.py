@@ -121,16 +121,37 @@ def roofline_of(avg, algo_bytes, names, traffic=None, extra=None):
     return r
 
 
-def pmc_traffic(kernel, workload=None):
-    """HBM bytes per launch (PMC, corrected) and the VALU summary of a kernel from the committed rocprofv3 passes
-    (profiles/collect.sh); the other workloads' records sit under their name in `workloads`"""
+def pmc_traffic(kernel, workload=None, from_table=False):
+    """HBM bytes per launch (PMC, corrected), the VALU summary and the CSV the bytes are a row of, for a kernel from the
+    committed rocprofv3 passes (profiles/collect.sh -> profiles/pmc_traffic.json); the other workloads' records sit under
+    their name in `workloads`.  from_table: the launch decoded from the container's own table (the decoders' BL variants are
+    kept apart from the ones that take the out-of-band index: profiles/summarise.py, `dec_units_bl`)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             rec = json.load(f)
-        rec = (rec.get(workload, {}) if workload else rec).get(kernel, {})
-        return rec.get("hbm_bytes_per_launch"), rec.get("valu")
+        rec = rec.get(workload, {}) if workload else rec
+        rec = (rec.get(kernel + "_bl") if from_table and kernel + "_bl" in rec else rec.get(kernel)) or {}
+        return rec.get("hbm_bytes_per_launch"), rec.get("valu"), rec.get("source")
     except (OSError, ValueError):
-        return None, None
+        return None, None, None
+
+
+def attach_traffic(roofline, algo_bytes, workload=None, from_table=False, scale=1.0):
+    """roofline.traffic (+ .valu, .traffic_source) from the committed PMC passes.  A record that says the kernel moves more
+    than four times its algorithmic bytes is not believed (a summary gone wrong, not a kernel): traffic stays null and the
+    line says why."""
+    if roofline is None:
+        return
+    t, valu, src = pmc_traffic(roofline["kernel"], workload, from_table)
+    if t is not None:
+        t = int(round(t * scale))
+        if t > 4 * algo_bytes:
+            roofline["traffic_rejected"] = f"{src}: {t} B per launch is more than 4x the algorithmic {int(algo_bytes)} B"
+            t = None
+    roofline["traffic"] = t
+    roofline["traffic_source"] = src if t is not None else None
+    if valu:
+        roofline["valu"] = valu
 
 
 def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen, seed, mode, steps, label):
@@ -188,10 +209,7 @@ def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen
         "roofline": roofline_of({**e, **d_oob}, algo, ENC_KERNELS + DEC_KERNELS,
                                 extra={"restart_table_in_container": int(n) - stream_bytes, "out_of_band_index": enc.index_bytes}),
     })
-    if res["roofline"]:             # HBM bytes of the dominant kernel by the PMC passes of this workload (profiles/collect.sh)
-        res["roofline"]["traffic"], valu = pmc_traffic(res["roofline"]["kernel"], tag)
-        if valu:
-            res["roofline"]["valu"] = valu
+    attach_traffic(res["roofline"], algo, tag)      # HBM bytes of the dominant kernel by the PMC passes of this workload (profiles/collect.sh)
     del enc, dec, img, out
     return res
 
@@ -260,10 +278,7 @@ def measure_tiles(torch, qb3_amd, synth, qdev, dev, ntiles, steps, seed0=1000):
                             "encode_MPixel_s": round(px / (t_enc_i / steps) / 1e6, 1), "decode_from_containers_MPixel_s": round(px / (t_dec_i / steps) / 1e6, 1),
                             "restart_table_bytes": table_bytes_all},
            "kernels": kernel_table(avg, algo), "roofline": roofline_of(avg, algo, ENC_KERNELS + DEC_KERNELS)}
-    if res["roofline"] is not None:
-        res["roofline"]["traffic"], valu = pmc_traffic(res["roofline"]["kernel"], "c5_one_rank")
-        if valu:
-            res["roofline"]["valu"] = valu
+    attach_traffic(res["roofline"], algo, "c5_one_rank")
     return res, tc, imgs, out
 
 
@@ -515,11 +530,10 @@ def main():
             del pimg
         torch.cuda.empty_cache()
 
-    dom_traffic, valu = pmc_traffic(max((k for k in avg if k in ENC_KERNELS + DEC_KERNELS), key=lambda k: avg[k][0]))
-    roofline = roofline_of(avg, algo, ENC_KERNELS + DEC_KERNELS, traffic=dom_traffic if args.size == 16384 else None,
-                           extra={"restart_table_in_container": int(n) - stream_bytes})
+    roofline = roofline_of(avg, algo, ENC_KERNELS + DEC_KERNELS, extra={"restart_table_in_container": int(n) - stream_bytes})
     if roofline is not None:
-        roofline["valu"] = valu if args.size == 16384 else None
+        if args.size == 16384:      # (the PMC passes are of this raster; the step decodes from the container's table: level 2 = the BL variant)
+            attach_traffic(roofline, algo, None, from_table=args.table_level == 2)
         roofline["device_copy_GBps"] = copy_peak(torch, dev)
         if roofline.get("traffic"):
             # what the kernel actually moves (PMC: more than the algorithmic bytes -- slots, index) against what a plain copy reaches here
@@ -750,7 +764,12 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
             dom = max(cand, key=lambda k: cand[k][0])
             algo = algo_all if dom in DEC_KERNELS else algo_batch
             roofline = roofline_of({dom: cand[dom]}, algo, (dom,))
-            roofline["launch_covers"] = f"{count if dom in DEC_KERNELS else nb} tiles of 4096x4096x3 (rank 0)"
+            covers = count if dom in DEC_KERNELS else nb
+            roofline["launch_covers"] = f"{covers} tiles of 4096x4096x3 (rank 0)"
+            # the PMC passes are of one rank's 32 tiles in one call (profiles/*_c5_*): per launch here = that, by tiles a launch covers
+            attach_traffic(roofline, algo, "c5_one_rank", scale=covers / 32.0)
+            if roofline.get("traffic") is not None:
+                roofline["traffic_source"] = f"{roofline['traffic_source']} x {covers}/32 tiles a launch"
     bytes_root = None
     if rank == 0:
         bytes_root = sum(sum(sl) for (_, sls) in got for sl in sls[1:])
