@@ -88,6 +88,9 @@ decsp qb3x_read_start(void *header, size_t header_size, size_t stream_size, size
  * QB3.h:133-141). */
 decsp qb3x_read_start_device(const void *d_container, size_t nbytes, size_t *image_size, void *stream);
 size_t qb3x_header_size_bound(const void *container, size_t avail);
+/* After qb3_read_info: entries of the restart table found in the container's header chunks that the decoder will use
+ * (0: none, or chunks that do not form one table -- the stream is then walked).  No counterpart in the reference. */
+size_t qb3x_decoder_table_entries(const decsp p);
 
 /* Self-indexing containers (off by default: the container then differs from the reference's by a few chunks).
  * When on, qb3_encode / qb3x_encode_device put a restart table -- the bit position and band state at the start of every

@@ -72,6 +72,7 @@ _PROTOS = {
     "qb3x_read_start": (_vp, [_vp, _sz, _sz, C.POINTER(_sz)]),
     "qb3x_read_start_device": (_vp, [_vp, _sz, C.POINTER(_sz), _vp]),
     "qb3x_header_size_bound": (_sz, [_vp, _sz]),
+    "qb3x_decoder_table_entries": (_sz, [_vp]),
     "qb3x_set_decoder_compat": (None, [_vp, C.c_uint]),
     "qb3_create_decoder": (_vp, [_vp, _sz, C.POINTER(_sz)]),
     "qb3_decode": (_sz, [_vp, _vp]),

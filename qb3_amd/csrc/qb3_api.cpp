@@ -37,7 +37,8 @@ static inline unsigned topbit(uint64_t v) { return 63u - (unsigned)__builtin_clz
 // around a fraction of a millisecond of kernels.  Bounded (POOL_ITEMS buffers, POOL_BYTES bytes); qb3x_trim() empties it.
 struct DevPool {
     struct Item { void *p; size_t cap; int dev; };
-    static constexpr size_t POOL_ITEMS = 24, POOL_BYTES = (size_t)3 << 30;
+    static constexpr size_t POOL_ITEMS = 24;
+    const size_t POOL_BYTES = [] { const char *e = getenv("QB3_POOL_MB"); return (e && e[0] ? (size_t)strtoull(e, nullptr, 10) : (size_t)3072) << 20; }();   // (0: nothing is kept)
     std::mutex mu;
     std::vector<Item> items;
     size_t bytes = 0;
@@ -92,8 +93,12 @@ struct DevBuf {
         cap = n;
         return true;
     }
-    void release() {
+    // hipFree waits for the device; a buffer that goes to the pool instead may be handed to another handle on another stream
+    // at once, so the same wait comes first -- unless the caller has just made it (`idle`: a handle's buffers go one after
+    // the other).  An error return in the middle of a call leaves kernels in flight; they end here, not in the next owner.
+    void release(bool idle = false) {
         if (p) {
+            if (!idle) (void)hipDeviceSynchronize();
             bool kept = false;
             try { kept = dev_pool().give(p, cap, dev); } catch (...) { kept = false; }
             if (!kept) (void)hipFree(p);
@@ -101,6 +106,12 @@ struct DevBuf {
         p = nullptr; cap = 0;
     }
 };
+template <class... B> static void release_all(B &...b) {
+    bool any = false;
+    for (bool h : {(b.p != nullptr)...}) any = any || h;
+    if (any) (void)hipDeviceSynchronize();
+    (void)std::initializer_list<int>{(b.release(true), 0)...};
+}
 
 static bool device_ok() {
     int n = 0;
@@ -336,7 +347,8 @@ QB3_API void qb3_reset_encoder(encsp p) {
 
 QB3_API void qb3_destroy_encoder(encsp p) {
     if (!p) return;
-    p->d_img.release(); p->d_out.release(); p->d_ws.release(); p->d_q.release(); p->d_idx.release(); p->d_rle.release(); p->stager.release();
+    release_all(p->d_img, p->d_out, p->d_ws, p->d_q, p->d_idx, p->d_rle);
+    p->stager.release();
     delete p;
 }
 
@@ -376,8 +388,9 @@ static Geometry make_geometry(size_t w, size_t h, size_t bands, int dtype, size_
 static bool is_rle_mode(int m) { return m == QB3M_RLE || m == QB3M_CF_RLE || m == QB3M_RLE_H || m == QB3M_CF_RLE_H; }
 // bytes the restart-table chunks add to a container of this handle (0: none would be written)
 static size_t ix_room(const encs *p) {
-    if (!p->ix_chunk || p->xsize < 4 || p->ysize < 4 || p->xsize * p->ysize <= 16 || p->mode == QB3M_STORED) return 0;
-    // The bound must not depend on the mode: the reference's callers size the buffer right after qb3_create_encoder and BEFORE
+    if (!p->ix_chunk || p->xsize < 4 || p->ysize < 4 || p->xsize * p->ysize <= 16) return 0;
+    // The bound must not depend on the mode (not even on QB3M_STORED, where a raw fallback leaves a handle: a caller that
+    // sizes its buffer again then, and sets a coding mode afterwards, must not get less than the next call writes): the reference's callers size the buffer right after qb3_create_encoder and BEFORE
     // qb3_set_encoder_mode (reference cqb3.cpp:405-464, test_qb3.cpp:84-102).  The largest table any mode would write for this
     // raster: FTL and BASE streams share a layout, the common-factor modes have another.
     size_t room = 0;
@@ -476,7 +489,8 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     if (e != hipSuccess) { set_error("encode kernels", (int)e); return false; }
     prof_collect();
     *bits = res.total_bits;
-    if (zero_run) *zero_run = rle0_may_win(res) ? (rle0_no_uniform_chunk(res) ? 2 : 1) : 0;      // (2: and no 4 KB of the stream hold one byte value only)
+    // (a chunk of the stream holds plan.nbp blocks of at least two bits a unit)
+    if (zero_run) *zero_run = rle0_may_win(res) ? (rle0_no_uniform_chunk(res, (uint64_t)plan.nbp * g.bands / 4) ? 2 : 1) : 0;      // (2: and no 4 KB of the stream hold one byte value only)
     if (carry)
         for (size_t c = 0; c < p->nbands; c++) {
             p->band[c].prev = (size_t)res.prev[c]; p->band[c].runbits = res.rung[c]; p->band[c].cf = (size_t)res.cf[c];
@@ -514,7 +528,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     ModeGuard guard(p);
     const qb3_mode mode = p->mode;
     const bool rle = is_rle_mode(mode);
-    const size_t ixroom = ix_room(p);
+    const size_t ixroom = mode == QB3M_STORED ? 0 : ix_room(p);   // (a handle left at STORED writes no table)
     if (rle) p->mode = (qb3_mode)((int)mode - 2);       // RLE is a post pass over the base mode's stream
     uint8_t hdrbuf[80];
     size_t hdr = write_headers(p, hdrbuf);
@@ -701,7 +715,7 @@ static size_t encode_tiles_body(encsp p, const void *d_src, size_t n, size_t src
     IxTable ixt;
     size_t hdr_stamp = hdr, ix_bytes = 0, isz_all = isz;
     void *index_all = d_index;
-    if (ix_room(p)) {
+    if (ix_room(p)) {                                     // (batchable: the mode is not QB3M_STORED)
         ixt = ix_layout(g, p->ix_chunk);
         hdr_stamp = write_headers(p, hdrbuf, false);
         ix_bytes = ix_total_bytes(ixt);
@@ -751,7 +765,8 @@ static size_t encode_tiles_body(encsp p, const void *d_src, size_t n, size_t src
 // ---------------------------------------------------------------- decoder handle
 QB3_API void qb3_destroy_decoder(decsp p) {
     if (!p) return;
-    p->d_in.release(); p->d_img.release(); p->d_ws.release(); p->d_ix.release(); p->d_rle.release(); p->d_tab.release(); p->stager.release();
+    release_all(p->d_in, p->d_img, p->d_ws, p->d_ix, p->d_rle, p->d_tab);
+    p->stager.release();
     delete p;
 }
 QB3_API size_t qb3_decoded_size(const decsp p) { return p->xsize * p->ysize * p->nbands * szof(p->type); }
@@ -899,7 +914,10 @@ QB3_API bool qb3_read_info(decsp p) {
                     // (ix_check_kernel) and need not be on the host at all (a 16384 x 16384 raster's level 2 table is 24 MB)
                     const uint64_t nblk = (uint64_t)((p->xsize + 3) / 4) * ((p->ysize + 3) / 4);
                     const uint64_t Kexp = blocks ? (nblk + blocks - 1) / blocks : 0;
-                    if (v2 && p->ix_per_chunk && Kexp > p->ix_per_chunk && Kexp < 0xffffffffull) {
+                    // -- only then: with the whole container on the host the chunks are walked one by one, as the reference's
+                    // parser walks them (garbage between the first chunk and "DT" is an error, not a table)
+                    const bool all_here = p->hdr_avail >= 11 + n;
+                    if (!all_here && v2 && p->ix_per_chunk && Kexp > p->ix_per_chunk && Kexp < 0xffffffffull) {
                         const uint64_t nch = (Kexp + p->ix_per_chunk - 1) / p->ix_per_chunk;
                         const uint64_t total = nch * (IX_HEAD + IX_PAD) + Kexp * E;
                         if (pos + total + 2 < n) {
@@ -977,6 +995,8 @@ static decsp read_start_device_body(const void *d_container, size_t nbytes, size
     return nullptr;
 }
 
+QB3_API size_t qb3x_decoder_table_entries(const decsp p) { return (p && p->stage == 2) ? p->ix_K : 0; }
+
 QB3_API size_t qb3x_decoder_index_size(const decsp p) {
     if (!p || p->stage != 2 || p->xsize < 4 || p->ysize < 4) return 0;
     Geometry g = make_geometry(p->xsize, p->ysize, p->nbands, p->type, 0, p->order, p->mode, nullptr, p->cband);
@@ -1047,6 +1067,9 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
     const size_t tsz = szof(p->type), line = p->xsize * p->nbands * tsz, total = qb3_decoded_size(p);
     const size_t data_off = (size_t)(p->s_in - p->s_start);
     const size_t dst_stride = (p->stride ? p->stride : p->xsize * p->nbands) * tsz;
+    // qb3x_read_start / qb3x_read_start_device handles hold a copy of the container's HEAD (hdr_avail bytes at s_start) while
+    // s_size spans the whole container: the host-pointer call would read the stream, and the table, past that copy
+    if (on_host && p->hdr_avail < data_off + p->s_size) { p->error = QB3E_EINV; return 0; }
     if (p->mode == QB3M_STORED) {           // reference QB3decode.cpp:356-375
         if (p->s_size != total) { p->error = QB3E_EINV; return 0; }
         if (on_host) {

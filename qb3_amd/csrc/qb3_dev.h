@@ -72,9 +72,15 @@ struct EncResult {
 // bytes, and it can only be shorter than n when that is below n: for most streams the counts decide without the byte pass.
 inline bool rle0_may_win(const EncResult &r) { return r.zero_run > 0 && 2 * r.zero_run + 2 > r.ff_pairs; }
 // 4 KB of zero bytes hold at least 1022 aligned all-zero dwords, of which at most two per chunk of the stream are shared with a
-// neighbour (a chunk is at least 64 bytes: 128 of them); 4 KB of 0xff hold three pairs in each of those dwords.  Below both
-// counts the table of one-valued 4 KB chunks the byte pass skips long runs by is all "no" and need not be made.
-inline bool rle0_no_uniform_chunk(const EncResult &r) { return r.zero_dwords < 800 && r.ff_pairs < 1024; }
+// neighbour; a chunk is at least min_chunk_bytes long (the plan's blocks per chunk x bands x two bits), so 4 KB touch at most
+// 4096 / min_chunk_bytes + 2 of them (the 8-bit lane-per-block plan: 63 bytes, 67 chunks, 888 dwords left); 4 KB of 0xff hold
+// three pairs in each of those dwords.  Below both counts the table of one-valued 4 KB chunks the byte pass skips long runs
+// by is all "no" and need not be made.  Plans with chunks too short for the count to say anything always make the table.
+inline bool rle0_no_uniform_chunk(const EncResult &r, uint64_t min_chunk_bytes) {
+    if (min_chunk_bytes < 16) return false;
+    const uint64_t shared = 2 * (4096 / min_chunk_bytes + 2);
+    return shared < 1000 && r.zero_dwords < 1022 - shared && r.ff_pairs < 1024;
+}
 
 // Workspace sizes
 struct EncPlan {

@@ -265,3 +265,79 @@ def test_pool_and_status_entry_points_without_a_device(qb3):
     qb3.lib.qb3x_trim()
     qb3.lib.qb3x_trim()
     assert qb3.lib.qb3x_last_decode_status(None) == 0
+
+
+def test_header_only_handle_refuses_the_host_pointer_call(qb3, oracle):
+    """A handle made by qb3x_read_start from a copy of the container's head (the stream itself elsewhere: in device memory)
+    holds fewer bytes than the container has; qb3_read_data on it must not read the stream past that copy:
+    QB3E_EINV, nothing touched -- decided before any device is asked for, so also here without a GPU."""
+    L = qb3.lib
+    img = oracle.generate(64, 64, 3, 0, "NOISY3", 1)
+    s = oracle.encode(img, 0, 8)
+    head = s[:64].copy()                            # header + "DT" + the first stream bytes
+    dims = (C.c_size_t * 3)()
+    p = L.qb3x_read_start(head.ctypes.data, head.size, s.size, dims)
+    assert p and L.qb3_read_info(p)
+    out = np.full(64 * 64 * 3, 0xa5, np.uint8)
+    assert L.qb3_read_data(p, out.ctypes.data) == 0
+    assert (out == 0xa5).all()
+    L.qb3_destroy_decoder(p)
+    # ... and for a raw-stored container, whose "decode" is a host copy of s_size bytes
+    e = oracle.Encoder(4, 4, 1, 0)
+    tiny = e.encode(np.arange(16, dtype=np.uint8).reshape(4, 4, 1))
+    assert tiny[10] == 255 and tiny.size == 13 + 16
+    p = L.qb3x_read_start(tiny.ctypes.data, 20, tiny.size, dims)
+    assert p and L.qb3_read_info(p)
+    out = np.full(16, 0xa5, np.uint8)
+    assert L.qb3_read_data(p, out.ctypes.data) == 0 and (out == 0xa5).all()
+    L.qb3_destroy_decoder(p)
+    # the whole container on the host: the stored copy works (no GPU needed)
+    p = L.qb3_read_start(tiny.ctypes.data, tiny.size, dims)
+    assert p and L.qb3_read_info(p)
+    assert L.qb3_read_data(p, out.ctypes.data) == 16 and (out == np.arange(16)).all()
+    L.qb3_destroy_decoder(p)
+
+
+def _with_table(stream, entries_per_chunk, nchunks, entry_bytes, blocks, junk=None):
+    """a container with a (fake but regular) version 2 restart table in front of "DT": nchunks "ix" + "zz" pairs"""
+    at = 11
+    while bytes(stream[at:at + 2]) in (b"CB", b"QV", b"SC"):
+        at += 4 + int(stream[at + 2]) + 256 * int(stream[at + 3])
+    assert bytes(stream[at:at + 2]) == b"DT"
+    chunks = b""
+    for c in range(nchunks):
+        ln = 12 + entries_per_chunk * entry_bytes
+        head = b"ix" + ln.to_bytes(2, "little") + bytes([2, 0, 0, 0]) + blocks.to_bytes(4, "little")
+        body = bytes(entries_per_chunk * entry_bytes)
+        if junk is not None and c == junk:
+            head = b"iy" + head[2:]                 # not a table chunk: an ignorable chunk of the same length
+        chunks += head + body + b"zz\x04\x00"
+    return np.frombuffer(bytes(stream[:at]) + chunks + bytes(stream[at:]), np.uint8).copy()
+
+
+def test_table_chunks_are_walked_one_by_one_on_the_host(qb3, oracle):
+    """With the whole container on the host qb3_read_info walks every chunk head in front of "DT" like the reference's parser
+    (QB3decode.cpp:176-264) instead of stepping over a regular table in one go: a foreign chunk in the middle of
+    the run of table chunks means there is no usable table -- and is found; the stream still parses."""
+    L = qb3.lib
+    w = h = 256
+    img = oracle.generate(w, h, 1, 0, "NOISY3", 1)           # (one band: no CB chunk, "DT" right behind the fixed header)
+    s = oracle.encode(img, 0, 8)
+    nseg = (w // 4) * (h // 4) // 64
+    E = 6 + 1 * 2
+    per = 16
+    assert nseg % per == 0
+    dims = (C.c_size_t * 3)()
+    good = _with_table(s, per, nseg // per, E, 64)
+    bad = _with_table(s, per, nseg // per, E, 64, junk=1)
+    for t, usable in ((good, True), (bad, False)):
+        p = L.qb3_read_start(t.ctypes.data, t.size, dims)
+        assert p and L.qb3_read_info(p), "the reference's parser steps over ignorable chunks"
+        assert L.qb3_get_mode(p) == 8
+        assert L.qb3x_decoder_table_entries(p) == (nseg if usable else 0)
+        L.qb3_destroy_decoder(p)
+    # a handle that has only the head (the table's middle is not on the host) may step over a regular table: it cannot see the junk
+    p = L.qb3x_read_start(bad.ctypes.data, 64, bad.size, dims)
+    assert p
+    L.qb3_read_info(p)
+    L.qb3_destroy_decoder(p)

@@ -421,6 +421,31 @@ def test_stored_fallback_and_sticky_mode(qb3, oracle):
     assert mode == 255 and np.array_equal(out, img.view(np.uint8).ravel())
 
 
+def test_table_room_survives_a_raw_fallback(qb3, oracle):
+    """qb3_max_encoded_size on a handle whose mode a raw fallback left at QB3M_STORED still includes the restart table's room:
+    a caller that sizes its buffer again then and sets a coding mode afterwards gets what the next call writes"""
+    L = qb3.lib
+    w = h = 128
+    p = L.qb3_create_encoder(w, h, 1, 0)
+    L.qb3x_set_encoder_index_chunk(p, 2)
+    L.qb3_set_encoder_mode(p, FTL)
+    room = L.qb3_max_encoded_size(p)
+    dst = np.zeros(room, np.uint8)
+    rnd = oracle.generate(w, h, 1, 0, "RANDOM", 4)
+    n = L.qb3_encode(p, rnd.ctypes.data, dst.ctypes.data)
+    assert n and dst[10] == 255 and L.qb3_set_encoder_mode(p, 99) == 255      # raw fallback, mode left at STORED
+    assert L.qb3_max_encoded_size(p) == room
+    L.qb3_reset_encoder(p)
+    L.qb3_set_encoder_mode(p, FTL)
+    assert L.qb3_max_encoded_size(p) == room
+    img = oracle.generate(w, h, 1, 0, "NOISY3", 4)
+    n = L.qb3_encode(p, img.ctypes.data, dst.ctypes.data)
+    assert 0 < n <= room and dst[10] == FTL
+    out, _, _, _ = qb3.decode(dst[:n])
+    assert np.array_equal(out, img.ravel())
+    L.qb3_destroy_encoder(p)
+
+
 def test_overlong_stream_fails_like_the_reference(qb3, oracle):
     """more than 7 unused bits after the last unit => read_data returns 0 (QB3decode.h:411,569)"""
     img = oracle.generate(32, 32, 3, 0, "NOISY3", 1)
