@@ -2,7 +2,8 @@
 """bench.py -- QB3M_FTL encode+decode throughput of the MI355X-native QB3 library.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: the command above starts its N ranks itself; python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+     bench.py --gpus N ..., what the driver runs, works as well)
 
 N = 1 -- BASELINE.json configs[1]: ONE 16384x16384 3-band uint8 raster (NOISY3, seed 2), resident in HBM before the
 clock starts.  A step = qb3x_encode_device (the container, self-indexed: the restart table travels INSIDE it as
@@ -18,7 +19,7 @@ tiles of 4096^2 x 3 through qb3x_encode_tiles / qb3x_decode_tiles) -- each with 
 
 N > 1 -- BASELINE.json configs[4]: every rank codes 32 independent 4096x4096x3 tiles per step (N = 8: the 256 tiles
 of the configuration; weak scaling), in batches through qb3x_encode_tiles; the containers of batch k travel to rank 0
-(RCCL send/recv over xGMI, one message per tile) while batch k+1 is coded; then every rank decodes its own tiles.
+(RCCL send/recv over xGMI, one message per peer and batch: the sender packs its containers back to back) while batch k+1 is coded; then every rank decodes its own tiles.
 The gather is INSIDE the timed step: `value` = pixels of all ranks / max over ranks of the time until every
 container is on rank 0 and every tile is decoded.  `coding_only` is the same loop without the gather.
 
@@ -317,14 +318,27 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks as fresh child processes -- BEFORE anything here touches the
+        # GPU (no torch import yet) -- through the same launcher the driver uses; rank 0 of the children prints the one JSON
+        # line on this process's stdout, a failing child makes the launcher (and this process) exit non-zero.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world:
+        sys.exit(f"bench.py --gpus {args.gpus} inside a job of {world} ranks: start it as `python bench.py --gpus N` or under torch.distributed.run with N ranks")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the QB3 block codec has no CPU fallback")
     if args.backend != "nccl":
@@ -688,9 +702,12 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
     out = torch.empty_like(imgs)
     nb = max(1, min(args.batch_tiles, count))
     batches = [(lo, min(nb, count - lo)) for lo in range(0, count, nb)]
-    recv = None
-    if rank == 0 and args.backend == "nccl":            # receive buffers, one per peer and batch slot, reused every step
-        recv = [[None if r == 0 else torch.empty(nb * tc.pitch, dtype=torch.uint8, device=dev) for r in range(world)] for _ in batches]
+    recv = send = None
+    if args.backend == "nccl":                          # buffers reused every step: on the root one per peer and batch slot to receive
+        if rank == 0:                                   # into, on a peer one per batch slot to pack its containers into (one message a batch)
+            recv = [[None if r == 0 else torch.empty(nb * tc.pitch, dtype=torch.uint8, device=dev) for r in range(world)] for _ in batches]
+        else:
+            send = [torch.empty(nb * tc.pitch, dtype=torch.uint8, device=dev) for _ in batches]
 
     def step(gather=True):
         pend = []
@@ -698,9 +715,9 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
             sizes = tc.encode(imgs, lo, cnt)             # synchronises: the containers of the batch are complete
             if gather:
                 pend.append(tiles.start_gather(tc.dst[lo * tc.pitch:(lo + cnt) * tc.pitch], tc.pitch, sizes, root=0,
-                                               recv_bufs=recv[b] if recv else None))
+                                               recv_bufs=recv[b] if recv else None, send_buf=send[b] if send else None, max_tiles=nb))
         tc.decode(out, use_index=False)                   # from the containers alone: every tile carries its restart table
-        got = [p.wait() for p in pend]
+        got = [p.wait() + (p.offset_lists,) for p in pend]
         return got
 
     got = step()
@@ -718,12 +735,12 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
     intact, anchors_ok = None, None
     if rank == 0:
         intact, checked = True, 0
-        for b, (bufs, size_lists) in enumerate(got):
+        for b, (bufs, size_lists, offset_lists) in enumerate(got):
             lo = batches[b][0]
             for r in range(1, world):
                 hb = bufs[r].cpu().numpy() if bufs[r] is not None else None
-                for t, sz in enumerate(size_lists[r]):
-                    ok = hb is not None and qb3_amd.fnv(hb[t * tc.pitch:t * tc.pitch + int(sz)]) == everyone[r][lo + t]
+                for t, (sz, off) in enumerate(zip(size_lists[r], offset_lists[r])):     # (a peer's containers arrive packed back to back)
+                    ok = hb is not None and qb3_amd.fnv(hb[off:off + int(sz)]) == everyone[r][lo + t]
                     intact, checked = intact and ok, checked + 1
         intact = bool(intact and checked == (world - 1) * count)
         anchors_ok = all(container_check(qb3_amd, np, host_all[t * tc.pitch:t * tc.pitch + int(tc.sizes[t])], tag)[0]
@@ -772,7 +789,7 @@ def run_tiles_multi(args, torch, dist, qb3_amd, synth, qdev, tiles, dev, rank, w
                 roofline["traffic_source"] = f"{roofline['traffic_source']} x {covers}/32 tiles a launch"
     bytes_root = None
     if rank == 0:
-        bytes_root = sum(sum(sl) for (_, sls) in got for sl in sls[1:])
+        bytes_root = sum(sum(sl) for (_, sls, _) in got for sl in sls[1:])
     px = total * w * h
     line = {
         "metric": "MPixel/s encode+decode (QB3M_FTL, 8-bit 3-band)",

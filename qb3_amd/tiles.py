@@ -3,7 +3,7 @@
 The path shards by image tile (every tile is its own QB3 stream): no collective while
 coding.  The only exchange is the variable-size gather of the finished containers to one rank, done with
 point-to-point sends (RCCL send/recv on the `nccl` backend; `gloo` on CPU in the tests), one message per
-peer sized to the bytes actually produced -- over xGMI each peer owns its own link to the root, so the
+peer and batch, sized to the bytes actually produced -- over xGMI each peer owns its own link to the root, so the
 gather is bound by the per-link rate, not by a ring.
 """
 import torch
@@ -63,61 +63,90 @@ def gather_streams(payload, sizes, root=0, group=None):
 
 class PendingGather:
     """A gather in flight (start_gather): wait() returns, on the root, ([per-rank buffer], [per-rank size list]) with tile
-    t of rank r at buffer[r][t * pitch : t * pitch + sizes[r][t]]; elsewhere (None, None)."""
+    t of rank r at buffer[r][offsets[r][t] : offsets[r][t] + sizes[r][t]] (`offset_lists`: the peers' tiles arrive packed
+    back to back, the root's own stay where the encoder put them, at t * pitch); elsewhere (None, None)."""
 
-    def __init__(self, reqs, bufs, size_lists, keep):
-        self.reqs, self.bufs, self.size_lists, self._keep = reqs, bufs, size_lists, keep
+    def __init__(self, reqs, bufs, size_lists, offset_lists, keep):
+        self.reqs, self.bufs, self.size_lists, self.offset_lists, self._keep = reqs, bufs, size_lists, offset_lists, keep
 
     def wait(self):
         for q in self.reqs:
             q.wait()
         self.reqs = []
+        self._keep = []
         return self.bufs, self.size_lists
 
 
-def start_gather(dst, pitch, sizes, root=0, group=None, recv_bufs=None):
+def _exchange_sizes(sizes, device, group, max_tiles):
+    """every rank's list of container sizes.  max_tiles (an upper bound of any rank's tile count, known to all): ONE small
+    all-gather of [count, sizes...]; without it the counts go first (two)."""
+    world = dist.get_world_size(group)
+    if max_tiles is None:
+        counts = torch.tensor([len(sizes)], dtype=torch.int64, device=device)
+        all_counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(all_counts, counts, group=group)
+        max_tiles = max(1, int(max(int(c.item()) for c in all_counts)))
+    if len(sizes) > max_tiles:
+        raise ValueError("start_gather: more tiles than max_tiles")
+    mine = torch.zeros(max_tiles + 1, dtype=torch.int64, device=device)
+    mine[0] = len(sizes)
+    if sizes:
+        mine[1:1 + len(sizes)] = torch.tensor([int(v) for v in sizes], dtype=torch.int64, device=device)
+    everyone = [torch.zeros(max_tiles + 1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(everyone, mine, group=group)
+    out = []
+    for v in everyone:
+        v = v.tolist()
+        out.append([int(x) for x in v[1:1 + int(v[0])]])
+    return out
+
+
+def start_gather(dst, pitch, sizes, root=0, group=None, recv_bufs=None, send_buf=None, max_tiles=None):
     """Starts the gather of this rank's tile containers -- tile t at dst[t * pitch : t * pitch + sizes[t]], the layout
-    qb3x_encode_tiles leaves -- to `root` and returns at once: one point-to-point message per tile, sized to the bytes
-    produced, so the transfer (RCCL send/recv on its own stream over xGMI, every peer on its own link to the root)
-    runs beside the coding of the next batch.  Only the tile counts and sizes are exchanged synchronously (two small
-    all-gathers).  recv_bufs: on the root, optional list of per-rank uint8 tensors to receive into (reused step after
-    step); the root's own entry is ignored (its tiles stay in dst)."""
+    qb3x_encode_tiles leaves -- to `root` and returns at once.  ONE point-to-point message per peer and call: the sender
+    packs its containers back to back (device-to-device copies, a fraction of the time the link takes) and sends that one
+    span, sized to the bytes produced; the sizes -- exchanged first, in one small all-gather when max_tiles is given --
+    are the offset table the root needs to take the span apart.  The transfer (RCCL send/recv on its own stream over
+    xGMI, every peer on its own link to the root) runs beside the coding of the next batch.
+    recv_bufs: on the root, optional list of per-rank uint8 tensors to receive into (reused step after step); the root's
+    own entry is ignored (its tiles stay in dst).  send_buf: on a peer, optional uint8 tensor to pack into."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     keep = []
     if dst.is_cuda and dist.get_backend(group) != "nccl":
         dst = dst.cpu()                 # gloo moves host memory (CPU tests, single-GPU rehearsals); RCCL moves HBM to HBM
-        recv_bufs = None
+        recv_bufs = send_buf = None
     device = dst.device
-    counts = torch.tensor([len(sizes)], dtype=torch.int64, device=device)
-    all_counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(all_counts, counts, group=group)
-    maxn = max(1, int(max(int(c.item()) for c in all_counts)))
-    mine = torch.zeros(maxn, dtype=torch.int64, device=device)
-    if sizes:
-        mine[:len(sizes)] = torch.tensor(list(sizes), dtype=torch.int64, device=device)
-    all_sizes = [torch.zeros(maxn, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(all_sizes, mine, group=group)
-    size_lists = [[int(v) for v in s[:int(c.item())].tolist()] for s, c in zip(all_sizes, all_counts)]
-    ops, bufs = [], None
+    size_lists = _exchange_sizes(list(sizes), device, group, max_tiles)
+    ops, bufs, offset_lists = [], None, None
     if rank == root:
-        bufs = []
+        bufs, offset_lists = [], []
         for r in range(world):
             if r == root:
                 bufs.append(dst)
+                offset_lists.append([t * pitch for t in range(len(size_lists[r]))])
                 continue
-            need = len(size_lists[r]) * pitch
-            b = recv_bufs[r] if recv_bufs is not None and recv_bufs[r] is not None and recv_bufs[r].numel() >= need \
-                else torch.empty(need, dtype=torch.uint8, device=device)
+            offs, total = [], 0
+            for n in size_lists[r]:
+                offs.append(total)
+                total += n
+            offset_lists.append(offs)
+            b = recv_bufs[r] if recv_bufs is not None and recv_bufs[r] is not None and recv_bufs[r].numel() >= total \
+                else torch.empty(total, dtype=torch.uint8, device=device)
             bufs.append(b)
-            for t, n in enumerate(size_lists[r]):
-                if n:
-                    ops.append(dist.P2POp(dist.irecv, b[t * pitch:t * pitch + n], r, group))
+            if total:
+                ops.append(dist.P2POp(dist.irecv, b[:total], r, group))
     else:
-        for t, n in enumerate(sizes):
-            if n:
-                piece = dst[t * pitch:t * pitch + n]
-                keep.append(piece)
-                ops.append(dist.P2POp(dist.isend, piece, root, group))
+        total = sum(int(n) for n in sizes)
+        if total:
+            pack = send_buf if send_buf is not None and send_buf.numel() >= total else torch.empty(total, dtype=torch.uint8, device=device)
+            off = 0
+            for t, n in enumerate(sizes):
+                n = int(n)
+                if n:
+                    pack[off:off + n].copy_(dst[t * pitch:t * pitch + n])
+                    off += n
+            keep.append(pack)
+            ops.append(dist.P2POp(dist.isend, pack[:total], root, group))
     reqs = dist.batch_isend_irecv(ops) if ops else []
-    return PendingGather(reqs, bufs if rank == root else None, size_lists if rank == root else None, keep)
+    return PendingGather(reqs, bufs, size_lists if rank == root else None, offset_lists, keep)

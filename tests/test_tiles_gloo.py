@@ -50,22 +50,26 @@ def _worker_pitched(rank, world, port, q, ntiles):
     pitch = 4096
     pending = []
     half = (count + 1) // 2
-    for lo, hi in ((0, half), (half, count)):           # two batches; a rank with no tiles still takes part
+    for bi, (lo, hi) in enumerate(((0, half), (half, count))):           # two batches; a rank with no tiles still takes part
         streams = [o.encode(o.generate(32, 24, 3, 0, "NOISY3", 1000 + t), 0, 8) for t in range(first + lo, first + hi)]
         dst = torch.zeros(max(1, len(streams)) * pitch, dtype=torch.uint8)
         for i, s in enumerate(streams):
             dst[i * pitch:i * pitch + len(s)] = torch.from_numpy(s)
-        pending.append(tiles.start_gather(dst, pitch, [len(s) for s in streams], root=0))
+        # (one message per peer and batch; the second batch also tells the bound of the tile count: one all-gather instead of two)
+        pending.append(tiles.start_gather(dst, pitch, [len(s) for s in streams], root=0, max_tiles=None if bi == 0 else ntiles))
     got = {}
     for b, pg in enumerate(pending):
+        assert len(pg.reqs) <= (world - 1 if rank == 0 else 1), "more than one message per peer and batch"
         bufs, size_lists = pg.wait()
         if rank == 0:
-            for r, (buf, sl) in enumerate(zip(bufs, size_lists)):
+            for r, (buf, sl, ol) in enumerate(zip(bufs, size_lists, pg.offset_lists)):
                 f, c = tiles.shard_range(ntiles, r, world)
                 h = (c + 1) // 2
                 base = f + (0 if b == 0 else h)
+                if r != 0 and sl:
+                    assert ol == [sum(sl[:i]) for i in range(len(sl))] and buf.numel() >= sum(sl)     # packed back to back
                 for i, n in enumerate(sl):
-                    got[base + i] = buf[i * pitch:i * pitch + n].numpy().copy()
+                    got[base + i] = buf[ol[i]:ol[i] + n].numpy().copy()
     if rank == 0:
         q.put([got[t] for t in sorted(got)])
     dist.barrier()
