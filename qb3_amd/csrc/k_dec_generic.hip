@@ -1,5 +1,5 @@
 // qb3_amd/csrc/k_dec_generic.hip -- generic decoders: unit-parallel (dec3_kernel), lane per segment (dec_kernel), serial index rebuild
-#include "qb3_kernels.h"
+#include "qb3_wide.h"
 
 namespace qb3dev {
 
@@ -162,54 +162,6 @@ __device__ __forceinline__ V block_exscan_1b(V v, V *wsum) {
     V base = 0;
     for (uint32_t i = 0; i < wave; i++) base += wsum[i];
     return (V)(base + x - v);
-}
-
-// reads the rung-switch code at bit `pos`: returns the delta (mod 2^UB), sets *gpos to the first value code
-template <typename T, typename PTR>
-__device__ __forceinline__ uint32_t dec3_switch(PTR src, uint32_t endw, uint32_t pos, uint32_t *gpos, bool *signal) {
-    constexpr uint32_t UB = UBits<T>::v;
-    ReaderT<PTR> rd;
-    rd.in = src; rd.endw = endw; rd.wp = pos >> 5;
-    const uint32_t sh = pos & 31;
-    rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
-    uint32_t delta = 0;
-    *signal = false;
-    if (rd.get(1)) delta = get_switch_noflag<UB, ReaderT<PTR>>(rd, *signal);
-    *gpos = (uint32_t)rd.position();
-    return delta;
-}
-
-// decodes the 16 values at bit `gpos`; run[i] = sum of the first i+1 deltas in curve order.
-// Rungs 1..7 go through the LDS table (one read per value, three values per refill of the bit buffer).
-template <typename T, bool STEP, typename PTR>
-__device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos, uint32_t rung, const uint16_t *dtab, T (&run)[16]) {
-    ReaderT<PTR> rd;
-    rd.in = src; rd.endw = endw; rd.wp = gpos >> 5;
-    const uint32_t sh = gpos & 31;
-    rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
-    if (rung >= 1 && rung < 8) {
-        const uint16_t *tab = dtab + dec_tab_off(rung);
-        const uint32_t mask = (4u << rung) - 1;
-        uint32_t rb = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 16; i++) {
-            if (i % 3 == 0) rd.ensure(32);          // three codes are at most 27 bits
-            const uint32_t x = (uint32_t)rd.buf & mask;
-            const uint32_t e = tab[x];              // value: off the critical path, the reads pipeline
-            rd.skip(rung + (x & 1) + ((x & 3) == 3));   // length from the two flag bits alone (QB3decode.h:119-129)
-            run[i] = (T)(e & 0xfff);
-            rb |= ((e >> rung) & 1) << i;
-        }
-        if (STEP && (rb & (rb + 1)) == 0) {         // undo the step (reference QB3decode.h:285-289)
-            const uint32_t m = __popc(rb);
-#pragma unroll
-            for (uint32_t i = 0; i < 16; i++) if (i == m) run[i] ^= (T)((T)1 << rung);
-        }
-    } else
-        get_group<T, STEP, ReaderT<PTR>>(rd, rung, run);
-    T acc = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 16; i++) { acc = (T)(acc + smag_t<T>(run[i])); run[i] = acc; }
 }
 
 // BL (32/64-bit data): no index -- position, entering rungs and values and a twelve-bit length per unit come from the segment's

@@ -122,6 +122,7 @@ uint32_t seg_blocks_for(const Geometry &g) {
             px16_split(g, &bg, &ng);
             if (bg) return 64 / ng;
         }
+        if (g.tsz >= 4 && g.bands == 1) return 64;       // 32/64-bit, one band: the lane-per-block decoder gives a segment to a wave
         uint32_t threads, bpp, passes;
         fast_geometry(g.bands, g.tsz, &threads, &bpp, &passes);
         while (passes > 1 && bpp * passes > 256) passes--;
@@ -269,11 +270,27 @@ static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *
     return ident || def;
 }
 
+// the 32/64-bit lane-per-block kernels: one band (a block is a unit), FTL / BASE, Hilbert or Z curve; any width, stride and
+// (value-aligned) pointer
+static bool pxw_eligible(const Geometry &g) {
+    return g.tsz >= 4 && g.bands == 1 && g.mode != CM_BEST && g.w >= 4 && g.h >= 4 && (g.order == HILBERT || g.order == ZCURVE) && !tuning().no_px;
+}
+
 EncPlan plan_encode(const Geometry &g) {
     EncPlan p;
     const uint32_t dpr = g.bands * g.tsz;
     p.px = px_eligible(g, &p.px_rgb);
     p.px16 = false; p.px16_bg = p.px16_ng = 0;
+    p.pxw = false;
+    if (!p.px && pxw_eligible(g)) {
+        p.pxw = true;
+        p.threads = g.tsz == 8 ? 128 : 256; p.slots = p.threads; p.nbp = p.threads - 1;
+        p.nchunks = (uint32_t)((g.nblocks + p.nbp - 1) / p.nbp);
+        const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp, p.threads);
+        p.lds_bytes = 64 + 4 * (size_t)L.slot_dw;
+        p.ws_bytes = L.total;
+        return p;
+    }
     if (p.px) {
         p.threads = 256; p.slots = 256; p.nbp = 255;
         p.nchunks = (uint32_t)((g.nblocks + 254) / 255);
@@ -311,6 +328,7 @@ static int launch_encode_all(const EncArgs &a, const EncPlan &plan, hipStream_t 
         launch_enc_px(a, plan, st);
     }
     else if (plan.px16 && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0) { ProfScope ps("enc_units", st); launch_enc_px16(a, plan, st); }
+    else if (plan.pxw && ((uintptr_t)a.img & (a.g.tsz - 1)) == 0 && !(a.ts_img & (a.g.tsz - 1))) { ProfScope ps("enc_units", st); launch_enc_pxw(a, plan, st); }
     else { ProfScope ps("enc_units", st); launch_enc_generic(a, plan, st); }
     launch_enc_post(a, plan, st);
     HIPCHK(hipGetLastError());
@@ -405,6 +423,13 @@ DecPlan plan_decode(const Geometry &g) {
         p.px_cap_dw = (p.px_cap_dw + 4 + 3) & ~3u;             // staged from a 16-byte aligned word, in 16-byte pieces
         p.lds_px = 4096 + 4 * 4 * ((size_t)p.px_cap_dw + 16);
     }
+    // 32/64-bit, one band: a wave per 64-block segment; staging for the longest valid segment + 8 zero words, behind the 2 KB table
+    p.pxw = !p.px && !p.px16 && p.fast && pxw_eligible(g) && NB == 64;
+    p.lds_pxw = 0;
+    if (p.pxw) {
+        p.px_cap_dw = (uint32_t)(((size_t)NB * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
+        p.lds_pxw = 2048 + 4 * 4 * ((size_t)p.px_cap_dw + 8);
+    }
     return p;
 }
 
@@ -455,6 +480,11 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     // 32/64-bit FTL/BASE streams that bring a restart table with an entry per index segment: the lengths-only walk too
     const bool wide_walk = rebuild && a.ix && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
     const bool unit_parallel = !use_px && !use_px16 && plan.fast && !best && a.g.tsz >= 4;
+    // ... of them, one band: the lane-per-block decoder (a wave per segment) instead of the unit-parallel workgroup
+    const bool use_pxw = unit_parallel && plan.pxw && ((uintptr_t)a.img & (a.g.tsz - 1)) == 0 && !(a.ts_img & (a.g.tsz - 1));
+    auto dec_units = [&](const DecArgs &t) {
+        if (use_px) launch_dec_px(t, plan, st); else if (use_px16) launch_dec_px16(t, plan, st); else if (use_pxw) launch_dec_pxw(t, plan, st); else launch_dec_generic(t, plan, st);
+    };
     const bool best_px = best && plan.px_best && a.g.tsz == 1;
     if (rebuild && best_px && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
         // the container's table has a field per block (bits, entering rungs): the lane-per-block decoder works from the entries alone
@@ -470,7 +500,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         DecArgs t = a;
         t.bl_mode = 1;
         ProfScope ps("dec_units", st);
-        if (use_px) launch_dec_px(t, plan, st); else if (use_px16) launch_dec_px16(t, plan, st); else launch_dec_generic(t, plan, st);
+        dec_units(t);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -488,7 +518,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
             ProfScope ps("dec_index_prev", st);
             DecArgs t = a;
             t.totals_only = 1;
-            if (use_px) launch_dec_px(t, plan, st); else if (use_px16) launch_dec_px16(t, plan, st); else launch_dec_generic(t, plan, st);
+            dec_units(t);
           }
           ProfScope ps("dec_index_scan", st);
           launch_prev_scan(a, st);
@@ -504,6 +534,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     if (best_px && !a.from_ix) { ProfScope ps("dec_units", st); launch_dec_px_best(a, plan, st); }
     else if (use_px) { ProfScope ps("dec_units", st); launch_dec_px(a, plan, st); }
     else if (use_px16) { ProfScope ps("dec_units", st); launch_dec_px16(a, plan, st); }
+    else if (use_pxw) { ProfScope ps("dec_units", st); launch_dec_pxw(a, plan, st); }
     else { ProfScope ps(plan.fast && !best ? "dec_units" : "dec_segments", st); launch_dec_generic(a, plan, st); }
     HIPCHK(hipGetLastError());
     return 0;
@@ -523,6 +554,12 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
         uint64_t cap = bits / 32 / g.nseg;
         cap = (cap + cap / 3 + 64 + 3) & ~(uint64_t)3;
         if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_px = 4096 + 4 * 4 * ((size_t)cap + 16); }
+    }
+    if (plan.pxw && !full_staging && g.nseg) {          // the same for 32/64-bit data (worst case: 4.3 / 8.4 KB a wave)
+        const uint64_t bits = tb.n ? tb.max_bits : in_bits;
+        uint64_t cap = bits / 32 / g.nseg;
+        cap = (cap + cap / 2 + 64 + 3) & ~(uint64_t)3;
+        if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_pxw = 2048 + 4 * 4 * ((size_t)cap + 8); }
     }
     a.in_cap_full = plan_in.px_cap_dw;
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
@@ -560,7 +597,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     HIPCHK(hipMemsetAsync(a.status, 0, status_bytes, st));
     a.lane_dw = dec_lane_dwords(g);
     a.dpr = g.bands * g.tsz;
-    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16 || plan.px_best) ? plan.px_cap_dw : plan.in_cap_dw;
+    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16 || plan.px_best || plan.pxw) ? plan.px_cap_dw : plan.in_cap_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.totals_only = 0;
     a.bl_mode = 0;

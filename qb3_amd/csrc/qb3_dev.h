@@ -94,6 +94,7 @@ struct EncPlan {
     bool px_rgb;            //   ... with the default R-G,G,B-G map (else identity)
     bool px16;              // 16-bit register-resident kernel applies (lane per block and band group)
     uint32_t px16_bg, px16_ng;      //   ... bands per lane (1..4), lanes per block
+    bool pxw;               // 32/64-bit single-band register-resident kernel applies (lane per block; k_enc_pxw.hip)
 };
 EncPlan plan_encode(const Geometry &g);
 constexpr uint32_t PXB_LDS_FIXED = 11664;      // LDS of the 8-bit common-factor lane-per-block encoder in front of its bit buffer
@@ -174,6 +175,8 @@ struct DecPlan {
     bool px16;              // 16-bit lane-per-(block, band group) kernel applies
     uint32_t px16_bg, px16_ng;
     bool px_best;           // 8-bit common-factor streams: the lane-per-block decoder applies (k_dec_px_best.hip)
+    bool pxw;               // 32/64-bit single-band FTL/BASE streams: the lane-per-block decoder applies (k_dec_pxw.hip)
+    size_t lds_pxw;
 };
 DecPlan plan_decode(const Geometry &g);
 

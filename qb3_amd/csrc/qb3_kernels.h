@@ -578,11 +578,13 @@ void launch_enc_best(const EncArgs &a, const EncPlan &plan, hipStream_t st);    
 void launch_enc_px(const EncArgs &a, const EncPlan &plan, hipStream_t st);         // k_enc_px.hip
 void launch_enc_px_best(const EncArgs &a, const EncPlan &plan, hipStream_t st);    // k_enc_px_best.hip
 void launch_enc_px16(const EncArgs &a, const EncPlan &plan, hipStream_t st);       // k_enc_px16.hip
+void launch_enc_pxw(const EncArgs &a, const EncPlan &plan, hipStream_t st);        // k_enc_pxw.hip
 void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st);       // k_enc_post.hip: scan, concat, seams, header, ix
 void launch_dec_generic(const DecArgs &a, const DecPlan &plan, hipStream_t st);    // k_dec_generic.hip: dec3_kernel / dec_kernel
 void launch_dec_index_serial(const DecArgs &a, hipStream_t st);                    // k_dec_generic.hip
 void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st);         // k_dec_px.hip
 void launch_dec_px16(const DecArgs &a, const DecPlan &plan, hipStream_t st);       // k_dec_px16.hip
+void launch_dec_pxw(const DecArgs &a, const DecPlan &plan, hipStream_t st);        // k_dec_pxw.hip
 void launch_dec_px_best(const DecArgs &a, const DecPlan &plan, hipStream_t st);    // k_dec_px_best.hip
 void launch_dec_walk(const DecArgs &a, hipStream_t st);                            // k_dec_walk.hip: unit lengths of an index-less 8/16-bit stream
 void launch_prev_scan(const DecArgs &a, hipStream_t st);                           // k_dec_walk.hip

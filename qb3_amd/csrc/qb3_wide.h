@@ -1,0 +1,79 @@
+// qb3_amd/csrc/qb3_wide.h -- pieces shared by the unit-parallel decoder (dec3_kernel, k_dec_generic.hip) and the 32/64-bit
+// lane-per-block decoder (k_dec_pxw.hip): a unit's switch and its sixteen values read at a known bit position.
+#pragma once
+#include "qb3_kernels.h"
+
+namespace qb3dev {
+
+// The decode table of rungs 1..7 as a compile-time constant (layout and entries of fill_dec_tab, qb3_kernels.h: entry =
+// len << 12 | value with the swap undone, rung r at [4 << r) - 8, indexed by the next r + 2 stream bits; reference
+// QB3decode.h:24-95,119-129) -- copied from L2 with 16-byte loads instead of being computed by every workgroup.
+struct WideDecTab { alignas(16) uint16_t e[1024]; };
+constexpr WideDecTab make_wide_dec_tab() {
+    WideDecTab t{};
+    for (uint32_t r = 1; r < 8; r++) {
+        const uint32_t top = 1u << r, half = top >> 1;
+        for (uint32_t x = 0; x < (4u << r); x++) {
+            uint32_t v = 0, len = 0;
+            if (!(x & 1)) { v = (x & (top - 1)) >> 1; len = r; }
+            else if (!(x & 2)) { v = ((x >> 2) & (half - 1)) | half; len = r + 1; }
+            else { v = ((x >> 2) & (top - 1)) | top; len = r + 2; }
+            if (v == top || v == top - 1) v ^= 2 * top - 1;
+            t.e[(4u << r) - 8 + x] = (uint16_t)((len << 12) | v);
+        }
+    }
+    return t;
+}
+static __device__ const WideDecTab wide_dec_tab = make_wide_dec_tab();
+
+// reads the rung-switch code at bit `pos`: returns the delta (mod 2^UB), sets *gpos to the first value code
+template <typename T, typename PTR>
+__device__ __forceinline__ uint32_t dec3_switch(PTR src, uint32_t endw, uint32_t pos, uint32_t *gpos, bool *signal) {
+    constexpr uint32_t UB = UBits<T>::v;
+    ReaderT<PTR> rd;
+    rd.in = src; rd.endw = endw; rd.wp = pos >> 5;
+    const uint32_t sh = pos & 31;
+    rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
+    uint32_t delta = 0;
+    *signal = false;
+    if (rd.get(1)) delta = get_switch_noflag<UB, ReaderT<PTR>>(rd, *signal);
+    *gpos = (uint32_t)rd.position();
+    return delta;
+}
+
+// decodes the 16 values at bit `gpos`; run[i] = sum of the first i+1 deltas in curve order.
+// Rungs 1..7 go through the LDS table (one read per value, three values per refill of the bit buffer).
+// (*end, when asked for: the bit behind the unit)
+template <typename T, bool STEP, typename PTR>
+__device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos, uint32_t rung, const uint16_t *dtab, T (&run)[16], uint32_t *end = nullptr) {
+    ReaderT<PTR> rd;
+    rd.in = src; rd.endw = endw; rd.wp = gpos >> 5;
+    const uint32_t sh = gpos & 31;
+    rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
+    if (rung >= 1 && rung < 8) {
+        const uint16_t *tab = dtab + dec_tab_off(rung);
+        const uint32_t mask = (4u << rung) - 1;
+        uint32_t rb = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            if (i % 3 == 0) rd.ensure(32);          // three codes are at most 27 bits
+            const uint32_t x = (uint32_t)rd.buf & mask;
+            const uint32_t e = tab[x];              // value: off the critical path, the reads pipeline
+            rd.skip(rung + (x & 1) + ((x & 3) == 3));   // length from the two flag bits alone (QB3decode.h:119-129)
+            run[i] = (T)(e & 0xfff);
+            rb |= ((e >> rung) & 1) << i;
+        }
+        if (STEP && (rb & (rb + 1)) == 0) {         // undo the step (reference QB3decode.h:285-289)
+            const uint32_t m = __popc(rb);
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) if (i == m) run[i] ^= (T)((T)1 << rung);
+        }
+    } else
+        get_group<T, STEP, ReaderT<PTR>>(rd, rung, run);
+    if (end) *end = (uint32_t)rd.position();
+    T acc = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) { acc = (T)(acc + smag_t<T>(run[i])); run[i] = acc; }
+}
+
+}  // namespace qb3dev
