@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(64) dec_index_serial(const DecArgs a0) {
             uint32_t rung = st_rung[c];
             T cf = (T)st_cf[c];
             const uint64_t ustart = rd.position();
-            if (c < 4) bt |= (rung & 15u) << (16 + 4 * c);
+            if (c < 4) bt |= (rung & (sizeof(T) >= 4 ? 63u : 15u)) << (16 + 4 * c);     // (32/64-bit data: one band, the whole rung)
             ok = parse_unit<T, MODE, Reader>(rd, rung, cf, g) && ok;
             if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint8_t)(rd.position() - ustart);
             else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint16_t)(rd.position() - ustart);
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(64) dec_index_staged(const DecArgs a0, uint32_
                     uint32_t rung = st_rung[c];
                     T cf = (T)st_cf[c];
                     const uint64_t ustart = rd.position();
-                    if (c < 4) bt |= (rung & 15u) << (16 + 4 * c);
+                    if (c < 4) bt |= (rung & (sizeof(T) >= 4 ? 63u : 15u)) << (16 + 4 * c);     // (32/64-bit data: one band, the whole rung)
                     ok = parse_unit<T, MODE, ReaderT<LdsWords>>(rd, rung, cf, g) && ok;
                     if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint8_t)(rd.position() - ustart);
                     else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint16_t)(rd.position() - ustart);

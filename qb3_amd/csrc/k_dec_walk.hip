@@ -1012,7 +1012,7 @@ __global__ void __launch_bounds__(64) walk_probe_kernel(const DecArgs a0, WalkSt
                 else if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[gb * B + c] = (uint8_t)(rd.position() - u0);
                 else if (a.g.ulen_sz == 4) {                               // (block table of the 8-bit common-factor decoder: the block's bits | its units' entering rungs)
                     if (c == 0) { bt = 0; b0 = u0; }
-                    if (c < 4) bt |= (rg_in & 15u) << (16 + 4 * c);
+                    if (c < 4) bt |= (rg_in & (sizeof(T) >= 4 ? 63u : 15u)) << (16 + 4 * c);
                     if (c + 1 == B) ((uint32_t *)a.idx.ulen)[gb] = bt | (uint32_t)((rd.position() - b0) & 0xffffu);
                 }
                 if (MODE == CM_BEST) {                                     // (common-factor streams: the segment's sum, for the scan that gives every segment its entering value)
@@ -1635,7 +1635,7 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
         uint32_t bt = 0;                                                                    // (8-bit common-factor streams: the block's entry of the lane-per-block decoder's table)
         for (uint32_t c = 0; c < B; c++) {
             const uint64_t u0 = rd.position();
-            if (c < 4) bt |= (rung[c] & 15u) << (16 + 4 * c);
+            if (c < 4) bt |= (rung[c] & (sizeof(T) >= 4 ? 63u : 15u)) << (16 + 4 * c);
             ok = parse_unit<T, MODE>(rd, rung[c], pcf[c], g) && ok;
             if (MODE != CM_BEST) {
                 if (sizeof(T) == 1) ((uint8_t *)a.idx.ulen)[U * B + c] = (uint8_t)(rd.position() - u0); else ((uint16_t *)a.idx.ulen)[U * B + c] = (uint16_t)(rd.position() - u0);
@@ -1660,7 +1660,7 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
                 }
             }
         }
-        if (MODE == CM_BEST && sizeof(T) == 1 && a.g.ulen_sz == 4) ((uint32_t *)a.idx.ulen)[U] = bt | (uint32_t)((rd.position() - b0) & 0xffffu);
+        if (MODE == CM_BEST && a.g.ulen_sz == 4) ((uint32_t *)a.idx.ulen)[U] = bt | (uint32_t)((rd.position() - b0) & 0xffffu);
     }
     if (!ok) atomicOr(a.status, 1u);
 }

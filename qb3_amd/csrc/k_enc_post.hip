@@ -290,34 +290,37 @@ __global__ void __launch_bounds__(256) ix_bl_fill_kernel(const EncArgs a0) {
     else if (t < 6 + 2 * B) e0[t] = ((const uint8_t *)a.idx.prev)[k * B + (t - 6 - B)];
 }
 
-// The same for 8-bit common-factor streams (grey / RGB / RGBA): a three-byte field per block -- its bits (12) and the rungs its
-// units are entered with (3 bits a band) -- from the index's block table; a thread per four blocks writes twelve bytes
-// and one byte of the entry's fixed part (position, rungs, entering values, factors in force: at most 6 + 3 * 4 bytes)
+// The same for common-factor streams with a block table (8-bit grey / RGB / RGBA; 32/64-bit, one band): a three-byte field per
+// block -- its bits (12) and the rungs its units are entered with (8-bit data: 3 bits a band; wide data: the band's whole rung)
+// -- from the index's block table; a thread per four blocks writes twelve bytes and its share of the entry's fixed part
+// (position, rungs, entering values, factors in force: 6 + bands * (1 + 2 * value size) bytes)
 __global__ void __launch_bounds__(256) ix_bl_best_fill_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // blocks 4 * grp .. 4 * grp + 3
-    const uint32_t B = a.g.bands;
+    const uint32_t B = a.g.bands, tsz = a.g.tsz;
     const uint64_t k = grp >> 4;                                                // 16 groups an entry (64 blocks)
     if (k >= a.ix_K) return;
     const uint64_t nblocks = a.g.nblocks, blk0 = 4 * grp;
     const uint32_t c = (uint32_t)(k / a.ix_per_chunk), jj = (uint32_t)(k - (uint64_t)c * a.ix_per_chunk);
     uint8_t *e0 = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E) + IX_HEAD + (uint64_t)jj * a.ix_E;
-    const uint32_t t = (uint32_t)(grp & 15), fixed = 6 + 3 * B;
+    const uint32_t t = (uint32_t)(grp & 15), fixed = 6 + B * (1 + 2 * tsz);
     uint8_t *e = e0 + fixed + 4 * IX_BL_BEST_BYTES * t;
 #pragma unroll
     for (uint32_t q = 0; q < 4; q++) {
         const uint32_t bt = blk0 + q < nblocks ? ((const uint32_t *)a.idx.ulen)[blk0 + q] : 0u;
         uint32_t f = bt & 0xfffu;
+        if (tsz == 1) {
 #pragma unroll
-        for (uint32_t cc = 0; cc < 4; cc++) f |= ((bt >> (16 + 4 * cc)) & 7u) << (12 + 3 * cc);
+            for (uint32_t cc = 0; cc < 4; cc++) f |= ((bt >> (16 + 4 * cc)) & 7u) << (12 + 3 * cc);
+        } else f |= ((bt >> 16) & 63u) << 12;
         e[3 * q] = (uint8_t)f; e[3 * q + 1] = (uint8_t)(f >> 8); e[3 * q + 2] = (uint8_t)(f >> 16);
     }
     for (uint32_t i = t; i < fixed; i += 16) {
         uint8_t v;
         if (i < 6) v = (uint8_t)(a.idx.bitpos[k] >> (8 * i));
         else if (i < 6 + B) v = a.idx.rung[k * B + (i - 6)];
-        else if (i < 6 + 2 * B) v = ((const uint8_t *)a.idx.prev)[k * B + (i - 6 - B)];
-        else v = ((const uint8_t *)a.idx.cf)[k * B + (i - 6 - 2 * B)];
+        else if (i < 6 + B + B * tsz) v = ((const uint8_t *)a.idx.prev)[k * B * tsz + (i - 6 - B)];
+        else v = ((const uint8_t *)a.idx.cf)[k * B * tsz + (i - 6 - B - B * tsz)];
         e0[i] = v;
     }
 }
@@ -424,9 +427,9 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
         const uint64_t want = std::max<uint64_t>(plan.nchunks + 1, a.have_idx ? std::min<uint64_t>(a.g.nseg, (uint64_t)1 << 20) : 0);
         hipLaunchKernelGGL(enc_finish_kernel, dim3((uint32_t)((want + 255) / 256), nt), dim3(256), 0, st, a);
     }
-    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1 && a.g.mode == CM_BEST) hipLaunchKernelGGL(ix_bl_best_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.mode == CM_BEST) hipLaunchKernelGGL(ix_bl_best_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
     else if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
-    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz >= 4) {
+    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz >= 4 && a.g.mode != CM_BEST) {
         const uint32_t tpe = (a.ix_blocks * a.g.bands + 1) / 2;
         hipLaunchKernelGGL(ix_blw_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * tpe + 255) / 256), nt), dim3(256), 0, st, a, tpe);
     }

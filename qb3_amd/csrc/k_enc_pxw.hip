@@ -8,10 +8,12 @@
 //   * the curve is a template parameter, so "gather in curve order" is register renaming; delta, mag-sign, rung in registers;
 //   * the rung of the block before comes from the neighbouring lane (DPP wave shift; LDS only across waves); lane 0 of the
 //     workgroup is the halo block (rung only), so a chunk is one block less than the workgroup has lanes;
-//   * codes come from the code RULE (three lengths: rung, rung + 1, rung + 2; the middle swap below rung 8), not from a table:
-//     nothing to copy into LDS, and wide data lives above the tables' eight rungs anyway;
-//   * one DPP workgroup scan of the unit lengths, a 64-bit LDS bit writer per lane, the chunk's bits to its slot.
-#include "qb3_kernels.h"
+//   * a unit below rung 8 (smooth data: its deltas fit a byte) is coded the way the 8-bit kernel codes: the sixteen values packed
+//     four to a register, six pieces of at most 27 bits, each built backwards with one v_alignbit per value out of the 2 KB code
+//     table in LDS (px_unit_pieces, qb3_px_enc.h); from rung 8 on the codes come from the code RULE (three lengths: rung,
+//     rung + 1, rung + 2; no swap up there) through a 64-bit bit writer;
+//   * one DPP workgroup scan of the unit lengths, the chunk's bits to its slot.
+#include "qb3_px_enc.h"
 
 namespace qb3dev {
 
@@ -38,9 +40,13 @@ __global__ void __launch_bounds__(NT) enc_pxw_kernel(const EncArgs a0) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
     const uint64_t stride = a.g.stride;
-    uint32_t *wsum = (uint32_t *)smem;                      // 16 dwords: [0..3] scan, [8..11] rung of each wave's last lane
+    uint32_t *etab = (uint32_t *)smem;                      // 512 entries: the code table of rungs 1..7 (qb3_px.h)
+    uint32_t *wsum = etab + 512;                            // 16 dwords: [0..3] scan, [8..11] rung of each wave's last lane
     uint32_t *outbuf = wsum + 16;                           // slot_dw dwords (a multiple of 4), 16-byte aligned
+    // the table is asked for now and written to LDS before the first barrier: its round trip runs beside the pixel loads
+    const uint4 tabv = ((const uint4 *)px_enc_tab.e)[tid & 127];
     for (uint32_t i = tid; i < a.slot_dw / 4; i += NT) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
+    const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
 
     const uint32_t chunk = blockIdx.x;
     const int64_t gs = (int64_t)chunk * (NT - 1) - 1 + tid; // lane 0 is the halo block
@@ -84,17 +90,26 @@ __global__ void __launch_bounds__(NT) enc_pxw_kernel(const EncArgs a0) {
     // rung of the block before: the neighbouring lane, the last lane of the wave before through LDS, the handle's state
     uint32_t prung = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rung, 0x138, 0xf, 0xf, false);      // wave_shr:1
     if (lane == 63) wsum[8 + wave] = rung;
+    if (tid < 128) ((uint4 *)etab)[tid] = tabv;
     __syncthreads();                                        // (also: the bit buffer is zero)
     if (lane == 0 && wave) prung = wsum[8 + wave - 1];
     if (gblk == 0) prung = (uint32_t)a0.st.rung[0] & UMASK;
 
     // ---- the unit's length (QB3encode.h:155-280): switch, then rung 0: flag (+ 16 bits), else sixteen three-length codes
     uint32_t len = 0, delta = 0;
+    uint32_t pc[6] = {0, 0, 0, 0, 0, 0}, pl[6] = {0, 0, 0, 0, 0, 0};
+    const bool narrow = used > 1 && rung < 8;               // the sixteen values fit a byte each
     if (payload) {
         delta = (rung - prung) & UMASK;
         len = cs_len<UB>(delta);
         if (used <= 1) len += 1 + (used ? 16 : 0);
-        else {
+        else if (narrow) {
+            uint32_t gq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                gq[q] = (uint32_t)g[4 * q] | (uint32_t)g[4 * q + 1] << 8 | (uint32_t)g[4 * q + 2] << 16 | (uint32_t)g[4 * q + 3] << 24;
+            len = px_unit_pieces<STEP>(gq, rung, len, cs_code<UB>(delta), etab_off + (8u << rung), pc, pl);
+        } else {
             const T top = (T)((T)1 << rung), half = (T)(top >> 1);
             if (STEP) {     // clear the rung bit of the last value of a 1..10..0 rung-bit run (QB3encode.h:169-176)
                 uint32_t bits = 0;
@@ -107,11 +122,6 @@ __global__ void __launch_bounds__(NT) enc_pxw_kernel(const EncArgs a0) {
                 }
             }
             uint32_t extra = 0;
-            if (rung < 8) {                                 // the tables' middle swap: top <-> top - 1 (QB3encode.h:30-33)
-                const T swp = (T)(2 * top - 1);
-#pragma unroll
-                for (int i = 0; i < 16; i++) g[i] = (g[i] == top || g[i] == (T)(top - 1)) ? (T)(g[i] ^ swp) : g[i];
-            }
 #pragma unroll
             for (int i = 0; i < 16; i++) extra += (uint32_t)(g[i] >= half) + (uint32_t)(g[i] >= top);
             len += 16 * rung + extra;
@@ -125,7 +135,13 @@ __global__ void __launch_bounds__(NT) enc_pxw_kernel(const EncArgs a0) {
 #pragma unroll
     for (uint32_t i = 0; i < NW; i++) { const uint32_t s = wsum[i]; if (i < wave) pos += s; total += s; }
 
-    if (payload) {
+    if (payload && narrow) {
+        LdsWriter32 wr;
+        wr.init(outbuf, pos);
+#pragma unroll
+        for (int k = 0; k < 6; k++) wr.put(pc[k], pl[k]);
+        wr.finish();
+    } else if (payload) {
         LdsWriter wr;
         wr.init(outbuf, pos);
         const uint32_t csl = cs_len<UB>(delta), csc = cs_code<UB>(delta);
@@ -140,6 +156,8 @@ __global__ void __launch_bounds__(NT) enc_pxw_kernel(const EncArgs a0) {
             for (int i = 0; i < 16; i++) put_value<T>(wr, g[i], rung);
         }
         wr.finish();
+    }
+    if (payload) {
         // coder state on leaving the image, for handle statefulness (QB3encode.h:446-449)
         if (gblk == nblocks - 1) { a.res->prev[0] = (uint64_t)lastv; a.res->rung[0] = rung; a.res->cf[0] = a0.st.cf[0]; }
         if (a.have_idx) {

@@ -272,8 +272,8 @@ static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *
 
 // the 32/64-bit lane-per-block kernels: one band (a block is a unit), FTL / BASE, Hilbert or Z curve; any width, stride and
 // (value-aligned) pointer
-static bool pxw_eligible(const Geometry &g) {
-    return g.tsz >= 4 && g.bands == 1 && g.mode != CM_BEST && g.w >= 4 && g.h >= 4 && (g.order == HILBERT || g.order == ZCURVE) && !tuning().no_px;
+static bool pxw_eligible(const Geometry &g, bool best = false) {
+    return g.tsz >= 4 && g.bands == 1 && (g.mode == CM_BEST) == best && g.w >= 4 && g.h >= 4 && (g.order == HILBERT || g.order == ZCURVE) && !tuning().no_px;
 }
 
 EncPlan plan_encode(const Geometry &g) {
@@ -287,7 +287,7 @@ EncPlan plan_encode(const Geometry &g) {
         p.threads = g.tsz == 8 ? 128 : 256; p.slots = p.threads; p.nbp = p.threads - 1;
         p.nchunks = (uint32_t)((g.nblocks + p.nbp - 1) / p.nbp);
         const EncWs L = enc_ws_layout(g, p.nchunks, p.nbp, p.threads);
-        p.lds_bytes = 64 + 4 * (size_t)L.slot_dw;
+        p.lds_bytes = 2048 + 64 + 4 * (size_t)L.slot_dw;
         p.ws_bytes = L.total;
         return p;
     }
@@ -430,6 +430,12 @@ DecPlan plan_decode(const Geometry &g) {
         p.px_cap_dw = (uint32_t)(((size_t)NB * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
         p.lds_pxw = 2048 + 4 * 4 * ((size_t)p.px_cap_dw + 8);
     }
+    // ... and the common-factor streams of such rasters (the index has a dword per block: ulen_sz == 4); no table, no barrier
+    p.pxw_best = g.ulen_sz == 4 && NB == 64 && pxw_eligible(g, true);
+    if (p.pxw_best) {
+        p.px_cap_dw = (uint32_t)(((size_t)NB * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
+        p.lds_pxw = 4 * 4 * ((size_t)p.px_cap_dw + 8);
+    }
     return p;
 }
 
@@ -485,13 +491,15 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     auto dec_units = [&](const DecArgs &t) {
         if (use_px) launch_dec_px(t, plan, st); else if (use_px16) launch_dec_px16(t, plan, st); else if (use_pxw) launch_dec_pxw(t, plan, st); else launch_dec_generic(t, plan, st);
     };
-    const bool best_px = best && plan.px_best && a.g.tsz == 1;
+    const bool best_pxw = best && plan.pxw_best && ((uintptr_t)a.img & (a.g.tsz - 1)) == 0 && !(a.ts_img & (a.g.tsz - 1));
+    const bool best_px = (best && plan.px_best && a.g.tsz == 1) || best_pxw;       // a lane-per-block common-factor decoder applies
+    auto dec_best_lpb = [&](const DecArgs &t) { if (best_pxw) launch_dec_pxw_best(t, plan, st); else launch_dec_px_best(t, plan, st); };
     if (rebuild && best_px && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
         // the container's table has a field per block (bits, entering rungs): the lane-per-block decoder works from the entries alone
         DecArgs t = a;
         t.bl_mode = 1;
         ProfScope ps("dec_units", st);
-        launch_dec_px_best(t, plan, st);
+        dec_best_lpb(t);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -531,7 +539,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         if (best_plain) { ProfScope ps("dec_index_scan", st); launch_prev_scan(a, st); }
         else { ProfScope ps("dec_index_serial", st); launch_dec_index_serial(a, st); }
     }
-    if (best_px && !a.from_ix) { ProfScope ps("dec_units", st); launch_dec_px_best(a, plan, st); }
+    if (best_px && !a.from_ix) { ProfScope ps("dec_units", st); dec_best_lpb(a); }
     else if (use_px) { ProfScope ps("dec_units", st); launch_dec_px(a, plan, st); }
     else if (use_px16) { ProfScope ps("dec_units", st); launch_dec_px16(a, plan, st); }
     else if (use_pxw) { ProfScope ps("dec_units", st); launch_dec_pxw(a, plan, st); }
@@ -555,11 +563,11 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
         cap = (cap + cap / 3 + 64 + 3) & ~(uint64_t)3;
         if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_px = 4096 + 4 * 4 * ((size_t)cap + 16); }
     }
-    if (plan.pxw && !full_staging && g.nseg) {          // the same for 32/64-bit data (worst case: 4.3 / 8.4 KB a wave)
+    if ((plan.pxw || plan.pxw_best) && !full_staging && g.nseg) {          // the same for 32/64-bit data (worst case: 4.3 / 8.4 KB a wave)
         const uint64_t bits = tb.n ? tb.max_bits : in_bits;
         uint64_t cap = bits / 32 / g.nseg;
         cap = (cap + cap / 2 + 64 + 3) & ~(uint64_t)3;
-        if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_pxw = 2048 + 4 * 4 * ((size_t)cap + 8); }
+        if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_pxw = (plan.pxw ? 2048 : 0) + 4 * 4 * ((size_t)cap + 8); }
     }
     a.in_cap_full = plan_in.px_cap_dw;
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
@@ -597,7 +605,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     HIPCHK(hipMemsetAsync(a.status, 0, status_bytes, st));
     a.lane_dw = dec_lane_dwords(g);
     a.dpr = g.bands * g.tsz;
-    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16 || plan.px_best || plan.pxw) ? plan.px_cap_dw : plan.in_cap_dw;
+    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16 || plan.px_best || plan.pxw || plan.pxw_best) ? plan.px_cap_dw : plan.in_cap_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.totals_only = 0;
     a.bl_mode = 0;

@@ -828,7 +828,8 @@ QB3_API size_t qb3x_header_size_bound(const void *container, size_t avail) {
     // ... and a table of 8-bit data may carry ten bits per block on top (an entry per 64 blocks)
     const size_t nblk = ((w + 3) / 4) * ((h + 3) / 4);
     const size_t bl = tsz == 1 ? (nblk / 64 + 1) * (64 * IX_BL_BEST_BYTES) : tsz == 2 ? (nblk * (nb / 4 + 1) / 64 + 1) * ((128 * IX_BL_BITS + 7) / 8)
-                               : (nblk * nb * IX_BL_BITS_WIDE) / 8 + (nblk / 12 + 1) * 2 + 64;       // (32/64-bit: a length per unit, an odd byte per entry)
+                               : std::max((nblk * nb * IX_BL_BITS_WIDE) / 8 + (nblk / 12 + 1) * 2 + 64,      // (32/64-bit: a length per unit, an odd byte per entry)
+                                          nblk * IX_BL_BEST_BYTES + 64);                                    // (... or, one band, common factor: a field per block)
     const size_t bytes = K * E + bl;
     return 128 + bytes + (bytes / 60000 + 1) * (IX_HEAD + IX_PAD);
 }

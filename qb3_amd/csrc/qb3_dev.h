@@ -52,7 +52,11 @@ IndexView index_view(const Geometry &g, void *base);
 uint32_t seg_blocks_for(const Geometry &g);      // needs w, h, bands, tsz, stride, order, mode, cband
 uint32_t ulen_size_for(uint32_t tsz, uint32_t mode, uint32_t bands);
 inline size_t ulen_table_bytes(const Geometry &g) { return g.ulen_sz == 4 ? (size_t)g.nblocks * 4 : (size_t)g.nblocks * g.bands * g.ulen_sz; }
-inline bool best_block_table(uint32_t tsz, uint32_t mode, uint32_t bands) { return mode == CM_BEST && tsz == 1 && (bands == 1 || bands == 3 || bands == 4); }
+// common-factor streams whose index holds a dword per BLOCK (its bits | the rungs its units are entered with << 16) for a
+// lane-per-block decoder: 8-bit rasters of 1/3/4 bands (four bits a band), 32/64-bit rasters of one band (the whole rung)
+inline bool best_block_table(uint32_t tsz, uint32_t mode, uint32_t bands) {
+    return mode == CM_BEST && ((tsz == 1 && (bands == 1 || bands == 3 || bands == 4)) || (tsz >= 4 && bands == 1));
+}
 
 // Results the encoder hands back to the host (device resident, copied once per encode)
 struct EncResult {
@@ -176,6 +180,7 @@ struct DecPlan {
     uint32_t px16_bg, px16_ng;
     bool px_best;           // 8-bit common-factor streams: the lane-per-block decoder applies (k_dec_px_best.hip)
     bool pxw;               // 32/64-bit single-band FTL/BASE streams: the lane-per-block decoder applies (k_dec_pxw.hip)
+    bool pxw_best;          // ... and its common-factor counterpart (dec_pxw_best_kernel)
     size_t lds_pxw;
 };
 DecPlan plan_decode(const Geometry &g);

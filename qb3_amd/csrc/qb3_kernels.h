@@ -585,6 +585,7 @@ void launch_dec_index_serial(const DecArgs &a, hipStream_t st);                 
 void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st);         // k_dec_px.hip
 void launch_dec_px16(const DecArgs &a, const DecPlan &plan, hipStream_t st);       // k_dec_px16.hip
 void launch_dec_pxw(const DecArgs &a, const DecPlan &plan, hipStream_t st);        // k_dec_pxw.hip
+void launch_dec_pxw_best(const DecArgs &a, const DecPlan &plan, hipStream_t st);   // k_dec_pxw.hip
 void launch_dec_px_best(const DecArgs &a, const DecPlan &plan, hipStream_t st);    // k_dec_px_best.hip
 void launch_dec_walk(const DecArgs &a, hipStream_t st);                            // k_dec_walk.hip: unit lengths of an index-less 8/16-bit stream
 void launch_prev_scan(const DecArgs &a, hipStream_t st);                           // k_dec_walk.hip

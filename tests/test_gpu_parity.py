@@ -1132,7 +1132,8 @@ def test_block_lengths_only_where_the_decoder_uses_them(qb3, oracle):
     table.  A common-factor stream has no unit-length table at any level; its level 2 table has the entries closer together
     (24 units, 12 for 32/64-bit data), and decodes from the container alone like the level 1 one.  The exception: 8-bit
     common-factor streams of 1/3/4 bands, whose table has a field per block (bits, entering rungs) at EITHER level -- what the
-    lane-per-block decoder of those streams works from"""
+    lane-per-block decoder of those streams works from -- and, since round 4, 32/64-bit common-factor streams of one band, whose
+    lane-per-block decoder (dec_pxw_best_kernel) works from the same kind of table"""
     for (w, h, b, dt, gen, mode) in [(256, 128, 5, 2, "LANDSAT16", FTL), (160, 120, 5, 0, "NOISY3", FTL)]:
         img = oracle.generate(w, h, b, dt, gen, 3)
         cb = None if b in (1, 3, 4) else list(range(b))
@@ -1151,7 +1152,7 @@ def test_block_lengths_only_where_the_decoder_uses_them(qb3, oracle):
         if ref[10] in (255, 2, 3, 6, 7):            # raw-stored, or the RLE0 pass won: no table either way
             assert np.array_equal(one, ref) and np.array_equal(two, ref)
             continue
-        if dt <= 1 and b in (1, 3, 4):
+        if (dt <= 1 and b in (1, 3, 4)) or (dt >= 4 and b == 1):
             assert np.array_equal(one, two) and len(one) > len(ref)
         else:
             assert len(two) > len(one) > len(ref)
