@@ -22,6 +22,7 @@
 #include "../../include/QB3.h"
 #include "../../include/qb3x.h"
 #include "qb3_dev.h"
+#include "qb3_host_io.h"
 
 using namespace qb3dev;
 
@@ -147,50 +148,25 @@ static hipError_t fetch_small(void *dst, const void *d_src, size_t n, hipStream_
 }
 
 // ---------------------------------------------------------------- host <-> device copies of the host-pointer API
-// The reference API hands over pageable host memory.  A plain hipMemcpyAsync from pageable memory goes through the
-// runtime's own bounce buffers on ONE host thread (measured: 11 GB/s, a fifth of the link).  Large copies here go
-// through a ring of pinned buffers instead, filled (or drained) by a few host threads while the previous slice is
-// on the link.
+// The reference API hands over pageable host memory (qb3_host_io.h: the ring of pinned slices, the pool of copy threads).
 struct Stager {
-    static constexpr size_t SLICE = 8u << 20, NSLOT = 4, MIN_BYTES = 4u << 20;
-    uint8_t *slot[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    bool ready = false, failed = false;
+    qb3host::PinnedRing *ring = nullptr;
+    static constexpr size_t SLICE = qb3host::PinnedRing::SLICE, NSLOT = qb3host::PinnedRing::NSLOT, MIN_BYTES = qb3host::PinnedRing::MIN_BYTES;
+    bool failed = false;
     bool init() {
-        if (ready || failed) return ready;
-        for (size_t i = 0; i < NSLOT; i++) {
-            if (hipHostMalloc((void **)&slot[i], SLICE, hipHostMallocDefault) != hipSuccess ||
-                hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { failed = true; (void)hipGetLastError(); release(); return false; }
-        }
-        return ready = true;
+        if (ring) return true;
+        if (failed) return false;
+        try { ring = qb3host::ring_acquire(); } catch (...) { ring = nullptr; }
+        failed = !ring;
+        return ring != nullptr;
     }
-    void release() {
-        for (size_t i = 0; i < NSLOT; i++) {
-            if (slot[i]) (void)hipHostFree(slot[i]);
-            if (ev[i]) (void)hipEventDestroy(ev[i]);
-            slot[i] = nullptr; ev[i] = nullptr;
-        }
-        ready = false;
-    }
+    void release() { try { qb3host::ring_release(ring); } catch (...) {} ring = nullptr; }
+    uint8_t *slot(size_t i) const { return ring->slot[i % NSLOT]; }
+    hipEvent_t ev(size_t i) const { return ring->ev[i % NSLOT]; }
 };
-// memcpy by a few threads (the copies are memory bound: one thread moves about 10 GB/s)
-static unsigned copy_threads() {
-    static const unsigned n = [] { unsigned h = std::thread::hardware_concurrency(); return h >= 16 ? 8u : h >= 8 ? 4u : h >= 4 ? 2u : 1u; }();
-    return n;
-}
 static void parallel_memcpy(uint8_t *dst, const uint8_t *src, size_t n) {
-    const unsigned T = copy_threads();
-    if (T <= 1 || n < (1u << 20)) { memcpy(dst, src, n); return; }
-    const size_t part = ((n + T - 1) / T + 4095) & ~(size_t)4095;
-    std::thread th[8];
-    unsigned started = 0;
-    for (unsigned t = 1; t < T && t * part < n; t++) {
-        // (a thread that cannot be had -- a pids or RLIMIT_NPROC limit -- must not send an exception across the C ABI: its part is copied here)
-        try { th[started] = std::thread([=] { memcpy(dst + t * part, src + t * part, std::min(part, n - t * part)); }); started++; }
-        catch (...) { memcpy(dst + t * part, src + t * part, std::min(part, n - t * part)); }
-    }
-    memcpy(dst, src, std::min(part, n));
-    for (unsigned t = 0; t < started; t++) th[t].join();
+    try { qb3host::CopyPool::get().copy(dst, src, n); }
+    catch (...) { memcpy(dst, src, n); }                    // (a pool that cannot be had: the caller's thread copies)
 }
 // host -> device; returns once the host bytes have been consumed (the last slices may still be on the link)
 static bool upload(Stager &sg, void *d_dst, const void *h_src, size_t bytes, hipStream_t st) {
@@ -201,11 +177,11 @@ static bool upload(Stager &sg, void *d_dst, const void *h_src, size_t bytes, hip
     }
     size_t i = 0;
     for (size_t off = 0; off < bytes; off += Stager::SLICE, i++) {
-        const size_t k = i % Stager::NSLOT, n = std::min(Stager::SLICE, bytes - off);
-        if (i >= Stager::NSLOT && hipEventSynchronize(sg.ev[k]) != hipSuccess) { set_error("upload: slot wait", 0); return false; }
-        parallel_memcpy(sg.slot[k], (const uint8_t *)h_src + off, n);
-        hipError_t e = hipMemcpyAsync((uint8_t *)d_dst + off, sg.slot[k], n, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipEventRecord(sg.ev[k], st);
+        const size_t n = std::min(Stager::SLICE, bytes - off);
+        if (i >= Stager::NSLOT && hipEventSynchronize(sg.ev(i)) != hipSuccess) { set_error("upload: slot wait", 0); return false; }
+        parallel_memcpy(sg.slot(i), (const uint8_t *)h_src + off, n);
+        hipError_t e = hipMemcpyAsync((uint8_t *)d_dst + off, sg.slot(i), n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(sg.ev(i), st);
         if (e != hipSuccess) { set_error("upload", (int)e); return false; }
     }
     return true;
@@ -221,16 +197,16 @@ static bool download(Stager &sg, void *h_dst, const void *d_src, size_t bytes, h
     const size_t nsl = (bytes + Stager::SLICE - 1) / Stager::SLICE;
     auto issue = [&](size_t i) -> hipError_t {
         const size_t off = i * Stager::SLICE, n = std::min(Stager::SLICE, bytes - off);
-        hipError_t e = hipMemcpyAsync(sg.slot[i % Stager::NSLOT], (const uint8_t *)d_src + off, n, hipMemcpyDeviceToHost, st);
-        return e == hipSuccess ? hipEventRecord(sg.ev[i % Stager::NSLOT], st) : e;
+        hipError_t e = hipMemcpyAsync(sg.slot(i), (const uint8_t *)d_src + off, n, hipMemcpyDeviceToHost, st);
+        return e == hipSuccess ? hipEventRecord(sg.ev(i), st) : e;
     };
     hipError_t e = hipSuccess;
     for (size_t i = 0; i < std::min(nsl, (size_t)Stager::NSLOT) && e == hipSuccess; i++) e = issue(i);
     for (size_t i = 0; i < nsl && e == hipSuccess; i++) {
-        e = hipEventSynchronize(sg.ev[i % Stager::NSLOT]);
+        e = hipEventSynchronize(sg.ev(i));
         if (e != hipSuccess) break;
         const size_t off = i * Stager::SLICE, n = std::min(Stager::SLICE, bytes - off);
-        parallel_memcpy((uint8_t *)h_dst + off, sg.slot[i % Stager::NSLOT], n);
+        parallel_memcpy((uint8_t *)h_dst + off, sg.slot(i), n);
         if (i + Stager::NSLOT < nsl) e = issue(i + Stager::NSLOT);
     }
     if (e != hipSuccess) { set_error("download", (int)e); return false; }
@@ -1318,7 +1294,7 @@ QB3_API int qb3x_decode_tile_ok(const decsp p, size_t i) { return (p && i < p->t
 // ---------------------------------------------------------------- misc
 // returns the device buffers that destroyed handles left in the library's pool to the runtime
 QB3_API unsigned qb3x_last_decode_status(const decsp p) { return p ? p->last_status : 0u; }
-QB3_API void qb3x_trim(void) { try { dev_pool().trim(); } catch (...) {} }
+QB3_API void qb3x_trim(void) { try { dev_pool().trim(); qb3host::ring_trim(); } catch (...) {} }
 
 QB3_API int qb3x_device_count(void) {
     int n = 0;

@@ -44,6 +44,14 @@ CASES = [
     (128, 128, 1, 5, "TERRACE", 4),
     (128, 128, 1, 7, "FEW", 4),
     (64, 64, 1, 6, "RUNG63", 4),          # 65-bit codes
+    # 32/64-bit rasters of one band take the lane-per-block kernels (k_enc_pxw.hip, k_dec_pxw.hip): shifted last column and
+    # row, several chunks, rungs below 8 (the piece builder) and far above, unsigned and signed
+    (509, 131, 1, 5, "DEM", 6),
+    (67, 61, 1, 7, "TERRACE", 4),
+    (1030, 12, 1, 4, "RANDOM", 8),
+    (1024, 260, 1, 6, "NOISY3", 9),
+    (260, 1024, 1, 4, "GRAD", 0),
+    (128, 128, 1, 5, "CONST", 0),
     (64, 64, 16, 0, "NOISY3", 11),
     (32, 32, 16, 6, "RANDOM", 12),
     (256, 256, 3, 0, "CONST", 0),
@@ -355,6 +363,42 @@ def test_16bit_segments_far_longer_than_the_average(qb3, oracle, bands, mode):
     out, dims, dtype, _ = qb3.decode(stream)                            # host API: from the stream alone
     assert dims == (w, h, bands) and np.array_equal(out, img.view(np.uint8).ravel())
     enc = qdev.DeviceEncoder(w, h, bands, 2, mode=mode, cband=cb)
+    dimg = torch.from_numpy(img.view(np.uint8).ravel().copy()).cuda()
+    dst, n, index = enc.encode(dimg)
+    assert n == len(stream) and np.array_equal(dst[:n].cpu().numpy(), stream)
+    dec = qdev.DeviceDecoder(dst, n)
+    assert torch.equal(dec.decode(dst, index=index).view(torch.uint8), dimg)
+    assert torch.equal(dec.decode(dst, index=None).view(torch.uint8), dimg)
+
+
+@pytest.mark.parametrize("dt", [4, 7])
+@pytest.mark.parametrize("mode", [FTL, BASE, 7])
+def test_wide_segments_far_longer_than_the_average(qb3, oracle, dt, mode):
+    """the 32/64-bit lane-per-block decoders (dec_pxw_kernel, dec_pxw_best_kernel) size their LDS staging for half above the
+    stream's AVERAGE segment like the 16-bit one: a flat raster with a patch of noise has segments many times that -- status
+    bit 4, the call again with the worst case, exact pixels -- with the index, from the stream alone (the exit walk), from the
+    container's own table, through the host API"""
+    import torch
+    from qb3_amd import device as qdev
+    w, h = 512, 256
+    rng = np.random.default_rng(7)
+    npdt = np.uint32 if dt == 4 else np.int64
+    img = np.full((h, w, 1), 1000, dtype=npdt)
+    hi = 2 ** 31 if dt == 4 else 2 ** 62
+    img[64:160, 128:320, :] = rng.integers(0, hi, size=(96, 192, 1)).astype(npdt)
+    stream = oracle.encode(img, dt, mode)
+    assert stream[10] != 255                                            # coded, not stored raw
+    out, dims, dtype, _ = qb3.decode(stream)                            # host API: from the stream alone
+    assert dims == (w, h, 1) and np.array_equal(out, img.view(np.uint8).ravel())
+    got = qb3.encode(img, dt, mode)
+    assert np.array_equal(got, stream)
+    self_indexed = qb3.encode(img, dt, mode, index_chunk=2)
+    assert len(self_indexed) > len(stream)
+    out, _, _, _ = qb3.decode(self_indexed)
+    assert np.array_equal(out, img.view(np.uint8).ravel())
+    if stream[10] in (2, 3, 6, 7):
+        return                                                          # (the RLE0 pass won: the device flavour below is the plain modes')
+    enc = qdev.DeviceEncoder(w, h, 1, dt, mode=mode)
     dimg = torch.from_numpy(img.view(np.uint8).ravel().copy()).cuda()
     dst, n, index = enc.encode(dimg)
     assert n == len(stream) and np.array_equal(dst[:n].cpu().numpy(), stream)
