@@ -23,8 +23,8 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     // Loads that depend on nothing but the segment number go out first -- positions, unit lengths, entering rungs and
     // values -- so that their round trips overlap the table copy and its barrier (a wave spends 45 % of its life waiting
     // for memory before it can start: the two dependent trips "position, then stream words").
-    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
-    const bool live = seg < a.g.nseg;
+    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
+    const bool live = seg < a.seg_end;
     const uint64_t segc = live ? seg : 0;
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
 template <int B, bool RGB>
 static void launch_dec_px_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
     if (a.bl_mode) {
         if (!z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, false, true>), grid, block, plan.lds_px, st, a);
         else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true, true>), grid, block, plan.lds_px, st, a);

@@ -117,8 +117,8 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
     const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
     // loads that depend on nothing but the segment number go out first; their round trips overlap the table copy and
     // its barrier (see dec_px_kernel)
-    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
-    const bool live = seg < a.g.nseg;
+    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
+    const bool live = seg < a.seg_end;
     const uint64_t segc = live ? seg : 0;
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
 template <int BG, bool RGB>
 static void launch_dec_px16_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
     if (a.bl_mode) {
         constexpr bool bl = true;
         if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, false, bl>), grid, block, plan.lds_px, st, a);

@@ -105,8 +105,8 @@ __global__ void __launch_bounds__(256) dec_px_best_kernel(const DecArgs a0) {
     uint32_t *stage = tab + 1024 + wave * (a.in_cap_dw + 8);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
     const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
-    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
-    const bool live = seg < a.g.nseg;
+    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
+    const bool live = seg < a.seg_end;
     const uint64_t segc = live ? seg : 0;
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) dec_px_best_kernel(const DecArgs a0) {
 
 template <int B, bool RGB>
 static void launch_dec_px_best_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
-    dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
     if (a.bl_mode) {
         if (a.g.order == ZCURVE) hipLaunchKernelGGL((dec_px_best_kernel<B, RGB, ZCURVE, true>), grid, block, plan.lds_px, st, a);
         else hipLaunchKernelGGL((dec_px_best_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);

@@ -48,8 +48,8 @@ __global__ void __launch_bounds__(256) dec_pxw_kernel(const DecArgs a0) {
     uint32_t *stage = (uint32_t *)(smem + 2048) + wave * (a.in_cap_dw + 8);
 
     // loads that depend on nothing but the segment number go out first: their round trips overlap the table copy
-    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
-    const bool live = seg < a.g.nseg;
+    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
+    const bool live = seg < a.seg_end;
     const uint64_t segc = live ? seg : 0;
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
@@ -174,8 +174,8 @@ __global__ void __launch_bounds__(256) dec_pxw_best_kernel(const DecArgs a0) {
     const uint32_t NB = 64, nbx = a.g.nbx;
     const uint64_t stride = a.g.stride;
     uint32_t *stage = (uint32_t *)smem + wave * (a.in_cap_dw + 8);         // nothing is shared between the waves: no barrier
-    const uint64_t seg = (uint64_t)blockIdx.x * nwaves + wave;
-    if (seg >= a.g.nseg) return;
+    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;
+    if (seg >= a.seg_end) return;
     const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
     const bool act = lane < nb_here;
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) dec_pxw_best_kernel(const DecArgs a0) {
 
 template <typename T>
 static void launch_dec_pxw_best_t(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
-    dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
     const size_t lds = plan.lds_pxw;
     const bool z = a.g.order == ZCURVE;
     if (a.bl_mode) {
@@ -313,7 +313,7 @@ void launch_dec_pxw_best(const DecArgs &a, const DecPlan &plan, hipStream_t st) 
 template <typename T>
 static void launch_dec_pxw_t(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    dim3 grid((uint32_t)((a.g.nseg + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
     const size_t lds = plan.lds_pxw;
     if (a.bl_mode) {
         if (!z && !step) hipLaunchKernelGGL((dec_pxw_kernel<T, HILBERT, false, true>), grid, block, lds, st, a);

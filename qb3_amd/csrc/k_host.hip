@@ -550,7 +550,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
 
 int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in32, uint32_t in_bit0, uint64_t in_bits,
                   void *img, const void *index, void *ws, uint32_t **status_out, void *stream, const TileBatch &tb,
-                  const uint64_t *tile_bits, const IxTable &ix, void *walk_tab, size_t walk_tab_bytes, bool full_staging, uint32_t wide_band) {
+                  const uint64_t *tile_bits, const IxTable &ix, void *walk_tab, size_t walk_tab_bytes, bool full_staging, uint32_t wide_band, const DecStrip *strip) {
     hipStream_t st = (hipStream_t)stream;
     DecArgs a;
     // 16-bit lane-per-block decoder: a wave stages its segment in LDS, and four worst-case segments (278 bits a unit) keep
@@ -602,7 +602,9 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     a.status = (uint32_t *)w;
     a.idx = index_view(g, rebuild ? (void *)(w + status_bytes) : const_cast<void *>(index));
     a.ts_idx = rebuild ? align8(index_bytes(g)) : tb.idx_pitch;
-    HIPCHK(hipMemsetAsync(a.status, 0, status_bytes, st));
+    if (!strip || strip->first) HIPCHK(hipMemsetAsync(a.status, 0, status_bytes, st));
+    a.seg0 = strip ? strip->seg0 : 0;
+    a.seg_end = strip ? std::min<uint64_t>(g.nseg, strip->seg0 + strip->nseg) : g.nseg;
     a.lane_dw = dec_lane_dwords(g);
     a.dpr = g.bands * g.tsz;
     a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16 || plan.px_best || plan.pxw || plan.pxw_best) ? plan.px_cap_dw : plan.in_cap_dw;
@@ -614,7 +616,29 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
     *status_out = a.status;
     if (g.tsz != 1 && g.tsz != 2 && g.tsz != 4 && g.tsz != 8) { set_error("decode: bad value size", 0); return -1; }
+    if (strip) {        // one launch of the lane-per-block decoder over the strip's segments, from the table's entries
+        if (rebuild && strip->first && a.ix && a.ix_K && (a.ix_ver >= 3 || a.ix_check_heads))
+            hipLaunchKernelGGL(ix_check_kernel, dim3((a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk, a.ntiles), dim3(256), 0, st, a);
+        if (!rebuild || !a.ix || !decode_strips_ok(g, plan_in, ix)) { set_error("decode: strips need the container's table", 0); return -1; }
+        a.bl_mode = 1;
+        ProfScope ps("dec_units", st);
+        const bool best = g.mode == CM_BEST;
+        if (best && plan.pxw_best) launch_dec_pxw_best(a, plan, st);
+        else if (best) launch_dec_px_best(a, plan, st);
+        else if (plan.px) launch_dec_px(a, plan, st);
+        else if (plan.px16) launch_dec_px16(a, plan, st);
+        else launch_dec_pxw(a, plan, st);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     return launch_decode_all(a, plan, rebuild, st, walk_tab, walk_tab_bytes, tb.n ? tb.max_bits : in_bits);
+}
+
+bool decode_strips_ok(const Geometry &g, const DecPlan &plan, const IxTable &ix) {
+    if (!ix.base || !ix.block_lens || !ix.blocks || ix.blocks != g.seg_blocks || !ix.per_chunk || tuning().slow_index || tuning().no_bl) return false;
+    if (ix.entry_bytes != ix_entry_bytes(g, true) || !ix_block_lens_ok(g) || ix.K != (g.nblocks + ix.blocks - 1) / ix.blocks) return false;
+    if (g.mode == CM_BEST) return (plan.px_best && g.tsz == 1) || plan.pxw_best;
+    return (plan.px && g.tsz == 1) || (plan.px16 && g.tsz == 2) || plan.pxw;
 }
 
 }  // namespace qb3dev

@@ -213,6 +213,37 @@ static bool download(Stager &sg, void *h_dst, const void *d_src, size_t bytes, h
     return true;
 }
 
+// Streams and events of a pipelined host call (upload, kernels and download of different strips at once), kept by the handle
+struct Pipe {
+    hipStream_t up = nullptr, k = nullptr, dn = nullptr;
+    std::vector<hipEvent_t> ev;
+    bool failed = false;
+    bool init() {
+        if (up) return true;
+        if (failed) return false;
+        if (hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&k, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&dn, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); release(); failed = true; return false; }
+        return true;
+    }
+    bool events(size_t n) {
+        while (ev.size() < n) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ev.push_back(e);
+        }
+        return true;
+    }
+    void sync() { if (up) { (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(k); (void)hipStreamSynchronize(dn); } }
+    void release() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        if (up) (void)hipStreamDestroy(up);
+        if (k) (void)hipStreamDestroy(k);
+        if (dn) (void)hipStreamDestroy(dn);
+        up = k = dn = nullptr;
+    }
+};
+
 struct band_state { size_t prev, runbits, cf; };
 
 struct encs {
@@ -255,7 +286,8 @@ struct decs {
     std::vector<uint8_t> tile_ok;   // qb3x_decode_tiles: per tile outcome of the last call
     uint32_t last_status = 0;       // status bits of the last decode call (qb3x_last_decode_status; tiles: of all tiles together)
     DevBuf d_in, d_img, d_ws, d_ix, d_rle, d_tab;      // d_rle: RLE0 workspace (+ the packed bytes of a host call); d_tab: the unit-length table a plain 8-bit stream is walked through
-    Stager stager;
+    Stager stager, stager2;                            // (stager2: the download ring of a pipelined host call)
+    Pipe pipe;                                         // ... its streams and events
 };
 
 // ---------------------------------------------------------------- small host bit writer for headers
@@ -742,7 +774,7 @@ static size_t encode_tiles_body(encsp p, const void *d_src, size_t n, size_t src
 QB3_API void qb3_destroy_decoder(decsp p) {
     if (!p) return;
     release_all(p->d_in, p->d_img, p->d_ws, p->d_ix, p->d_rle, p->d_tab);
-    p->stager.release();
+    p->stager.release(); p->stager2.release(); p->pipe.release();
     delete p;
 }
 QB3_API size_t qb3_decoded_size(const decsp p) { return p->xsize * p->ysize * p->nbands * szof(p->type); }
@@ -1035,6 +1067,146 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
     return true;
 }
 
+
+// ---------------------------------------------------------------- qb3_read_data, pipelined
+// A self-indexed container (level 2 table: an entry per segment with its blocks' fields) decodes segment by segment with
+// nothing but its table, so the call can be cut into STRIPS of block rows: while the stream of strip k + 1 goes up the link,
+// strip k is decoded and the rows of strip k - 1 come down -- three streams, two rings of pinned slices, the host copies
+// (caller's memory <-> pinned) by the pool of copy threads.  The link moves 48 GB/s each way at once (tools/pcie_probe.cpp),
+// so the call is bound by its larger direction -- the raster -- instead of the sum of both.
+// Returns the decoded size; 0 with p->error == QB3E_OK: not taken or not trusted (a table that fails its check, a segment
+// that does not decode) -- the caller goes on with the one-after-the-other path, which has the fallback ladder;
+// 0 with p->error set: a HIP failure.
+static size_t decode_pipelined(decsp p, const Geometry &g, const IxTable &ix_host, void *host_dst, size_t nbytes, size_t total, size_t line) {
+    using qb3host::CopyPool;
+    constexpr size_t SLICE = Stager::SLICE, NSLOT = Stager::NSLOT;
+    static const bool dbg = getenv("QB3_DEBUG_PIPE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    const DecPlan plan = plan_decode(g);
+    IxTable ixt = ix_host;
+    const size_t tab_bytes = ix_total_bytes(ixt) + 2;
+    if (!p->d_ix.ensure(tab_bytes + 16)) return 0;
+    ixt.base = (uint8_t *)p->d_ix.p;
+    if (!decode_strips_ok(g, plan, ixt)) return 0;
+    // strips of block rows, about 48 MB of raster each, the last one at least two block rows (a shifted last row overlaps the one before)
+    const uint32_t nby = g.nby, nbx = g.nbx, NB = g.seg_blocks;
+    uint32_t BR = (uint32_t)std::max<size_t>(2, ((size_t)48 << 20) / (4 * line));
+    uint32_t nstrips = (nby + BR - 1) / BR;
+    if (nstrips > 1 && nby - (nstrips - 1) * BR < 2) nstrips--;
+    if (nstrips < 3) return 0;
+    if (!p->pipe.init() || !p->pipe.events(2 * (size_t)nstrips) || !p->stager.init() || !p->stager2.init()) return 0;
+    if (!p->d_in.ensure(nbytes + 8) || !p->d_img.ensure(total) || !p->d_ws.ensure(plan.ws_bytes)) return 0;
+    // where the stream must have arrived for a strip to be decoded: the position of the segment behind its last one, from
+    // the table in the caller's memory (untrusted: not monotonous or behind the stream's end means "not this way")
+    const uint8_t *tab_host = p->s_start + p->ix_off;
+    auto entry_pos = [&](uint64_t k) -> uint64_t {
+        const uint64_t c = k / ixt.per_chunk, j = k - c * ixt.per_chunk;
+        const uint8_t *e = tab_host + c * (IX_HEAD + (ixt.pads ? IX_PAD : 0) + (uint64_t)ixt.per_chunk * ixt.entry_bytes) + IX_HEAD + j * ixt.entry_bytes;
+        uint64_t v = 0;
+        for (int i = 0; i < 6; i++) v |= (uint64_t)e[i] << (8 * i);
+        return v;
+    };
+    struct Strip { uint64_t seg0, nseg; size_t need, row0, row1; };
+    std::vector<Strip> strips(nstrips);
+    size_t prev_need = 0;
+    for (uint32_t s = 0; s < nstrips; s++) {
+        const uint32_t br0 = s * BR, br1 = s + 1 == nstrips ? nby : (s + 1) * BR;
+        const uint64_t b0 = (uint64_t)br0 * nbx, b1 = (uint64_t)br1 * nbx;
+        Strip &t = strips[s];
+        t.seg0 = b0 / NB;
+        const uint64_t seg1 = std::min<uint64_t>(g.nseg, (b1 + NB - 1) / NB);
+        t.nseg = seg1 - t.seg0;
+        const uint64_t pos = seg1 < g.nseg ? entry_pos(seg1) : (uint64_t)nbytes * 8;
+        if (pos > (uint64_t)nbytes * 8) return 0;
+        t.need = std::min(nbytes, (size_t)(pos / 8) + 16);
+        if (t.need < prev_need) return 0;
+        prev_need = t.need;
+        t.row0 = (size_t)4 * br0; t.row1 = s + 1 == nstrips ? g.h : (size_t)4 * br1;
+    }
+    strips[nstrips - 1].need = nbytes;
+    // the slices: up = the table, then the stream; down = every strip's rows
+    struct Slice { uint8_t *dev; uint8_t *host; size_t n; uint32_t strip; };
+    std::vector<Slice> up, dn;
+    for (size_t off = 0; off < tab_bytes; off += SLICE) up.push_back({(uint8_t *)p->d_ix.p + off, const_cast<uint8_t *>(tab_host) + off, std::min(SLICE, tab_bytes - off), 0});
+    const size_t n_tab = up.size();
+    for (size_t off = 0; off < nbytes; off += SLICE) up.push_back({(uint8_t *)p->d_in.p + off, p->s_in + off, std::min(SLICE, nbytes - off), 0});
+    for (uint32_t s = 0; s < nstrips; s++) {
+        const size_t a = strips[s].row0 * line, b = strips[s].row1 * line;
+        for (size_t off = a; off < b; off += SLICE) dn.push_back({(uint8_t *)p->d_img.p + off, (uint8_t *)host_dst + off, std::min(SLICE, b - off), s});
+    }
+    CopyPool &pool = CopyPool::get();
+    CopyPool::Batch b_up[NSLOT], b_dn[NSLOT];
+    Stager &r1 = p->stager, &r2 = p->stager2;
+    hipStream_t sU = p->pipe.up, sK = p->pipe.k, sD = p->pipe.dn;
+    const double t_setup = ms_since();
+    double t_up_done = 0, t_first_dn = 0;
+    size_t up_started = 0, up_enq = 0, stream_enq = 0, dn_avail = 0, dn_issued = 0, dn_copy = 0, dn_freed = 0;
+    uint32_t next_strip = 0;
+    int last_strip_waited = -1;
+    uint32_t *d_status = nullptr;
+    hipError_t e = hipSuccess;
+    bool launch_failed = false;
+    auto ok = [&] { return e == hipSuccess && !launch_failed; };
+    while (ok() && (up_enq < up.size() || dn_freed < dn.size())) {
+        bool progress = false;
+        // ---- up: the host copy of a slice into its pinned slot (two in flight), then its DMA
+        if (up_started < up.size() && up_started - up_enq < 2 && (up_started < NSLOT || hipEventQuery(r1.ev(up_started)) == hipSuccess)) {
+            pool.submit(r1.slot(up_started), up[up_started].host, up[up_started].n, b_up[up_started % NSLOT]);
+            up_started++; progress = true;
+        }
+        if (up_enq < up_started && pool.done(b_up[up_enq % NSLOT])) {
+            e = hipMemcpyAsync(up[up_enq].dev, r1.slot(up_enq), up[up_enq].n, hipMemcpyHostToDevice, sU);
+            if (e == hipSuccess) e = hipEventRecord(r1.ev(up_enq), sU);
+            if (up_enq >= n_tab) stream_enq += up[up_enq].n;
+            up_enq++; progress = true;
+            if (dbg && up_enq == up.size()) t_up_done = ms_since();
+            // strips whose stream is on its way: their kernel waits for it on the kernel stream
+            while (ok() && up_enq >= n_tab && next_strip < nstrips && strips[next_strip].need <= stream_enq) {
+                hipEvent_t ev_u = p->pipe.ev[2 * next_strip], ev_k = p->pipe.ev[2 * next_strip + 1];
+                e = hipEventRecord(ev_u, sU);
+                if (e == hipSuccess) e = hipStreamWaitEvent(sK, ev_u, 0);
+                if (e != hipSuccess) break;
+                const DecStrip st = { strips[next_strip].seg0, strips[next_strip].nseg, next_strip == 0 };
+                if (launch_decode(g, plan, (const uint32_t *)p->d_in.p, 0, (uint64_t)nbytes * 8, p->d_img.p, nullptr, p->d_ws.p, &d_status, sK, TileBatch(), nullptr, ixt,
+                                  nullptr, 0, false, 16, &st)) { launch_failed = true; break; }
+                e = hipEventRecord(ev_k, sK);
+                while (dn_avail < dn.size() && dn[dn_avail].strip == next_strip) dn_avail++;
+                next_strip++;
+            }
+        }
+        // ---- down: the DMA of a slice into its pinned slot once its strip's kernel is done, then the host copy out of it
+        if (ok() && dn_issued < dn_avail && dn_issued - dn_freed < NSLOT) {
+            if ((int)dn[dn_issued].strip != last_strip_waited) {
+                e = hipStreamWaitEvent(sD, p->pipe.ev[2 * dn[dn_issued].strip + 1], 0);
+                last_strip_waited = (int)dn[dn_issued].strip;
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(r2.slot(dn_issued), dn[dn_issued].dev, dn[dn_issued].n, hipMemcpyDeviceToHost, sD);
+            if (e == hipSuccess) e = hipEventRecord(r2.ev(dn_issued), sD);
+            dn_issued++; progress = true;
+        }
+        if (ok() && dn_copy < dn_issued) {
+            const hipError_t q = hipEventQuery(r2.ev(dn_copy));
+            if (q == hipSuccess) { if (dbg && !dn_copy) t_first_dn = ms_since(); pool.submit(dn[dn_copy].host, r2.slot(dn_copy), dn[dn_copy].n, b_dn[dn_copy % NSLOT]); dn_copy++; progress = true; }
+            else if (q != hipErrorNotReady) e = q;
+        }
+        while (dn_freed < dn_copy && pool.done(b_dn[dn_freed % NSLOT])) { dn_freed++; progress = true; }
+        if (!progress && !pool.help_one()) std::this_thread::yield();
+    }
+    (void)hipGetLastError();                                // (hipErrorNotReady of the queries is not an error)
+    for (size_t i = 0; i < NSLOT; i++) { pool.wait(b_up[i]); pool.wait(b_dn[i]); }
+    p->pipe.sync();
+    if (dbg) fprintf(stderr, "decode_pipelined: setup %.2f ms, last upload enqueued %.2f, first slice down %.2f, done %.2f (%u strips, %zu + %zu slices)\n", t_setup, t_up_done, t_first_dn, ms_since(), nstrips, up.size(), dn.size());
+    if (!ok()) { if (!launch_failed) set_error("pipelined decode", (int)e); p->error = QB3E_LIBERR; return 0; }
+    uint32_t status = 0;
+    e = hipMemcpy(&status, d_status, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("pipelined decode: status", (int)e); p->error = QB3E_LIBERR; return 0; }
+    prof_collect();
+    p->last_status = status;
+    if (status) return 0;                                   // not trusted: the caller decodes again, one step after the other
+    return total;
+}
+
 static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_dst, const void *d_index, hipStream_t st) {
     if (p->stage != 2 || p->error != QB3E_OK || p->s_in == nullptr || p->s_size == 0) {
         if (p->error == QB3E_OK) p->error = QB3E_EINV;
@@ -1061,6 +1233,21 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
     if (p->xsize * p->ysize < 16) { p->error = QB3E_EINV; return 0; }
     if (!device_ok()) { p->error = QB3E_LIBERR; return 0; }
 
+    // a large self-indexed container in host memory: upload, decode and download strip by strip, all three at once
+    static const bool no_pipeline = [] { const char *e = getenv("QB3_NO_PIPELINE"); return e && e[0] && e[0] != '0'; }();
+    if (on_host && !is_rle_mode(p->mode) && p->ix_K && p->ix_bl && p->quanta <= 1 && p->xsize >= 4 && p->ysize >= 4 && dst_stride == line &&
+        total >= ((size_t)64 << 20) && !no_pipeline) {
+        uint8_t cb[QB3_MAXBANDS];
+        for (size_t c = 0; c < QB3_MAXBANDS; c++) cb[c] = p->cband[c];
+        if (!p->saw_cb && !(p->compat & QB3X_REF_CBAND0)) for (size_t c = 0; c < p->nbands; c++) cb[c] = (uint8_t)c;
+        const Geometry gp = make_geometry(p->xsize, p->ysize, p->nbands, p->type, 0, p->order, p->mode, nullptr, cb);
+        IxTable ixh;
+        ixh.K = p->ix_K; ixh.blocks = p->ix_blocks; ixh.entry_bytes = p->ix_E; ixh.per_chunk = p->ix_per_chunk; ixh.pads = p->ix_pads; ixh.block_lens = p->ix_bl;
+        ixh.version = p->ix_ver; ixh.check_heads = p->ix_heads_unchecked;
+        const size_t r = decode_pipelined(p, gp, ixh, host_dst, p->s_size, total, line);
+        if (r) return r;
+        if (p->error != QB3E_OK) return 0;
+    }
     // locate the block stream on the device
     const uint8_t *dev_buf = nullptr;
     size_t off = 0, nbytes = p->s_size;

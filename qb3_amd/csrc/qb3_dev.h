@@ -185,6 +185,7 @@ struct DecPlan {
 };
 DecPlan plan_decode(const Geometry &g);
 
+struct DecStrip { uint64_t seg0, nseg; bool first; };     // first: zero the status words, check the table; later strips skip both
 // Decode a block stream.  in32/in_bit0 locate the first stream bit like out32/out_bit0 above; in_bits is
 // the stream length in bits (bytes*8).  index == nullptr: the index is first rebuilt in ws by a serial
 // boundary scan on the GPU.  status (device u32 inside ws, zeroed here) gets nonzero on decode failure.
@@ -195,8 +196,13 @@ int launch_decode(const Geometry &g, const DecPlan &plan, const uint32_t *in32, 
                   const IxTable &ix = IxTable(),
                   void *walk_tab = nullptr, size_t walk_tab_bytes = 0,     // table memory for plain 8-bit streams (null: the one-wave walk)
                   bool full_staging = false,    // 16-bit data: worst-case LDS staging (after a call that ended with status bit 4)
-                  uint32_t wide_band = 16);     // plain 32/64-bit streams: rungs the walk's table covers (16; 14: byte entries, 8: half rows -- QB3_WIDE_BAND, test hooks; the first
+                  uint32_t wide_band = 16,      // plain 32/64-bit streams: rungs the walk's table covers (16; 14: byte entries, 8: half rows -- QB3_WIDE_BAND, test hooks; the first
                                                 // unit of a block row, entered from the far end of the row before, sits many rungs above its neighbours)
+                  const DecStrip *strip = nullptr);     // a strip of a pipelined host call (decode_strips_ok): only these segments, from the container's table
+
+// can a container's table (with block fields, an entry per index segment) be decoded strip by strip: one launch of a
+// lane-per-block decoder per range of segments, nothing else
+bool decode_strips_ok(const Geometry &g, const DecPlan &plan, const IxTable &ix);
 
 // The RLE0 byte pass of the *_RLE modes on device buffers (k_rle0.hip; reference QB3encode.cpp:271-332, QB3decode.cpp:267-307).
 // ws: rle0_ws_bytes(n) bytes of device memory.  rle0_device_size returns the size of the coded (decode = false) or

@@ -54,6 +54,12 @@ public:
             else std::this_thread::yield();
         }
     }
+    bool help_one() {                                       // one piece of whatever is queued, if anything is
+        Job j;
+        if (!pop(j, false)) return false;
+        run(j);
+        return true;
+    }
     void copy(void *dst, const void *src, size_t n) {       // parallel memcpy, returns when done
         if (n < ((size_t)1 << 20)) { memcpy(dst, src, n); return; }
         Batch b;

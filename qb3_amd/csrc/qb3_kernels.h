@@ -323,6 +323,7 @@ struct DecArgs {
     uint32_t ix_bl;                 // the entries carry block lengths: the lane-per-block decoder needs no walk and no index
     uint32_t ix_ver, ix_check_heads;    // version of the table's chunks (3: with checks); the host has not seen the chunk heads behind the first
     uint32_t bl_mode;               // ... and this launch decodes from them
+    uint64_t seg0, seg_end;         // lane-per-block decoders: the segments this launch decodes ([0, nseg) but for the strips of a pipelined host call)
     uint32_t wide_band;             // plain 32/64-bit streams: rungs in the band the walk's table covers (16; 8: QB3_WIDE_BAND, a test hook)
     // batched tiles (blockIdx.y = tile): byte strides, and each tile's stream length in bits (null: in_bits for all)
     uint32_t ntiles;
