@@ -13,7 +13,7 @@ __global__ void enc_kernel(const EncArgs a0) {
     const uint32_t bands = a.g.bands, nblocks = (uint32_t)a.g.nblocks;
     T g[16];
     EncFront<T> f;
-    enc_front<T>(a, a0, smem, (31 + (a.slots - 1) * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1, f, g, blockIdx.x);
+    enc_front<T>(a, a0, smem, (31 + (a.slots - 1) * bands * (UB + 2 + 16 * (8 * (uint32_t)sizeof(T) + 1))) / 32 + 1, f, g, a.chunk0 + blockIdx.x);
     const uint32_t c = f.c, gblk = f.gblk, rung = f.rung, chunk = f.chunk;
     const bool payload = f.payload;
     const T used = f.used, pv = f.pv, lastv = f.lastv;
@@ -117,7 +117,7 @@ __global__ void enc_kernel(const EncArgs a0) {
 
 template <typename T>
 static void launch_enc_generic_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
-    dim3 grid(plan.nchunks, a.ntiles), block(plan.threads);
+    dim3 grid(a.chunk_end - a.chunk0, a.ntiles), block(plan.threads);
     if (a.g.mode != CM_FTL) hipLaunchKernelGGL((enc_kernel<T, true>), grid, block, plan.lds_bytes, st, a);
     else hipLaunchKernelGGL((enc_kernel<T, false>), grid, block, plan.lds_bytes, st, a);
 }

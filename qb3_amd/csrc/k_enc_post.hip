@@ -72,8 +72,8 @@ __device__ __forceinline__ uint32_t ff_pairs_in(uint32_t v) {
 // too rarely (never across dwords, never in bits another chunk owns) -- both on the side of running the pass.
 __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
-    const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (chunk >= a.nchunks) return;
+    const uint32_t chunk = a.chunk0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (chunk >= a.chunk_end) return;
     const uint64_t G = (uint64_t)a.out_bit0 + chunk_start(a, chunk);
     const uint32_t total = a.chunk_bits[chunk];
     const uint32_t phase = (uint32_t)(G & 31), nsrc = (total + 31) >> 5;
@@ -186,15 +186,36 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
 //   the chunk's check (ix_seal_kernel), blocks per entry.  The pad makes the container parse the same if a reader adds the 4
 //   head bytes to the length.  (Entries with block lengths: their fill kernel writes the fixed fields too.);
 // * the container header in front of the stream (device flavour).
+// the dword that holds the boundary in front of chunk k (k == nchunks: the stream's end): the OR of the edge dwords of the
+// chunks that meet in it, written by the thread of the FIRST boundary inside the dword.  cs(j): start of chunk j in the stream.
+template <class CS>
+__device__ __forceinline__ void finish_seam(const EncArgs &a, uint32_t k, CS cs) {
+    const uint64_t Ek = (uint64_t)a.out_bit0 + cs(k);
+    if (k == a.nchunks) { a.res->total_bits = Ek - a.out_bit0; }
+    if ((Ek & 31) == 0) return;
+    const uint64_t d = Ek >> 5;
+    if (k > 0) { const uint64_t Ep = (uint64_t)a.out_bit0 + cs(k - 1); if ((Ep >> 5) == d && (Ep & 31)) return; }
+    uint32_t v = k > 0 ? a.seams[2 * (k - 1) + 1] : 0u;
+    for (uint32_t j = k; j < a.nchunks; j++) {
+        v |= a.seams[2 * j];
+        const uint64_t En = (uint64_t)a.out_bit0 + cs(j + 1);
+        if ((En >> 5) != d || (En & 31) == 0) break;       // chunk j reaches the end of the dword
+    }
+    if (k == 0 && a.out_bit0) {                             // the dword the header ends in: the stream's bytes only
+        uint8_t *p8 = (uint8_t *)(a.out32 + d);
+        for (uint32_t i = a.out_bit0 >> 3; i < 4; i++) p8[i] = (uint8_t)(v >> (8 * i));
+    } else a.out32[d] = v;
+}
+
 __global__ void __launch_bounds__(256) enc_finish_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     const uint32_t B = a.g.bands, tsz = a.g.tsz;
-    if (blockIdx.x == 0 && a.hdr_len) {                     // the stream starts at out32 + out_bit0 / 8; the prepared header bytes end hdr_back before
+    if ((a.finish_what & 2) && blockIdx.x == 0 && a.hdr_len) {     // the stream starts at out32 + out_bit0 / 8; the prepared header bytes end hdr_back before
         uint8_t *start = (uint8_t *)a.out32 + (a.out_bit0 >> 3) - a.hdr_back;
         for (uint32_t i = threadIdx.x; i < a.hdr_len; i += blockDim.x) start[i] = a0.hdr[i];
     }
-    if (a.have_idx)
+    if ((a.finish_what & 2) && a.have_idx)
         for (uint64_t sgi = k; sgi < a.g.nseg; sgi += nthreads) {
             const uint64_t v = a.idx.bitpos[sgi];
             const uint64_t bp = chunk_start(a, (uint32_t)(v >> 32)) + (v & 0xffffffffu);
@@ -227,22 +248,40 @@ __global__ void __launch_bounds__(256) enc_finish_kernel(const EncArgs a0) {
                 for (uint32_t i = 0; i < B * tsz; i++) e[i] = cf[i];
             }
         }
-    if (k > a.nchunks) return;
-    const uint64_t Ek = (uint64_t)a.out_bit0 + chunk_start(a, k);
-    if (k == a.nchunks) { a.res->total_bits = Ek - a.out_bit0; }
-    if ((Ek & 31) == 0) return;
-    const uint64_t d = Ek >> 5;
-    if (k > 0) { const uint64_t Ep = (uint64_t)a.out_bit0 + chunk_start(a, k - 1); if ((Ep >> 5) == d && (Ep & 31)) return; }
-    uint32_t v = k > 0 ? a.seams[2 * (k - 1) + 1] : 0u;
-    for (uint32_t j = k; j < a.nchunks; j++) {
-        v |= a.seams[2 * j];
-        const uint64_t En = (uint64_t)a.out_bit0 + chunk_start(a, j + 1);
-        if ((En >> 5) != d || (En & 31) == 0) break;       // chunk j reaches the end of the dword
+    if (!(a.finish_what & 1) || k > a.nchunks) return;
+    finish_seam(a, k, [&](uint32_t j) { return chunk_start(a, j); });
+}
+
+// ---- the strips of a pipelined host call (qb3_api.cpp, encode_pipelined).  A strip is a scan group of chunks; the strips are
+// launched in order on one stream, so what a strip needs from the ones before -- the bits they produced, their last chunk's
+// edge dword -- is there: offsets are prefix sums, the dependency only points backwards.
+// scan: the strip's chunk offsets inside the group, and the running total behind it: group_sum[strip + 1] = group_sum[strip] + bits
+__global__ void __launch_bounds__(SCAN_GROUP / 4) enc_scan_strip_kernel(const EncArgs a0, const uint32_t strip) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, i0 = strip * SCAN_GROUP + 4 * tid;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = (i0 + k < a.nchunks) ? a.chunk_bits[i0 + k] : 0; sum += v[k]; }
+    uint32_t total;
+    uint64_t off = block_exscan(sum, wsum, &total);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i0 + k < a.nchunks) { a.chunk_off[i0 + k] = off; off += v[k]; }
+    if (tid == 0) {
+        const uint64_t base = strip ? a.group_sum[strip] : 0ull;
+        if (!strip) a.group_sum[0] = 0;
+        a.group_sum[strip + 1] = base + total;              // (the last strip's: the stream length, where chunk_start looks for it)
     }
-    if (k == 0 && a.out_bit0) {                             // the dword the header ends in: the stream's bytes only
-        uint8_t *p8 = (uint8_t *)(a.out32 + d);
-        for (uint32_t i = a.out_bit0 >> 3; i < 4; i++) p8[i] = (uint8_t)(v >> (8 * i));
-    } else a.out32[d] = v;
+}
+// seams: the boundaries in front of the strip's chunks (the one in front of its first chunk closes the strip before), and
+// behind the last strip the stream's end
+__global__ void __launch_bounds__(256) enc_finish_strip_kernel(const EncArgs a0, const uint32_t strip) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    const uint32_t k = a.chunk0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool last = a.chunk_end == a.nchunks;
+    if (k > a.chunk_end || (k == a.chunk_end && !last)) return;
+    // (the offset of the chunk behind the strip is the running total: its own chunk_off is the next strip's to write)
+    finish_seam(a, k, [&](uint32_t j) { return j >= a.chunk_end ? a.group_sum[strip + 1] : a.group_sum[j / SCAN_GROUP] + a.chunk_off[j]; });
 }
 
 // Block lengths behind the entries' fixed fields (tables of level 2).  A block's bit length is the sum of its units'
@@ -412,6 +451,7 @@ __global__ void __launch_bounds__(256) ix_seal_kernel(const EncArgs a0) {
     }
 }
 
+static void launch_enc_tables(const EncArgs &a, hipStream_t st);
 void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const uint32_t nt = a.ntiles;
     {
@@ -427,6 +467,30 @@ void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
         const uint64_t want = std::max<uint64_t>(plan.nchunks + 1, a.have_idx ? std::min<uint64_t>(a.g.nseg, (uint64_t)1 << 20) : 0);
         hipLaunchKernelGGL(enc_finish_kernel, dim3((uint32_t)((want + 255) / 256), nt), dim3(256), 0, st, a);
     }
+    launch_enc_tables(a, st);
+}
+// one strip (a.chunk0 .. a.chunk_end = scan group `strip`): offsets, concatenation, seams -- behind it the stream is final up
+// to the dword that holds the strip's end
+void launch_enc_post_strip(const EncArgs &a, const EncPlan &plan, hipStream_t st, uint32_t strip) {
+    (void)plan;
+    const uint32_t nt = a.ntiles, n = a.chunk_end - a.chunk0;
+    { ProfScope ps("enc_scan", st); hipLaunchKernelGGL(enc_scan_strip_kernel, dim3(1, nt), dim3(SCAN_GROUP / 4), 0, st, a, strip); }
+    { ProfScope ps("enc_concat", st); hipLaunchKernelGGL(enc_concat_kernel, dim3((n + 3) / 4, nt), dim3(256), 0, st, a); }
+    ProfScope ps("enc_seams", st);
+    hipLaunchKernelGGL(enc_finish_strip_kernel, dim3((n + 1 + 255) / 256, nt), dim3(256), 0, st, a, strip);
+}
+// behind the last strip: index positions, the restart table, the header bytes (a.finish_what == 2)
+void launch_enc_post_tail(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    (void)plan;
+    ProfScope ps("enc_seams", st);
+    if (a.have_idx || a.hdr_len) {
+        const uint64_t want = std::max<uint64_t>(1, a.have_idx ? std::min<uint64_t>(a.g.nseg, (uint64_t)1 << 20) : 0);
+        hipLaunchKernelGGL(enc_finish_kernel, dim3((uint32_t)((want + 255) / 256), a.ntiles), dim3(256), 0, st, a);
+    }
+    launch_enc_tables(a, st);
+}
+static void launch_enc_tables(const EncArgs &a, hipStream_t st) {
+    const uint32_t nt = a.ntiles;
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.mode == CM_BEST) hipLaunchKernelGGL(ix_bl_best_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
     else if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz >= 4 && a.g.mode != CM_BEST) {

@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
     for (uint32_t i = tid; i < a.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
     const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
 
-    const uint32_t chunk = blockIdx.x;
+    const uint32_t chunk = a.chunk0 + blockIdx.x;      // (chunk0: the first chunk of this launch -- 0 but for the strips of a pipelined host call)
     const int64_t gs = (int64_t)chunk * (S - 1) - 1 + slot; // slot 0 is the halo block
     const bool valid = slot < S && gs >= 0 && gs < (int64_t)nblocks, payload = valid && slot >= 1;
     const uint32_t gblk = valid ? (uint32_t)gs : 0u;
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256, 2) enc_px16_kernel(const EncArgs a0) {
 template <int BG, bool RGB>
 static void launch_enc_px16_b(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    dim3 grid(plan.nchunks, a.ntiles), block(256);
+    dim3 grid(a.chunk_end - a.chunk0, a.ntiles), block(256);
     if (!z && !step) hipLaunchKernelGGL((enc_px16_kernel<BG, RGB, HILBERT, false>), grid, block, plan.lds_bytes, st, a);
     else if (!z && step) hipLaunchKernelGGL((enc_px16_kernel<BG, RGB, HILBERT, true>), grid, block, plan.lds_bytes, st, a);
     else if (z && !step) hipLaunchKernelGGL((enc_px16_kernel<BG, RGB, ZCURVE, false>), grid, block, plan.lds_bytes, st, a);

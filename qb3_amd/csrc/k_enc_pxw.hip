@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(NT) enc_pxw_kernel(const EncArgs a0) {
     for (uint32_t i = tid; i < a.slot_dw / 4; i += NT) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
     const uint32_t etab_off = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
 
-    const uint32_t chunk = blockIdx.x;
+    const uint32_t chunk = a.chunk0 + blockIdx.x;      // (chunk0: the first chunk of this launch -- 0 but for the strips of a pipelined host call)
     const int64_t gs = (int64_t)chunk * (NT - 1) - 1 + tid; // lane 0 is the halo block
     const bool valid = gs >= 0 && gs < (int64_t)nblocks, payload = valid && tid >= 1;
     const uint32_t gblk = valid ? (uint32_t)gs : 0u;
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(NT) enc_pxw_kernel(const EncArgs a0) {
 template <typename T, int NT>
 static void launch_enc_pxw_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    dim3 grid(plan.nchunks, a.ntiles), block(NT);
+    dim3 grid(a.chunk_end - a.chunk0, a.ntiles), block(NT);
     if (!z && !step) hipLaunchKernelGGL((enc_pxw_kernel<T, HILBERT, false, NT>), grid, block, plan.lds_bytes, st, a);
     else if (!z && step) hipLaunchKernelGGL((enc_pxw_kernel<T, HILBERT, true, NT>), grid, block, plan.lds_bytes, st, a);
     else if (z && !step) hipLaunchKernelGGL((enc_pxw_kernel<T, ZCURVE, false, NT>), grid, block, plan.lds_bytes, st, a);

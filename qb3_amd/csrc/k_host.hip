@@ -321,7 +321,7 @@ EncPlan plan_encode(const Geometry &g) {
     return p;
 }
 
-static int launch_encode_all(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+static void launch_enc_units(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     if (a.g.mode == CM_BEST) { if (plan.px && a.g.tsz == 1) launch_enc_px_best(a, plan, st); else launch_enc_best(a, plan, st); }
     else if (plan.px && a.g.tsz == 1) {
         ProfScope ps("enc_units", st);
@@ -330,15 +330,18 @@ static int launch_encode_all(const EncArgs &a, const EncPlan &plan, hipStream_t 
     else if (plan.px16 && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0) { ProfScope ps("enc_units", st); launch_enc_px16(a, plan, st); }
     else if (plan.pxw && ((uintptr_t)a.img & (a.g.tsz - 1)) == 0 && !(a.ts_img & (a.g.tsz - 1))) { ProfScope ps("enc_units", st); launch_enc_pxw(a, plan, st); }
     else { ProfScope ps("enc_units", st); launch_enc_generic(a, plan, st); }
+}
+static int launch_encode_all(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    launch_enc_units(a, plan, st);
     launch_enc_post(a, plan, st);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
-                  const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb,
-                  const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix, bool zrun_probe) {
-    EncArgs a;
+// the argument block of the encoder kernels (workspace carve, index view, table layout)
+static bool make_enc_args(EncArgs &a, const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
+                          const BandState &st_in, void *ws, void *index, const TileBatch &tb,
+                          const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix, bool zrun_probe) {
     a.zrun_probe = zrun_probe ? 1u : 0u;
     a.ix_dst = ix.base; a.ix_K = ix.K; a.ix_E = ix.entry_bytes; a.ix_per_chunk = ix.per_chunk; a.ix_blocks = ix.blocks;
     a.ix_spe = g.seg_blocks ? ix.blocks / g.seg_blocks : 0;
@@ -348,6 +351,7 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     for (uint32_t i = 0; i < a.hdr_len; i++) a.hdr[i] = hdr[i];
     a.g = g; a.img = img; a.out32 = out32; a.out_bit0 = out_bit0;
     a.slots = plan.slots; a.nchunks = plan.nchunks; a.dpr = g.bands * g.tsz;
+    a.chunk0 = 0; a.chunk_end = plan.nchunks; a.finish_what = 3;
     a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
     uint8_t *w = (uint8_t *)ws;
     const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp, plan.threads);
@@ -368,8 +372,52 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
     a.idx_no_ulen = index && ix.base && ix.own_index && !ix.block_lens;      // (block lengths are sums of the unit lengths)
     a.ix_bl = ix.base && ix.block_lens;
     a.idx = index ? index_view(g, index) : IndexView{nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (g.tsz != 1 && g.tsz != 2 && g.tsz != 4 && g.tsz != 8) { set_error("encode: bad value size", 0); return -1; }
+    if (g.tsz != 1 && g.tsz != 2 && g.tsz != 4 && g.tsz != 8) { set_error("encode: bad value size", 0); return false; }
+    return true;
+}
+
+int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
+                  const BandState &st_in, void *ws, void *index, void *stream, const TileBatch &tb,
+                  const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix, bool zrun_probe) {
+    EncArgs a;
+    if (!make_enc_args(a, g, plan, img, out32, out_bit0, st_in, ws, index, tb, hdr, hdr_len, ix, zrun_probe)) return -1;
     return launch_encode_all(a, plan, (hipStream_t)stream);
+}
+
+// ---- a pipelined host call codes the raster strip by strip: a strip is a scan group of chunks (SCAN_GROUP of them), coded,
+// scanned, moved into place and sealed by launches of its own, so that its part of the stream is final -- and can go down the
+// link -- while later strips are still on their way up.  FTL / BASE only (the common-factor modes carry a factor across chunks).
+bool encode_strips_ok(const Geometry &g, const EncPlan &plan) { return g.mode != CM_BEST && plan.nchunks > 2 * SCAN_GROUP; }
+uint32_t encode_strip_count(const EncPlan &plan) { return (plan.nchunks + SCAN_GROUP - 1) / SCAN_GROUP; }
+uint64_t encode_strip_blocks(const EncPlan &plan, uint32_t strip) {         // blocks (from the raster's first) the strip and those before it hold
+    const uint64_t c = std::min<uint64_t>(plan.nchunks, ((uint64_t)strip + 1) * SCAN_GROUP);
+    return c * plan.nbp;
+}
+const uint64_t *encode_strip_total(const Geometry &g, const EncPlan &plan, void *ws, uint32_t strip) {     // device address of "stream bits behind this strip"
+    const EncWs L = enc_ws_layout(g, plan.nchunks, plan.nbp, plan.threads);
+    return (const uint64_t *)((uint8_t *)ws + L.gsum) + strip + 1;
+}
+int launch_encode_strip(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
+                        const BandState &st_in, void *ws, void *index, void *stream, const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix, uint32_t strip) {
+    EncArgs a;
+    if (!make_enc_args(a, g, plan, img, out32, out_bit0, st_in, ws, index, TileBatch(), hdr, hdr_len, ix, false)) return -1;
+    a.chunk0 = strip * SCAN_GROUP;
+    a.chunk_end = std::min<uint32_t>(plan.nchunks, a.chunk0 + SCAN_GROUP);
+    a.finish_what = 1;
+    hipStream_t st = (hipStream_t)stream;
+    launch_enc_units(a, plan, st);
+    launch_enc_post_strip(a, plan, st, strip);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int launch_encode_tail(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
+                       const BandState &st_in, void *ws, void *index, void *stream, const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix) {
+    EncArgs a;
+    if (!make_enc_args(a, g, plan, img, out32, out_bit0, st_in, ws, index, TileBatch(), hdr, hdr_len, ix, false)) return -1;
+    a.finish_what = 2;
+    launch_enc_post_tail(a, plan, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // LDS dwords per decoder lane: 16*bands values + 2*bands state values + bands rung bytes.  The count is made

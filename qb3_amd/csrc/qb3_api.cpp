@@ -217,12 +217,16 @@ static bool download(Stager &sg, void *h_dst, const void *d_src, size_t bytes, h
 struct Pipe {
     hipStream_t up = nullptr, k = nullptr, dn = nullptr;
     std::vector<hipEvent_t> ev;
+    uint64_t *words = nullptr;                      // pinned: a few result words the kernel stream copies down (WORDS of them)
+    static constexpr size_t WORDS = 2048;
     bool failed = false;
     bool init() {
         if (up) return true;
         if (failed) return false;
         if (hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&k, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&dn, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); release(); failed = true; return false; }
+            hipStreamCreateWithFlags(&dn, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void **)&words, 8 * WORDS, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError(); release(); failed = true; return false;
+        }
         return true;
     }
     bool events(size_t n) {
@@ -240,7 +244,8 @@ struct Pipe {
         if (up) (void)hipStreamDestroy(up);
         if (k) (void)hipStreamDestroy(k);
         if (dn) (void)hipStreamDestroy(dn);
-        up = k = dn = nullptr;
+        if (words) (void)hipHostFree(words);
+        up = k = dn = nullptr; words = nullptr;
     }
 };
 
@@ -257,7 +262,8 @@ struct encs {
     bool away;
     int ix_chunk;           // qb3x_set_encoder_index_chunk: embed the restart table ("ix" chunks); 2: with block lengths
     DevBuf d_img, d_out, d_ws, d_q, d_idx, d_rle;      // d_rle: workspace of the RLE0 passes (k_rle0.hip)
-    Stager stager;
+    Stager stager, stager2;                            // (stager2: the download ring of a pipelined host call)
+    Pipe pipe;                                         // ... its streams and events
 };
 
 struct decs {
@@ -356,7 +362,7 @@ QB3_API void qb3_reset_encoder(encsp p) {
 QB3_API void qb3_destroy_encoder(encsp p) {
     if (!p) return;
     release_all(p->d_img, p->d_out, p->d_ws, p->d_q, p->d_idx, p->d_rle);
-    p->stager.release();
+    p->stager.release(); p->stager2.release(); p->pipe.release();
     delete p;
 }
 
@@ -514,6 +520,130 @@ struct ModeGuard {
     ~ModeGuard() { if (armed) p->mode = mode; }
 };
 
+
+// ---------------------------------------------------------------- qb3_encode, pipelined
+// The raster goes up the link in slices; as soon as the rows of a STRIP (a scan group of chunks, about 50 MB of an 8-bit RGB
+// raster) are in device memory the strip is coded, scanned, moved into place and sealed (launch_encode_strip) -- its bits start
+// where the strips before it ended, the dependency only points backwards -- and the part of the stream that is final comes
+// down the link while later strips are still going up.  Three streams, two rings of pinned slices, host copies by the pool.
+// Returns 1: the stream (and its table) is in host_dst behind the header's place, *bits_out and the handle's band state are
+// set; 0: not taken (the caller goes the one-after-the-other way); -1: failed (p->error set).
+static int encode_pipelined(encsp p, const Geometry &g, const void *host_src, void *host_dst, size_t src_bytes, size_t line, uint8_t *out_dev, size_t hdr,
+                            const uint8_t *hdrbuf, size_t hdr_stamp, const IxTable &ixt, void *d_index, bool carry, uint64_t *bits_out) {
+    using qb3host::CopyPool;
+    constexpr size_t SLICE = Stager::SLICE, NSLOT = Stager::NSLOT;
+    static const bool dbg = getenv("QB3_DEBUG_PIPE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    const EncPlan plan = plan_encode(g);
+    if (!encode_strips_ok(g, plan)) return 0;
+    const uint32_t nstrips = encode_strip_count(plan);
+    if (nstrips < 3 || nstrips + 64 > Pipe::WORDS) return 0;
+    if (!p->pipe.init() || !p->pipe.events((size_t)nstrips + 1) || !p->stager.init() || !p->stager2.init()) return 0;
+    if (!p->d_img.ensure(src_bytes) || !p->d_ws.ensure(plan.ws_bytes)) { p->error = QB3E_LIBERR; return -1; }
+    BandState bs;
+    memset(&bs, 0, sizeof(bs));
+    for (size_t c = 0; c < p->nbands; c++) { bs.prev[c] = p->band[c].prev; bs.cf[c] = p->band[c].cf; bs.rung[c] = (uint8_t)p->band[c].runbits; }
+    uint32_t *out32 = (uint32_t *)(out_dev + (hdr & ~(size_t)3));
+    const uint32_t out_bit0 = (uint32_t)(8 * (hdr & 3));
+    // raster bytes a strip needs in device memory: the rows of its last block (the block before its first one is in the strip before)
+    std::vector<size_t> need(nstrips);
+    for (uint32_t s = 0; s < nstrips; s++) {
+        const uint64_t blocks = std::min<uint64_t>(g.nblocks, encode_strip_blocks(plan, s));
+        const uint64_t brow = (blocks - 1) / g.nbx;
+        need[s] = std::min(src_bytes, (size_t)std::min<uint64_t>(g.h, 4 * (brow + 1)) * line);
+    }
+    need[nstrips - 1] = src_bytes;
+    struct Slice { const uint8_t *dev; uint8_t *host; size_t n; };
+    std::vector<Slice> dn;
+    const size_t n_up = (src_bytes + SLICE - 1) / SLICE;
+    CopyPool &pool = CopyPool::get();
+    CopyPool::Batch b_up[NSLOT], b_dn[NSLOT];
+    Stager &r1 = p->stager, &r2 = p->stager2;
+    hipStream_t sU = p->pipe.up, sK = p->pipe.k, sD = p->pipe.dn;
+    uint64_t *totals = p->pipe.words;                       // [s]: stream bits behind strip s; behind them the EncResult
+    EncResult *res_host = (EncResult *)(totals + nstrips);
+    const uint8_t *dres = (const uint8_t *)p->d_ws.p + plan.ws_bytes - sizeof(EncResult);
+    size_t up_started = 0, up_enq = 0, bytes_enq = 0, dn_issued = 0, dn_copy = 0, dn_freed = 0, x_prev = hdr;
+    uint32_t next_strip = 0, known = 0;
+    bool tail_seen = false, launch_failed = false;
+    hipError_t e = hipSuccess;
+    auto ok = [&] { return e == hipSuccess && !launch_failed; };
+    auto add_span = [&](size_t a, size_t b) {               // bytes [a, b) of the container are final in device memory
+        for (size_t off = a; off < b; off += SLICE) dn.push_back({out_dev + off, (uint8_t *)host_dst + off, std::min(SLICE, b - off)});
+    };
+    const double t_setup = ms_since();
+    double t_up_done = 0, t_first_dn = 0;
+    while (ok() && (up_enq < n_up || !tail_seen || dn_freed < dn.size())) {
+        bool progress = false;
+        // ---- up
+        if (up_started < n_up && up_started - up_enq < 2 && (up_started < NSLOT || hipEventQuery(r1.ev(up_started)) == hipSuccess)) {
+            const size_t off = up_started * SLICE;
+            pool.submit(r1.slot(up_started), (const uint8_t *)host_src + off, std::min(SLICE, src_bytes - off), b_up[up_started % NSLOT]);
+            up_started++; progress = true;
+        }
+        if (up_enq < up_started && pool.done(b_up[up_enq % NSLOT])) {
+            const size_t off = up_enq * SLICE, n = std::min(SLICE, src_bytes - off);
+            e = hipMemcpyAsync((uint8_t *)p->d_img.p + off, r1.slot(up_enq), n, hipMemcpyHostToDevice, sU);
+            if (e == hipSuccess) e = hipEventRecord(r1.ev(up_enq), sU);
+            bytes_enq += n;
+            up_enq++; progress = true;
+            if (dbg && up_enq == n_up) t_up_done = ms_since();
+            while (ok() && next_strip < nstrips && need[next_strip] <= bytes_enq) {
+                hipEvent_t ev_u = p->pipe.ev[nstrips];     // (one event for "the rows are on their way": recorded and waited for at once)
+                e = hipEventRecord(ev_u, sU);
+                if (e == hipSuccess) e = hipStreamWaitEvent(sK, ev_u, 0);
+                if (e != hipSuccess) break;
+                if (launch_encode_strip(g, plan, p->d_img.p, out32, out_bit0, bs, p->d_ws.p, d_index, sK, hdrbuf, (uint32_t)hdr_stamp, ixt, next_strip)) { launch_failed = true; break; }
+                e = hipMemcpyAsync(&totals[next_strip], encode_strip_total(g, plan, p->d_ws.p, next_strip), 8, hipMemcpyDeviceToHost, sK);
+                if (e == hipSuccess && next_strip + 1 == nstrips) {        // behind the last strip: index positions, the table, the result words
+                    if (launch_encode_tail(g, plan, p->d_img.p, out32, out_bit0, bs, p->d_ws.p, d_index, sK, hdrbuf, (uint32_t)hdr_stamp, ixt)) { launch_failed = true; break; }
+                    e = hipMemcpyAsync(res_host, dres, sizeof(EncResult), hipMemcpyDeviceToHost, sK);
+                }
+                if (e == hipSuccess) e = hipEventRecord(p->pipe.ev[next_strip], sK);
+                next_strip++;
+            }
+        }
+        // ---- a strip is done: what is final behind it (all but the dword its end falls into; the last strip: everything, and the table)
+        if (ok() && known < next_strip) {
+            const hipError_t q = hipEventQuery(p->pipe.ev[known]);
+            if (q == hipSuccess) {
+                const uint64_t P = totals[known];
+                const bool last = known + 1 == nstrips;
+                const size_t x = last ? hdr + (size_t)((P + 7) / 8) : (hdr & ~(size_t)3) + 4 * (size_t)((out_bit0 + P) >> 5);
+                if (x > x_prev) { add_span(x_prev, x); x_prev = x; }
+                if (last) { if (hdr > hdr_stamp) add_span(hdr_stamp, hdr); tail_seen = true; }
+                known++; progress = true;
+            } else if (q != hipErrorNotReady) e = q;
+        }
+        // ---- down
+        if (ok() && dn_issued < dn.size() && dn_issued - dn_freed < NSLOT) {
+            e = hipMemcpyAsync(r2.slot(dn_issued), dn[dn_issued].dev, dn[dn_issued].n, hipMemcpyDeviceToHost, sD);
+            if (e == hipSuccess) e = hipEventRecord(r2.ev(dn_issued), sD);
+            dn_issued++; progress = true;
+        }
+        if (ok() && dn_copy < dn_issued) {
+            const hipError_t q = hipEventQuery(r2.ev(dn_copy));
+            if (q == hipSuccess) { if (dbg && !dn_copy) t_first_dn = ms_since(); pool.submit(dn[dn_copy].host, r2.slot(dn_copy), dn[dn_copy].n, b_dn[dn_copy % NSLOT]); dn_copy++; progress = true; }
+            else if (q != hipErrorNotReady) e = q;
+        }
+        while (dn_freed < dn_copy && pool.done(b_dn[dn_freed % NSLOT])) { dn_freed++; progress = true; }
+        if (!progress && !pool.help_one()) std::this_thread::yield();
+    }
+    (void)hipGetLastError();                                // (hipErrorNotReady of the queries is not an error)
+    for (size_t i = 0; i < NSLOT; i++) { pool.wait(b_up[i]); pool.wait(b_dn[i]); }
+    p->pipe.sync();
+    if (dbg) fprintf(stderr, "encode_pipelined: setup %.2f ms, last upload enqueued %.2f, first slice down %.2f, done %.2f (%u strips, %zu + %zu slices)\n", t_setup, t_up_done, t_first_dn, ms_since(), nstrips, n_up, dn.size());
+    if (!ok()) { if (!launch_failed) set_error("pipelined encode", (int)e); p->error = QB3E_LIBERR; return -1; }
+    prof_collect();
+    *bits_out = res_host->total_bits;
+    if (carry)
+        for (size_t c = 0; c < p->nbands; c++) {
+            p->band[c].prev = (size_t)res_host->prev[c]; p->band[c].runbits = res_host->rung[c]; p->band[c].cf = (size_t)res_host->cf[c];
+        }
+    return 1;
+}
+
 // Shared by qb3_encode (host buffers) and qb3x_encode_device (device buffers).
 // host_src/host_dst are null in the device flavour; d_src/d_dst are null in the host flavour.
 static size_t encode_common(encsp p, const void *host_src, void *host_dst, const void *d_src, void *d_dst,
@@ -560,11 +690,17 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
         small = remap_small(hs, p->xsize, p->ysize, p->nbands * tsz, src_stride_bytes, w, h);
         stride = 0;
     }
-    if (on_host || narrow) {
+    // a large raster in host memory, coded as it is: upload, coding and download strip by strip, all three at once (encode_pipelined)
+    static const bool no_pipeline = [] { const char *e = getenv("QB3_NO_PIPELINE"); return e && e[0] && e[0] != '0'; }();
+    bool want_pipe = on_host && !narrow && !rle && p->quanta < 2 && src_stride_bytes == line && src_span >= ((size_t)64 << 20) && !no_pipeline;
+    auto upload_now = [&]() -> bool {
         const uint8_t *hs = narrow ? small.data() : (const uint8_t *)host_src;
         const size_t bytes = narrow ? small.size() : src_span;
-        if (!p->d_img.ensure(bytes)) { p->error = QB3E_LIBERR; return 0; }
-        if (!upload(p->stager, p->d_img.p, hs, bytes, st)) { p->error = QB3E_LIBERR; return 0; }
+        return p->d_img.ensure(bytes) && upload(p->stager, p->d_img.p, hs, bytes, st);
+    };
+    if (on_host || narrow) {
+        if (!want_pipe && !upload_now()) { p->error = QB3E_LIBERR; return 0; }
+        if (want_pipe && !p->d_img.ensure(src_span)) { p->error = QB3E_LIBERR; return 0; }
         img_dev = p->d_img.p;
     }
     Geometry g = make_geometry(w, h, p->nbands, p->type, stride, p->order, p->mode, p->cband, nullptr);
@@ -602,7 +738,14 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     }
     uint64_t bits = 0;
     int has_run = 1;        // (RLE0 modes: the concatenation pass counts zero runs and pairs of 0xff; rle0_may_win, qb3_dev.h)
-    if (!encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits, hdrbuf, hdr_stamp, ixt, rle ? &has_run : nullptr)) {   // the index describes the block stream, RLE0 wrapped or not
+    bool piped = false;
+    if (want_pipe) {
+        const int r = encode_pipelined(p, g, host_src, host_dst, src_span, line, out_dev, hdr, hdrbuf, hdr_stamp, ixt, d_index, carry, &bits);
+        if (r < 0) return 0;
+        piped = r > 0;
+        if (!piped && !upload_now()) { p->error = QB3E_LIBERR; return 0; }
+    }
+    if (!piped && !encode_blocks_device(p, g, img_dev, out_dev, hdr, d_index, st, carry, &bits, hdrbuf, hdr_stamp, ixt, rle ? &has_run : nullptr)) {   // the index describes the block stream, RLE0 wrapped or not
         p->error = QB3E_LIBERR; return 0;
     }
     p->error = 0;
@@ -640,7 +783,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     if (raw_size(p) > len_ref) {
         if (on_host) {
             memcpy(host_dst, hdrbuf, hdr_stamp);
-            if (!download(p->stager, (uint8_t *)host_dst + hdr_stamp, out_dev + hdr_stamp, len - hdr_stamp, st)) { p->error = QB3E_LIBERR; return 0; }
+            if (!piped && !download(p->stager, (uint8_t *)host_dst + hdr_stamp, out_dev + hdr_stamp, len - hdr_stamp, st)) { p->error = QB3E_LIBERR; return 0; }
         }       // device flavour: the header was written by enc_finish_kernel, in stream order
         return len;
     }

@@ -163,6 +163,17 @@ int launch_encode(const Geometry &g, const EncPlan &plan, const void *img, uint3
                   const IxTable &ix = IxTable(),
                   bool zrun_probe = false);     // count runs of zero bytes and pairs of 0xff while concatenating (EncResult::zero_run, ff_pairs)
 
+// Strips of a pipelined host call (k_host.hip): can this coding be cut into strips; how many; blocks of the raster a strip and
+// its predecessors cover (what must be in device memory before it is coded); where the running stream length behind a strip is
+bool encode_strips_ok(const Geometry &g, const EncPlan &plan);
+uint32_t encode_strip_count(const EncPlan &plan);
+uint64_t encode_strip_blocks(const EncPlan &plan, uint32_t strip);
+const uint64_t *encode_strip_total(const Geometry &g, const EncPlan &plan, void *ws, uint32_t strip);
+int launch_encode_strip(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
+                        const BandState &st_in, void *ws, void *index, void *stream, const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix, uint32_t strip);
+int launch_encode_tail(const Geometry &g, const EncPlan &plan, const void *img, uint32_t *out32, uint32_t out_bit0,
+                       const BandState &st_in, void *ws, void *index, void *stream, const uint8_t *hdr, uint32_t hdr_len, const IxTable &ix);
+
 struct DecPlan {
     uint32_t threads;       // lanes per workgroup, one index segment per lane
     uint32_t nwg;

@@ -223,6 +223,8 @@ struct EncArgs {
     uint32_t have_idx;
     uint32_t zrun_probe;    // enc_concat_kernel also looks for four zero bytes in a row (res->zero_run; RLE0 can only win on such a stream)
     uint32_t idx_no_ulen;   // the index is the library's own, only sampled for the restart table: segment entries, no unit lengths
+    uint32_t chunk0, chunk_end;     // the chunks this launch codes / moves ([0, nchunks) but for the strips of a pipelined host call)
+    uint32_t finish_what;           // enc_finish_kernel: 1 = seams and stream length, 2 = index positions, table entries, header; 3 = both
 };
 
 
@@ -581,6 +583,8 @@ void launch_enc_px_best(const EncArgs &a, const EncPlan &plan, hipStream_t st); 
 void launch_enc_px16(const EncArgs &a, const EncPlan &plan, hipStream_t st);       // k_enc_px16.hip
 void launch_enc_pxw(const EncArgs &a, const EncPlan &plan, hipStream_t st);        // k_enc_pxw.hip
 void launch_enc_post(const EncArgs &a, const EncPlan &plan, hipStream_t st);       // k_enc_post.hip: scan, concat, seams, header, ix
+void launch_enc_post_strip(const EncArgs &a, const EncPlan &plan, hipStream_t st, uint32_t strip);     // ... of one strip (a scan group of chunks): scan, concat, seams
+void launch_enc_post_tail(const EncArgs &a, const EncPlan &plan, hipStream_t st);  // ... behind the last strip: index positions, table, header
 void launch_dec_generic(const DecArgs &a, const DecPlan &plan, hipStream_t st);    // k_dec_generic.hip: dec3_kernel / dec_kernel
 void launch_dec_index_serial(const DecArgs &a, hipStream_t st);                    // k_dec_generic.hip
 void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st);         // k_dec_px.hip
