@@ -380,6 +380,9 @@ def test_wide_segments_far_longer_than_the_average(qb3, oracle, dt, mode):
     container's own table, through the host API"""
     import torch
     from qb3_amd import device as qdev
+    if dt == 7 and mode == 7:
+        pytest.skip("64-bit noise in a common-factor mode: the reference's index-size sentinel (defect B-2) makes its stream undecodable; "
+                    "the device encoder deliberately differs (DESIGN.md section 7) -- covered by test_encode_common_factor_modes")
     w, h = 512, 256
     rng = np.random.default_rng(7)
     npdt = np.uint32 if dt == 4 else np.int64
@@ -393,11 +396,12 @@ def test_wide_segments_far_longer_than_the_average(qb3, oracle, dt, mode):
     got = qb3.encode(img, dt, mode)
     assert np.array_equal(got, stream)
     self_indexed = qb3.encode(img, dt, mode, index_chunk=2)
-    assert len(self_indexed) > len(stream)
     out, _, _, _ = qb3.decode(self_indexed)
     assert np.array_equal(out, img.view(np.uint8).ravel())
     if stream[10] in (2, 3, 6, 7):
-        return                                                          # (the RLE0 pass won: the device flavour below is the plain modes')
+        assert np.array_equal(self_indexed, stream)                     # (the RLE0 pass won: no table either way)
+        return                                                          # (... and the device flavour below is the plain modes')
+    assert len(self_indexed) > len(stream)
     enc = qdev.DeviceEncoder(w, h, 1, dt, mode=mode)
     dimg = torch.from_numpy(img.view(np.uint8).ravel().copy()).cuda()
     dst, n, index = enc.encode(dimg)
@@ -487,6 +491,40 @@ def test_table_room_survives_a_raw_fallback(qb3, oracle):
     assert 0 < n <= room and dst[10] == FTL
     out, _, _, _ = qb3.decode(dst[:n])
     assert np.array_equal(out, img.ravel())
+    L.qb3_destroy_encoder(p)
+
+
+@pytest.mark.parametrize("case", [(8192, 4099, 3, 0, "NOISY3", FTL), (8192, 4099, 3, 0, "NOISY3", BASE), (16384, 8196, 1, 0, "NOISY3", FTL),
+                                  (8192, 4100, 1, 5, "DEM", BASE), (4096, 8200, 4, 2, "LANDSAT16", BASE)],
+                         ids=lambda c: "%dx%dx%d-t%d-m%d" % (c[0], c[1], c[2], c[3], c[5]))
+def test_host_api_pipelined_strips(qb3, oracle, case):
+    """qb3_encode / qb3_read_data on rasters large enough for the strip pipeline (encode_pipelined / decode_pipelined, qb3_api.cpp:
+    three or more scan groups of chunks, upload / coding / download of different strips at once): the container is the
+    oracle's byte for byte -- with a shifted last block row, for the 8-bit, 16-bit and 32-bit lane-per-block kernels, FTL and
+    BASE -- plain and self-indexed (the table chunks aside), and decodes exactly through the host API (the self-indexed one strip
+    by strip)"""
+    w, h, b, dt, gen, mode = case
+    img = oracle.generate(w, h, b, dt, gen, 5)
+    ref = oracle.encode(img, dt, mode)
+    assert ref[10] == mode
+    got = qb3.encode(img, dt, mode)
+    assert len(got) == len(ref) and np.array_equal(got, ref), f"first diff at byte {first_diff(got, ref)} of {len(ref)}"
+    two = qb3.encode(img, dt, mode, index_chunk=2)
+    extra, dt_at = len(two) - len(ref), bytes(ref[:64]).index(b"DT", 11)
+    assert extra > 0 and np.array_equal(two[:dt_at], ref[:dt_at]) and np.array_equal(two[dt_at + extra:], ref[dt_at:])
+    out, dims, _, _ = qb3.decode(two)
+    assert dims == (w, h, b) and np.array_equal(out, img.view(np.uint8).ravel())
+    # the handle's band state after the pipelined call is what the reference's is: a second call on the same handle
+    L = qb3.lib
+    p = L.qb3_create_encoder(w, h, b, dt)
+    e = oracle.Encoder(w, h, b, dt)
+    L.qb3_set_encoder_mode(p, mode)
+    e.set_mode(mode)
+    dst = np.empty(L.qb3_max_encoded_size(p), np.uint8)
+    for _ in range(2):
+        n = L.qb3_encode(p, img.ctypes.data, dst.ctypes.data)
+        want = e.encode(img)
+        assert n == len(want) and np.array_equal(dst[:n], want)
     L.qb3_destroy_encoder(p)
 
 
