@@ -1,115 +1,20 @@
-// qb3_amd/csrc/k_dec_walk.hip -- index-less 8/16-bit FTL/BASE streams: find the unit lengths by walking
+// qb3_amd/csrc/k_dec_walk.hip -- index-less streams: find the unit lengths (and segment entries) by walking
 #include "qb3_kernels.h"
 #include <type_traits>
 
 namespace qb3dev {
 
-// ---- foreign streams, 8/16-bit FTL/BASE: rebuild the index without decoding values --------------------------
+// ---- foreign streams: rebuild the index without decoding values ---------------------------------------------
 // The stream has no restart points, so unit positions can only be found by walking it; what CAN be parallel is
-// everything else.  dec_walk_kernel walks unit LENGTHS only (a code's length is its rung plus what its low two bits
-// say, reference QB3decode.h:119-129): one wave per tile, the stream staged through LDS in windows by all lanes,
-// then every lane runs the same walk (uniform control flow and LDS broadcast reads; the next stream word is always
-// already in a register).  It writes the per-unit lengths and each segment's bit position and rungs.  The values
-// entering the segments then come from the parallel decoder itself: one pass in TOTALS mode leaves every segment's
-// per-band sum in idx.prev, prev_scan_kernel turns the sums into exclusive prefixes, the normal pass follows.
-template <uint32_t UB>
-__global__ void __launch_bounds__(64) dec_walk_kernel(const DecArgs a0) {
-    const DecArgs a = dec_for_tile(a0, blockIdx.x);
-    constexpr uint32_t WIN = 4096, UMASK = (1u << UB) - 1, NRUNG = 1u << UB;
-    constexpr uint32_t MAXU = UB + 2 + 16 * ((8u << (UB - 3)) + 1);    // longest unit: 149 bits (8-bit), 278 (16-bit)
-    static_assert(MAXU == (UB == 3 ? 149u : 278u), "unit length bound");
-    __shared__ uint32_t win[WIN + 4];
-    const uint32_t lane = threadIdx.x, B = a.g.bands, NB = a.g.seg_blocks, nblocks = (uint32_t)a.g.nblocks;
-    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
-    uint64_t R = 0;                         // current rungs, 4 bits per band
-    uint64_t P = a.in_bit0;                 // bit position, from a.in32
-    uint32_t gb = 0, gb_end = nblocks, inseg = 0;
-    uint64_t seg = 0;
-    P = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(P >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)P);
-    bool bad = false;
-    while (gb < gb_end) {
-        const uint64_t w0 = P >> 5;         // stage the window that starts in the word of P
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t base = 0; base < WIN + 4; base += 1024) {        // sixteen loads in flight per lane
-            uint32_t sw[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) { const uint32_t i = base + lane + 64 * q; sw[q] = (i < WIN + 4 && w0 + i < endw_abs) ? a.in32[w0 + i] : 0u; }
-#pragma unroll
-            for (int q = 0; q < 16; q++) { const uint32_t i = base + lane + 64 * q; if (i < WIN + 4) win[i] = sw[q]; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // bit reader over the window: 64-bit buffer, the next word prefetched
-        // (readfirstlane: the words are the same in every lane -- keep the whole walk in scalar registers, a dependent
-        // scalar instruction issues twice as fast as a dependent vector one)
-        uint32_t wp = (uint32_t)(P - 32 * w0) >> 5;
-        const uint32_t sh = (uint32_t)P & 31;
-        uint64_t buf = (uint64_t)((uint32_t)__builtin_amdgcn_readfirstlane(win[wp]) >> sh);     // the builtin returns int
-        uint32_t n = 32 - sh;
-        // the next word is requested one refill ahead and only moved to a scalar register when it is consumed, so the
-        // LDS latency is off the walk
-        uint32_t nxt_v = win[++wp];
-        auto refill = [&]() {
-            if (n <= 32) { buf |= (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(nxt_v) << n; n += 32; nxt_v = win[++wp]; }   // wp <= WIN + 3 by the loop bound
-        };
-        // walk whole blocks while the longest possible block still fits in the window
-        while (gb < gb_end && 32 * wp + B * MAXU + 64 <= 32 * WIN) {
-            if (inseg == 0) {
-                if (lane == 0) {
-                    a.idx.bitpos[seg] = 32 * (w0 + wp) - n - a.in_bit0;
-                    for (uint32_t c = 0; c < B; c++) a.idx.rung[seg * B + c] = (uint8_t)((R >> (4 * c)) & 15u);
-                }
-                seg++;
-            }
-            if (++inseg == NB) inseg = 0;
-            for (uint32_t c = 0; c < B; c++) {
-                refill();                                   // >= 33 bits: the switch code is at most UB + 2
-                uint32_t x = (uint32_t)buf, ulen;
-                uint32_t rung = (uint32_t)(R >> (4 * c)) & 15u;
-                if (!(x & 1)) ulen = 1;
-                else {                                      // code at rung UB - 1 (reference QB3decode.h:97-116)
-                    constexpr uint32_t r = UB - 1, half = 1u << (r - 1), top = 1u << r;
-                    x >>= 1;
-                    uint32_t m, len;
-                    if (!(x & 1)) { m = (x & (top - 1)) >> 1; len = r; }
-                    else if (!(x & 2)) { m = ((x >> 2) & (half - 1)) | half; len = r + 1; }
-                    else { m = ((x >> 2) & (top - 1)) | top; len = r + 2; }
-                    ulen = 1 + len;
-                    if (m == NRUNG - 2) bad = true;         // signal: a common-factor stream, not for this walker
-                    const uint32_t delta = (m & 1) ? (NRUNG - (m + 1) / 2) & UMASK : m / 2 + 1;
-                    rung = (rung + delta) & UMASK;
-                    R = (R & ~(15ull << (4 * c))) | ((uint64_t)rung << (4 * c));
-                }
-                buf >>= ulen; n -= ulen;
-                if (rung == 0) {                            // one flag, then 16 raw bits
-                    refill();
-                    const uint32_t l = ((uint32_t)buf & 1) ? 17 : 1;
-                    buf >>= l; n -= l; ulen += l;
-                } else {
-                    uint32_t glen = 0;
-                    const uint32_t kr = rung * 0x01010101u + 0x02000100u;    // code length by the low two bits: r, r+1, r, r+2
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        if (UB == 3 ? (i % 3 == 0) : true) refill();     // 3 x 9 bits, or one code of up to 17
-                        const uint32_t len = (kr >> (((uint32_t)buf & 3u) << 3)) & 0xffu;
-                        buf >>= len; n -= len; glen += len;
-                    }
-                    ulen += glen;
-                }
-                if (lane == 0) {
-                    if (UB == 3) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * B + c] = (uint8_t)ulen;
-                    else ((uint16_t *)a.idx.ulen)[(uint64_t)gb * B + c] = (uint16_t)ulen;
-                }
-            }
-            gb++;
-        }
-        P = 32 * (w0 + wp) - n;
-    }
-    if (bad && lane == 0) atomicOr(a.status, 1u);
-}
-
+// everything else.  The walks here find unit LENGTHS only (a code's length is its rung plus what its low two bits say,
+// reference QB3decode.h:119-129) and each segment's bit position and rungs: from the restart points of the container's
+// own table (dec_walk_lanes_kernel, a lane per entry), else through tables of "where would a unit starting at this bit
+// with this rung end" made by the whole chip -- followed by one lane (the chains) or composed as exits of super-windows.
+// The values entering the segments then come from the parallel decoder itself: one pass in TOTALS mode leaves every
+// segment's per-band sum in idx.prev, prev_scan_kernel turns the sums into exclusive prefixes, the normal pass follows.
+// Without memory for a table (or under QB3_SLOW_WALK) a stream goes to the one-lane parser of k_dec_generic.hip
+// (dec_index_staged): the one last-resort walk of every width and mode (round 4 retired the one-wave length walk that
+// 8/16-bit streams had beside it).
 // idx.prev holds every segment's per-band sum of values: make it the value entering the segment (exclusive prefix,
 // modulo the value width; a stream starts from zero).  One workgroup per tile.
 template <typename T>
@@ -1376,11 +1281,7 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
 #pragma unroll 1
         for (uint32_t rb = 0; tabled && rb < E::NRB; rb++) {                                // the rung the switch leads to
             const uint32_t r = R0 + rb;
-#ifdef EXIT_EXP_NOTAB
-            if (r && rb == 0) {
-#else
             if (r) {                                                                        // extras of two, four, eight codes at rung r
-#endif
                 for (uint32_t i = tid; i < NPT - MAXC; i += NT) { const uint32_t e = t1[i]; eA[i] = (uint8_t)(e + t1[i + r + e]); }
                 __syncthreads();
                 for (uint32_t i = tid; i < NPT - 3 * MAXC; i += NT) { const uint32_t e = eA[i]; eB[i] = (uint8_t)(e + eA[i + 2 * r + e]); }
@@ -1408,9 +1309,6 @@ __global__ void __launch_bounds__(1024) walk_exitW_kernel(const DecArgs a0, uint
             bool stop = false;
             typedef typename WalkValue<UB>::type TT;
             TT cfv = (TT)S.cf; uint32_t xfl = 0;                                            // (common-factor streams) the factor in force: the one behind the first segment until a unit brings its own
-#ifdef EXIT_EXP_NOWALK
-            pos = W + (pos & 255);
-#endif
             while (true) {
                 if (r < NR) {
                     if (pos >= W) break;                                                    // behind the window, in the band: the next window's
@@ -1689,15 +1587,6 @@ template <uint32_t B, bool CF = false> struct exitB {
     static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
 };
 
-// diagnostic build (-DEXITB_STAMPS): shader clocks spent per phase, summed over the workgroups of the first launches (scratch/stamps_exitb.py)
-#ifdef EXITB_STAMPS
-__device__ unsigned long long exitb_stamps[16];
-#define XB_T0() unsigned long long xb_t = clock64()
-#define XB_PH(k) do { if (threadIdx.x == 0) { const unsigned long long n_ = clock64(); atomicAdd(&exitb_stamps[k], n_ - xb_t); xb_t = n_; } } while (0)
-#else
-#define XB_T0() do { } while (0)
-#define XB_PH(k) do { } while (0)
-#endif
 template <uint32_t B, bool CF>
 __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint32_t *xg, uint32_t s_begin, uint32_t s_count, const WalkState16 *states, uint32_t dcap) {
     typedef exitB<B, CF> E;
@@ -1757,7 +1646,6 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
         if (n > E::CNTM) return E::X_STOP;
         return (b & E::KEYM) | (n << E::KEYB) | ((a | b) & E::X_DEP);
     };
-    XB_T0();
     uint32_t D = 0;
 #pragma unroll 1
     for (uint32_t k = 0; k < E::K; k++) {
@@ -1765,7 +1653,6 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
         const uint32_t sh = (uint32_t)q0 & 31;
         for (uint32_t i = tid; i < NP1 / 32 + 3; i += NT) words[i] = w0 + i < endw ? a.in32[w0 + i] : 0u;
         __syncthreads();
-        XB_PH(0);
         auto bits = [&](uint32_t i) { const uint32_t b = sh + i, j = b >> 5; return __builtin_amdgcn_alignbit(words[j + 1], words[j], b & 31); };
         for (uint32_t i = tid; i < NP1; i += NT) { const uint32_t x = bits(i); t1[i] = (uint8_t)((x & 1) + ((x & 3) == 3)); }
         for (uint32_t o = tid; o < TP; o += NT) {
@@ -1775,7 +1662,6 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
         }
         for (uint32_t i = tid; i < TP * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;
         __syncthreads();
-        XB_PH(1);
 #pragma unroll 1
         for (uint32_t r = 0; r < NRUNG; r++) {                                              // the rung the switch leads to
             if (r) {
@@ -1796,7 +1682,6 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
             }
             __syncthreads();
         }
-        XB_PH(2);
         if (CF) {       // the units with the signal code: their places, then every (place, band, entering rung) parsed by a lane of its own
             if (tid == 0) s_nsig = 0;
             for (uint32_t o = tid; o < TP; o += NT) sig_slot[o] = 0xffu;
@@ -1827,7 +1712,6 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
             }
             __syncthreads();
         }
-        XB_PH(3);
         if (k == 0) {
             for (uint32_t i = tid; i < E::BMW; i += NT) bm[i] = 0;
             __syncthreads();
@@ -1837,7 +1721,6 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
                 if ((x & E::KEYM) != E::X_STOP) atomicOr(&bm[(x & E::KEYM) >> 5], 1u << (x & 31u));
             }
             __syncthreads();
-            XB_PH(4);
             // rank of every distinct exit: exclusive prefix of the bitmap words' bit counts (the scan's scratch: Xd, not yet in use)
             constexpr uint32_t PER = (E::BMW + NT - 1) / NT;
             uint32_t mine = 0;
@@ -1865,7 +1748,6 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
                 while (m) { const uint32_t b = __ffs(m) - 1; Xd[j++] = w * 32 + b; m &= m - 1; }
             }
             __syncthreads();
-            XB_PH(5);
         } else {
             for (uint32_t j = tid; j < D; j += NT) {                                        // the distinct walks through this window
                 const uint32_t x = Xd[j];
@@ -1874,7 +1756,6 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
                 Xd[j] = compose(x, y);
             }
             __syncthreads();
-            XB_PH(6);
         }
     }
     for (uint32_t key = tid; key < NKEY; key += NT) {                                       // every state: its first-window exit, then what became of that
@@ -1885,7 +1766,6 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
         G[key] = compose(e, x);
     }
     __syncthreads();
-    XB_PH(7);
 }
 
 // the hop for rasters of B bands: entries {position lo, hi, block, rungs (4 bits a band)} {factors in force (a byte a band)}
@@ -2135,7 +2015,7 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
     }
     if (a.g.tsz >= 4) {         // 32/64-bit FTL/BASE: the first segment parsed outright (band of rungs, entry state), then table + chain
         WalkState16 *states = (WalkState16 *)tab;
-        const uint32_t nr = a.wide_band == 8 ? 8u : a.wide_band == 14 ? 14u : 16u;
+        const uint32_t nr = 16u;    // (a band of eight rungs and a byte-entry table of fourteen were built and measured: DESIGN.md section 4, "Tried and measured")
         const bool exits = a.g.bands == 1 && a.wide_band == 16 && lds_ok && nt <= 16;      // one band: exits of super-windows composed, a hop per 32768 bits (wide_band 17: the chain, a test hook)
         auto probe = [&](uint32_t few) {
             ProfScope ps("dec_index_serial", st);
@@ -2156,8 +2036,7 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
                 [&](hipStream_t s, const uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch, uint8_t *sts, uint32_t) {
                     hipLaunchKernelGGL((walk_chainW_kernel<UB, NRB>), dim3(nt), dim3(WIDE_THREADS), W::LDS_BYTES, s, a, rows, s0, nwin, pitch, (WalkState16 *)sts); });
         };
-        if (a.g.tsz == 4) { if (nr == 16) run(WideTag<5, 16>()); else if (nr == 8) run(WideTag<5, 8>()); else run(WideTag<5, 14>()); }
-        else { if (nr == 16) run(WideTag<6, 16>()); else if (nr == 8) run(WideTag<6, 8>()); else run(WideTag<6, 14>()); }
+        if (a.g.tsz == 4) run(WideTag<5, 16>()); else run(WideTag<6, 16>());
         return;
     }
     if (a.g.tsz == 2) {
@@ -2205,9 +2084,7 @@ void launch_dec_walk(const DecArgs &a, hipStream_t st) {
         return;
     }
 
-    const dim3 wg(a.ntiles, 1);
-    if (a.g.tsz == 1) hipLaunchKernelGGL(dec_walk_kernel<3>, wg, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(dec_walk_kernel<4>, wg, dim3(64), 0, st, a);
+    set_error("launch_dec_walk: no restart table (the caller parses such a stream with one lane)", 0);
 }
 void launch_prev_scan(const DecArgs &a, hipStream_t st) {
     if (a.g.tsz == 1) hipLaunchKernelGGL(prev_scan_kernel<uint8_t>, dim3(a.ntiles, a.g.bands), dim3(1024), 0, st, a);
@@ -2217,8 +2094,3 @@ void launch_prev_scan(const DecArgs &a, hipStream_t st) {
 }
 
 }  // namespace qb3dev
-#ifdef EXITB_STAMPS
-extern "C" __attribute__((visibility("default"))) int qb3x_debug_exitb_stamps(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qb3dev::exitb_stamps), sizeof(qb3dev::exitb_stamps));
-}
-#endif

@@ -22,13 +22,6 @@ namespace qb3dev {
 
 constexpr uint32_t PXB_CAP = 256;           // queue entries a round = lanes of the workgroup
 
-// diagnostic build (-DPXB_STAMPS): the shader clock at the phase boundaries of one chunk in every 1024, read back by scratch/stamps_best.py
-#ifdef PXB_STAMPS
-__device__ unsigned long long pxb_stamps[64 * 16];
-#define PXB_STAMP(k) do { if (FIRST && threadIdx.x == 0 && (chunk & 1023u) == 512u && (chunk >> 10) < 64u) pxb_stamps[(chunk >> 10) * 16 + (k)] = (unsigned long long)clock64(); } while (0)
-#else
-#define PXB_STAMP(k) do { } while (0)
-#endif
 
 // any byte of x equal to 1 or 2 (a mag-sign value of magnitude 1)
 __device__ __forceinline__ uint32_t swar_has_mag1(uint32_t x) {
@@ -285,7 +278,6 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     uint32_t *hq = (uint32_t *)(smem + PXB_HQ);                 // [5][PXB_CAP]: four dwords of mag-sign values, one of rungs and flags
     uint32_t *hr = (uint32_t *)(smem + PXB_HR);                 // [3][PXB_CAP]: analysis results / bit position
     uint32_t *outbuf = (uint32_t *)(smem + PXB_OUT);            // slot_dw dwords
-    PXB_STAMP(0);
     const uint4 tabv = ((const uint4 *)px_enc_tab.e)[tid & 127];
     for (uint32_t i = tid; i < a.slot_dw / 4; i += 256) ((uint4 *)outbuf)[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) { wsum[40] = 0; wsum[41] = 0; }
@@ -303,7 +295,6 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     uint32_t usedp = 0, lastp = 0, pvp = 0;     // the bands' used / leaving / entering values, a byte each
 #pragma unroll
     for (int c = 0; c < B; c++) { usedp |= f.usedv[c] << (8 * c); lastp |= f.lastv[c] << (8 * c); pvp |= f.pvv[c] << (8 * c); }
-    PXB_STAMP(1);
 
     // ---- per band: the plain form of the unit (QB3M_BASE's, from the lane's registers), and is the unit settled by it.
     // One bitmap of the sixteen mag-sign values answers both questions while they are below 32 (rungs up to 4).
@@ -353,15 +344,8 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
                 if (rung == 4) vb += __popc(bm & 0xffffff00u) + __popc(bm & 0xfffe8000u);
                 const uint32_t head = 5 + sw_noflag_len<3>(UMASK - prung) + sw_noflag_len<3>(rung - prung);
                 const uint32_t floor_ = head + 32 + (n > 2 ? n - 2 : 0) + (n > 4 ? n - 4 : 0) + vb;
-#ifdef PXB_EXP_NOIDX
-                const bool idx_may = false;
-#else
                 const bool idx_may = rung > 3 && n <= 8 && floor_ < lenN;
-#endif
                 hard = factor || idx_may;
-#ifdef PXB_EXP_NOHARD
-                hard = false;
-#endif
                 idxm |= (uint32_t)idx_may << c;
             }
         }
@@ -375,7 +359,6 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
         }
     }
     __syncthreads();
-    PXB_STAMP(2);
     // ---- analysis of the hard units: cf | trung << 8 | writer << 12, szBase | szCf << 16, index size
     uint32_t res0[B], res1[B], res2[B];
 #pragma unroll
@@ -413,7 +396,6 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
         if (r0 + PXB_CAP < nh) __syncthreads();
     }
 
-    PXB_STAMP(3);
     // ---- who wrote the band's factor last: a ballot per band and wave, the value per lane
 #pragma unroll
     for (int c = 0; c < B; c++) {
@@ -439,7 +421,6 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     }
     if (FIRST && summary_only) return;  // (workgroup uniform)
 
-    PXB_STAMP(4);
     // ---- the coding of every unit and its length (QB3encode.h:679-713)
     const uint32_t seg = gblk / a.g.seg_blocks;
     const bool seg_start = payload && a.have_idx && seg * a.g.seg_blocks == gblk;
@@ -472,7 +453,6 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
     const uint32_t myblen = blen[0];
     block_exscan_dpp<1>(blen, wsum);            // (one barrier)
     const uint32_t pos = blen[0], total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    PXB_STAMP(5);
 
     // ---- emission: plain units from the lane's pieces, the others queued for the dense lanes
     uint32_t qe[B], upos[B];
@@ -514,11 +494,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
         }
     }
     __syncthreads();                    // every unit to emit densely is counted (and the analysis queue is free again)
-    PXB_STAMP(6);
     const uint32_t ne = wsum[41];
-#ifdef PXB_STAMPS
-    if (FIRST && tid == 0 && (chunk & 1023u) == 512u && (chunk >> 10) < 64u) { pxb_stamps[(chunk >> 10) * 16 + 10] = nh; pxb_stamps[(chunk >> 10) * 16 + 11] = ne; }
-#endif
     for (uint32_t r0 = 0; r0 < ne; r0 += PXB_CAP) {
 #pragma unroll
         for (int c = 0; c < B; c++)
@@ -538,13 +514,11 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
         }
         __syncthreads();
     }
-    PXB_STAMP(7);
     // the chunk's bits go to its slot; enc_concat_kernel moves them into place once every chunk is counted
     const uint32_t nd4 = (total + 127) >> 7;
     uint4 *slot = (uint4 *)(a.scratch + (uint64_t)chunk * a.slot_dw);
     for (uint32_t d = tid; d < nd4; d += 256) slot[d] = ((const uint4 *)outbuf)[d];
     if (tid == 0) a.chunk_bits[chunk] = total;
-    PXB_STAMP(8);
     if (FIRST) {
         if (tid < B) a.cw_used[(uint64_t)chunk * B + tid] = (uint8_t)used_entry[tid];
         if (tid == 0) a.recode_need[chunk] = 0;
@@ -610,8 +584,3 @@ void launch_enc_px_best(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
 
 }  // namespace qb3dev
 
-#ifdef PXB_STAMPS
-extern "C" __attribute__((visibility("default"))) int qb3x_debug_stamps(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qb3dev::pxb_stamps), sizeof(qb3dev::pxb_stamps));
-}
-#endif

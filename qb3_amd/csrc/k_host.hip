@@ -567,9 +567,11 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         // produce the values entering the segments (totals pass + scan)
         // plain 8-bit stream: through the table of unit lengths by position when the caller brought memory for it
         const bool has_ix = a.ix != nullptr;
+        bool have_prev = false;             // the index's entering values are there already
         if ((use_px || use_px16 || wide_plain) && !has_ix && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk) launch_dec_walk_table(a, st, walk_tab, walk_tab_bytes, max_bits);
-        else { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
-        if (!(a.ix && a.ix_blocks == a.g.seg_blocks) && !wide_walk) {         // (an entry per segment: the walk copied the entering values)
+        else if (has_ix) { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
+        else { ProfScope ps("dec_index_serial", st); launch_dec_index_serial(a, st); have_prev = true; }       // no table memory: one lane parses the stream (values included)
+        if (!have_prev && !(a.ix && a.ix_blocks == a.g.seg_blocks) && !wide_walk) {         // (an entry per segment: the walk copied the entering values)
           {
             ProfScope ps("dec_index_prev", st);
             DecArgs t = a;
