@@ -12,6 +12,7 @@ namespace qb3dev {
 // the remainder; ff pairs), every other byte costs one byte; chunk sums, a scan, and the same walk again writes.
 // Long runs are skipped a 4 KB chunk at a time through a table that says which chunks hold one byte value only.
 constexpr uint32_t RLE_CHUNK = 4096, RLE_THREADS = 256, RLE_PER_THREAD = RLE_CHUNK / RLE_THREADS;
+constexpr uint32_t RLE_SCAN_GROUP = 4096;                  // chunks per workgroup of rle0_scan_kernel
 
 // sixteen bytes of s from p on as four dwords, the byte before them and the byte behind them, through aligned dword loads
 // (p > 0 and p + 17 <= n: every dword read holds at least one byte of s)
@@ -137,7 +138,7 @@ __device__ __forceinline__ bool rle_special(uint8_t c) { return c == 0 || c == 0
 
 // MODE 0: bytes per chunk; MODE 1: write (chunk_off known)
 template <int MODE, bool DECODE>
-__global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64_t n, const uint16_t *uniform, uint32_t *chunk_out, const uint64_t *chunk_off, uint8_t *dst, uint64_t *total);
+__global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64_t n, const uint16_t *uniform, uint32_t *chunk_out, const uint64_t *chunk_off, uint8_t *dst, uint64_t *total, const uint64_t *gsum);
 
 // ---- decoding (reference QB3decode.cpp:267-291): ff ff x is a code wherever it STARTS at a code boundary, and a maximal
 // run of ff bytes always starts at one (the byte before it is a copied byte or the count of a zero code).  Of a run of L
@@ -162,8 +163,8 @@ __device__ uint64_t derle0_run(const uint8_t *s, uint64_t n, uint64_t a, const u
 }
 
 template <int MODE, bool DECODE>
-__global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64_t n, const uint16_t *uniform, uint32_t *chunk_out, const uint64_t *chunk_off, uint8_t *dst, uint64_t *total) {
-    __shared__ uint32_t part[256];
+__global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64_t n, const uint16_t *uniform, uint32_t *chunk_out, const uint64_t *chunk_off, uint8_t *dst, uint64_t *total, const uint64_t *gsum) {
+    __shared__ uint32_t part[4];
     const uint32_t tid = threadIdx.x;
     const uint64_t p0 = (uint64_t)blockIdx.x * RLE_CHUNK + (uint64_t)tid * RLE_PER_THREAD;
     // one pass over the thread's bytes: what each of them contributes.  MODE 1 runs it twice: sizes, then (after the
@@ -204,61 +205,133 @@ __global__ void __launch_bounds__(256) rle0_pass_kernel(const uint8_t *s, uint64
 #pragma unroll
             for (int k = 0; k < 4; k++) adj |= f[k] & __builtin_amdgcn_alignbit(f[k + 1], f[k], 8);
             quick = adj == 0;
-        } else
-            quick = (rle_ff4(r.w[0]) | rle_ff4(r.w[1]) | rle_ff4(r.w[2]) | rle_ff4(r.w[3]) | rle_ff4(r.prev | 0x01010100u)) == 0;
+        } else {
+            // expanding: an ff with no ff next to it is a copied byte too (a run of one: QB3decode.cpp:267-291), and the byte
+            // behind it is not a count -- sixteen bytes with no two ff in a row, the bytes around them included, are sixteen out
+            uint32_t f[5];
+#pragma unroll
+            for (int k = 0; k < 4; k++) f[k] = rle_ff4(r.w[k]);
+            f[4] = rle_ff4(r.next | 0x01010100u);
+            uint32_t adj = rle_ff4(r.prev | 0x01010100u) & 0x80u;       // (an ff just before: the run it ends may make the first byte a count)
+#pragma unroll
+            for (int k = 0; k < 4; k++) adj |= f[k] & __builtin_amdgcn_alignbit(f[k + 1], f[k], 8);
+            quick = adj == 0;
+        }
     }
     const uint64_t mine = quick ? RLE_PER_THREAD : walk(nullptr);
-    part[tid] = (uint32_t)mine;                             // (a thread's share is below 2^32: the output of one region is at most 3/2 of its bytes + 258 per code)
+    // (a thread's share is below 2^32: the output of one region is at most 3/2 of its bytes + 258 per code)
+    // the workgroup's scan: DPP inside the waves, the four wave sums through LDS, one barrier
+    const uint32_t inc_w = wave_iscan32((uint32_t)mine);
+    if ((tid & 63) == 63) part[tid >> 6] = inc_w;
     __syncthreads();
+    uint32_t before = 0, chunk_total = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) { const uint32_t v = part[i]; if (i < (tid >> 6)) before += v; chunk_total += v; }
+    const uint32_t inc = before + inc_w;                    // inclusive prefix of the thread's bytes inside the chunk
     if (MODE == 0) {
-        for (uint32_t d = 128; d > 0; d >>= 1) { if (tid < d) part[tid] += part[tid + d]; __syncthreads(); }
         if (tid == 0) {     // total = n + what the chunks' sizes differ from their byte counts by: most chunks add nothing
-            chunk_out[blockIdx.x] = part[0];
+            chunk_out[blockIdx.x] = chunk_total;
             const uint64_t c0 = (uint64_t)blockIdx.x * RLE_CHUNK, in = n - c0 < RLE_CHUNK ? n - c0 : RLE_CHUNK;
-            if (part[0] != in) atomicAdd((unsigned long long *)total, (unsigned long long)part[0] - (unsigned long long)in);   // (wraps: two's complement)
+            if (chunk_total != in) atomicAdd((unsigned long long *)total, (unsigned long long)chunk_total - (unsigned long long)in);   // (wraps: two's complement)
         }
         return;
     }
-    for (uint32_t d = 1; d < 256; d <<= 1) {                // inclusive scan
-        const uint32_t y = tid >= d ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += y;
-        __syncthreads();
+    // The write.  Nearly every thread is "quick": its sixteen bytes go out as they are, only shifted to wherever the bytes
+    // before them ended.  A byte at a time that is 435 M one-byte stores for a 16384 x 16384 x 3 raster's stream (1.3 ms, five
+    // times what the bytes cost to move), so:
+    //  * a wave in which EVERY thread is quick is a shifted copy of its kilobyte: each lane stores the sixteen output bytes
+    //    of an ALIGNED group (one 16-byte store, the sources funnel-shifted out of aligned loads), the kilobyte's first
+    //    and last few bytes -- the groups it shares with its neighbours -- go byte by byte;
+    //  * elsewhere a quick thread stores its head bytes up to the next aligned dword, three or four dwords, its tail bytes.
+    uint8_t *base = dst + gsum[blockIdx.x / RLE_SCAN_GROUP] + chunk_off[blockIdx.x];
+    // (per WAVE: 64 quick threads are a shifted copy of their kilobyte -- of a stream's waves more than nine in ten)
+    if (__all(quick)) {
+        const uint32_t wv = tid >> 6, lane = tid & 63;
+        const uint64_t w0 = (uint64_t)blockIdx.x * RLE_CHUNK + 1024 * wv;          // the wave's first input byte
+        uint8_t *ow = base + before;                                            // ... and where its 1024 bytes go
+        const uint32_t head = (uint32_t)((0 - (uintptr_t)ow) & 15);             // bytes in front of the first 16-byte aligned output address
+        const uint32_t ngroups = (1024 - head) >> 4;                            // 63 or 64 aligned groups of sixteen
+        if (lane < ngroups) {
+            const Rle16 r = rle_load16(s, w0 + head + 16 * (uint64_t)lane);     // (w0 > 0 and three bytes at least follow the wave's: quick threads said so)
+            *(uint4 *)(ow + head + 16 * (uint64_t)lane) = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+        }
+        const uint32_t tail0 = head + 16 * ngroups;                             // bytes behind the last group (fewer than sixteen)
+        if (lane < head) ow[lane] = s[w0 + lane];
+        if (lane >= 32 && lane - 32 < 1024 - tail0) ow[tail0 + (lane - 32)] = s[w0 + tail0 + (lane - 32)];
+        return;
     }
-    if (mine) walk(dst + chunk_off[blockIdx.x] + (part[tid] - (uint32_t)mine));     // (a quick thread's sixteen bytes are copied by the walk)
+    if (!mine) return;
+    uint8_t *o = base + (inc - (uint32_t)mine);
+    if (quick) {
+        const Rle16 r = rle_load16(s, p0);
+        const uint32_t a = (uint32_t)((0 - (uintptr_t)o) & 3);                  // head bytes up to the next aligned dword
+        const uint32_t w4[5] = { r.w[0], r.w[1], r.w[2], r.w[3], 0u };
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) if (k < a) o[k] = (uint8_t)(r.w[0] >> (8 * k));
+        uint32_t *od = (uint32_t *)(o + a);
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) od[k] = a ? __builtin_amdgcn_alignbit(w4[k + 1], w4[k], 8 * a) : w4[k];
+        if (a == 0) od[3] = r.w[3];
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < 3; k++) if (k < 4 - a) o[a + 12 + k] = (uint8_t)(r.w[3] >> (8 * (a + k)));
+        }
+        return;
+    }
+    walk(o);
 }
 
-// chunk_off = exclusive prefix of chunk_out (one workgroup; only the write pass needs it); total[0] = the sum again
-__global__ void __launch_bounds__(1024) rle0_scan_kernel(const uint32_t *chunk_out, uint64_t *chunk_off, uint64_t nchunks, uint64_t *total) {
-    __shared__ uint64_t part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint64_t per = (nchunks + 1023) / 1024, c0 = (uint64_t)tid * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+// chunk_off = exclusive prefix of chunk_out (only the write pass needs it); total[0] = the sum again.  A workgroup per 4096
+// chunks (four a thread, 16-byte loads) leaves its chunks' offsets inside the group and the group's sum; the workgroup that
+// finishes LAST (a counter behind the group sums) scans the group sums and adds them in -- enc_scan_kernel's scheme.
+__global__ void __launch_bounds__(1024) rle0_scan_kernel(const uint32_t *chunk_out, uint64_t *chunk_off, uint64_t nchunks, uint64_t *total, uint64_t *gsum) {
+    __shared__ uint64_t wsum[16];
+    __shared__ uint32_t is_last;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ngroups = gridDim.x;
+    const uint64_t i0 = (uint64_t)blockIdx.x * RLE_SCAN_GROUP + 4 * tid;
+    uint32_t v[4];
     uint64_t sum = 0;
-    for (uint64_t c = c0; c < c1; c++) sum += chunk_out[c];
-    part[tid] = sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = i0 + k < nchunks ? chunk_out[i0 + k] : 0u; sum += v[k]; }
+    uint64_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(x, d, 64); if (lane >= (uint32_t)d) x += y; }
+    if (lane == 63) wsum[wave] = x;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint64_t y = tid >= d ? part[tid - d] : 0ull;
-        __syncthreads();
-        part[tid] += y;
-        __syncthreads();
+    uint64_t off = x - sum, tot = 0;
+    for (uint32_t i = 0; i < 16; i++) { const uint64_t w = wsum[i]; if (i < wave) off += w; tot += w; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i0 + k < nchunks) { chunk_off[i0 + k] = off; off += v[k]; }
+    if (tid == 0) {
+        gsum[blockIdx.x] = tot;
+        __threadfence();
+        is_last = atomicAdd((uint32_t *)&gsum[ngroups + 1], 1u) == ngroups - 1;
     }
-    uint64_t run = part[tid] - sum;
-    for (uint64_t c = c0; c < c1; c++) { chunk_off[c] = run; run += chunk_out[c]; }
-    if (tid == 1023) total[0] = part[1023];
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (tid == 0) {             // a few dozen groups: one thread
+        uint64_t run = 0;
+        for (uint32_t g = 0; g < ngroups; g++) { const uint64_t t = __hip_atomic_load(&gsum[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); gsum[g] = run; run += t; }
+        gsum[ngroups] = run; gsum[ngroups + 1] = 0;         // (the counter is ready for the next call)
+        total[0] = run;
+    }
 }
 
 // ---- host entry points.  ws: rle0_ws_bytes(n) of device memory; the size pass leaves what the write pass needs in it.
 size_t rle0_ws_bytes(uint64_t n) {
     const uint64_t nchunks = (n + RLE_CHUNK - 1) / RLE_CHUNK;
-    return (size_t)(16 + 8 * nchunks + 4 * nchunks + 2 * nchunks + 64);
+    const uint64_t ngroups = (nchunks + RLE_SCAN_GROUP - 1) / RLE_SCAN_GROUP;
+    return (size_t)(16 + 8 * (ngroups + 2) + 8 * nchunks + 4 * nchunks + 2 * nchunks + 64);
 }
-struct RleWs { uint64_t *total, *off; uint32_t *out; uint16_t *uniform; uint64_t nchunks; };
+struct RleWs { uint64_t *total, *gsum, *off; uint32_t *out; uint16_t *uniform; uint64_t nchunks, ngroups; };
 static RleWs rle_ws(void *ws, uint64_t n) {
     RleWs w;
     w.nchunks = (n + RLE_CHUNK - 1) / RLE_CHUNK;
     uint8_t *p = (uint8_t *)ws;
+    w.ngroups = (w.nchunks + RLE_SCAN_GROUP - 1) / RLE_SCAN_GROUP;
     w.total = (uint64_t *)p; p += 16;
+    w.gsum = (uint64_t *)p; p += 8 * (w.ngroups + 2);       // per group of chunks: bytes before it; the total; the scan's count of finished workgroups
     w.off = (uint64_t *)p; p += 8 * w.nchunks;
     w.out = (uint32_t *)p; p += 4 * w.nchunks;
     w.uniform = (uint16_t *)p;
@@ -279,8 +352,8 @@ int rle0_device_size(const void *d_src, uint64_t n, void *ws, bool decode, uint6
     ProfScope ps(decode ? "rle0_expand_size" : "rle0_size", st);
     if (no_uniform_chunk) hipLaunchKernelGGL(rle0_no_uniform_kernel, dim3((uint32_t)((w.nchunks + 255) / 256)), dim3(256), 0, st, w.uniform, w.nchunks, n, w.total);
     else hipLaunchKernelGGL(rle0_uniform_kernel, dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.total);
-    if (decode) hipLaunchKernelGGL((rle0_pass_kernel<0, true>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr, w.total);
-    else hipLaunchKernelGGL((rle0_pass_kernel<0, false>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr, w.total);
+    if (decode) hipLaunchKernelGGL((rle0_pass_kernel<0, true>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr, w.total, (const uint64_t *)w.gsum);
+    else hipLaunchKernelGGL((rle0_pass_kernel<0, false>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)nullptr, w.total, (const uint64_t *)w.gsum);
     }
     HIPCHK(hipMemcpyAsync(total, w.total, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -293,9 +366,10 @@ int rle0_device_write(const void *d_src, uint64_t n, void *ws, bool decode, void
     const RleWs w = rle_ws(ws, n);
     const uint8_t *s = (const uint8_t *)d_src;
     ProfScope ps(decode ? "rle0_expand" : "rle0_write", st);
-    hipLaunchKernelGGL(rle0_scan_kernel, dim3(1), dim3(1024), 0, st, w.out, w.off, w.nchunks, w.total + 1);      // (the size pass left the chunk sums)
-    if (decode) hipLaunchKernelGGL((rle0_pass_kernel<1, true>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)d_dst, w.total + 1);
-    else hipLaunchKernelGGL((rle0_pass_kernel<1, false>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)d_dst, w.total + 1);
+    HIPCHK(hipMemsetAsync(w.gsum + w.ngroups + 1, 0, 8, st));                                                 // the scan's counter
+    hipLaunchKernelGGL(rle0_scan_kernel, dim3((uint32_t)w.ngroups), dim3(1024), 0, st, w.out, w.off, w.nchunks, w.total + 1, w.gsum);      // (the size pass left the chunk sums)
+    if (decode) hipLaunchKernelGGL((rle0_pass_kernel<1, true>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)d_dst, w.total + 1, (const uint64_t *)w.gsum);
+    else hipLaunchKernelGGL((rle0_pass_kernel<1, false>), dim3((uint32_t)w.nchunks), dim3(256), 0, st, s, n, w.uniform, w.out, w.off, (uint8_t *)d_dst, w.total + 1, (const uint64_t *)w.gsum);
     HIPCHK(hipGetLastError());
     return 0;
 }

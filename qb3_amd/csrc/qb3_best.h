@@ -15,15 +15,17 @@ namespace qb3dev {
 // assumption was wrong and mattered; those are coded again (on data without common factors: none).
 // x mod y and x / y for magnitudes.  8- and 16-bit data: through the float reciprocal (exact after one correction step:
 // both operands are below 2^16); wider data: the integer operations.
+// x mod y through the float reciprocal: exact after one correction step while both operands are below 2^23 (they and their
+// quotient are then exact in a float's mantissa but for the reciprocal's last bit)
+__device__ __forceinline__ uint32_t mod_f23(uint32_t a, uint32_t b) {      // b != 0
+    const uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
+    int32_t r = (int32_t)(a - q * b);
+    r += r < 0 ? (int32_t)b : 0;
+    r -= r >= (int32_t)b ? (int32_t)b : 0;
+    return (uint32_t)r;
+}
 template <typename T> __device__ __forceinline__ T mod_t(T x, T y) {       // y != 0
-    if (sizeof(T) <= 2) {
-        const uint32_t a = (uint32_t)x, b = (uint32_t)y;
-        const uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
-        int32_t r = (int32_t)(a - q * b);
-        r += r < 0 ? (int32_t)b : 0;
-        r -= r >= (int32_t)b ? (int32_t)b : 0;
-        return (T)r;
-    }
+    if (sizeof(T) <= 2) return (T)mod_f23((uint32_t)x, (uint32_t)y);
     return (T)(x % y);
 }
 template <typename T> __device__ __forceinline__ T div_exact_t(T x, T y) { // y divides x
@@ -46,6 +48,25 @@ template <typename T> __device__ __forceinline__ T gcf_t(const T (&g)[16], bool 
         mn = (m[i] != 0 && m[i] < mn) ? m[i] : mn;
     }
     T x = (one || !active) ? (T)1 : mn;         // (an active unit has a non-zero magnitude: its rung is at least 1)
+    if (sizeof(T) >= 4) {
+        // 32/64-bit data: an integer modulo is tens (64-bit: a hundred and more) of instructions.  Elevation and count rasters
+        // keep their deltas small: when no magnitude of the WAVE's units reaches 2^23 the float reciprocal does it (mod_f23)
+        T mx = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) mx |= m[i];
+        if (!__any(active && (mx >> 23) != 0)) {
+            uint32_t xs = (uint32_t)x;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) {
+                if (!__any(xs != 1)) break;
+                if (xs != 1) {
+                    uint32_t y = mod_f23((uint32_t)m[i], xs);
+                    while (y) { const uint32_t t = mod_f23(xs, y); xs = y; y = t; }
+                }
+            }
+            return (T)xs;
+        }
+    }
 #pragma unroll
     for (uint32_t i = 0; i < 16; i++) {
         if (!__any(x != 1)) break;
@@ -136,9 +157,10 @@ template <typename T> __device__ __forceinline__ uint32_t distinct_t(const T (&g
     // All the caller asks is "at most 8 distinct values, and then how many" (index coding holds no more).
     uint32_t distinct = 99;
     bool open = need;                   // lanes that still need the exact count
-    if (sizeof(T) == 1) {
-        // 8-bit data: the values' low five bits in a 32-bit bitmap: exact up to rung 4 (values below 32), else a LOWER
-        // bound -- more than 8 there settles the lane (on noisy data nearly every lane, with 32-bit operations)
+    {
+        // the values' low five bits in a 32-bit bitmap: exact up to rung 4 (values below 32), else a LOWER bound (values
+        // that differ there differ) -- more than 8 settles the lane: on noisy data nearly every lane, with 32-bit operations
+        // whatever the value width
         if (__any(need)) {
             uint32_t bm = 0;
 #pragma unroll
