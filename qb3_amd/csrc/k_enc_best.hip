@@ -33,7 +33,9 @@ __device__ __forceinline__ bool writers_find(const WriterBoard &wb, uint32_t ban
 // the image starts with; it also leaves the chunk's summary (its last factor writer per band, and whether anything in
 // it depended on the entering factor).  !FIRST: a chunk coded again with its true entering factor (best_scan_kernel
 // lists the chunks whose assumption was wrong AND mattered: on data without common factors, none).
-template <typename T, bool FIRST>
+// FRONT: 0 the unit-per-lane front end (an LDS tile, any band count); 1 / 2: 32/64-bit rasters of one band, lane per block, the
+// block in registers (pxw_front; Hilbert / Z curve)
+template <typename T, bool FIRST, int FRONT = 0>
 __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, uint8_t *smem, uint32_t chunk, bool summary_only) {
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
@@ -41,7 +43,9 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
     T g[16];
     EncFront<T> f;
     const uint32_t outdw = a.slot_dw;
-    enc_front<T>(a, a0, smem, outdw, f, g, chunk);
+    if constexpr (FRONT == 1) pxw_front<T, HILBERT>(a, a0, smem, outdw, f, g, chunk);
+    else if constexpr (FRONT == 2) pxw_front<T, ZCURVE>(a, a0, smem, outdw, f, g, chunk);
+    else enc_front<T>(a, a0, smem, outdw, f, g, chunk);
     const uint32_t c = f.c, gblk = f.gblk, rung = f.rung;
     const bool payload = f.payload;
     const T used = f.used;
@@ -57,7 +61,7 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
     BestUnit<T> u;
     u.writer = false; u.cf = 1; u.szN = u.szBase = u.szCf = 0; u.idx = 0xffffffffu; u.trung = 0;
     const bool analyse = payload && used > 1;
-    if (payload) oldrung = (gblk == 0) ? a0.st.rung[c] : f.rungs[tid - bands];
+    if (payload) oldrung = (gblk == 0) ? a0.st.rung[c] : (FRONT ? f.prung : f.rungs[tid - bands]);
     {
         T cf = 1;
         if (__any(analyse)) cf = gcf_t<T>(g, analyse);
@@ -198,37 +202,37 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
 }
 
 // The image is coded in one pass when it has no common factors to speak of, in two when it has: a SAMPLE of the chunks
-// (one in every nchunks/1024) is analysed first; if factor writers that change the state are common in it (recode_n[1]
+// (best_sample_count of them, evenly spread) is analysed first; if factor writers that change the state are common in it (recode_n[1]
 // counts them), the first pass only collects the chunk summaries (cheap) while the last pass codes every chunk with its
 // true entering factor;
 // otherwise the first pass codes every chunk assuming the starting state and the last pass repairs the listed few.
-template <typename T>
+template <typename T, int FRONT = 0>
 __global__ void __launch_bounds__(256) enc_best_sample_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t step = (a.nchunks + gridDim.x - 1) / gridDim.x, chunk = blockIdx.x * step;
     if (chunk >= a.nchunks) return;
-    best_chunk<T, true>(a, a0, smem, chunk, true);
+    best_chunk<T, true, FRONT>(a, a0, smem, chunk, true);
     // what counts is a writer that moves the factor AWAY from the state the one-pass coding assumes
     if (threadIdx.x < a.g.bands && a.cw_has[(uint64_t)chunk * a.g.bands + threadIdx.x] &&
         a.cw_val[(uint64_t)chunk * a.g.bands + threadIdx.x] != a0.st.cf[threadIdx.x]) atomicAdd(&a.recode_n[1], 1u);
 }
 // two passes when more than one in sixteen of the sampled (chunk, band) pairs had such a writer
 __device__ __forceinline__ bool best_two_pass(const EncArgs &a) {
-    const uint32_t sampled = a.nchunks < 1024 ? a.nchunks : 1024;
+    const uint32_t sampled = best_sample_count(a.nchunks);
     return a.recode_n[1] > ((sampled * a.g.bands) >> 4);
 }
 
-template <typename T, bool FIRST>
+template <typename T, bool FIRST, int FRONT = 0>
 __global__ void __launch_bounds__(256) enc_best_kernel(const EncArgs a0) {      // (256 = the plan's largest block: without the bound the compiler budgets for 1024 threads and the recode loop spills)
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     enc_scan_counter_reset(a);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const bool two_pass = best_two_pass(a);
-    if (FIRST) { best_chunk<T, true>(a, a0, smem, blockIdx.x, two_pass); return; }
+    if (FIRST) { best_chunk<T, true, FRONT>(a, a0, smem, blockIdx.x, two_pass); return; }
     const uint32_t n = two_pass ? a.nchunks : a.recode_n[0];
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        best_chunk<T, false>(a, a0, smem, two_pass ? i : a.recode_list[i], false);
+        best_chunk<T, false, FRONT>(a, a0, smem, two_pass ? i : a.recode_list[i], false);
         __syncthreads();
     }
 }
@@ -335,19 +339,30 @@ void launch_best_scan(const EncArgs &a, hipStream_t st) {
     }
 }
 
-template <typename T>
-static void launch_enc_best_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+template <typename T, int FRONT>
+static void launch_enc_best_f(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     dim3 grid(plan.nchunks, a.ntiles), block(plan.threads);
     {
         ProfScope ps("enc_best_units", st);
         if (a.ntiles > 1) (void)hipMemset2DAsync(a.recode_n, a.ts_ws, 0, 8, a.ntiles, st);
         else (void)hipMemsetAsync(a.recode_n, 0, 8, st);
-        hipLaunchKernelGGL((enc_best_sample_kernel<T>), dim3(plan.nchunks < 1024 ? plan.nchunks : 1024, a.ntiles), block, plan.lds_bytes, st, a);
-        hipLaunchKernelGGL((enc_best_kernel<T, true>), grid, block, plan.lds_bytes, st, a);
+        hipLaunchKernelGGL((enc_best_sample_kernel<T, FRONT>), dim3(best_sample_count(plan.nchunks), a.ntiles), block, plan.lds_bytes, st, a);
+        hipLaunchKernelGGL((enc_best_kernel<T, true, FRONT>), grid, block, plan.lds_bytes, st, a);
     }
     launch_best_scan_t<T>(a, st);
     ProfScope ps("enc_best_recode", st);
-    hipLaunchKernelGGL((enc_best_kernel<T, false>), dim3(plan.nchunks < 4096 ? plan.nchunks : 4096, a.ntiles), block, plan.lds_bytes, st, a);
+    hipLaunchKernelGGL((enc_best_kernel<T, false, FRONT>), dim3(plan.nchunks < 4096 ? plan.nchunks : 4096, a.ntiles), block, plan.lds_bytes, st, a);
+}
+template <typename T>
+static void launch_enc_best_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
+    if constexpr (sizeof(T) >= 4) {
+        // one band of 32/64-bit data (value-aligned pointers): the lane-per-block front end
+        if (plan.pxw_best && ((uintptr_t)a.img & (sizeof(T) - 1)) == 0 && !(a.ts_img & (sizeof(T) - 1))) {
+            if (a.g.order == ZCURVE) launch_enc_best_f<T, 2>(a, plan, st); else launch_enc_best_f<T, 1>(a, plan, st);
+            return;
+        }
+    }
+    launch_enc_best_f<T, 0>(a, plan, st);
 }
 void launch_enc_best(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
     switch (a.g.tsz) {

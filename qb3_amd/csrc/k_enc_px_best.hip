@@ -527,7 +527,7 @@ __device__ __forceinline__ void px_best_chunk(const EncArgs &a, const EncArgs &a
 
 // The driver kernels: as k_enc_best.hip's (a sample of the chunks decides between one coding pass plus repairs and two passes)
 __device__ __forceinline__ bool pxb_two_pass(const EncArgs &a) {
-    const uint32_t sampled = a.nchunks < 1024 ? a.nchunks : 1024;
+    const uint32_t sampled = best_sample_count(a.nchunks);
     return a.recode_n[1] > ((sampled * a.g.bands) >> 4);
 }
 template <int B, bool RGB, uint64_t ORDER>
@@ -564,7 +564,7 @@ static void launch_enc_px_best_o(const EncArgs &a, const EncPlan &plan, hipStrea
         ProfScope ps("enc_best_units", st);
         if (a.ntiles > 1) (void)hipMemset2DAsync(a.recode_n, a.ts_ws, 0, 8, a.ntiles, st);
         else (void)hipMemsetAsync(a.recode_n, 0, 8, st);
-        hipLaunchKernelGGL((enc_px_best_sample_kernel<B, RGB, ORDER>), dim3(plan.nchunks < 1024 ? plan.nchunks : 1024, a.ntiles), block, plan.lds_bytes, st, a);
+        hipLaunchKernelGGL((enc_px_best_sample_kernel<B, RGB, ORDER>), dim3(best_sample_count(plan.nchunks), a.ntiles), block, plan.lds_bytes, st, a);
         hipLaunchKernelGGL((enc_px_best_kernel<B, RGB, ORDER, true>), grid, block, plan.lds_bytes, st, a);
     }
     launch_best_scan(a, st);

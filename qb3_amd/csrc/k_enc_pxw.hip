@@ -14,22 +14,9 @@
 //     rung + 1, rung + 2; no swap up there) through a 64-bit bit writer;
 //   * one DPP workgroup scan of the unit lengths, the chunk's bits to its slot.
 #include "qb3_px_enc.h"
+#include "qb3_wide.h"
 
 namespace qb3dev {
-
-template <typename T> struct WideVec;
-template <> struct WideVec<uint32_t> { typedef uint32_t v4 __attribute__((ext_vector_type(4), aligned(4))); };
-template <> struct WideVec<uint64_t> { typedef uint64_t v2 __attribute__((ext_vector_type(2), aligned(8))); };
-
-// four values of a row at any T-aligned address
-__device__ __forceinline__ void pxw_load_row(const uint32_t *p, uint32_t (&r)[4]) {
-    const WideVec<uint32_t>::v4 v = *(const WideVec<uint32_t>::v4 *)p;
-    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
-}
-__device__ __forceinline__ void pxw_load_row(const uint64_t *p, uint64_t (&r)[4]) {
-    const WideVec<uint64_t>::v2 a = *(const WideVec<uint64_t>::v2 *)p, b = *(const WideVec<uint64_t>::v2 *)(p + 2);
-    r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
-}
 
 template <typename T, uint64_t ORDER, bool STEP, int NT>
 __global__ void __launch_bounds__(NT) enc_pxw_kernel(const EncArgs a0) {

@@ -282,6 +282,7 @@ EncPlan plan_encode(const Geometry &g) {
     p.px = px_eligible(g, &p.px_rgb);
     p.px16 = false; p.px16_bg = p.px16_ng = 0;
     p.pxw = false;
+    p.pxw_best = !p.px && pxw_eligible(g, true);        // (same chunks as the generic plan below: one band, slots = threads)
     if (!p.px && pxw_eligible(g)) {
         p.pxw = true;
         p.threads = g.tsz == 8 ? 128 : 256; p.slots = p.threads; p.nbp = p.threads - 1;
@@ -317,6 +318,8 @@ EncPlan plan_encode(const Geometry &g) {
     const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1;
     p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * ((outdw + 1) & ~(size_t)1);
     if (g.mode == CM_BEST) p.lds_bytes += 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8 + 4 * (size_t)p.slots;     // the writer board: a value per lane, a ballot per wave, a word per band; a word per block (the index's block table)
+    // (the lane-per-block front end has no tile: scan scratch, the code table, the bit buffer -- of the worst common-factor unit -- and the board)
+    if (p.pxw_best) p.lds_bytes = 256 + 1024 + 4 * (size_t)enc_ws_layout(g, p.nchunks, nbp, p.threads).slot_dw + 8 + 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8 + 4 * (size_t)p.slots;
     p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp, p.threads).total;
     return p;
 }

@@ -99,6 +99,7 @@ struct EncPlan {
     bool px16;              // 16-bit register-resident kernel applies (lane per block and band group)
     uint32_t px16_bg, px16_ng;      //   ... bands per lane (1..4), lanes per block
     bool pxw;               // 32/64-bit single-band register-resident kernel applies (lane per block; k_enc_pxw.hip)
+    bool pxw_best;          // ... its front end under the common-factor analysis (k_enc_best.hip, FRONT = 1 / 2)
 };
 EncPlan plan_encode(const Geometry &g);
 constexpr uint32_t PXB_LDS_FIXED = 11664;      // LDS of the 8-bit common-factor lane-per-block encoder in front of its bit buffer

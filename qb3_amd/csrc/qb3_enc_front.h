@@ -1,6 +1,7 @@
 // qb3_amd/csrc/qb3_enc_front.h -- front end of the unit-per-lane encoder kernels (k_enc_generic.hip, k_enc_best.hip)
 #pragma once
 #include "qb3_kernels.h"
+#include "qb3_wide.h"
 
 namespace qb3dev {
 
@@ -10,6 +11,7 @@ template <typename T> struct EncFront {
     uint32_t s, c, cb, gblk, rung, nbp, chunk;
     bool valid, payload;
     T used, pv, lastv;
+    uint32_t prung;         // rung of the block before (the lane-per-block front end; the generic one leaves the rungs in LDS)
 };
 
 template <typename T>
@@ -123,6 +125,66 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, u
     f.s = s; f.c = c; f.cb = cb; f.gblk = gblk; f.rung = rung;
     f.valid = valid; f.payload = valid && s >= 1;
     f.used = used; f.pv = pv; f.lastv = lastv;
+}
+
+// The same for 32/64-bit rasters of ONE band, lane per block, the block in registers (the front half of enc_pxw_kernel,
+// k_enc_pxw.hip): four 16-byte row loads straight from HBM, the curve as register renaming, the rung of the block before by a
+// DPP wave shift.  A chunk is the same run of blocks the generic front end gives a workgroup (slots = threads for one band),
+// so everything behind the front end -- scans across chunks, index, table -- is shared.  No LDS tile: the carve is scan
+// scratch, the code table (a compile-time constant copied from L2), the bit buffer.
+template <typename T, uint64_t ORDER>
+__device__ __forceinline__ void pxw_front(const EncArgs &a, const EncArgs &a0, uint8_t *smem, uint32_t outdw, EncFront<T> &f, T (&g)[16], uint32_t chunk) {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nblocks = (uint32_t)a.g.nblocks, nbx = a.g.nbx;
+    const uint64_t stride = a.g.stride;
+    f.slot_base = nullptr; f.tile = nullptr; f.rungs = nullptr;
+    f.wsum = (uint32_t *)smem;                              // 64 dwords of scan scratch ([32 ..]: rung of each wave's last lane)
+    f.etab = (uint16_t *)(f.wsum + 64);                     // 512 entries
+    f.outbuf = (uint32_t *)(f.etab + 512);
+    const uint4 tabv = ((const uint4 *)wide_enc_tab.e)[tid & 63];
+    for (uint32_t i = tid; i < outdw; i += nthr) f.outbuf[i] = 0;
+    const int64_t gs = (int64_t)chunk * (nthr - 1) - 1 + tid;       // lane 0 is the halo block
+    const bool valid = gs >= 0 && gs < (int64_t)nblocks;
+    const uint32_t gblk = valid ? (uint32_t)gs : 0u;
+    T w[4][4], pv = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) w[r][x] = 0;
+    constexpr uint32_t n15 = (uint32_t)(ORDER & 15);
+    if (valid) {
+        const uint32_t by = gblk / nbx, bx = gblk - by * nbx;
+        const uint32_t x0 = (4 * bx + 4 > a.g.w) ? a.g.w - 4 : 4 * bx;
+        const uint32_t y0 = (4 * by + 4 > a.g.h) ? a.g.h - 4 : 4 * by;
+        const T *p0 = (const T *)a.img + (uint64_t)y0 * stride + x0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) pxw_load_row(p0 + (uint64_t)r * stride, w[r]);
+        if (gblk) {
+            const uint32_t pb = gblk - 1, pby = pb / nbx, pbx = pb - pby * nbx;
+            const uint32_t px0 = (4 * pbx + 4 > a.g.w) ? a.g.w - 4 : 4 * pbx;
+            const uint32_t py0 = (4 * pby + 4 > a.g.h) ? a.g.h - 4 : 4 * pby;
+            pv = ((const T *)a.img)[(uint64_t)(py0 + (n15 >> 2)) * stride + px0 + (n15 & 3)];
+        } else pv = (T)a0.st.prev[0];
+    }
+    T used = 0, prv = pv;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        constexpr uint64_t O = ORDER;
+        const uint32_t nib = (uint32_t)(O >> (60 - 4 * i)) & 15u;
+        const T v = w[nib >> 2][nib & 3];
+        g[i] = mags_t<T>((T)(v - prv));
+        used |= g[i];
+        prv = v;
+    }
+    const uint32_t rung = valid ? topbit_t<T>(used) : 0u;
+    uint32_t prung = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rung, 0x138, 0xf, 0xf, false);      // wave_shr:1
+    if (lane == 63) f.wsum[32 + wave] = rung;
+    if (tid < 64) ((uint4 *)f.etab)[tid] = tabv;
+    __syncthreads();
+    if (lane == 0 && wave) prung = f.wsum[32 + wave - 1];
+    f.s = tid; f.c = 0; f.cb = 0; f.gblk = gblk; f.rung = rung; f.nbp = nthr - 1; f.chunk = chunk;
+    f.valid = valid; f.payload = valid && tid >= 1;
+    f.used = used; f.pv = pv; f.lastv = prv; f.prung = prung;
 }
 
 }  // namespace qb3dev

@@ -284,6 +284,8 @@ template <typename T> __device__ __forceinline__ void put_value(LdsWriter &w, T 
 }
 
 constexpr uint32_t SCAN_GROUP = 4096;      // chunks per workgroup of enc_scan_kernel
+// chunks the common-factor encoders analyse first, to choose between one coding pass and two: an eighth of them, 64 at least, 1024 at most
+__host__ __device__ constexpr uint32_t best_sample_count(uint32_t nchunks) { return nchunks <= 64 ? nchunks : (nchunks / 8 < 64 ? 64u : nchunks / 8 > 1024 ? 1024u : nchunks / 8); }
 // every coding kernel's first workgroup: the counter by which enc_scan_kernel's last workgroup knows itself (behind the group sums)
 __device__ __forceinline__ void enc_scan_counter_reset(const EncArgs &a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) a.group_sum[(a.nchunks + SCAN_GROUP - 1) / SCAN_GROUP + 1] = 0;

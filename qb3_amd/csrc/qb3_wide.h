@@ -26,6 +26,38 @@ constexpr WideDecTab make_wide_dec_tab() {
 }
 static __device__ const WideDecTab wide_dec_tab = make_wide_dec_tab();
 
+template <typename T> struct WideVec;
+template <> struct WideVec<uint32_t> { typedef uint32_t v4 __attribute__((ext_vector_type(4), aligned(4))); };
+template <> struct WideVec<uint64_t> { typedef uint64_t v2 __attribute__((ext_vector_type(2), aligned(8))); };
+
+// four values of a row at any T-aligned address
+__device__ __forceinline__ void pxw_load_row(const uint32_t *p, uint32_t (&r)[4]) {
+    const WideVec<uint32_t>::v4 v = *(const WideVec<uint32_t>::v4 *)p;
+    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+}
+__device__ __forceinline__ void pxw_load_row(const uint64_t *p, uint64_t (&r)[4]) {
+    const WideVec<uint64_t>::v2 a = *(const WideVec<uint64_t>::v2 *)p, b = *(const WideVec<uint64_t>::v2 *)(p + 2);
+    r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+}
+
+// The encode table of rungs 1..7 as a compile-time constant (layout and entries of fill_enc_tab, qb3_kernels.h: entry =
+// len << 12 | code with the middle swap applied, rung r at [2 << r) - 4, indexed by the mag-sign value)
+struct WideEncTab { alignas(16) uint16_t e[512]; };
+constexpr WideEncTab make_wide_enc_tab() {
+    WideEncTab t{};
+    for (uint32_t r = 1; r < 8; r++) {
+        const uint32_t top = 1u << r, half = top >> 1;
+        for (uint32_t m = 0; m < (2u << r); m++) {
+            uint32_t v = m;
+            if (v == top || v == top - 1) v ^= 2 * top - 1;
+            const uint32_t code = (v < half) ? (v << 1) : (v < top) ? (((v - half) << 2) | 1) : (((v - top) << 2) | 3);
+            t.e[(2u << r) - 4 + m] = (uint16_t)(((r + (v >= half) + (v >= top)) << 12) | code);
+        }
+    }
+    return t;
+}
+static __device__ const WideEncTab wide_enc_tab = make_wide_enc_tab();
+
 // reads the rung-switch code at bit `pos`: returns the delta (mod 2^UB), sets *gpos to the first value code
 template <typename T, typename PTR>
 __device__ __forceinline__ uint32_t dec3_switch(PTR src, uint32_t endw, uint32_t pos, uint32_t *gpos, bool *signal) {
