@@ -495,14 +495,16 @@ def test_table_room_survives_a_raw_fallback(qb3, oracle):
 
 
 @pytest.mark.parametrize("case", [(8192, 4099, 3, 0, "NOISY3", FTL), (8192, 4099, 3, 0, "NOISY3", BASE), (16384, 8196, 1, 0, "NOISY3", FTL),
-                                  (8192, 4100, 1, 5, "DEM", BASE), (4096, 8200, 4, 2, "LANDSAT16", BASE)],
+                                  (8192, 4100, 1, 5, "DEM", BASE), (4096, 8200, 4, 2, "LANDSAT16", BASE),
+                                  (8192, 4099, 3, 0, "NOISY3", 5), (8192, 4100, 1, 5, "DEM", 5)],
                          ids=lambda c: "%dx%dx%d-t%d-m%d" % (c[0], c[1], c[2], c[3], c[5]))
 def test_host_api_pipelined_strips(qb3, oracle, case):
     """qb3_encode / qb3_read_data on rasters large enough for the strip pipeline (encode_pipelined / decode_pipelined, qb3_api.cpp:
     three or more scan groups of chunks, upload / coding / download of different strips at once): the container is the
     oracle's byte for byte -- with a shifted last block row, for the 8-bit, 16-bit and 32-bit lane-per-block kernels, FTL and
     BASE -- plain and self-indexed (the table chunks aside), and decodes exactly through the host API (the self-indexed one strip
-    by strip)"""
+    by strip).  The common-factor modes (mode 5: QB3M_CF_H) code in one piece -- a factor is carried across chunks -- but their
+    self-indexed containers decode strip by strip through the lane-per-block common-factor decoders"""
     w, h, b, dt, gen, mode = case
     img = oracle.generate(w, h, b, dt, gen, 5)
     ref = oracle.encode(img, dt, mode)
