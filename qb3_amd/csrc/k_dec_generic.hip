@@ -1,5 +1,6 @@
 // qb3_amd/csrc/k_dec_generic.hip -- generic decoders: unit-parallel (dec3_kernel), lane per segment (dec_kernel), serial index rebuild
 #include "qb3_wide.h"
+#include "qb3_walk.h"
 
 namespace qb3dev {
 
@@ -27,7 +28,7 @@ __device__ __forceinline__ void dec_segment(const DecArgs &a, const DecArgs &a0,
         }
     } else
         for (uint32_t c = 0; c < bands; c++) {
-            prev[c] = ((const T *)a.idx.prev)[seg * bands + c];
+            prev[c] = a.totals_only ? (T)0 : ((const T *)a.idx.prev)[seg * bands + c];      // (totals_only: the segment's sums, not pixels)
             pcf[c] = (MODE == CM_BEST) ? ((const T *)a.idx.cf)[seg * bands + c] : (T)0;
             rungs[c] = a.idx.rung[seg * bands + c];
         }
@@ -51,6 +52,7 @@ __device__ __forceinline__ void dec_segment(const DecArgs &a, const DecArgs &a0,
             }
             prev[c] = prv;
         }
+        if (a.totals_only) continue;        // (a plain stream, first pass: only what the segment's values add up to is wanted)
         // add the core band back, sequentially in place like the strip epilogue (reference QB3decode.h:560-567)
         for (uint32_t c = 0; c < bands; c++) {
             const uint32_t cb = a0.g.cband[c];
@@ -70,6 +72,10 @@ __device__ __forceinline__ void dec_segment(const DecArgs &a, const DecArgs &a0,
         }
     }
     if (!ok) atomicOr(a.status, 1u);
+    if (a.totals_only) {        // leave the per-band sums where the entering values go (prev_scan_kernel turns them into those)
+        for (uint32_t c = 0; c < bands; c++) ((T *)a.idx.prev)[seg * bands + c] = prev[c];
+        return;
+    }
     if (seg == nseg - 1) {
         // reference: fails when more than 7 bits are left (QB3decode.h:411,569,740); also flag overruns
         const uint64_t used = rd.position() + pos_bias - a.in_bit0;
@@ -480,6 +486,89 @@ __global__ void __launch_bounds__(64) dec_index_staged(const DecArgs a0, uint32_
     }
     if (lane == 0 && s_bad) atomicOr(a.status, 1u);
 }
+
+// Plain COMMON-FACTOR streams of several bands (no table memory helps them: the factor in force is part of the walk's state): the
+// same one-wave walk, but a unit WITHOUT the signal code -- nearly all of them -- is walked by LENGTH only (walk_unit, qb3_walk.h:
+// a code's length is its rung plus what its two low bits say; an eighth of what a full parse costs one lane), a unit with it is
+// parsed outright (its values decide the rung it leaves, QB3decode.h:619-716).  Leaves the segment entries (position, rungs,
+// factors); the entering VALUES come from the parallel decoder: dec_kernel in totals mode, then prev_scan_kernel.
+template <typename T>
+__global__ void __launch_bounds__(64) dec_index_walk_best(const DecArgs a0, uint32_t block_bits) {
+    const DecArgs a = dec_for_tile(a0, blockIdx.x);
+    constexpr uint32_t UB = UBits<T>::v;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[SERIAL_WIN + 8];
+    __shared__ uint64_t st_cf[MAXBANDS], s_P;
+    __shared__ uint32_t st_rung[MAXBANDS], s_gb, s_bad;
+    const uint32_t bands = a.g.bands, S = a.g.seg_blocks, lane = threadIdx.x, nblocks = (uint32_t)a.g.nblocks;
+    const uint32_t stage_bit0 = 8 * (uint32_t)(uintptr_t)(LdsWords)stage;
+    if (lane < bands) { st_cf[lane] = 0; st_rung[lane] = 0; }
+    if (lane == 0) { s_P = a.in_bit0; s_gb = 0; s_bad = 0; }
+    const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
+    __syncthreads();
+    while (true) {
+        const uint64_t P = s_P;
+        const uint32_t gb0 = s_gb;
+        if (gb0 >= nblocks || s_bad) break;
+        const uint64_t w0 = (P >> 5) & ~(uint64_t)3;
+        for (uint32_t i = lane; i < SERIAL_WIN + 8; i += 64) stage[i] = w0 + i < endw_abs ? a.in32[w0 + i] : 0u;
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t pos = (uint32_t)(P - 32 * w0);                 // bit position inside the window
+            bool ok = true;
+            uint32_t gb = gb0;
+            T g[16];
+            // a block is walked only while the longest possible one still ends inside the window
+            while (gb < nblocks && ok && pos + block_bits + 64 <= 32u * SERIAL_WIN) {
+                if (gb % S == 0) {
+                    const uint64_t seg = gb / S;
+                    a.idx.bitpos[seg] = 32 * w0 + pos - a.in_bit0;
+                    for (uint32_t c = 0; c < bands; c++) {
+                        ((T *)a.idx.cf)[seg * bands + c] = (T)st_cf[c];
+                        a.idx.rung[seg * bands + c] = (uint8_t)st_rung[c];
+                    }
+                }
+                const uint32_t b0 = pos;
+                uint32_t bt = 0;                                    // (block-table shapes: the block's bits | its units' entering rungs)
+                for (uint32_t c = 0; c < bands; c++) {
+                    uint32_t rung = st_rung[c];
+                    if (c < 4) bt |= (rung & (sizeof(T) >= 4 ? 63u : 15u)) << (16 + 4 * c);
+                    bool sig = false;
+                    const uint32_t len = walk_unit<UB>(stage_bit0 + pos, rung, sig);
+                    if (!sig) pos += len;
+                    else {                                          // common-factor or index form: the whole unit
+                        ReaderT<LdsWords> rd;
+                        rd.init((LdsWords)stage, pos, 32ull * (SERIAL_WIN + 8));
+                        rung = st_rung[c];
+                        T cf = (T)st_cf[c];
+                        ok = parse_unit<T, CM_BEST, ReaderT<LdsWords>>(rd, rung, cf, g) && ok;
+                        st_cf[c] = (uint64_t)cf;
+                        pos = (uint32_t)rd.position();
+                    }
+                    st_rung[c] = rung;
+                }
+                if (a.g.ulen_sz == 4) ((uint32_t *)a.idx.ulen)[gb] = bt | ((pos - b0) & 0xffffu);
+                gb++;
+            }
+            s_P = 32 * w0 + pos;
+            if (gb == gb0 && ok) ok = false;        // (no block fits the window: cannot happen for a valid geometry; do not spin)
+            s_gb = gb;
+            if (!ok) s_bad = 1;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && s_bad) atomicOr(a.status, 1u);
+}
+void launch_dec_index_walk_best(const DecArgs &a, hipStream_t st) {
+    const uint32_t block_bits = a.g.bands * max_unit_bits(a.g.tsz, a.g.mode);
+    const dim3 grid(a.ntiles), block(64);
+    switch (a.g.tsz) {
+    case 1: hipLaunchKernelGGL((dec_index_walk_best<uint8_t>), grid, block, 0, st, a, block_bits); break;
+    case 2: hipLaunchKernelGGL((dec_index_walk_best<uint16_t>), grid, block, 0, st, a, block_bits); break;
+    case 4: hipLaunchKernelGGL((dec_index_walk_best<uint32_t>), grid, block, 0, st, a, block_bits); break;
+    default: hipLaunchKernelGGL((dec_index_walk_best<uint64_t>), grid, block, 0, st, a, block_bits); break;
+    }
+}
+bool dec_index_walk_best_ok(const DecArgs &a) { return a.g.mode == CM_BEST && (a.g.ulen_sz == 0 || a.g.ulen_sz == 4) && a.g.bands * max_unit_bits(a.g.tsz, a.g.mode) + 64 + 64 <= 32 * SERIAL_WIN; }
 
 template <typename T>
 static void launch_dec_generic_t(const DecArgs &a, const DecPlan &plan, hipStream_t st) {

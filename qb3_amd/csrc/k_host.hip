@@ -590,6 +590,15 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         const bool best_plain = best && !a.ix && (a.g.bands == 1 || (a.g.bands == 3 && a.g.tsz == 1)) && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&
                                 !tuning().slow_walk && !tuning().slow_index && launch_dec_walk_best(a, st, walk_tab, walk_tab_bytes, max_bits);
         if (best_plain) { ProfScope ps("dec_index_scan", st); launch_prev_scan(a, st); }
+        else if (best && !a.ix && dec_index_walk_best_ok(a) && !tuning().slow_index) {
+            // common-factor streams the exits do not take (several bands; no table memory): one wave walks lengths (units with
+            // the signal code parsed outright), the generic decoder adds up every segment's values, a scan makes entering values
+            // of the sums
+            { ProfScope ps("dec_index_serial", st); launch_dec_index_walk_best(a, st); }
+            { ProfScope ps("dec_index_prev", st); DecArgs t = a; t.totals_only = 1; launch_dec_generic(t, plan, st); }
+            ProfScope ps("dec_index_scan", st);
+            launch_prev_scan(a, st);
+        }
         else { ProfScope ps("dec_index_serial", st); launch_dec_index_serial(a, st); }
     }
     if (best_px && !a.from_ix) { ProfScope ps("dec_units", st); dec_best_lpb(a); }

@@ -589,6 +589,8 @@ void launch_enc_post_strip(const EncArgs &a, const EncPlan &plan, hipStream_t st
 void launch_enc_post_tail(const EncArgs &a, const EncPlan &plan, hipStream_t st);  // ... behind the last strip: index positions, table, header
 void launch_dec_generic(const DecArgs &a, const DecPlan &plan, hipStream_t st);    // k_dec_generic.hip: dec3_kernel / dec_kernel
 void launch_dec_index_serial(const DecArgs &a, hipStream_t st);                    // k_dec_generic.hip
+void launch_dec_index_walk_best(const DecArgs &a, hipStream_t st);                 // k_dec_generic.hip: plain common-factor streams of several bands: lengths by one wave, values by the parallel decoder
+bool dec_index_walk_best_ok(const DecArgs &a);
 void launch_dec_px(const DecArgs &a, const DecPlan &plan, hipStream_t st);         // k_dec_px.hip
 void launch_dec_px16(const DecArgs &a, const DecPlan &plan, hipStream_t st);       // k_dec_px16.hip
 void launch_dec_pxw(const DecArgs &a, const DecPlan &plan, hipStream_t st);        // k_dec_pxw.hip

@@ -34,6 +34,23 @@ def main():
         rep = qdev.profile_report()
         print(name, {k: round(ms / max(c, 1), 4) for k, (ms, c) in sorted(rep.items())}, flush=True)
     print("container", int(n), "raw", raw.numel(), "ratio", round(int(n) / raw.numel(), 4))
+    if os.environ.get("PROBE_PLAIN"):           # the same raster as the reference writes it (no table), decoded from the stream alone
+        import time
+        penc = qdev.DeviceEncoder(w, h, b, dt, mode=mode)
+        pdst, pn, _ = penc.encode(img)
+        pdec = qdev.DeviceDecoder(pdst, pn)
+        out.zero_()
+        pdec.decode(pdst, out=out, index=None)
+        assert torch.equal(out, raw), "plain decode != x"
+        qdev.profile_reset(); qdev.profile_enable(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pdec.decode(pdst, out=out, index=None)
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        qdev.profile_enable(False)
+        print("decode_plain", {k: round(ms / max(c, 1), 3) for k, (ms, c) in sorted(qdev.profile_report().items())}, "wall ms", round(dt_s * 1e3, 2), "MPixel/s", round(w * h / dt_s / 1e6, 1),
+              "status", qb3_amd.lib.qb3x_last_decode_status(pdec.p))
 
 
 if __name__ == "__main__":
