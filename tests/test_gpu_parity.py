@@ -1067,6 +1067,40 @@ def test_handles_are_independent_across_threads(qb3, oracle):
     assert not errors, errors
 
 
+def test_pipelined_host_calls_from_two_threads(qb3, oracle):
+    """the strip pipeline (three streams, two rings of pinned slices a handle, ONE pool of copy threads a process) under two
+    host threads at once, each with its own handles and a raster large enough for it: streams equal the oracle's, pixels exact"""
+    import threading
+    cases = [(8192, 4099, 3, 0, "NOISY3", FTL), (8192, 4100, 1, 5, "DEM", BASE)]
+    imgs = [oracle.generate(w, h, b, dt, gen, 40 + i) for i, (w, h, b, dt, gen, m) in enumerate(cases)]
+    refs = [oracle.encode(img, c[3], c[5]) for img, c in zip(imgs, cases)]
+    errors = []
+
+    def work(i):
+        w, h, b, dt, gen, mode = cases[i]
+        try:
+            for _ in range(3):
+                got = qb3.encode(imgs[i], dt, mode)
+                if not np.array_equal(got, refs[i]):
+                    errors.append("thread %d: stream differs" % i)
+                    return
+                two = qb3.encode(imgs[i], dt, mode, index_chunk=2)
+                out, _, _, _ = qb3.decode(two)
+                if not np.array_equal(out, imgs[i].view(np.uint8).ravel()):
+                    errors.append("thread %d: pixels differ" % i)
+                    return
+        except Exception as e:      # noqa: BLE001 -- report whatever a worker thread hit
+            errors.append("thread %d: %r" % (i, e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    qb3.lib.qb3x_trim()                                 # (the rings and pooled buffers of the handles that went)
+
+
 @pytest.mark.parametrize("case", [(1024, 1024, 3, 0, "NOISY3", 4), (509, 259, 1, 0, "GRAD", 8), (1024, 768, 8, 2, "LANDSAT16", 4),
                                   (300, 200, 2, 2, "LANDSAT16", 8), (512, 512, 1, 4, "DEM", 8), (256, 256, 1, 7, "DEM", 4)])
 def test_restart_table_does_not_depend_on_the_index_request(qb3, oracle, case):
