@@ -15,6 +15,7 @@
 namespace qb3dev {
 
 __device__ __forceinline__ uint32_t wave_exscan_t(uint32_t v) { return wave_iscan32(v) - v; }
+__device__ __forceinline__ uint16_t wave_exscan_t(uint16_t v) { return (uint16_t)(wave_iscan32((uint32_t)v) - (uint32_t)v); }
 __device__ __forceinline__ uint64_t wave_exscan_t(uint64_t v) {
     const uint32_t lane = threadIdx.x & 63;
     uint64_t x = v;
@@ -27,6 +28,11 @@ __device__ __forceinline__ uint64_t wave_exscan_t(uint64_t v) {
 }
 __device__ __forceinline__ void pxw_store_row(uint32_t *p, const uint32_t (&r)[4]) {
     typedef uint32_t v4 __attribute__((ext_vector_type(4), aligned(4)));
+    const v4 v = { r[0], r[1], r[2], r[3] };
+    *(v4 *)p = v;
+}
+__device__ __forceinline__ void pxw_store_row(uint16_t *p, const uint16_t (&r)[4]) {
+    typedef uint16_t v4 __attribute__((ext_vector_type(4), aligned(2)));
     const v4 v = { r[0], r[1], r[2], r[3] };
     *(v4 *)p = v;
 }
@@ -306,7 +312,8 @@ static void launch_dec_pxw_best_t(const DecArgs &a, const DecPlan &plan, hipStre
     else hipLaunchKernelGGL((dec_pxw_best_kernel<T, HILBERT, false>), grid, block, lds, st, a);
 }
 void launch_dec_pxw_best(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
-    if (a.g.tsz == 4) launch_dec_pxw_best_t<uint32_t>(a, plan, st);
+    if (a.g.tsz == 2) launch_dec_pxw_best_t<uint16_t>(a, plan, st);
+    else if (a.g.tsz == 4) launch_dec_pxw_best_t<uint32_t>(a, plan, st);
     else launch_dec_pxw_best_t<uint64_t>(a, plan, st);
 }
 

@@ -355,8 +355,8 @@ static void launch_enc_best_f(const EncArgs &a, const EncPlan &plan, hipStream_t
 }
 template <typename T>
 static void launch_enc_best_t(const EncArgs &a, const EncPlan &plan, hipStream_t st) {
-    if constexpr (sizeof(T) >= 4) {
-        // one band of 32/64-bit data (value-aligned pointers): the lane-per-block front end
+    if constexpr (sizeof(T) >= 2) {
+        // one band of 16/32/64-bit data (value-aligned pointers): the lane-per-block front end
         if (plan.pxw_best && ((uintptr_t)a.img & (sizeof(T) - 1)) == 0 && !(a.ts_img & (sizeof(T) - 1))) {
             if (a.g.order == ZCURVE) launch_enc_best_f<T, 2>(a, plan, st); else launch_enc_best_f<T, 1>(a, plan, st);
             return;

@@ -497,7 +497,7 @@ static void launch_enc_tables(const EncArgs &a, hipStream_t st) {
         const uint32_t tpe = (a.ix_blocks * a.g.bands + 1) / 2;
         hipLaunchKernelGGL(ix_blw_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * tpe + 255) / 256), nt), dim3(256), 0, st, a, tpe);
     }
-    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 2) hipLaunchKernelGGL(ix_bl16_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * (a.g.bands == 1 ? 16 : 32) + 255) / 256), nt), dim3(256), 0, st, a);
+    if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 2 && a.g.mode != CM_BEST) hipLaunchKernelGGL(ix_bl16_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * (a.g.bands == 1 ? 16 : 32) + 255) / 256), nt), dim3(256), 0, st, a);
     if (a.ix_dst && a.have_idx) hipLaunchKernelGGL(ix_seal_kernel, dim3((a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk, nt), dim3(256), 0, st, a);
 }
 

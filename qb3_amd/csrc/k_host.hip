@@ -272,8 +272,9 @@ static bool px16_eligible(const Geometry &g, bool *rgb, uint32_t *bg, uint32_t *
 
 // the 32/64-bit lane-per-block kernels: one band (a block is a unit), FTL / BASE, Hilbert or Z curve; any width, stride and
 // (value-aligned) pointer
+// (the common-factor kernels also take 16-bit rasters of one band -- int16 elevation: their FTL / BASE streams have the 16-bit kernels)
 static bool pxw_eligible(const Geometry &g, bool best = false) {
-    return g.tsz >= 4 && g.bands == 1 && (g.mode == CM_BEST) == best && g.w >= 4 && g.h >= 4 && (g.order == HILBERT || g.order == ZCURVE) && !tuning().no_px;
+    return (g.tsz >= 4 || (best && g.tsz == 2)) && g.bands == 1 && (g.mode == CM_BEST) == best && g.w >= 4 && g.h >= 4 && (g.order == HILBERT || g.order == ZCURVE) && !tuning().no_px;
 }
 
 EncPlan plan_encode(const Geometry &g) {

@@ -1180,7 +1180,7 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
     uint32_t status = 0;
     IxTable table = ix;
     // (32/64-bit plain streams: the table of a band of sixteen rungs; a stream that leaves the band goes to the one-lane parser)
-    bool walk_tab_ok = true;
+    bool walk_tab_ok = true, dropped_table = false;
     const uint32_t wide_band = 16;
     for (int turn = 0; turn < 3; turn++) {
         for (int full = 0; full < 2; full++) {      // (second turn: a 16-bit segment outgrew the staging sized for the stream's average)
@@ -1189,6 +1189,7 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
                 return false;
             const hipError_t e = fetch_small(&status, d_status, 4, st);
             if (e != hipSuccess) { set_error("decode kernels", (int)e); return false; }
+            { static const bool dbg = getenv("QB3_DEBUG_DEC") != nullptr; if (dbg) fprintf(stderr, "decode turn %d full %d: status %u (table %d)\n", turn, full, status, table.base != nullptr); }
             if (!(status & 16)) break;
         }
         // The container's restart table is a convenience the format does not protect: when its check fails (bit 5) or the
@@ -1197,12 +1198,13 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
         if (!(status & (27 | 32)) || d_index) break;
         if (table.base) {
             table = IxTable();
+            dropped_table = true;
             if (!walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
         } else if (walk_tab_ok && (g.tsz >= 4 || g.mode == CM_BEST) && p->d_tab.p && walk_table_applies(g, plan)) walk_tab_ok = false;
         else break;
     }
     prof_collect();
-    p->last_status = status;
+    p->last_status = status | (dropped_table ? 32u : 0u);        // (bit 5: the container's table was not used in the end, whatever made it so)
     // bit 0: corrupt unit, bit 1: more than 7 unused bits at the end (reference QB3decode.h:411,569,740).
     // bit 2 (ran past the end) is not an error in the reference, whose reader clamps (bitstream.h:36).
     // bit 3: the index handed in does not describe this stream (a segment longer than any valid one).

@@ -53,9 +53,9 @@ uint32_t seg_blocks_for(const Geometry &g);      // needs w, h, bands, tsz, stri
 uint32_t ulen_size_for(uint32_t tsz, uint32_t mode, uint32_t bands);
 inline size_t ulen_table_bytes(const Geometry &g) { return g.ulen_sz == 4 ? (size_t)g.nblocks * 4 : (size_t)g.nblocks * g.bands * g.ulen_sz; }
 // common-factor streams whose index holds a dword per BLOCK (its bits | the rungs its units are entered with << 16) for a
-// lane-per-block decoder: 8-bit rasters of 1/3/4 bands (four bits a band), 32/64-bit rasters of one band (the whole rung)
+// lane-per-block decoder: 8-bit rasters of 1/3/4 bands (four bits a band), 16/32/64-bit rasters of one band (the whole rung)
 inline bool best_block_table(uint32_t tsz, uint32_t mode, uint32_t bands) {
-    return mode == CM_BEST && ((tsz == 1 && (bands == 1 || bands == 3 || bands == 4)) || (tsz >= 4 && bands == 1));
+    return mode == CM_BEST && ((tsz == 1 && (bands == 1 || bands == 3 || bands == 4)) || (tsz >= 2 && bands == 1));
 }
 
 // Results the encoder hands back to the host (device resident, copied once per encode)

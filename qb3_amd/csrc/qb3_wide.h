@@ -29,10 +29,15 @@ static __device__ const WideDecTab wide_dec_tab = make_wide_dec_tab();
 template <typename T> struct WideVec;
 template <> struct WideVec<uint32_t> { typedef uint32_t v4 __attribute__((ext_vector_type(4), aligned(4))); };
 template <> struct WideVec<uint64_t> { typedef uint64_t v2 __attribute__((ext_vector_type(2), aligned(8))); };
+template <> struct WideVec<uint16_t> { typedef uint16_t v4 __attribute__((ext_vector_type(4), aligned(2))); };
 
 // four values of a row at any T-aligned address
 __device__ __forceinline__ void pxw_load_row(const uint32_t *p, uint32_t (&r)[4]) {
     const WideVec<uint32_t>::v4 v = *(const WideVec<uint32_t>::v4 *)p;
+    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+}
+__device__ __forceinline__ void pxw_load_row(const uint16_t *p, uint16_t (&r)[4]) {
+    const WideVec<uint16_t>::v4 v = *(const WideVec<uint16_t>::v4 *)p;
     r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
 }
 __device__ __forceinline__ void pxw_load_row(const uint64_t *p, uint64_t (&r)[4]) {

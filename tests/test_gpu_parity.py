@@ -1067,6 +1067,33 @@ def test_handles_are_independent_across_threads(qb3, oracle):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("case", [(512, 384, 3, 0, "NOISY3", FTL), (512, 384, 1, 0, "NOISY3", BASE), (512, 384, 4, 0, "NOISY3", 5), (512, 384, 3, 0, "NOISY3", 5),
+                                  (384, 256, 8, 2, "LANDSAT16", BASE), (384, 256, 4, 3, "DEM", FTL), (384, 256, 1, 2, "LANDSAT16", BASE), (384, 256, 3, 2, "LANDSAT16", FTL),
+                                  (384, 256, 1, 3, "DEM", 5), (384, 256, 1, 2, "LANDSAT16", 7), (320, 256, 1, 5, "DEM", FTL), (320, 256, 1, 7, "DEM", BASE),
+                                  (320, 256, 1, 5, "DEM", 5), (320, 256, 1, 6, "TERRACE", 5), (320, 256, 5, 0, "NOISY3", FTL), (320, 256, 2, 5, "DEM", 5)],
+                         ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % c)
+def test_self_indexed_containers_decode_from_their_table(qb3, oracle, case):
+    """a container written with its restart table decodes FROM the table: the decode reports status 0 -- no fallback to the walk
+    (bit 5 says the table was dropped: a table the decoder cannot use costs time silently otherwise, as the 16-bit common-factor
+    table did while two fill kernels wrote it), for every raster shape that gets a table, at both levels"""
+    import torch
+    from qb3_amd import device as qdev, synth
+    w, h, b, dt, gen, mode = case
+    img = synth.generate(w, h, b, dt, gen, 12)
+    raw = img.reshape(-1).view(torch.uint8)
+    cb = None if b in (1, 3, 4) else list(range(b))
+    for level in (1, 2):
+        enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cb, index_chunk=level, want_index=False)
+        dst, n, _ = enc.encode(img)
+        if int(dst[10]) in (255, 2, 3, 6, 7):
+            continue                                    # raw-stored, or the RLE0 pass won: no table
+        dec = qdev.DeviceDecoder(dst, n)
+        assert qb3.lib.qb3x_decoder_table_entries(dec.p) > 0, level
+        out = dec.decode(dst, index=None)
+        assert torch.equal(out.view(torch.uint8), raw), level
+        assert qb3.lib.qb3x_last_decode_status(dec.p) == 0, (level, qb3.lib.qb3x_last_decode_status(dec.p))
+
+
 def test_pipelined_host_calls_from_two_threads(qb3, oracle):
     """the strip pipeline (three streams, two rings of pinned slices a handle, ONE pool of copy threads a process) under two
     host threads at once, each with its own handles and a raster large enough for it: streams equal the oracle's, pixels exact"""
