@@ -237,6 +237,14 @@ size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits, uint32_t tsz) {
     return (((size_t)ntiles * sizeof(WalkState16) + 255) & ~(size_t)255) + (size_t)win_bytes * ntiles * need + 4096;
 }
 size_t walk_table_min_bytes(uint32_t ntiles, uint32_t tsz) { return walk_table_bytes(ntiles, 2 * 16 * walk_cw(tsz), tsz); }
+// ... and what the walk that will actually run wants: a raster that walks by exits needs 2-14 bytes a stream bit, not the
+// chains' 16-32 (a decoder handle keeps this memory, and its pool after it)
+size_t walk_memory_bytes(const Geometry &g, uint32_t ntiles, uint64_t max_bits) {
+    const size_t chain = walk_table_bytes(ntiles, max_bits, g.tsz), least = walk_table_min_bytes(ntiles, g.tsz);
+    const size_t ex = walk_exit_bytes(g.tsz, g.bands, g.mode == CM_BEST, ntiles, max_bits);
+    if (!ex) return chain;
+    return ex < least ? least : ex;       // (the chain must still fit as the fallback's first rung)
+}
 
 void launch_dec_walk(const DecArgs &a, hipStream_t st) {
     if (a.ix) {                             // the containers' own restart tables: a lane per entry

@@ -719,6 +719,25 @@ bool launch_dec_walk_best(const DecArgs &a, hipStream_t st, void *tab, size_t ta
     return a.g.tsz == 1 ? launch_walk_exit<3, uint8_t, CM_BEST>(a, st, tab, tab_bytes, max_bits) : a.g.tsz == 2 ? launch_walk_exit<4, uint16_t, CM_BEST>(a, st, tab, tab_bytes, max_bits)
          : a.g.tsz == 4 ? launch_walk_exit<5, uint32_t, CM_BEST>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<6, uint64_t, CM_BEST>(a, st, tab, tab_bytes, max_bits);
 }
+// table memory that takes `max_bits` of every stream through the exits in ONE round (states, entries, the exits of every
+// super-window); 0: a raster of this shape, in a batch of this many tiles, does not walk by exits (launch_dec_walk_table's rules)
+size_t walk_exit_bytes(uint32_t tsz, uint32_t bands, bool best, uint32_t nt, uint64_t max_bits) {
+    uint64_t sw = 0, nx = 0;
+    if (bands == 1 && nt <= 16) {
+        switch (tsz) {
+        case 1: sw = exitW<3>::SW; nx = exitW<3>::NX; break;
+        case 2: sw = exitW<4>::SW; nx = exitW<4>::NX; break;
+        case 4: sw = exitW<5>::SW; nx = exitW<5>::NX; break;
+        default: sw = exitW<6>::SW; nx = exitW<6>::NX; break;
+        }
+    } else if (tsz == 1 && bands == 3 && nt <= 4) {
+        if (best) { sw = exitB<3, true>::SW; nx = exitB<3, true>::NKEY; } else { sw = exitB<3, false>::SW; nx = exitB<3, false>::NKEY; }
+    } else return 0;
+    const uint64_t ns = (max_bits + sw - 1) / sw;
+    const size_t fixed = (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255) + (((size_t)nt * (ns + 2) * 32 + 255) & ~(size_t)255);
+    return fixed + (size_t)nt * nx * 4 * ns + 4096;
+}
+
 bool walk_exit_lds_ok() {
     static const bool lds_ok = [] {
         bool ok = true;

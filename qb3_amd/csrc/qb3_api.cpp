@@ -1162,7 +1162,7 @@ QB3_API size_t qb3x_decoder_index_size(const decsp p) {
 // the decoder holds one -- the whole call in one round, or walk_table_cap() and several rounds.  False: out of memory.
 static bool walk_table_ready(decsp p, const Geometry &g, const DecPlan &plan, uint32_t ntiles, uint64_t max_bits) {
     if (!walk_table_applies(g, plan)) return true;
-    size_t want = walk_table_bytes(ntiles, max_bits, g.tsz);
+    size_t want = walk_memory_bytes(g, ntiles, max_bits);
     const size_t least = walk_table_min_bytes(ntiles, g.tsz);
     const size_t cap = walk_table_cap();
     if (want > cap) want = cap > least ? cap : least;

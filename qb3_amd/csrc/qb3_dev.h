@@ -145,6 +145,7 @@ struct TileBatch { uint32_t n = 0; uint64_t src_pitch = 0, dst_pitch = 0, ws_pit
 // walk_table_bytes: memory that takes the whole call in one round; less means more rounds, down to walk_table_min_bytes.
 size_t walk_table_bytes(uint32_t ntiles, uint64_t max_bits, uint32_t tsz);
 size_t walk_table_min_bytes(uint32_t ntiles, uint32_t tsz);
+size_t walk_memory_bytes(const Geometry &g, uint32_t ntiles, uint64_t max_bits);     // what the walk that will run for this raster wants (exits need far less than chains)
 size_t walk_table_cap();                // what a decoder allocates at most (1 GiB; QB3_WALK_TAB_KB overrides)
 struct DecPlan;
 bool walk_table_applies(const Geometry &g, const DecPlan &plan);

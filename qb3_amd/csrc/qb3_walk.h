@@ -176,6 +176,7 @@ void walk_chain_16bit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_by
 void walk_chain_wide(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);      // (probes the first segment itself)
 // k_dec_walk_exit.hip: the walks by exits; false: not taken (no table memory for them)
 bool walk_exit_lds_ok();
+size_t walk_exit_bytes(uint32_t tsz, uint32_t bands, bool best, uint32_t nt, uint64_t max_bits);
 bool walk_exits_one_band(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);  // FTL / BASE, one band of any width
 bool walk_exits_rgb(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);       // FTL / BASE, 8-bit RGB
 
