@@ -542,6 +542,17 @@ def main():
             plain[ptag] = {"workload": f"4096x4096x1 {pname}, plain container, index = NULL"}
             plain[ptag].update(plain_decode(pimg, 4096, 1, pdt_, pmode))
             del pimg
+        # several bands beyond 8-bit RGB: the chained table walks (FTL / BASE) and, for common-factor streams, one wave walking
+        # unit lengths ("what comes next" (1): these are at or below one CPU core's pace)
+        for ptag, pw, pb, pdt_, pgen, pmode, pname in (("uint8x4_ftl", 2048, 4, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_FTL, "x4 uint8 NOISY3, QB3M_FTL"),
+                                                       ("uint8x4_best", 2048, 4, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_BEST, "x4 uint8 NOISY3, QB3M_BEST"),
+                                                       ("uint16x8_base", 2048, 8, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BASE, "x8 uint16 LANDSAT16, QB3M_BASE"),
+                                                       ("uint16x8_best", 1024, 8, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BEST, "x8 uint16 LANDSAT16, QB3M_BEST"),
+                                                       ("int32x2_base", 2048, 2, qb3_amd.QB3_I32, "DEM", qb3_amd.QB3M_BASE, "x2 int32 DEM, QB3M_BASE")):
+            pimg = synth.generate(pw, pw, pb, pdt_, pgen, 4, device=dev)
+            plain[ptag] = {"workload": f"{pw}x{pw}{pname} seed 4, plain container, index = NULL"}
+            plain[ptag].update(plain_decode(pimg, pw, pb, pdt_, pmode))
+            del pimg
         torch.cuda.empty_cache()
 
     roofline = roofline_of(avg, algo, ENC_KERNELS + DEC_KERNELS, extra={"restart_table_in_container": int(n) - stream_bytes})
@@ -600,8 +611,9 @@ def main():
 
 
 def host_api_times(qb3_amd, img, W, H, table_level):
-    """qb3_encode / qb3_read_data of the headline raster through HOST pointers (the literal drop-in calls): best of two,
-    PCIe transfers included -- not part of `value`"""
+    """qb3_encode / qb3_read_data of the headline raster through HOST pointers (the literal drop-in calls): best of three,
+    the host link included (upload, coding and download of different strips at once: qb3_api.cpp, encode_pipelined /
+    decode_pipelined) -- not part of `value`"""
     import numpy as np
     L = qb3_amd.lib
     host = np.ascontiguousarray(img.cpu().numpy()).reshape(H, W, 3)

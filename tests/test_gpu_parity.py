@@ -320,29 +320,51 @@ def test_quanta(qb3, oracle, dtype, q, away):
     assert np.array_equal(out, ref_out)
 
 
-def test_stride(qb3, oracle):
+@pytest.mark.parametrize("case", [(30, 18, 3, 0, "NOISY3", FTL), (70, 26, 1, 5, "DEM", FTL), (70, 26, 1, 7, "DEM", BASE), (70, 26, 1, 5, "DEM", 5),
+                                  (70, 26, 1, 3, "DEM", 5), (70, 26, 1, 6, "TERRACE", 5), (66, 22, 8, 2, "LANDSAT16", BASE)],
+                         ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % c)
+def test_stride(qb3, oracle, case):
+    """a line stride (in values, QB3.h:116-120,146-148) on both sides: rows that start at odd multiples of the value size --
+    for the lane-per-block kernels of every width (the 32/64-bit ones read and write rows as 16-byte pieces at value
+    alignment only), FTL, BASE and the common-factor modes"""
     import ctypes as C
-    w, h, b = 30, 18, 3
+    w, h, b, dt, gen, mode = case
+    npdt = {0: np.uint8, 2: np.uint16, 3: np.int16, 5: np.int32, 6: np.uint64, 7: np.int64}[dt]
     stride = w * b + 7
-    canvas = np.zeros((h, stride), np.uint8)
-    img = oracle.generate(w, h, b, 0, "NOISY3", 2)
+    canvas = np.zeros((h, stride), npdt)
+    img = oracle.generate(w, h, b, dt, gen, 2)
     canvas[:, :w * b] = img.reshape(h, w * b)
+    cb = None if b in (1, 3, 4) else list(range(b))
     L = qb3.lib
-    p = L.qb3_create_encoder(w, h, b, 0)
+    p = L.qb3_create_encoder(w, h, b, dt)
+    L.qb3_set_encoder_mode(p, mode)
+    if cb is not None:
+        arr = (C.c_size_t * b)(*cb)
+        L.qb3_set_encoder_coreband(p, b, arr)
     L.qb3_set_encoder_stride(p, stride)
     dst = np.zeros(L.qb3_max_encoded_size(p), np.uint8)
     n = L.qb3_encode(p, canvas.ctypes.data, dst.ctypes.data)
     L.qb3_destroy_encoder(p)
-    ref = oracle.encode(img, 0)
+    ref = oracle.encode(img, dt, mode, cband=cb)
     assert n == len(ref) and np.array_equal(dst[:n], ref)
     dims = (C.c_size_t * 3)()
     d = L.qb3_read_start(ref.ctypes.data, ref.size, dims)
     assert L.qb3_read_info(d)
     L.qb3_set_decoder_stride(d, stride)
-    out = np.zeros((h, stride), np.uint8)
+    out = np.zeros((h, stride), npdt)
     assert L.qb3_read_data(d, out.ctypes.data) == img.nbytes
     L.qb3_destroy_decoder(d)
     assert np.array_equal(out[:, :w * b], img.reshape(h, w * b)) and not out[:, w * b:].any()
+    # ... and straight into a strided device buffer (the device flavour decodes in place: no compact copy in between)
+    import torch
+    from qb3_amd import device as qdev
+    dref = torch.from_numpy(ref.copy()).cuda()
+    dec = qdev.DeviceDecoder(dref, len(ref))
+    L.qb3_set_decoder_stride(dec.p, stride)
+    dout = torch.zeros(h * stride * img.itemsize, dtype=torch.uint8, device="cuda")
+    assert L.qb3x_decode_device(dec.p, dref.data_ptr(), dout.data_ptr(), None, None) == img.nbytes
+    got = dout.cpu().numpy().view(npdt).reshape(h, stride)
+    assert np.array_equal(got[:, :w * b], img.reshape(h, w * b)) and not got[:, w * b:].any()
 
 
 @pytest.mark.parametrize("bands,mode", [(8, FTL), (8, BASE), (4, FTL), (2, BASE)])
