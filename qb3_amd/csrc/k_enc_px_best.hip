@@ -564,7 +564,7 @@ static void launch_enc_px_best_o(const EncArgs &a, const EncPlan &plan, hipStrea
         ProfScope ps("enc_best_units", st);
         if (a.ntiles > 1) (void)hipMemset2DAsync(a.recode_n, a.ts_ws, 0, 8, a.ntiles, st);
         else (void)hipMemsetAsync(a.recode_n, 0, 8, st);
-        hipLaunchKernelGGL((enc_px_best_sample_kernel<B, RGB, ORDER>), dim3(best_sample_count(plan.nchunks), a.ntiles), block, plan.lds_bytes, st, a);
+        if (plan.nchunks >= tuning().best_sample_min) hipLaunchKernelGGL((enc_px_best_sample_kernel<B, RGB, ORDER>), dim3(best_sample_count(plan.nchunks), a.ntiles), block, plan.lds_bytes, st, a);
         hipLaunchKernelGGL((enc_px_best_kernel<B, RGB, ORDER, true>), grid, block, plan.lds_bytes, st, a);
     }
     launch_best_scan(a, st);

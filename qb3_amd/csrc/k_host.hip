@@ -22,6 +22,7 @@ const Tuning &tuning() {
         v.slow_index = on("QB3_SLOW_INDEX");         // index-less streams: the one-lane index rebuild instead of the walkers
         { const char *e = getenv("QB3_WIDE_BAND"); v.wide_band = e && e[0] ? atoi(e) : 0; }      // plain 32/64-bit streams: rungs in the table's band (test hook)
         v.no_bl = on("QB3_NO_BLOCK_LENGTHS");        // containers whose table carries block lengths: walk them like the others
+        { const char *e = getenv("QB3_BEST_SAMPLE_MIN"); v.best_sample_min = e && e[0] ? (uint32_t)strtoul(e, nullptr, 10) : BEST_SAMPLE_MIN; }   // chunks from which the common-factor encoders sample before they code (0: always -- how the tests reach the two-pass coding on small rasters)
         return v;
     }();
     return t;

@@ -285,6 +285,9 @@ template <typename T> __device__ __forceinline__ void put_value(LdsWriter &w, T 
 
 constexpr uint32_t SCAN_GROUP = 4096;      // chunks per workgroup of enc_scan_kernel
 // chunks the common-factor encoders analyse first, to choose between one coding pass and two: an eighth of them, 64 at least, 1024 at most
+// (a raster of fewer than BEST_SAMPLE_MIN chunks is not sampled at all: coding it once and again where the assumption was wrong costs at
+// most a second pass, which is what the sample could save -- and the sample is a launch of its own, a fifth of such a raster's coding time)
+constexpr uint32_t BEST_SAMPLE_MIN = 32768;
 __host__ __device__ constexpr uint32_t best_sample_count(uint32_t nchunks) { return nchunks <= 64 ? nchunks : (nchunks / 8 < 64 ? 64u : nchunks / 8 > 1024 ? 1024u : nchunks / 8); }
 // every coding kernel's first workgroup: the counter by which enc_scan_kernel's last workgroup knows itself (behind the group sums)
 __device__ __forceinline__ void enc_scan_counter_reset(const EncArgs &a) {
@@ -571,7 +574,7 @@ struct ProfScope {
 };
 
 // process-wide debugging switches, read once from the environment (k_host.hip)
-struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool no_bl; size_t walk_tab_kb; int wide_band; };
+struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool no_bl; size_t walk_tab_kb; int wide_band; uint32_t best_sample_min; };
 const Tuning &tuning();
 
 uint32_t magic_div(uint32_t d);

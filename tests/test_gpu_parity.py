@@ -1358,6 +1358,43 @@ def test_tiles_with_block_length_tables(qb3, oracle):
     assert torch.equal(out, imgs) and buf.value == b"dec_units", buf.value
 
 
+def test_common_factor_two_pass_coding_on_small_rasters(qb3, oracle):
+    """The common-factor encoders sample a raster before they code it only from 32768 chunks on (below that coding once and
+    again where needed costs no more than the sample would save); QB3_BEST_SAMPLE_MIN=0 makes them sample always, which is how
+    the two-pass coding -- data whose every unit brings a factor: all values scaled by three -- stays tested on small rasters,
+    for the 8-bit lane-per-block kernel, the unit-per-lane kernel and the 32-bit lane-per-block front end.  (A child process:
+    the switch is read once.)"""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import qb3_amd
+from oracle import pyoracle as o
+for (w, h, b, dt, gen, mode) in [(1024, 768, 3, 0, "NOISY3", 5), (1024, 768, 3, 0, "SCALED", 5), (512, 512, 2, 2, "SCALED", 7), (1024, 512, 1, 5, "SCALED", 5),
+                                 (1024, 512, 1, 5, "DEM", 7), (640, 480, 1, 3, "SCALED", 5), (512, 512, 1, 7, "SCALED", 1)]:
+    if gen == "SCALED":
+        base = o.generate(w, h, b, dt, "NOISY3" if dt < 4 else "DEM", 9)
+        img = ((base.astype(np.int64) // 3) * 3).astype(base.dtype)
+    else:
+        img = o.generate(w, h, b, dt, gen, 9)
+    cb = None if b in (1, 3, 4) else list(range(b))
+    ref = o.encode(img, dt, mode, cband=cb)
+    for rep in range(2):
+        got = qb3_amd.encode(img, dt, mode, cband=cb)
+        assert len(got) == len(ref) and np.array_equal(got, ref), (w, h, b, dt, gen, mode, rep)
+    out, _, _, _ = qb3_amd.decode(got)
+    assert np.array_equal(out, img.view(np.uint8).ravel()), (w, h, b, dt, gen, mode)
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for val in ("0", None):
+        env = dict(os.environ)
+        if val is not None:
+            env["QB3_BEST_SAMPLE_MIN"] = val
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (val, r.stdout[-2000:] + r.stderr[-4000:])
+
+
 @pytest.mark.parametrize("switch", ["QB3_NO_PX", "QB3_SLOW_INDEX", "QB3_SLOW_WALK", "QB3_WALK_TAB_KB=2048"])
 def test_alternative_kernel_paths(qb3, oracle, switch, tmp_path):
     """the paths that are not the default -- the generic
