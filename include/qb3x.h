@@ -113,7 +113,8 @@ size_t qb3x_decoder_table_entries(const decsp p);
  * that adds the 4 head bytes to it.  This library's decoder uses the table when no out-of-band index is given:
  * qb3_read_data / qb3x_decode_device(d_index = NULL) then walk (FTL/BASE) or decode (common-factor modes) the stream
  * from every entry at once, one lane each, instead of serially.  qb3_max_encoded_size() grows by the table's size while the switch is on.  Not written for
- * RLE0 modes, narrow images and STORED output.  A decoder handle for a container in device memory: qb3x_read_start_device
+ * narrow images and STORED output; a container whose RLE0 pass wins keeps its table in front of "DT" (the entries describe the
+ * block stream, which the decoder has again once it has expanded the bytes).  A decoder handle for a container in device memory: qb3x_read_start_device
  * (two small copies whatever the table's size); or, from a host copy of the container up to its "DT" mark,
  * qb3x_read_start (qb3x_header_size_bound() bytes always suffice).  qb3_max_encoded_size() does not depend on the mode:
  * it is the room of the largest table any mode writes for the raster (callers size their buffer before setting the mode).
@@ -129,17 +130,19 @@ size_t qb3x_decoder_table_entries(const decsp p);
  * a field per block (its unit's length), 80 bytes an entry.  32/64-bit rasters
  * (FTL/BASE, where the unit-parallel decoder applies): an entry ends with a twelve-bit length per UNIT of its segment
  * (band-minor, little endian) -- about 10 % of a stream of small units (4096 x 4096 int32: 0.06 ms instead of 0.40).
- * Common-factor streams of 16/32/64-bit data have no length table at any level (a unit's form depends on the factor in
- * force); their level 2 table has the entries closer together -- about 24 units (12 for 32/64-bit data) instead of 64 (32):
- * 7-12 % of the stream, and the decode from the container alone takes what it takes with the out-of-band index (4096 x 4096
- * int32 CF: 0.14 ms instead of 0.38).  8-bit common-factor streams of 1, 3 or 4 bands (round 3): at EITHER level an entry
+ * Every OTHER FTL/BASE raster (8-bit data of 2 or more than 4 bands, 16-bit data of an odd band count above 4, 32/64-bit data of
+ * several bands: the lane-per-unit decoder, a wave per segment of 64 / bands blocks): the same twelve-bit length per unit.
+ * Common-factor streams of one band of 16/32/64-bit data: a three-byte field per block (= unit) at either level: its bits (12)
+ * | the rung it is entered with << 12.  8-bit common-factor streams of 1, 3 or 4 bands (round 3): at EITHER level an entry
  * per 64-block segment -- position, rungs, entering values, factors in force -- that ends with a three-byte field per
  * block: the block's bits (12) | the rungs its units are entered with (3 bits a band) << 12, little endian; 6 + 3 * bands +
  * 192 bytes an entry, about 12 % of a typical stream.  It is what the lane-per-block decoder of those streams works from
  * (a common-factor unit leaves its band at the rung of the MULTIPLIED values, so rungs cannot be scanned from the switch
  * codes; the factor in force is found by a ballot of the units that bring their own): 16384 x 16384 x 3 in QB3M_BEST
- * decodes from the container alone in 0.47 ms (round 2: 2.4 ms).  For any other raster (8-bit data of 2 or 5+ bands,
- * 16-bit data of other band counts) level 2 writes the level 1 table. */
+ * decodes from the container alone in 0.47 ms (round 2: 2.4 ms).  Every other common-factor stream (several bands; round 4):
+ * at either level an entry per segment of 64 / bands blocks that ends with a three-byte field per UNIT (band-minor): the
+ * unit's bits (12) | the rung it is entered with << 12 -- what the lane-per-unit decoder works from (8192 x 8192 x 8 uint16
+ * in QB3M_CF_H from the container alone: 1.0 ms; 2.3 before). */
 void qb3x_set_encoder_index_chunk(encsp p, int on);
 
 /* Compatibility switches. */

@@ -403,9 +403,11 @@ __global__ void __launch_bounds__(64) dec_index_serial(const DecArgs a0) {
             T cf = (T)st_cf[c];
             const uint64_t ustart = rd.position();
             if (c < 4) bt |= (rung & (sizeof(T) >= 4 ? 63u : 15u)) << (16 + 4 * c);     // (32/64-bit data: one band, the whole rung)
+            const uint32_t rung_in = rung;
             ok = parse_unit<T, MODE, Reader>(rd, rung, cf, g) && ok;
             if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint8_t)(rd.position() - ustart);
             else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint16_t)(rd.position() - ustart);
+            else if (a.g.ulen_sz == ULEN_UNIT) ((uint32_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint32_t)((rd.position() - ustart) & 0xffffu) | (rung_in << 16);
             T sum = 0;
 #pragma unroll
             for (uint32_t i = 0; i < 16; i++) sum = (T)(sum + smag_t<T>(g[i]));
@@ -464,9 +466,11 @@ __global__ void __launch_bounds__(64) dec_index_staged(const DecArgs a0, uint32_
                     T cf = (T)st_cf[c];
                     const uint64_t ustart = rd.position();
                     if (c < 4) bt |= (rung & (sizeof(T) >= 4 ? 63u : 15u)) << (16 + 4 * c);     // (32/64-bit data: one band, the whole rung)
+                    const uint32_t rung_in = rung;
                     ok = parse_unit<T, MODE, ReaderT<LdsWords>>(rd, rung, cf, g) && ok;
                     if (a.g.ulen_sz == 1) ((uint8_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint8_t)(rd.position() - ustart);
                     else if (a.g.ulen_sz == 2) ((uint16_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint16_t)(rd.position() - ustart);
+                    else if (a.g.ulen_sz == ULEN_UNIT) ((uint32_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = (uint32_t)((rd.position() - ustart) & 0xffffu) | (rung_in << 16);
                     T sum = 0;
 #pragma unroll
                     for (uint32_t i = 0; i < 16; i++) sum = (T)(sum + smag_t<T>(g[i]));
@@ -532,6 +536,7 @@ __global__ void __launch_bounds__(64) dec_index_walk_best(const DecArgs a0, uint
                 for (uint32_t c = 0; c < bands; c++) {
                     uint32_t rung = st_rung[c];
                     if (c < 4) bt |= (rung & (sizeof(T) >= 4 ? 63u : 15u)) << (16 + 4 * c);
+                    const uint32_t u0 = pos;
                     bool sig = false;
                     const uint32_t len = walk_unit<UB>(stage_bit0 + pos, rung, sig);
                     if (!sig) pos += len;
@@ -544,6 +549,7 @@ __global__ void __launch_bounds__(64) dec_index_walk_best(const DecArgs a0, uint
                         st_cf[c] = (uint64_t)cf;
                         pos = (uint32_t)rd.position();
                     }
+                    if (a.g.ulen_sz == ULEN_UNIT) ((uint32_t *)a.idx.ulen)[(uint64_t)gb * bands + c] = ((pos - u0) & 0xffffu) | (st_rung[c] << 16);     // (the lane-per-unit decoder: bits | entering rung)
                     st_rung[c] = rung;
                 }
                 if (a.g.ulen_sz == 4) ((uint32_t *)a.idx.ulen)[gb] = bt | ((pos - b0) & 0xffffu);
@@ -568,7 +574,7 @@ void launch_dec_index_walk_best(const DecArgs &a, hipStream_t st) {
     default: hipLaunchKernelGGL((dec_index_walk_best<uint64_t>), grid, block, 0, st, a, block_bits); break;
     }
 }
-bool dec_index_walk_best_ok(const DecArgs &a) { return a.g.mode == CM_BEST && (a.g.ulen_sz == 0 || a.g.ulen_sz == 4) && a.g.bands * max_unit_bits(a.g.tsz, a.g.mode) + 64 + 64 <= 32 * SERIAL_WIN; }
+bool dec_index_walk_best_ok(const DecArgs &a) { return a.g.mode == CM_BEST && (a.g.ulen_sz == 0 || a.g.ulen_sz == 4 || a.g.ulen_sz == ULEN_UNIT) && a.g.bands * max_unit_bits(a.g.tsz, a.g.mode) + 64 + 64 <= 32 * SERIAL_WIN; }
 
 template <typename T>
 static void launch_dec_generic_t(const DecArgs &a, const DecPlan &plan, hipStream_t st) {

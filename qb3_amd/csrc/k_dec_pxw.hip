@@ -88,12 +88,13 @@ __global__ void __launch_bounds__(256) dec_pxw_kernel(const DecArgs a0) {
     for (uint32_t i = tid; i < 128; i += blockDim.x) ((uint4 *)dtab)[i] = ((const uint4 *)wide_dec_tab.e)[i];
     __syncthreads();                                        // the only workgroup barrier
     if (!live) return;
+    if (!BL && P1 < P0) P1 = P0;        // (the last segment of a truncated stream starts behind its end: it reads zeros)
     const uint64_t w0 = (a.in_bit0 + P0) >> 5;
     const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
     const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0;
     // positions out of a container's table are untrusted: a segment that does not lie inside the stream, or is longer than
     // the longest valid one, reads nothing (status bit 3: "this index does not describe this stream")
-    const bool sane = P0 <= P1 && P1 <= a.in_bits;
+    const bool sane = P0 <= P1 && (!BL || P1 <= a.in_bits);       // (a truncated stream reads as zeros behind its end, like the reference's: bitstream.h:36)
     const bool fits = sane && ndw64 <= a.in_cap_dw;
     // (the staging may be sized for this stream's average segment: a longer -- but valid -- one raises status bit 4 and the
     // host runs the call again with the worst case)
@@ -209,10 +210,11 @@ __global__ void __launch_bounds__(256) dec_pxw_best_kernel(const DecArgs a0) {
         bt = act ? ((const uint32_t *)a.idx.ulen)[(uint64_t)g0 + lane] : 0u;
         pv0 = ((const T *)a.idx.prev)[seg]; cf0 = ((const T *)a.idx.cf)[seg];
     }
+    if (!BL && P1 < P0) P1 = P0;        // (the last segment of a truncated stream starts behind its end: it reads zeros)
     const uint64_t w0 = (a.in_bit0 + P0) >> 5;
     const uint64_t endw_abs = (a.in_bit0 + a.in_bits + 31) >> 5;
     const uint64_t ndw64 = ((a.in_bit0 + P1 + 31) >> 5) - w0;
-    const bool sane = P0 <= P1 && P1 <= a.in_bits;
+    const bool sane = P0 <= P1 && (!BL || P1 <= a.in_bits);       // (a truncated stream reads as zeros behind its end, like the reference's: bitstream.h:36)
     const bool fits = sane && ndw64 <= a.in_cap_dw;
     const uint32_t misfit = (sane && ndw64 <= a.in_cap_full) ? 16u : 8u;      // 16: the staging was sized for the stream's average; the host calls again with the worst case
     const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;

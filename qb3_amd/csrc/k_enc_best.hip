@@ -181,6 +181,7 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
         }
         if (a.have_idx) {
             if (a.g.ulen_sz == 4 && c == 0) ((uint32_t *)a.idx.ulen)[gblk] = blk_tab[f.s];
+            if (a.g.ulen_sz == ULEN_UNIT) ((uint32_t *)a.idx.ulen)[(uint64_t)gblk * bands + c] = len | (oldrung << 16);      // (the lane-per-unit decoder: the unit's bits | the rung it is entered with)
             const uint32_t seg = gblk / a.g.seg_blocks;
             if (seg * a.g.seg_blocks == gblk) {
                 ((T *)a.idx.prev)[(uint64_t)seg * bands + c] = f.pv;

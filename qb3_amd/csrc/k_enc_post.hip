@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256) ix_blw_fill_kernel(const EncArgs a0, cons
     uint32_t len[2] = {0, 0};
     for (uint32_t q = 0; q < 2; q++) {
         const uint32_t f = 2 * t + q;
-        if (f < upe && u0 + f < nunits) len[q] = ((const uint16_t *)a.idx.ulen)[u0 + f];
+        if (f < upe && u0 + f < nunits) len[q] = a.g.ulen_sz == 1 ? (uint32_t)((const uint8_t *)a.idx.ulen)[u0 + f] : (uint32_t)((const uint16_t *)a.idx.ulen)[u0 + f];
     }
     const uint32_t bits = len[0] | len[1] << 12;
     const uint32_t c = (uint32_t)(k / a.ix_per_chunk), jj = (uint32_t)(k - (uint64_t)c * a.ix_per_chunk);
@@ -430,6 +430,38 @@ __global__ void __launch_bounds__(256) ix_blw_fill_kernel(const EncArgs a0, cons
         if (i < 6) e0[i] = (uint8_t)(a.idx.bitpos[k] >> (8 * i));
         else if (i < 6 + B) e0[i] = a.idx.rung[k * B + (i - 6)];
         else e0[i] = ((const uint8_t *)a.idx.prev)[k * B * tsz + (i - 6 - B)];
+    }
+}
+
+// Common-factor streams of the lane-per-unit decoder (k_dec_pxu.hip): a three-byte field per UNIT of the entry's segment -- its bits (12)
+// | the rung it is entered with << 12 -- from the index's unit table; a thread per four units, sixteen threads an entry (a segment is at
+// most 64 units), which also share the entry's fixed part
+__global__ void __launch_bounds__(256) ix_blu_best_fill_kernel(const EncArgs a0) {
+    const EncArgs a = enc_for_tile(a0, blockIdx.y);
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t B = a.g.bands, tsz = a.g.tsz, upe = a.ix_blocks * B;         // units per entry
+    const uint64_t k = idx >> 4;
+    if (k >= a.ix_K) return;
+    const uint32_t t = (uint32_t)(idx & 15);
+    const uint64_t u0 = k * upe, nunits = a.g.nblocks * B;
+    const uint32_t c = (uint32_t)(k / a.ix_per_chunk), jj = (uint32_t)(k - (uint64_t)c * a.ix_per_chunk);
+    uint8_t *e0 = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E) + IX_HEAD + (uint64_t)jj * a.ix_E;
+    const uint32_t fixed = 6 + B * (1 + 2 * tsz);
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t f = 4 * t + q;
+        if (f >= upe) break;
+        const uint32_t bt = u0 + f < nunits ? ((const uint32_t *)a.idx.ulen)[u0 + f] : 0u;
+        const uint32_t fld = (bt & 0xfffu) | ((bt >> 16) & 63u) << 12;
+        uint8_t *e = e0 + fixed + IX_BL_BEST_BYTES * f;
+        e[0] = (uint8_t)fld; e[1] = (uint8_t)(fld >> 8); e[2] = (uint8_t)(fld >> 16);
+    }
+    for (uint32_t i = t; i < fixed; i += 16) {
+        uint8_t v;
+        if (i < 6) v = (uint8_t)(a.idx.bitpos[k] >> (8 * i));
+        else if (i < 6 + B) v = a.idx.rung[k * B + (i - 6)];
+        else if (i < 6 + B + B * tsz) v = ((const uint8_t *)a.idx.prev)[k * B * tsz + (i - 6 - B)];
+        else v = ((const uint8_t *)a.idx.cf)[k * B * tsz + (i - 6 - B - B * tsz)];
+        e0[i] = v;
     }
 }
 
@@ -491,6 +523,15 @@ void launch_enc_post_tail(const EncArgs &a, const EncPlan &plan, hipStream_t st)
 }
 static void launch_enc_tables(const EncArgs &a, hipStream_t st) {
     const uint32_t nt = a.ntiles;
+    if (a.ix_dst && a.have_idx && a.ix_bl && lane_per_unit_shape(a.g.tsz, a.g.mode, a.g.bands)) {       // a field per unit (k_dec_pxu.hip)
+        if (a.g.mode == CM_BEST) hipLaunchKernelGGL(ix_blu_best_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
+        else {
+            const uint32_t tpe = (a.ix_blocks * a.g.bands + 1) / 2;
+            hipLaunchKernelGGL(ix_blw_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * tpe + 255) / 256), nt), dim3(256), 0, st, a, tpe);
+        }
+        hipLaunchKernelGGL(ix_seal_kernel, dim3((a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk, nt), dim3(256), 0, st, a);
+        return;
+    }
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.mode == CM_BEST) hipLaunchKernelGGL(ix_bl_best_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
     else if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz == 1) hipLaunchKernelGGL(ix_bl_fill_kernel, dim3((uint32_t)(((uint64_t)a.ix_K * 16 + 255) / 256), nt), dim3(256), 0, st, a);
     if (a.ix_dst && a.have_idx && a.ix_bl && a.g.tsz >= 4 && a.g.mode != CM_BEST) {

@@ -114,6 +114,8 @@ static void px16_split(const Geometry &g, uint32_t *bg, uint32_t *ng) {
 uint32_t px16_bands_per_lane(const Geometry &g) { uint32_t bg, ng; px16_split(g, &bg, &ng); return bg; }
 
 uint32_t seg_blocks_for(const Geometry &g) {
+    // rasters of the lane-per-unit kernels (k_dec_pxu.hip): a wave owns a segment, a lane a unit
+    if (lane_per_unit_shape(g.tsz, g.mode, g.bands)) return 64 / g.bands;
     if (g.mode != CM_BEST) {      // one segment = the blocks of one decoder workgroup, at most 256
         // 8-bit grey/RGB/RGBA: the lane-per-block decoder gives a segment to a WAVE (a function of type and band
         // count only: encoder and decoder must agree whatever kernel either of them ends up using)
@@ -138,13 +140,15 @@ uint32_t seg_blocks_for(const Geometry &g) {
 // fields of IX_BL_BITS bits behind an entry's fixed part: a block length per block of the segment (8-bit data) or two
 // band-pair lengths per lane of the decoder's wave (16-bit data, four bands a lane: 64 lanes)
 // ... or a unit length per unit of the segment (32/64-bit data: the unit-parallel decoder)
-uint32_t ix_bl_fields(const Geometry &g) { return g.tsz == 1 ? g.seg_blocks : g.tsz == 2 ? (g.bands == 1 ? 64 : 128) : g.seg_blocks * g.bands; }
+uint32_t ix_bl_fields(const Geometry &g) { return lane_per_unit_shape(g.tsz, g.mode, g.bands) ? g.seg_blocks * g.bands : g.tsz == 1 ? g.seg_blocks : g.tsz == 2 ? (g.bands == 1 ? 64 : 128) : g.seg_blocks * g.bands; }
 uint32_t ix_entry_bytes(const Geometry &g, bool block_lens) {
     return 6 + g.bands * (1 + g.tsz * (g.mode == CM_BEST ? 2 : 1)) + (block_lens ? ix_bl_bytes(g.tsz, g.bands, g.seg_blocks, g.mode == CM_BEST) : 0);
 }
 // Block lengths: for the rasters the 8-bit lane-per-block decoder takes (a block of at most four units of at most 149 bits
 // fits ten bits), an entry per 64-block segment
 bool ix_block_lens_ok(const Geometry &g) {
+    // rasters of the lane-per-unit kernels: a field per unit of the segment (common factor: bits | entering rung; else twelve bits of length)
+    if (lane_per_unit_shape(g.tsz, g.mode, g.bands)) return g.seg_blocks == 64 / g.bands;
     // 8-bit common-factor streams of 1/3/4 bands: a field per block of the 64-block segment (its bits and entering rungs),
     // what the lane-per-block decoder needs besides the entry's fixed part; without it a lane would walk 64 blocks
     if (g.mode == CM_BEST) return best_block_table(g.tsz, g.mode, g.bands) && g.seg_blocks == 64;
@@ -165,7 +169,7 @@ bool ix_block_lens_ok(const Geometry &g) {
 IxTable ix_layout(const Geometry &g, int level) {
     IxTable t;
     if (!g.seg_blocks || !g.nseg) return t;
-    t.block_lens = (level >= 2 || best_block_table(g.tsz, g.mode, g.bands)) && ix_block_lens_ok(g);
+    t.block_lens = (level >= 2 || best_block_table(g.tsz, g.mode, g.bands) || (g.mode == CM_BEST && lane_per_unit_shape(g.tsz, g.mode, g.bands))) && ix_block_lens_ok(g);
     t.entry_bytes = ix_entry_bytes(g, t.block_lens);
     const uint64_t units_per_seg = (uint64_t)g.seg_blocks * g.bands;
     const bool per_seg = g.mode != CM_BEST;
@@ -175,13 +179,13 @@ IxTable ix_layout(const Geometry &g, int level) {
     // (level 2, common-factor streams: the entries closer together -- 24 units, 12 for 32/64-bit data: two to three times the lanes,
     // each with a piece as much shorter, for 10-20 % of the stream)
     const uint64_t target = level >= 2 ? (g.tsz >= 4 ? 12 : 24) : (g.tsz >= 4 ? 32 : 64);
-    const uint64_t spe = (per_seg || units_per_seg >= target) ? 1 : target / units_per_seg; // index segments per entry
+    const uint64_t spe = (per_seg || units_per_seg >= target || t.block_lens) ? 1 : target / units_per_seg; // index segments per entry
     t.blocks = (uint32_t)(spe * g.seg_blocks);
     t.K = (uint32_t)((g.nseg + spe - 1) / spe);
     t.per_chunk = (65535 - IX_HEAD) / t.entry_bytes;
     return t;
 }
-uint32_t ulen_size_for(uint32_t tsz, uint32_t mode, uint32_t bands) { return mode == CM_BEST ? (best_block_table(tsz, mode, bands) ? 4 : 0) : (tsz == 1 ? 1 : 2); }
+uint32_t ulen_size_for(uint32_t tsz, uint32_t mode, uint32_t bands) { return mode == CM_BEST ? (best_block_table(tsz, mode, bands) ? 4 : ULEN_UNIT) : (tsz == 1 ? 1 : 2); }
 
 static size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 size_t index_bytes(const Geometry &g) {
@@ -489,6 +493,13 @@ DecPlan plan_decode(const Geometry &g) {
         p.px_cap_dw = (uint32_t)(((size_t)NB * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
         p.lds_pxw = 4 * 4 * ((size_t)p.px_cap_dw + 8);
     }
+    // every other raster: a wave per segment of 64 / bands blocks, a lane per unit (k_dec_pxu.hip); core bands must themselves be core
+    bool core_ok = true;
+    for (uint32_t c = 0; c < g.bands; c++) core_ok = core_ok && g.cband[c] < g.bands && g.cband[g.cband[c]] == g.cband[c];
+    const bool pxu_shape = lane_per_unit_shape(g.tsz, g.mode, g.bands) && NB == 64 / g.bands && core_ok && g.w >= 4 && g.h >= 4 && !tuning().no_px;
+    p.pxu = pxu_shape && g.mode != CM_BEST && g.ulen_sz != 0 && !p.px && !p.px16 && !p.pxw;
+    p.pxu_best = pxu_shape && g.mode == CM_BEST && g.ulen_sz == ULEN_UNIT;
+    if (p.pxu || p.pxu_best) p.px_cap_dw = (uint32_t)(((size_t)NB * g.bands * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
     return p;
 }
 
@@ -541,12 +552,17 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     const bool unit_parallel = !use_px && !use_px16 && plan.fast && !best && a.g.tsz >= 4;
     // ... of them, one band: the lane-per-block decoder (a wave per segment) instead of the unit-parallel workgroup
     const bool use_pxw = unit_parallel && plan.pxw && ((uintptr_t)a.img & (a.g.tsz - 1)) == 0 && !(a.ts_img & (a.g.tsz - 1));
+    // every raster no lane-per-block kernel takes: a lane per unit (value-aligned pointers)
+    const bool val_aligned = ((uintptr_t)a.img & (a.g.tsz - 1)) == 0 && !(a.ts_img & (a.g.tsz - 1));
+    const bool use_pxu = !use_px && !use_px16 && !use_pxw && plan.pxu && plan.fast && !best && val_aligned;
     auto dec_units = [&](const DecArgs &t) {
-        if (use_px) launch_dec_px(t, plan, st); else if (use_px16) launch_dec_px16(t, plan, st); else if (use_pxw) launch_dec_pxw(t, plan, st); else launch_dec_generic(t, plan, st);
+        if (use_px) launch_dec_px(t, plan, st); else if (use_px16) launch_dec_px16(t, plan, st); else if (use_pxw) launch_dec_pxw(t, plan, st);
+        else if (use_pxu) launch_dec_pxu(t, plan, st); else launch_dec_generic(t, plan, st);
     };
     const bool best_pxw = best && plan.pxw_best && ((uintptr_t)a.img & (a.g.tsz - 1)) == 0 && !(a.ts_img & (a.g.tsz - 1));
-    const bool best_px = (best && plan.px_best && a.g.tsz == 1) || best_pxw;       // a lane-per-block common-factor decoder applies
-    auto dec_best_lpb = [&](const DecArgs &t) { if (best_pxw) launch_dec_pxw_best(t, plan, st); else launch_dec_px_best(t, plan, st); };
+    const bool best_pxu = best && plan.pxu_best && val_aligned;
+    const bool best_px = (best && plan.px_best && a.g.tsz == 1) || best_pxw || best_pxu;       // a lane-per-block (or per-unit) common-factor decoder applies
+    auto dec_best_lpb = [&](const DecArgs &t) { if (best_pxw) launch_dec_pxw_best(t, plan, st); else if (best_pxu) launch_dec_pxu_best(t, plan, st); else launch_dec_px_best(t, plan, st); };
     if (rebuild && best_px && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
         // the container's table has a field per block (bits, entering rungs): the lane-per-block decoder works from the entries alone
         DecArgs t = a;
@@ -556,7 +572,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         HIPCHK(hipGetLastError());
         return 0;
     }
-    if (rebuild && (use_px || (use_px16 && ix_block_lens_ok(a.g)) || unit_parallel) && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
+    if (rebuild && (use_px || (use_px16 && ix_block_lens_ok(a.g)) || unit_parallel || use_pxu) && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
         // the container's table carries block (16-bit data: band pair) lengths: the lane-per-block decoder works from the entries alone
         DecArgs t = a;
         t.bl_mode = 1;
@@ -597,7 +613,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
             // the signal code parsed outright), the generic decoder adds up every segment's values, a scan makes entering values
             // of the sums
             { ProfScope ps("dec_index_serial", st); launch_dec_index_walk_best(a, st); }
-            { ProfScope ps("dec_index_prev", st); DecArgs t = a; t.totals_only = 1; launch_dec_generic(t, plan, st); }
+            { ProfScope ps("dec_index_prev", st); DecArgs t = a; t.totals_only = 1; if (best_pxu) launch_dec_pxu_best(t, plan, st); else launch_dec_generic(t, plan, st); }
             ProfScope ps("dec_index_scan", st);
             launch_prev_scan(a, st);
         }
@@ -607,6 +623,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     else if (use_px) { ProfScope ps("dec_units", st); launch_dec_px(a, plan, st); }
     else if (use_px16) { ProfScope ps("dec_units", st); launch_dec_px16(a, plan, st); }
     else if (use_pxw) { ProfScope ps("dec_units", st); launch_dec_pxw(a, plan, st); }
+    else if (use_pxu) { ProfScope ps("dec_units", st); launch_dec_pxu(a, plan, st); }
     else { ProfScope ps(plan.fast && !best ? "dec_units" : "dec_segments", st); launch_dec_generic(a, plan, st); }
     HIPCHK(hipGetLastError());
     return 0;
@@ -632,6 +649,12 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
         uint64_t cap = bits / 32 / g.nseg;
         cap = (cap + cap / 2 + 64 + 3) & ~(uint64_t)3;
         if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_pxw = (plan.pxw ? 2048 : 0) + 4 * 4 * ((size_t)cap + 8); }
+    }
+    if ((plan.pxu || plan.pxu_best) && !full_staging && g.nseg) {        // ... and for the lane-per-unit kernels
+        const uint64_t bits = tb.n ? tb.max_bits : in_bits;
+        uint64_t cap = bits / 32 / g.nseg;
+        cap = (cap + cap / 2 + 64 + 3) & ~(uint64_t)3;
+        if (bits && cap < plan.px_cap_dw) plan.px_cap_dw = (uint32_t)cap;
     }
     a.in_cap_full = plan_in.px_cap_dw;
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
@@ -671,13 +694,13 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     a.seg_end = strip ? std::min<uint64_t>(g.nseg, strip->seg0 + strip->nseg) : g.nseg;
     a.lane_dw = dec_lane_dwords(g);
     a.dpr = g.bands * g.tsz;
-    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16 || plan.px_best || plan.pxw || plan.pxw_best) ? plan.px_cap_dw : plan.in_cap_dw;
+    a.bpp = plan.bpp; a.passes = plan.passes; a.in_cap_dw = (plan.px || plan.px16 || plan.px_best || plan.pxw || plan.pxw_best || plan.pxu || plan.pxu_best) ? plan.px_cap_dw : plan.in_cap_dw;
     a.px_ng = plan.px16 ? plan.px16_ng : 1; a.px_magic_ng = magic_div(a.px_ng);
     a.totals_only = 0;
     a.bl_mode = 0;
     a.wide_band = tuning().wide_band ? (uint32_t)tuning().wide_band : wide_band;
     a.px_aligned = !(g.w & 3) && !((g.stride * g.tsz) & 3) && !((uintptr_t)img & 3) && !(tb.dst_pitch & 3);
-    a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr);
+    a.magic_bpp = magic_div(plan.bpp); a.magic_dpr = magic_div(a.dpr); a.magic_bands = magic_div(g.bands);
     *status_out = a.status;
     if (g.tsz != 1 && g.tsz != 2 && g.tsz != 4 && g.tsz != 8) { set_error("decode: bad value size", 0); return -1; }
     if (strip) {        // one launch of the lane-per-block decoder over the strip's segments, from the table's entries

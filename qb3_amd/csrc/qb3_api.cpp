@@ -722,7 +722,7 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
     // check_info (reference QB3encode.h:364-373); cband is kept in range by the setter
     if (g.w < 4 || g.h < 4) { p->error = 1; return 0; }
 
-    // optional restart table inside the container (a winning RLE0 pass rewrites the container without it)
+    // optional restart table inside the container (a winning RLE0 pass keeps it in front of its bytes)
     IxTable ixt;
     size_t hdr_stamp = hdr;                               // header bytes prepared on the host
     if (ixroom && !narrow) {
@@ -764,18 +764,25 @@ static size_t encode_common(encsp p, const void *host_src, void *host_dst, const
             if (!p->d_rle.ensure(rle0_ws_bytes(n)) || rle0_device_size(out_dev + hdr, n, p->d_rle.p, false, &rsz64, st, has_run == 2)) { p->error = QB3E_LIBERR; return 0; }
             const size_t rsz = (size_t)rsz64;
             if (rsz <= maxsz - len_ref && rsz < n) {
+                // the RLE mode's header, the restart table when one was asked for (its chunks and the "DT" behind them stand in the
+                // buffer as written: the table describes the block stream, which the decoder sees again once it has expanded the
+                // bytes), then the RLE0 bytes
                 uint8_t hdr2[80];
-                const size_t h2 = write_headers(p, hdr2);
+                const size_t tbl = ixt.base ? hdr - hdr_stamp : 0;      // (chunks + "DT")
+                const size_t h2 = write_headers(p, hdr2, tbl == 0);
                 if (!p->d_q.ensure(rsz) || rle0_device_write(out_dev + hdr, n, p->d_rle.p, false, p->d_q.p, st)) { p->error = QB3E_LIBERR; return 0; }
                 if (on_host) {
                     memcpy(host_dst, hdr2, h2);
-                    if (!download(p->stager, (uint8_t *)host_dst + h2, p->d_q.p, rsz, st)) { p->error = QB3E_LIBERR; return 0; }
+                    if (tbl && !download(p->stager, (uint8_t *)host_dst + h2, out_dev + hdr_stamp, tbl, st)) { p->error = QB3E_LIBERR; return 0; }
+                    if (!download(p->stager, (uint8_t *)host_dst + h2 + tbl, p->d_q.p, rsz, st)) { p->error = QB3E_LIBERR; return 0; }
                 } else {
-                    HIPOK(hipMemcpyAsync((uint8_t *)d_dst + h2, p->d_q.p, rsz, hipMemcpyDeviceToDevice, st));
+                    // (device flavour: out_dev IS d_dst and h2 == hdr_stamp -- the modes' headers differ in one byte -- so the table stays where it is)
+                    if (tbl && h2 != hdr_stamp) HIPOK(hipMemcpyAsync((uint8_t *)d_dst + h2, out_dev + hdr_stamp, tbl, hipMemcpyDeviceToDevice, st));
+                    HIPOK(hipMemcpyAsync((uint8_t *)d_dst + h2 + tbl, p->d_q.p, rsz, hipMemcpyDeviceToDevice, st));
                     HIPOK(hipMemcpyAsync(d_dst, hdr2, h2, hipMemcpyHostToDevice, st));
                     HIPOK(hipStreamSynchronize(st));
                 }
-                return h2 + rsz;
+                return h2 + tbl + rsz;
             }
         }
     }
@@ -981,7 +988,9 @@ QB3_API size_t qb3x_header_size_bound(const void *container, size_t avail) {
     const size_t bl = tsz == 1 ? (nblk / 64 + 1) * (64 * IX_BL_BEST_BYTES) : tsz == 2 ? (nblk * (nb / 4 + 1) / 64 + 1) * ((128 * IX_BL_BITS + 7) / 8)
                                : std::max((nblk * nb * IX_BL_BITS_WIDE) / 8 + (nblk / 12 + 1) * 2 + 64,      // (32/64-bit: a length per unit, an odd byte per entry)
                                           nblk * IX_BL_BEST_BYTES + 64);                                    // (... or, one band, common factor: a field per block)
-    const size_t bytes = K * E + bl;
+    // ... and a table of the lane-per-unit decoder's rasters a field per UNIT: three bytes (common factor) or twelve bits
+    const size_t blu = nblk * nb * IX_BL_BEST_BYTES + 64 * IX_BL_BEST_BYTES;
+    const size_t bytes = K * E + std::max(bl, blu);
     return 128 + bytes + (bytes / 60000 + 1) * (IX_HEAD + IX_PAD);
 }
 
@@ -1438,10 +1447,10 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
         if (!p->d_img.ensure((size_t)g.w * g.h * g.bands * tsz)) { p->error = QB3E_LIBERR; return 0; }
         img_dev = p->d_img.p;
     }
-    // a restart table inside the container stands in for a missing index (not under RLE0: the legacy modes keep
-    // the plain path)
+    // a restart table inside the container stands in for a missing index (also under RLE0: the table describes the block stream,
+    // which is what the expansion above has just made)
     IxTable ixt;
-    if (!d_index && p->ix_K && !rle && !narrow) {
+    if (!d_index && p->ix_K && !narrow) {
         ixt.K = p->ix_K; ixt.blocks = p->ix_blocks; ixt.entry_bytes = p->ix_E; ixt.per_chunk = p->ix_per_chunk; ixt.pads = p->ix_pads; ixt.block_lens = p->ix_bl;
         ixt.version = p->ix_ver; ixt.check_heads = p->ix_heads_unchecked;
         if (on_host) {

@@ -23,7 +23,8 @@ struct Geometry {
     uint32_t seg_blocks;            // blocks per index segment
     uint64_t nseg;                  // number of index segments
     uint32_t ulen_sz;               // bytes per entry of the per-unit bit-length table (1, 2; 0 = none); 4: a dword per BLOCK instead
-                                    // (8-bit common-factor streams of 1/3/4 bands: the block's bits | entering rungs << 16, four bits a band)
+                                    // (8-bit common-factor streams of 1/3/4 bands: the block's bits | entering rungs << 16, four bits a band);
+                                    // ULEN_UNIT: a dword per UNIT (every other common-factor stream of several bands: the unit's bits | the rung it is entered with << 16)
     uint8_t cband[MAXBANDS];
 };
 
@@ -51,11 +52,24 @@ size_t index_bytes(const Geometry &g);
 IndexView index_view(const Geometry &g, void *base);
 uint32_t seg_blocks_for(const Geometry &g);      // needs w, h, bands, tsz, stride, order, mode, cband
 uint32_t ulen_size_for(uint32_t tsz, uint32_t mode, uint32_t bands);
-inline size_t ulen_table_bytes(const Geometry &g) { return g.ulen_sz == 4 ? (size_t)g.nblocks * 4 : (size_t)g.nblocks * g.bands * g.ulen_sz; }
+constexpr uint32_t ULEN_UNIT = 8;
+inline size_t ulen_table_bytes(const Geometry &g) { return g.ulen_sz == 4 ? (size_t)g.nblocks * 4 : g.ulen_sz == ULEN_UNIT ? (size_t)g.nblocks * g.bands * 4 : (size_t)g.nblocks * g.bands * g.ulen_sz; }
 // common-factor streams whose index holds a dword per BLOCK (its bits | the rungs its units are entered with << 16) for a
 // lane-per-block decoder: 8-bit rasters of 1/3/4 bands (four bits a band), 16/32/64-bit rasters of one band (the whole rung)
 inline bool best_block_table(uint32_t tsz, uint32_t mode, uint32_t bands) {
     return mode == CM_BEST && ((tsz == 1 && (bands == 1 || bands == 3 || bands == 4)) || (tsz >= 2 && bands == 1));
+}
+
+// Rasters of the lane-per-UNIT kernels (k_dec_pxu.hip): every shape no lane-per-block kernel takes -- 8-bit rasters of 2 or more than 4
+// bands, 16-bit rasters of an odd band count above 4, 32/64-bit rasters of several bands; of the common-factor streams every one without a
+// block table.  A wave owns an index segment of 64 / bands blocks, a lane one unit.  A function of value size, band count and mode
+// only: encoder and decoder derive the segment size from it.
+inline bool lane_per_unit_shape(uint32_t tsz, uint32_t mode, uint32_t bands) {
+    if (bands < 1 || bands > (uint32_t)MAXBANDS) return false;
+    if (mode == CM_BEST) return !best_block_table(tsz, mode, bands);
+    if (tsz == 1) return !(bands == 1 || bands == 3 || bands == 4);
+    if (tsz == 2) return bands > 4 && (bands & 1);
+    return bands >= 2;
 }
 
 // Results the encoder hands back to the host (device resident, copied once per encode)
@@ -128,8 +142,12 @@ uint32_t px16_bands_per_lane(const Geometry &g);  // 16-bit lane-per-block kerne
 inline uint32_t ix_bl_bits(uint32_t tsz) { return tsz >= 4 ? IX_BL_BITS_WIDE : IX_BL_BITS; }
 constexpr uint32_t IX_BL_BEST_BYTES = 3;  // ... of a block's field in a table of 8-bit common-factor data: the block's bits (12) | the rungs its units are entered with (3 bits a band) << 12
 // bytes of the fields behind the fixed part of an entry that covers `blocks` blocks (cf: the stream is a common-factor one)
+// (rasters of the lane-per-unit kernels: a field per UNIT -- three bytes in a common-factor table (the unit's bits | the rung it is
+// entered with << 12), twelve bits of length otherwise, whatever the value size)
 inline uint32_t ix_bl_bytes(uint32_t tsz, uint32_t bands, uint32_t blocks, bool cf) {
-    if (cf) return IX_BL_BEST_BYTES * blocks;
+    const bool per_unit = lane_per_unit_shape(tsz, cf ? CM_BEST : CM_FTL, bands);
+    if (cf) return IX_BL_BEST_BYTES * blocks * (per_unit ? bands : 1u);
+    if (per_unit) return (blocks * bands * IX_BL_BITS_WIDE + 7) / 8;
     const uint32_t fields = tsz == 1 ? blocks : tsz == 2 ? (bands == 1 ? 64u : 128u) : blocks * bands;
     return (fields * ix_bl_bits(tsz) + 7) / 8;
 }
@@ -195,6 +213,7 @@ struct DecPlan {
     bool pxw;               // 32/64-bit single-band FTL/BASE streams: the lane-per-block decoder applies (k_dec_pxw.hip)
     bool pxw_best;          // ... and its common-factor counterpart (dec_pxw_best_kernel)
     size_t lds_pxw;
+    bool pxu, pxu_best;     // the lane-per-unit decoders apply (k_dec_pxu.hip: lane_per_unit_shape): FTL / BASE, common factor
 };
 DecPlan plan_decode(const Geometry &g);
 

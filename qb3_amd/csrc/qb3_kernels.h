@@ -319,6 +319,7 @@ struct DecArgs {
     uint32_t dpr;
     // unit-parallel kernel (dec3_kernel)
     uint32_t bpp, passes, in_cap_dw, magic_bpp, magic_dpr;
+    uint32_t magic_bands;           // lane-per-unit kernels (k_dec_pxu.hip): lane / bands
     uint32_t from_ix;        // lane-per-segment decoder: the segments are the pieces between the entries of the container's restart table
     uint32_t seg_cap_dw;     // lane-per-segment decoder: stream words a workgroup may stage in LDS (0: lanes read global memory)
     uint32_t in_cap_full;    // 16-bit lane-per-block decoder: the worst-case staging (in_cap_dw may be sized for this stream's average)
@@ -599,6 +600,9 @@ void launch_dec_px16(const DecArgs &a, const DecPlan &plan, hipStream_t st);    
 void launch_dec_pxw(const DecArgs &a, const DecPlan &plan, hipStream_t st);        // k_dec_pxw.hip
 void launch_dec_pxw_best(const DecArgs &a, const DecPlan &plan, hipStream_t st);   // k_dec_pxw.hip
 void launch_dec_px_best(const DecArgs &a, const DecPlan &plan, hipStream_t st);    // k_dec_px_best.hip
+void launch_dec_pxu(const DecArgs &a, const DecPlan &plan, hipStream_t st);        // k_dec_pxu.hip: lane per unit, any band count
+void launch_dec_pxu_best(const DecArgs &a, const DecPlan &plan, hipStream_t st);   // k_dec_pxu.hip
+size_t pxu_lds_bytes(uint32_t in_cap_dw, uint32_t tsz, bool best);
 void launch_dec_walk(const DecArgs &a, hipStream_t st);                            // k_dec_walk.hip: unit lengths of an index-less 8/16-bit stream
 void launch_prev_scan(const DecArgs &a, hipStream_t st);                           // k_dec_walk.hip
 bool launch_dec_walk_best(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);    // k_dec_walk.hip: plain single-band 32/64-bit common-factor streams

@@ -421,7 +421,12 @@ def test_wide_segments_far_longer_than_the_average(qb3, oracle, dt, mode):
     out, _, _, _ = qb3.decode(self_indexed)
     assert np.array_equal(out, img.view(np.uint8).ravel())
     if stream[10] in (2, 3, 6, 7):
-        assert np.array_equal(self_indexed, stream)                     # (the RLE0 pass won: no table either way)
+        # the RLE0 pass won: the table stands between the reference's header and its "DT", the RLE0 bytes are the reference's
+        dt_at = bytes(stream).index(b"DT", 11)
+        extra = len(self_indexed) - len(stream)
+        assert extra > 0 and bytes(self_indexed[:dt_at]) == bytes(stream[:dt_at]) and bytes(self_indexed[dt_at + extra:]) == bytes(stream[dt_at:])
+        want, _, _, _ = oracle.decode(self_indexed, identity=True)
+        assert want is not None and np.array_equal(want, img.view(np.uint8).ravel()), "the reference decoder must step over the chunks"
         return                                                          # (... and the device flavour below is the plain modes')
     assert len(self_indexed) > len(stream)
     enc = qdev.DeviceEncoder(w, h, 1, dt, mode=mode)
@@ -997,16 +1002,16 @@ def test_index_chunk_version_1_still_decodes(qb3, oracle):
 
 
 def test_index_chunk_not_written_where_it_cannot_be(qb3, oracle):
-    """a winning RLE0 pass (it rewrites the container), narrow images and STORED output carry no table"""
+    """narrow images and STORED output carry no table; a winning RLE0 pass keeps it (the table describes the block stream the
+    decoder has again after the expansion), like the base mode's container when the pass loses"""
     img = oracle.generate(96, 64, 1, 5, "TERRACE", 4)
     for mode in (2, 3, 6, 7):
         ref, got = oracle.encode(img, 5, mode), qb3.encode(img, 5, mode, index_chunk=True)
-        if ref[10] == mode:         # the RLE0 pass won
-            assert np.array_equal(got, ref)
-        else:                       # it did not: the base mode's container, with the table
-            dt_at, extra = bytes(ref).index(b"DT", 11), len(got) - len(ref)
-            assert extra > 0 and bytes(got[dt_at:dt_at + 2]) == b"ix"
-            assert np.array_equal(np.concatenate([got[:dt_at], got[dt_at + extra:]]), ref)
+        dt_at, extra = bytes(ref).index(b"DT", 11), len(got) - len(ref)
+        assert extra > 0 and bytes(got[dt_at:dt_at + 2]) == b"ix"
+        assert np.array_equal(np.concatenate([got[:dt_at], got[dt_at + extra:]]), ref)
+        out, _, _, _ = qb3.decode(got)
+        assert np.array_equal(out, img.view(np.uint8).ravel())
     narrow = oracle.generate(2, 40, 3, 0, "NOISY3", 1)
     assert np.array_equal(qb3.encode(narrow, 0, FTL, index_chunk=True), oracle.encode(narrow, 0, FTL))
     noise = oracle.generate(64, 64, 3, 0, "RANDOM", 1)         # incompressible: falls back to STORED
@@ -1107,8 +1112,8 @@ def test_self_indexed_containers_decode_from_their_table(qb3, oracle, case):
     for level in (1, 2):
         enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cb, index_chunk=level, want_index=False)
         dst, n, _ = enc.encode(img)
-        if int(dst[10]) in (255, 2, 3, 6, 7):
-            continue                                    # raw-stored, or the RLE0 pass won: no table
+        if int(dst[10]) == 255:
+            continue                                    # raw-stored: no table (a winning RLE0 pass keeps it)
         dec = qdev.DeviceDecoder(dst, n)
         assert qb3.lib.qb3x_decoder_table_entries(dec.p) > 0, level
         out = dec.decode(dst, index=None)
@@ -1295,41 +1300,46 @@ print("ok")
 
 
 def test_block_lengths_only_where_the_decoder_uses_them(qb3, oracle):
-    """level 2 asked for a raster whose decoder takes no lengths (16-bit or 8-bit of five bands): the table is the level 1
-    table.  A common-factor stream has no unit-length table at any level; its level 2 table has the entries closer together
-    (24 units, 12 for 32/64-bit data), and decodes from the container alone like the level 1 one.  The exception: 8-bit
-    common-factor streams of 1/3/4 bands, whose table has a field per block (bits, entering rungs) at EITHER level -- what the
-    lane-per-block decoder of those streams works from -- and, since round 4, 32/64-bit common-factor streams of one band, whose
-    lane-per-block decoder (dec_pxw_best_kernel) works from the same kind of table"""
-    for (w, h, b, dt, gen, mode) in [(256, 128, 5, 2, "LANDSAT16", FTL), (160, 120, 5, 0, "NOISY3", FTL)]:
-        img = oracle.generate(w, h, b, dt, gen, 3)
-        cb = None if b in (1, 3, 4) else list(range(b))
-        one = qb3.encode(img, dt, mode, cband=cb, index_chunk=1)
-        two = qb3.encode(img, dt, mode, cband=cb, index_chunk=2)
-        assert np.array_equal(one, two)
-        out, _, _, _ = qb3.decode(two)
-        assert np.array_equal(out, img.view(np.uint8).ravel())
-    for (w, h, b, dt, gen, mode) in [(256, 256, 3, 0, "NOISY3", 7), (300, 200, 1, 0, "PALETTE", 5), (256, 192, 8, 2, "LANDSAT16", 1),
-                                     (200, 160, 1, 5, "DEM", 5), (128, 128, 1, 7, "TERRACE", 7), (1024, 1024, 3, 0, "FEW", 5)]:
+    """Level 2 tables carry what the raster's decoder places its units by.  FTL / BASE rasters of the lane-per-unit decoder
+    (k_dec_pxu.hip: 8-bit rasters of 2 or more than 4 bands, 16-bit of an odd band count above 4, 32/64-bit of several bands): a
+    twelve-bit length per unit, so level 2 is larger than level 1 and both decode from the container alone.  A common-factor
+    stream has a field per block (8-bit grey / RGB / RGBA; one band of wider values) or per unit (everything else: the
+    lane-per-unit decoder) at EITHER level -- its bits and the rung it is entered with -- because that is what its decoder
+    works from: levels 1 and 2 are the same container."""
+    for (w, h, b, dt, gen, mode) in [(256, 128, 5, 2, "LANDSAT16", FTL), (160, 120, 5, 0, "NOISY3", FTL), (96, 200, 2, 0, "NOISY3", 4), (130, 70, 3, 5, "DEM", 4),
+                                     (64, 64, 2, 7, "DEM", FTL), (100, 52, 16, 0, "NOISY3", FTL), (77, 41, 7, 2, "LANDSAT16", 4)]:
         img = oracle.generate(w, h, b, dt, gen, 3)
         cb = None if b in (1, 3, 4) else list(range(b))
         ref = oracle.encode(img, dt, mode, cband=cb)
         one = qb3.encode(img, dt, mode, cband=cb, index_chunk=1)
         two = qb3.encode(img, dt, mode, cband=cb, index_chunk=2)
-        if ref[10] in (255, 2, 3, 6, 7):            # raw-stored, or the RLE0 pass won: no table either way
+        assert len(two) > len(one) > len(ref), (w, h, b, dt)
+        for c in (one, two):
+            extra, dt_at = len(c) - len(ref), bytes(ref).index(b"DT", 11)
+            assert bytes(c[:dt_at]) == bytes(ref[:dt_at]) and bytes(c[dt_at + extra:]) == bytes(ref[dt_at:])
+            out, _, _, _ = qb3.decode(c)
+            assert np.array_equal(out, img.view(np.uint8).ravel()), (w, h, b, dt, gen, mode)
+        want, _, _, _ = oracle.decode(two, identity=True)
+        assert want is not None and np.array_equal(want, img.view(np.uint8).ravel()), "the reference decoder must step over the chunks"
+    for (w, h, b, dt, gen, mode) in [(256, 256, 3, 0, "NOISY3", 7), (300, 200, 1, 0, "PALETTE", 5), (256, 192, 8, 2, "LANDSAT16", 1),
+                                     (200, 160, 1, 5, "DEM", 5), (128, 128, 1, 7, "TERRACE", 7), (1024, 1024, 3, 0, "FEW", 5),
+                                     (160, 120, 5, 0, "NOISY3", 5), (128, 96, 2, 5, "DEM", 5), (96, 64, 3, 7, "TERRACE", 5), (200, 100, 2, 0, "PALETTE", 5),
+                                     (120, 88, 3, 2, "LANDSAT16", 5), (64, 48, 16, 2, "FEW", 1)]:
+        img = oracle.generate(w, h, b, dt, gen, 3)
+        cb = None if b in (1, 3, 4) else list(range(b))
+        ref = oracle.encode(img, dt, mode, cband=cb)
+        one = qb3.encode(img, dt, mode, cband=cb, index_chunk=1)
+        two = qb3.encode(img, dt, mode, cband=cb, index_chunk=2)
+        if ref[10] == 255:                          # raw-stored: no table either way
             assert np.array_equal(one, ref) and np.array_equal(two, ref)
             continue
-        if (dt <= 1 and b in (1, 3, 4)) or (dt >= 4 and b == 1):
-            assert np.array_equal(one, two) and len(one) > len(ref)
-        else:
-            assert len(two) > len(one) > len(ref)
+        assert np.array_equal(one, two) and len(one) > len(ref), (w, h, b, dt, gen, mode)
         extra, dt_at = len(two) - len(ref), bytes(ref).index(b"DT", 11)
         assert bytes(two[:dt_at]) == bytes(ref[:dt_at]) and bytes(two[dt_at + extra:]) == bytes(ref[dt_at:])
         want, _, _, _ = oracle.decode(two, identity=True)
         assert want is not None and np.array_equal(want, img.view(np.uint8).ravel()), "the reference decoder must step over the chunks"
-        for c in (one, two):
-            out, _, _, _ = qb3.decode(c)
-            assert np.array_equal(out, img.view(np.uint8).ravel()), (w, h, b, dt, gen, mode)
+        out, _, _, _ = qb3.decode(two)
+        assert np.array_equal(out, img.view(np.uint8).ravel()), (w, h, b, dt, gen, mode)
 
 
 def test_tiles_with_block_length_tables(qb3, oracle):
@@ -1973,3 +1983,168 @@ def test_handles_come_and_go(qb3, oracle):
             dec.close()
         if rnd == 1:
             L.qb3x_trim()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the lane-per-unit decoders (k_dec_pxu.hip): every raster no lane-per-block kernel takes
+
+PXU_CASES = [
+    # w, h, bands, dtype, gen, core band map (None: identity)
+    (96, 80, 2, 0, "NOISY3", None),
+    (131, 77, 2, 0, "PALETTE", [1, 1]),
+    (160, 120, 5, 0, "NOISY3", [1, 1, 1, 3, 4]),
+    (67, 61, 7, 1, "NOISY3", None),
+    (100, 52, 16, 0, "FEW", None),
+    (61, 67, 5, 3, "DEM", [0, 0, 2, 2, 4]),
+    (256, 36, 7, 2, "LANDSAT16", None),
+    (128, 40, 9, 2, "LANDSAT16", [1, 1, 1, 3, 4, 5, 6, 7, 8]),
+    (130, 70, 2, 5, "DEM", None),
+    (64, 132, 3, 4, "NOISY3", [1, 1, 1]),
+    (64, 64, 2, 7, "DEM", [1, 1]),
+    (36, 36, 16, 6, "RANDOM", None),
+    (48, 40, 5, 6, "RUNG63", None),
+    (8, 4, 2, 5, "DEM", None),             # two blocks: a segment that is mostly empty
+]
+PXU_CF_ONLY = [
+    # rasters whose FTL / BASE streams have lane-per-block kernels but whose common-factor streams do not
+    (128, 64, 2, 2, "LANDSAT16", None),
+    (120, 88, 3, 2, "TERRACE", [1, 1, 1]),
+    (256, 64, 4, 3, "DEM", None),
+    (96, 48, 8, 2, "FEW", None),
+    (64, 36, 12, 3, "PALETTE", None),
+]
+
+
+def _kernels_of(qb3, fn):
+    import ctypes as C
+    L = qb3.lib
+    L.qb3x_profile_enable(1); L.qb3x_profile_reset()
+    r = fn()
+    buf = C.create_string_buffer(2048)
+    L.qb3x_profile_names(buf, 2048)
+    L.qb3x_profile_enable(0)
+    return r, set(buf.value.decode().split(","))
+
+
+@pytest.mark.parametrize("mode", [FTL, BASE, BASE_Z, 5, 1])
+@pytest.mark.parametrize("case", PXU_CASES + PXU_CF_ONLY, ids=lambda c: "%dx%dx%d-t%d-%s" % c[:5])
+def test_lane_per_unit_decoders(qb3, oracle, case, mode):
+    """index, table (levels 1 and 2) and plain decode of the rasters of k_dec_pxu.hip, against the oracle's streams; the decode with
+    an index runs dec_units and nothing else (the lane-per-segment decoder's name is dec_segments)"""
+    import torch
+    from qb3_amd import synth, device as qdev
+    w, h, b, dt, gen, cb = case
+    if case in PXU_CF_ONLY and mode not in (5, 1):
+        pytest.skip("this raster's FTL / BASE streams have a lane-per-block kernel")
+    if gen == "RUNG63" and mode in (5, 1):
+        pytest.skip("64-bit index units: the reference's sentinel defect (SURVEY B-2), which the device encoder does not reproduce")
+    img = oracle.generate(w, h, b, dt, gen, 7)
+    raw = img.view(np.uint8).ravel()
+    cbm = cb if cb is not None else list(range(b))
+    ref = oracle.encode(img, dt, mode, cband=cbm)
+    assert np.array_equal(qb3.encode(img, dt, mode, cband=cbm), ref)
+    if ref[10] == 255:
+        pytest.skip("stored raw")
+    # plain container: walk, then the parallel decoder
+    out, dims, _, _ = qb3.decode(ref)
+    assert dims == (w, h, b) and np.array_equal(out, raw), "plain decode"
+    # out-of-band index through the device calls
+    dimg = torch.from_numpy(img.view(np.uint8).reshape(-1).copy()).cuda()
+    enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, cband=cbm)
+    dst, n, index = enc.encode(dimg)
+    assert np.array_equal(dst[:n].cpu().numpy(), ref)
+    dec = qdev.DeviceDecoder(dst, n)
+    got, names = _kernels_of(qb3, lambda: dec.decode(dst, index=index))
+    assert torch.equal(got, torch.from_numpy(raw).cuda()), "indexed decode"
+    assert "dec_units" in names and "dec_segments" not in names, names
+    # self-indexed containers
+    for level in (1, 2):
+        c = qb3.encode(img, dt, mode, cband=cbm, index_chunk=level)
+        assert len(c) > len(ref)
+        want, _, _, _ = oracle.decode(c, identity=True)
+        assert want is not None and np.array_equal(want, raw), "the reference decoder must step over the chunks"
+        dc = torch.from_numpy(c).cuda()
+        d2 = qdev.DeviceDecoder(dc, len(c))
+        got, names = _kernels_of(qb3, lambda: d2.decode(dc, index=None))
+        assert torch.equal(got, torch.from_numpy(raw).cuda()), ("table decode", level)
+        assert qb3.lib.qb3x_last_decode_status(d2.p) == 0
+        if level == 2 or mode in (5, 1):
+            assert names == {"dec_units"}, (level, names)       # from the entries alone: one kernel
+    # a damaged field costs time, not pixels
+    c = qb3.encode(img, dt, mode, cband=cbm, index_chunk=2).copy()
+    at = bytes(c).index(b"ix", 11) + 12 + 6 + b * (1 + img.itemsize * (2 if mode in (5, 1) else 1)) + 1
+    c[at] ^= 0x15
+    out, _, _, _ = qb3.decode(c)
+    assert np.array_equal(out, raw), "decode with a damaged table"
+
+
+def test_lane_per_unit_stride_and_tiles(qb3, oracle):
+    """line strides and batched tiles through the lane-per-unit decoders"""
+    import torch
+    from qb3_amd import device as qdev
+    for (w, h, b, dt, gen, mode) in [(100, 36, 5, 0, "NOISY3", FTL), (64, 44, 2, 5, "DEM", 5), (72, 40, 7, 2, "LANDSAT16", BASE)]:
+        img = oracle.generate(w, h, b, dt, gen, 9)
+        cbm = list(range(b))
+        ref = oracle.encode(img, dt, mode, cband=cbm)
+        L = qb3.lib
+        buf = np.ascontiguousarray(ref)
+        dims = (C_sz() * 3)()
+        p = L.qb3_read_start(buf.ctypes.data, buf.size, dims)
+        assert p and L.qb3_read_info(p)
+        stride = (w * b + 5) * img.itemsize             # bytes; the call takes values (QB3.h:146-148)
+        L.qb3_set_decoder_stride(p, w * b + 5)
+        out = np.full(stride * h, 0xa5, dtype=np.uint8)
+        assert L.qb3_read_data(p, out.ctypes.data) != 0
+        L.qb3_destroy_decoder(p)
+        rows = out.reshape(h, stride)
+        assert np.array_equal(rows[:, :w * b * img.itemsize].ravel(), img.view(np.uint8).ravel())
+        assert (rows[:, w * b * img.itemsize:] == 0xa5).all(), "bytes between the lines are not written"
+        n = 5
+        imgs = torch.stack([torch.from_numpy(oracle.generate(w, h, b, dt, gen, 40 + t).view(np.uint8).reshape(-1).copy()) for t in range(n)]).cuda()
+        for ic in (False, 2):
+            tc = qdev.TileBatchCoder(w, h, b, dt, n, mode=mode, want_index=not ic, index_chunk=ic)
+            tc.encode(imgs)
+            o = torch.zeros_like(imgs)
+            tc.decode(o, use_index=not ic)
+            assert torch.equal(o, imgs), (w, h, b, dt, mode, ic)
+            tc.close()
+
+
+def C_sz():
+    import ctypes
+    return ctypes.c_size_t
+
+
+def test_rle0_containers_keep_their_table(qb3, oracle):
+    """a self-indexed container whose RLE0 pass wins: the table stays in front of "DT" (it describes the block stream, which the
+    decoder has again after the expansion), the bytes behind it are the reference's RLE0 bytes, the reference's reader steps over the
+    chunks, and the decode uses the table (status bit 5 clear, one decoder kernel behind the expansion)"""
+    import torch
+    from qb3_amd import device as qdev
+    won = 0
+    for (w, h, b, dt, gen, mode) in [(512, 256, 3, 0, "CONST", 6), (256, 256, 3, 4, "NOISY3", 7), (300, 100, 1, 5, "TERRACE", 7), (256, 128, 5, 2, "CONST", 3),
+                                     (200, 120, 2, 0, "GRAD", 2)]:
+        img = oracle.generate(w, h, b, dt, gen, 3)
+        raw = img.view(np.uint8).ravel()
+        cb = None if b in (1, 3, 4) else list(range(b))
+        ref = oracle.encode(img, dt, mode, cband=cb)
+        if ref[10] not in (2, 3, 6, 7):
+            continue
+        won += 1
+        for level in (1, 2):
+            c = qb3.encode(img, dt, mode, cband=cb, index_chunk=level)
+            dt_at = bytes(ref).index(b"DT", 11)
+            extra = len(c) - len(ref)
+            assert extra > 0 and bytes(c[:dt_at]) == bytes(ref[:dt_at]) and bytes(c[dt_at + extra:]) == bytes(ref[dt_at:]), (w, h, b, dt, mode, level)
+            want, _, _, _ = oracle.decode(c, identity=True)
+            assert want is not None and np.array_equal(want, raw)
+            out, _, _, _ = qb3.decode(c)
+            assert np.array_equal(out, raw)
+            dc = torch.from_numpy(c).cuda()
+            d = qdev.DeviceDecoder(dc, len(c))
+            assert qb3.lib.qb3x_decoder_table_entries(d.p) > 0
+            got, names = _kernels_of(qb3, lambda: d.decode(dc, index=None))
+            assert torch.equal(got, torch.from_numpy(raw).cuda())
+            assert qb3.lib.qb3x_last_decode_status(d.p) == 0, "the table was dropped"
+            assert "dec_index_serial" not in names or level == 1, names
+    assert won >= 2
