@@ -43,6 +43,10 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
     T g[16];
     EncFront<T> f;
     const uint32_t outdw = a.slot_dw;
+    // the first 2 KB of LDS: factor signatures of the mag-sign values below 512 (gcf_sig_any; visible behind the front end's barrier)
+    uint32_t *gsig = (uint32_t *)smem;
+    fill_gcf_sig(gsig);
+    smem += GCF_SIG_BYTES;
     if constexpr (FRONT == 1) pxw_front<T, HILBERT>(a, a0, smem, outdw, f, g, chunk);
     else if constexpr (FRONT == 2) pxw_front<T, ZCURVE>(a, a0, smem, outdw, f, g, chunk);
     else enc_front<T>(a, a0, smem, outdw, f, g, chunk);
@@ -64,7 +68,12 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
     if (payload) oldrung = (gblk == 0) ? a0.st.rung[c] : (FRONT ? f.prung : f.rungs[tid - bands]);
     {
         T cf = 1;
-        if (__any(analyse)) cf = gcf_t<T>(g, analyse);
+        // units whose magnitudes all stay below 256 -- nearly every unit of 8- and 16-bit imagery and of smooth wide rasters --
+        // ask the signature table whether there is a factor at all (rung <= 8); Euclid runs only in a wave that holds such a unit (or a larger magnitude)
+        const bool small = rung <= 8;               // (mag-sign values below 512: magnitudes of at most 256)
+        bool maybe = analyse;
+        if (__any(analyse && small)) { const bool y = gcf_sig_any<T>(g, gsig); if (small) maybe = analyse && y; }
+        if (__any(maybe)) cf = gcf_t<T>(g, maybe);
         if (analyse) best_analyse<T>(g, rung, oldrung, cf, summary_only, u);
     }
     // who wrote the band's factor last

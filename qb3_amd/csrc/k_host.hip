@@ -323,9 +323,9 @@ EncPlan plan_encode(const Geometry &g) {
     p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
     const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1;
     p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * ((outdw + 1) & ~(size_t)1);
-    if (g.mode == CM_BEST) p.lds_bytes += 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8 + 4 * (size_t)p.slots;     // the writer board: a value per lane, a ballot per wave, a word per band; a word per block (the index's block table)
+    if (g.mode == CM_BEST) p.lds_bytes += 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8 + 4 * (size_t)p.slots + 4 * 512;     // the writer board: a value per lane, a ballot per wave, a word per band; a word per block (the index's block table)
     // (the lane-per-block front end has no tile: scan scratch, the code table, the bit buffer -- of the worst common-factor unit -- and the board)
-    if (p.pxw_best) p.lds_bytes = 256 + 1024 + 4 * (size_t)enc_ws_layout(g, p.nchunks, nbp, p.threads).slot_dw + 8 + 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8 + 4 * (size_t)p.slots;
+    if (p.pxw_best) p.lds_bytes = 256 + 1024 + 4 * (size_t)enc_ws_layout(g, p.nchunks, nbp, p.threads).slot_dw + 8 + 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8 + 4 * (size_t)p.slots + 4 * 512;
     p.ws_bytes = enc_ws_layout(g, p.nchunks, nbp, p.threads).total;
     return p;
 }
@@ -508,7 +508,8 @@ bool walk_table_applies(const Geometry &g, const DecPlan &plan) {
     // 8- and 16-bit rasters the lane-per-block decoders take; 32/64-bit rasters the unit-parallel decoder takes (a band of sixteen rungs)
     // ... and single-band common-factor streams of any width (the exits of k_dec_walk.hip)
     if (g.mode == CM_BEST) return (g.bands == 1 || (g.bands == 3 && g.tsz == 1)) && !tuning().slow_walk && !tuning().slow_index;
-    return ((plan.px && g.tsz == 1) || (plan.px16 && g.tsz == 2) || (g.tsz >= 4 && plan.fast)) && !tuning().slow_walk && !tuning().slow_index;
+    // (16-bit rasters of the lane-per-unit decoder too: the 16-bit chain takes any band count and segment size)
+    return ((plan.px && g.tsz == 1) || ((plan.px16 || plan.pxu) && g.tsz == 2) || (g.tsz >= 4 && plan.fast)) && !tuning().slow_walk && !tuning().slow_index;
 }
 
 // A restart table is untrusted input that the decoder takes positions, rungs and values from: before any of it is used the
@@ -583,13 +584,14 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     }
     // plain 32/64-bit FTL/BASE streams: unit lengths through the table of a band of rungs, when the caller brought memory for it
     const bool wide_plain = rebuild && !a.ix && unit_parallel && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk;
-    if (rebuild && (use_px || use_px16 || wide_walk || wide_plain) && !tuning().slow_index) {
+    const bool pxu16_plain = rebuild && !a.ix && use_pxu && a.g.tsz == 2 && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk;
+    if (rebuild && (use_px || use_px16 || wide_walk || wide_plain || pxu16_plain) && !tuning().slow_index) {
         // index-less stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
         // produce the values entering the segments (totals pass + scan)
         // plain 8-bit stream: through the table of unit lengths by position when the caller brought memory for it
         const bool has_ix = a.ix != nullptr;
         bool have_prev = false;             // the index's entering values are there already
-        if ((use_px || use_px16 || wide_plain) && !has_ix && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk) launch_dec_walk_table(a, st, walk_tab, walk_tab_bytes, max_bits);
+        if ((use_px || use_px16 || wide_plain || pxu16_plain) && !has_ix && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk) launch_dec_walk_table(a, st, walk_tab, walk_tab_bytes, max_bits);
         else if (has_ix) { ProfScope ps("dec_index_serial", st); launch_dec_walk(a, st); }
         else { ProfScope ps("dec_index_serial", st); launch_dec_index_serial(a, st); have_prev = true; }       // no table memory: one lane parses the stream (values included)
         if (!have_prev && !(a.ix && a.ix_blocks == a.g.seg_blocks) && !wide_walk) {         // (an entry per segment: the walk copied the entering values)

@@ -77,6 +77,43 @@ template <typename T> __device__ __forceinline__ T gcf_t(const T (&g)[16], bool 
     }
     return x;
 }
+// ---- "is there a common factor" without Euclid, for mag-sign values below 512 (rungs up to 8: smooth and noisy rasters alike).  A
+// table holds for every mag-sign value g, of magnitude m <= 256: the primes up to 13 that divide m (six bits) and what is left of m when
+// they are divided out -- 1 or ONE prime (17 .. 251: two of them would exceed 256).  Some prime divides every non-zero magnitude of a unit exactly
+// when the AND of the masks is not empty or all the cofactors are the same prime: sixteen look-ups, no loop, no divergence -- where gcf_t
+// costs a wave its slowest lane's Euclid chains.  Entry: mask | cofactor << 8 | cofactor << 16; for m = 0 (a magnitude the gcd ignores):
+// 0x3f | 0xff << 8 | 0.  A compile-time constant, copied to LDS from L2 with 16-byte loads.
+struct GcfSig { alignas(16) uint32_t e[512]; };
+constexpr GcfSig make_gcf_sig() {
+    GcfSig t{};
+    for (uint32_t g = 0; g < 512; g++) {
+        const uint32_t m = (g >> 1) + (g & 1);
+        uint32_t e = 0x3fu | 0xff00u;
+        if (m) {
+            uint32_t mask = 0, c = m;
+            const uint32_t pr[6] = {2, 3, 5, 7, 11, 13};
+            for (int k = 0; k < 6; k++)
+                if (c % pr[k] == 0) { mask |= 1u << k; while (c % pr[k] == 0) c /= pr[k]; }
+            e = mask | c << 8 | c << 16;
+        }
+        t.e[g] = e;
+    }
+    return t;
+}
+static __device__ const GcfSig gcf_sig_tab = make_gcf_sig();
+constexpr uint32_t GCF_SIG_BYTES = 2048;
+__device__ __forceinline__ void fill_gcf_sig(uint32_t *sig) {       // the caller's next barrier makes it visible
+    for (uint32_t i = threadIdx.x; i < GCF_SIG_BYTES / 16; i += blockDim.x) ((uint4 *)sig)[i] = ((const uint4 *)gcf_sig_tab.e)[i];
+}
+// true exactly when the unit's non-zero magnitudes have a common factor above 1 (mag-sign values all below 512)
+template <typename T> __device__ __forceinline__ bool gcf_sig_any(const T (&g)[16], const uint32_t *sig) {
+    uint32_t a = 0xffffffffu, o = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) { const uint32_t e = sig[(uint32_t)g[i] & 511u]; a &= e; o |= e; }
+    const uint32_t ca = (a >> 8) & 0xffu, co = (o >> 16) & 0xffu;
+    return (a & 0x3fu) != 0 || (ca == co && ca > 1);
+}
+
 // bit length of one value coded on its own at rung r (reference qb3csztbl, QB3encode.h:144-150): rung 0 is one raw
 // bit, rungs 1-2 plain, rungs 3-7 with the middle swap, above that plain
 template <typename T> __device__ __forceinline__ uint32_t vlen_t(T v, uint32_t r) {
