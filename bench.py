@@ -155,7 +155,7 @@ def attach_traffic(roofline, algo_bytes, workload=None, from_table=False, scale=
         roofline["valu"] = valu
 
 
-def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen, seed, mode, steps, label):
+def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen, seed, mode, steps, label, traffic_tag=None):
     """One raster: self-indexed encode, decode from the container alone and with the out-of-band index."""
     import numpy as np
     img = synth.generate(w, h, bands, dtype, gen, seed, device=dev)
@@ -210,7 +210,7 @@ def measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, h, bands, dtype, gen
         "roofline": roofline_of({**e, **d_oob}, algo, ENC_KERNELS + DEC_KERNELS,
                                 extra={"restart_table_in_container": int(n) - stream_bytes, "out_of_band_index": enc.index_bytes}),
     })
-    attach_traffic(res["roofline"], algo, tag)      # HBM bytes of the dominant kernel by the PMC passes of this workload (profiles/collect.sh)
+    attach_traffic(res["roofline"], algo, traffic_tag or tag)      # HBM bytes of the dominant kernel by the PMC passes of this workload (profiles/collect.sh)
     del enc, dec, img, out
     return res
 
@@ -311,7 +311,7 @@ def main():
                          "segments' unit lengths first), 2 = entries with the blocks' bit lengths (5.5 %%, no walk)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the short measurements of configs 3, 4, 5")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2best", "c3", "c4", "c5", "plain", "shapes"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2best", "c3", "c3cf", "c4", "c5", "plain", "shapes"],
                     help="N = 1: make this configuration the only one run (for profiling); c2 is the headline")
     ap.add_argument("--tiles-per-rank", type=int, default=32)
     ap.add_argument("--batch-tiles", type=int, default=8)
@@ -576,7 +576,7 @@ def main():
         del img, out, enc, dec, dst
         torch.cuda.empty_cache()
         workloads = {}
-        for wl in ("c2best", "c3", "c4", "c5", "shapes"):
+        for wl in ("c2best", "c3", "c3cf", "c4", "c5", "shapes"):
             workloads.update(run_other(wl, args, torch, qb3_amd, synth, qdev, dev))
 
     cpu = None if args.no_cpu_baseline else cpu_baseline()
@@ -685,19 +685,23 @@ def run_other(wl, args, torch, qb3_amd, synth, qdev, dev):
     elif wl == "c2best":    # not a BASELINE configuration: the raster of configs[1] in QB3M_BEST (common factor + index coding)
         out["c2_best"] = measure_image(torch, qb3_amd, synth, qdev, dev, "c2_best", 16384, 16384, 3, qb3_amd.QB3_U8, "NOISY3", 2, qb3_amd.QB3M_BEST, steps,
                                        "16384x16384x3 uint8 NOISY3 seed 2, QB3M_BEST")
-    elif wl == "shapes":    # not BASELINE configurations: config 3's raster in the common-factor modes, and rasters no lane-per-block kernel takes
-        # (the lane-per-unit kernels of k_dec_pxu.hip; the encoders of these are the unit-per-lane kernels of k_enc_generic.hip / k_enc_best.hip)
-        for tag, w, b, dt_, gen, mode, name in (
-                ("c3_cf", 8192, 8, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_CF_H, "8192x8192x8 uint16 LANDSAT16 seed 3, QB3M_CF_H (config 3's raster, common factor + index coding)"),
-                ("c3_best", 8192, 8, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BEST, "8192x8192x8 uint16 LANDSAT16 seed 3, QB3M_BEST (= CF_H + the RLE0 pass, which wins on this raster)"),
-                ("u8x2_ftl", 4096, 2, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_FTL, "4096x4096x2 uint8 NOISY3 seed 3, QB3M_FTL"),
-                ("u8x5_ftl", 4096, 5, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_FTL, "4096x4096x5 uint8 NOISY3 seed 3, QB3M_FTL"),
-                ("u16x7_base", 4096, 7, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BASE, "4096x4096x7 uint16 LANDSAT16 seed 3, QB3M_BASE"),
-                ("i32x2_ftl", 4096, 2, qb3_amd.QB3_I32, "DEM", qb3_amd.QB3M_FTL, "4096x4096x2 int32 DEM seed 3, QB3M_FTL"),
-                ("i64x2_ftl", 4096, 2, qb3_amd.QB3_I64, "DEM", qb3_amd.QB3M_FTL, "4096x4096x2 int64 DEM seed 3, QB3M_FTL"),
-                ("u8x5_cf", 4096, 5, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_CF_H, "4096x4096x5 uint8 NOISY3 seed 3, QB3M_CF_H"),
-                ("i32x3_best", 4096, 3, qb3_amd.QB3_I32, "DEM", qb3_amd.QB3M_BEST, "4096x4096x3 int32 DEM seed 3, QB3M_BEST")):
-            out[tag] = measure_image(torch, qb3_amd, synth, qdev, dev, tag, w, w, b, dt_, gen, 3, mode, steps, name)
+    elif wl == "c3cf":      # not a BASELINE configuration: config 3's raster in the common-factor modes (the lane-per-unit decoder, the unit-per-lane encoder)
+        for tag, mode, name in (("c3_cf", qb3_amd.QB3M_CF_H, "QB3M_CF_H (common factor + index coding)"),
+                                ("c3_best", qb3_amd.QB3M_BEST, "QB3M_BEST (= CF_H + the RLE0 pass, which wins on this raster)")):
+            out[tag] = measure_image(torch, qb3_amd, synth, qdev, dev, tag, 8192, 8192, 8, qb3_amd.QB3_U16, "LANDSAT16", 3, mode, steps,
+                                     "8192x8192x8 uint16 LANDSAT16 seed 3, " + name, traffic_tag="c3_cf")
+            torch.cuda.empty_cache()
+    elif wl == "shapes":    # not BASELINE configurations: rasters no lane-per-block kernel takes (decoders: k_dec_pxu.hip, a lane per unit;
+        # encoders: the unit-per-lane kernels of k_enc_generic.hip / k_enc_best.hip).  One raster per value type and mode family, so that
+        # every raster's kernels are symbols of their own in a profile of this workload (profiles/summarise.py keys them by that)
+        for tag, b, dt_, gen, mode, name in (
+                ("u8x5_ftl", 5, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_FTL, "x5 uint8 NOISY3 seed 3, QB3M_FTL"),
+                ("u16x7_base", 7, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BASE, "x7 uint16 LANDSAT16 seed 3, QB3M_BASE"),
+                ("i32x2_ftl", 2, qb3_amd.QB3_I32, "DEM", qb3_amd.QB3M_FTL, "x2 int32 DEM seed 3, QB3M_FTL"),
+                ("i64x2_ftl", 2, qb3_amd.QB3_I64, "DEM", qb3_amd.QB3M_FTL, "x2 int64 DEM seed 3, QB3M_FTL"),
+                ("u8x5_cf", 5, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_CF_H, "x5 uint8 NOISY3 seed 3, QB3M_CF_H"),
+                ("i32x3_best", 3, qb3_amd.QB3_I32, "DEM", qb3_amd.QB3M_BEST, "x3 int32 DEM seed 3, QB3M_BEST")):
+            out[tag] = measure_image(torch, qb3_amd, synth, qdev, dev, tag, 4096, 4096, b, dt_, gen, 3, mode, steps, "4096x4096" + name)
             torch.cuda.empty_cache()
     elif wl == "c3":
         out["c3"] = measure_image(torch, qb3_amd, synth, qdev, dev, "c3", 8192, 8192, 8, qb3_amd.QB3_U16, "LANDSAT16", 3, qb3_amd.QB3M_BASE, steps,

@@ -20,7 +20,7 @@ PROFILE_CMD="python3 $CMD" python3 profiles/summarise.py $TAG $OUT/trace $OUT/fe
 cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc_hbm.csv profiles/${TAG}_sq.csv profiles/pmc_traffic.json $OUT/
 grep '^{' $OUT/bench_under_rocprof.json > $OUT/${TAG}_bench_under_rocprof.json || true
 fi
-for WL in ${WORKLOADS:-c2best c3 c4 c5 plain}; do
+for WL in ${WORKLOADS:-c2best c3 c3cf c4 c5 plain shapes}; do
     W="bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $WL"
     rocprofv3 --kernel-trace --stats -d $OUT/trace_$WL -o t --output-format csv -- python3 $W > $OUT/${TAG}_${WL}_bench_under_rocprof.json 2> $OUT/trace_$WL.log
     PROFILE_CMD="python3 $W" python3 profiles/summarise.py --stats-only ${TAG}_$WL $OUT/trace_$WL

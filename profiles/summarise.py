@@ -36,7 +36,7 @@ SQ_NAMES = ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LD
 KEYS = [("walk_exitW_kernel", "dec_index_table"), ("walk_exitB_kernel", "dec_index_table"), ("walk_exitB_chain", "dec_index_serial"), ("walk_exit_", "dec_index_serial"),
         ("walk_probe", "dec_index_serial"), ("walk_tableW", "dec_index_table"), ("walk_chainW", "dec_index_serial"), ("walk_table16", "dec_index_table"), ("walk_chain16", "dec_index_serial"),
         ("enc_px_best_sample_kernel", "enc_best_sample"), ("enc_best_sample_kernel", "enc_best_sample"), ("enc_pxw_best_kernel", "enc_best_units"),
-        ("enc_px_best_kernel", "enc_best_units"), ("dec_px_best_kernel", "dec_units"), ("dec_pxw_best_kernel", "dec_units"), ("ix_bl_best_fill", "ix_bl_fill"),
+        ("enc_px_best_kernel", "enc_best_units"), ("dec_px_best_kernel", "dec_units"), ("dec_pxw_best_kernel", "dec_units"), ("dec_pxu_best_kernel", "dec_units"), ("dec_pxu_kernel", "dec_units"), ("ix_blu_best_fill", "ix_bl_fill"), ("ix_bl_best_fill", "ix_bl_fill"),
         ("best_idx_fix", "enc_best_idx_fix"), ("ix_bl16_fill", "ix_bl_fill"), ("ix_blw_fill", "ix_bl_fill"), ("rle0_", "rle0"), ("enc_px_kernel", "enc_units"), ("enc_px16_kernel", "enc_units"),
         ("enc_pxw_kernel", "enc_units"), ("enc_kernel", "enc_units"),
         ("enc_best_kernel<unsigned char, false>", "enc_best_recode"), ("enc_best_kernel<unsigned short, false>", "enc_best_recode"),
@@ -49,13 +49,15 @@ KEYS = [("walk_exitW_kernel", "dec_index_table"), ("walk_exitB_kernel", "dec_ind
         ("dec_index_serial", "dec_index_serial"), ("dec_index_staged", "dec_index_serial"), ("dec_kernel", "dec_segments")]
 # kernels with a variant that decodes from the container's own table (last template argument BL = true): the two variants
 # run in different calls (decode from the container alone / with the out-of-band index), never in one -- apart, not summed
-BL_VARIANTS = ("dec_px_kernel<", "dec_px16_kernel<", "dec_px_best_kernel<", "dec_pxw_kernel<", "dec_pxw_best_kernel<", "dec3_kernel<")
+BL_VARIANTS = ("dec_px_kernel<", "dec_px16_kernel<", "dec_px_best_kernel<", "dec_pxw_kernel<", "dec_pxw_best_kernel<", "dec3_kernel<", "dec_pxu_kernel<", "dec_pxu_best_kernel<")
 
 
 def key_of(name):
     if "qb3dev" not in name:
         return None
     if ("enc_px_best_kernel" in name or "enc_pxw_best_kernel" in name) and re.search(r", false>\(", name):
+        return "enc_best_recode"
+    if re.search(r"enc_best_kernel<[a-z ]+, false", name):      # (FIRST = false: the recode pass, whatever the front end)
         return "enc_best_recode"
     for sub, key in KEYS:
         if sub in name:
@@ -108,7 +110,12 @@ def subtag_of(wl, name):
         t = "i64" if "unsigned long" in name else "i32"
         best = any(k in name for k in ("enc_best", "enc_pxw_best", "dec_pxw_best", "best_scan", "best_idx_fix", "dec_kernel<", "dec_index"))
         return "c4_%s_%s" % (t, "best" if best else "ftl")
-    return {"c2best": "c2_best", "c5": "c5_one_rank"}.get(wl, wl)
+    if wl == "shapes":      # one raster per value type and mode family (bench.py run_other): the symbol says which
+        t = "u64" if "unsigned long" in name else "u32" if "unsigned int" in name else "u16" if "unsigned short" in name else "u8" if "unsigned char" in name else None
+        best = "best" in name
+        return {("u8", False): "u8x5_ftl", ("u16", False): "u16x7_base", ("u32", False): "i32x2_ftl", ("u64", False): "i64x2_ftl",
+                ("u8", True): "u8x5_cf", ("u32", True): "i32x3_best"}.get((t, best), "shapes")
+    return {"c2best": "c2_best", "c5": "c5_one_rank", "c3cf": "c3_cf"}.get(wl, wl)
 
 
 def counters(tag, wl, fetch_dir, write_dir, sq_dir, cmd):

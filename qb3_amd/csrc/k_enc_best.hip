@@ -54,7 +54,7 @@ __device__ __forceinline__ void best_chunk(const EncArgs &a, const EncArgs &a0, 
     const bool payload = f.payload;
     const T used = f.used;
     WriterBoard wb;
-    wb.vals = (uint64_t *)(f.outbuf + ((outdw + 1) & ~1u));     // nthr values, then one mask per wave, then a "used the entry state" word per band
+    wb.vals = (uint64_t *)f.board;                              // nthr values, then one mask per wave, then a "used the entry state" word per band
     wb.masks = wb.vals + nthr;
     uint32_t *used_entry = (uint32_t *)(wb.masks + 16);
     uint32_t *blk_tab = used_entry + MAXBANDS + 2;             // a word per block slot: the index's block table (ulen_sz == 4)

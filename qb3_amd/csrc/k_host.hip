@@ -321,8 +321,9 @@ EncPlan plan_encode(const Geometry &g) {
     const uint32_t nbp = p.slots - 1;
     p.nbp = nbp;
     p.nchunks = (uint32_t)((g.nblocks + nbp - 1) / nbp);
-    const size_t outdw = (31 + (size_t)nbp * g.bands * max_unit_bits(g.tsz, g.mode)) / 32 + 1;
-    p.lds_bytes = 8 * (size_t)p.slots + 4 * (size_t)(4 * p.slots * dpr) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7) + 4 * ((outdw + 1) & ~(size_t)1);
+    // (the pixel tile and the bit buffer -- of slot_dw dwords, what the common-factor kernels zero -- share their memory: enc_front, qb3_enc_front.h)
+    const size_t outdw = enc_ws_layout(g, p.nchunks, nbp, p.threads).slot_dw, tiledw = 4 * (size_t)p.slots * dpr;
+    p.lds_bytes = 8 * (size_t)p.slots + 4 * std::max(tiledw, (outdw + 1) & ~(size_t)1) + 256 + 1024 + (((size_t)p.slots * g.bands + 7) & ~(size_t)7);
     if (g.mode == CM_BEST) p.lds_bytes += 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8 + 4 * (size_t)p.slots + 4 * 512;     // the writer board: a value per lane, a ballot per wave, a word per band; a word per block (the index's block table)
     // (the lane-per-block front end has no tile: scan scratch, the code table, the bit buffer -- of the worst common-factor unit -- and the board)
     if (p.pxw_best) p.lds_bytes = 256 + 1024 + 4 * (size_t)enc_ws_layout(g, p.nchunks, nbp, p.threads).slot_dw + 8 + 8 * (size_t)p.threads + 8 * 16 + 4 * MAXBANDS + 8 + 4 * (size_t)p.slots + 4 * 512;

@@ -8,12 +8,18 @@ namespace qb3dev {
 // Everything a unit-per-lane encoder kernel needs before coding: LDS carve, tile staging, gather, deltas.
 template <typename T> struct EncFront {
     uint64_t *slot_base; uint32_t *tile, *wsum; uint8_t *rungs; uint16_t *etab; uint32_t *outbuf;
+    uint8_t *board;         // the LDS behind the front end's own (the common-factor kernels' writer board)
     uint32_t s, c, cb, gblk, rung, nbp, chunk;
     bool valid, payload;
     T used, pv, lastv;
     uint32_t prung;         // rung of the block before (the lane-per-block front end; the generic one leaves the rungs in LDS)
 };
 
+// dwords the tile (4 rows of rowdw) and the bit buffer (outdw) share
+__host__ __device__ inline uint32_t enc_front_union_dw(uint32_t rowdw, uint32_t outdw) {
+    const uint32_t t = 4 * rowdw, o = (outdw + 1) & ~1u;
+    return t > o ? t : o;
+}
 template <typename T>
 __device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, uint8_t *smem, uint32_t outdw, EncFront<T> &f, T (&g)[16], uint32_t chunk) {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
@@ -22,13 +28,16 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, u
     const uint64_t stride = a.g.stride;
     const uint32_t rowdw = slots * dpr;
 
-    // LDS carve (all offsets multiples of 8)
+    // LDS carve (all offsets multiples of 8).  The pixel tile and the bit buffer share their memory: the tile is dead once the units are
+    // gathered, the buffer is zeroed behind that barrier and written after the callers' scan -- 16 + 17 KB a workgroup of two int32
+    // bands became 17, twice the workgroups a CU holds (enc_front_lds_dw: the plan's arithmetic)
     f.slot_base = (uint64_t *)smem;
     f.tile = (uint32_t *)(f.slot_base + slots);
-    f.wsum = f.tile + 4 * rowdw;                          // 64 dwords of scan scratch
+    f.outbuf = f.tile;
+    f.wsum = f.tile + enc_front_union_dw(rowdw, outdw);   // 64 dwords of scan scratch
     f.rungs = (uint8_t *)(f.wsum + 64);                   // slots*bands bytes, padded to 8
     f.etab = (uint16_t *)(f.rungs + ((slots * bands + 7) & ~7u));     // ENC_TAB_SIZE + pad
-    f.outbuf = (uint32_t *)(f.etab + 512);
+    f.board = (uint8_t *)(f.etab + 512);
     fill_enc_tab(f.etab);
     uint64_t *slot_base = f.slot_base; uint32_t *tile = f.tile;
 
@@ -52,7 +61,6 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, u
         block_origin(slot_block(tid, valid), x0, y0);
         slot_base[tid] = (uint64_t)y0 * stride + (uint64_t)x0 * bands;
     }
-    for (uint32_t i = tid; i < outdw; i += nthr) f.outbuf[i] = 0;
     __syncthreads();
 
     // ---- stage the 4-row tile: coalesced dword loads, [row][slot][pixel][band] as in memory
@@ -122,6 +130,8 @@ __device__ __forceinline__ void enc_front(const EncArgs &a, const EncArgs &a0, u
         f.rungs[tid] = (uint8_t)rung;
     }
     __syncthreads();
+    // the tile has been read: its memory becomes the (zeroed) bit buffer; the callers' scans put a barrier in front of the first write
+    for (uint32_t i = tid; i < outdw; i += nthr) f.outbuf[i] = 0;
     f.s = s; f.c = c; f.cb = cb; f.gblk = gblk; f.rung = rung;
     f.valid = valid; f.payload = valid && s >= 1;
     f.used = used; f.pv = pv; f.lastv = lastv;
@@ -141,6 +151,7 @@ __device__ __forceinline__ void pxw_front(const EncArgs &a, const EncArgs &a0, u
     f.wsum = (uint32_t *)smem;                              // 64 dwords of scan scratch ([32 ..]: rung of each wave's last lane)
     f.etab = (uint16_t *)(f.wsum + 64);                     // 512 entries
     f.outbuf = (uint32_t *)(f.etab + 512);
+    f.board = (uint8_t *)(f.outbuf + ((outdw + 1) & ~1u));
     const uint4 tabv = ((const uint4 *)wide_enc_tab.e)[tid & 63];
     for (uint32_t i = tid; i < outdw; i += nthr) f.outbuf[i] = 0;
     const int64_t gs = (int64_t)chunk * (nthr - 1) - 1 + tid;       // lane 0 is the halo block
