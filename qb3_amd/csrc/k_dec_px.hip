@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     } else {
         P0 = a.idx.bitpos[segc];
         P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
+        if (P1 < P0) P1 = P0;       // (the last segment of a truncated stream starts behind its end: it reads zeros, like the reference's reader, bitstream.h:36)
         const uint8_t *ul = (const uint8_t *)a.idx.ulen + ((uint64_t)g0 + lane) * B;
 #pragma unroll
         for (int c = 0; c < B; c++) {

@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
     } else {
         P0 = a.idx.bitpos[segc];
         P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
+        if (P1 < P0) P1 = P0;       // (the last segment of a truncated stream starts behind its end: it reads zeros, like the reference's reader, bitstream.h:36)
         // a lane's BG lengths, rungs and entering values are contiguous: one load each where the address allows
         const uint16_t *ul = (const uint16_t *)a.idx.ulen + ((uint64_t)g0 + slot) * B + band0;
         const uint16_t *pvp = (const uint16_t *)a.idx.prev + segc * B + band0;

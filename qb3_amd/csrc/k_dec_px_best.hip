@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256) dec_px_best_kernel(const DecArgs a0) {
     } else {
         P0 = a.idx.bitpos[segc];
         P1 = (segc + 1 < a.g.nseg) ? a.idx.bitpos[segc + 1] : a.in_bits;
+        if (P1 < P0) P1 = P0;       // (the last segment of a truncated stream starts behind its end: it reads zeros, like the reference's reader, bitstream.h:36)
         bt = act ? ((const uint32_t *)a.idx.ulen)[(uint64_t)g0 + lane] : 0u;
 #pragma unroll
         for (int c = 0; c < B; c++) { pv0[c] = ((const uint8_t *)a.idx.prev)[segc * B + c]; cf0[c] = ((const uint8_t *)a.idx.cf)[segc * B + c]; }
@@ -173,11 +174,12 @@ __global__ void __launch_bounds__(256) dec_px_best_kernel(const DecArgs a0) {
     // the rungs the NEXT block is entered with are the rungs this block's units must leave: checked, not trusted
     const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(bt >> 16), 0x130, 0xf, 0xf, false);      // wave_shl:1
     uint32_t rp[B][8], spk[NW], sinc[NW];
+    bool clamped = false;
 #pragma unroll
     for (int k = 0; k < NW; k++) spk[k] = 0;
 #pragma unroll
     for (int c = 0; c < B; c++) {
-        pos = pos < limit ? pos : limit;
+        if (pos > limit) { pos = limit; clamped = true; }       // (a stream cut short: the unit reads zeros wherever it starts behind the end)
         const uint32_t oldrung = (bt >> (16 + 4 * c)) & 7u;
         bool sig; uint32_t csl;
         const uint32_t d = px_switch(pos, &csl, &sig);
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(256) dec_px_best_kernel(const DecArgs a0) {
         spk[c >> 1] |= (act ? tot : 0u) << (16 * (c & 1));
         pos = end;
     }
-    if (act && pos != blk_end) bad = true;              // the index's lengths are not this stream's
+    if (act && !clamped && pos != blk_end) bad = true;  // the index's lengths are not this stream's
 #pragma unroll
     for (int k = 0; k < NW; k++) sinc[k] = wave_iscan32(spk[k]);
     if (act) {

@@ -221,7 +221,9 @@ __global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const
         uint32_t Rn = 0;
         for (int c = 0; c < B; c++) Rn |= ((R[c] >> 1) & 7u) << (4 * c);
         S->P = stuck ? ~0ull : Pn; S->gb = nblocks - left; S->rungs = Rn; S->bad = (bad & 1u) | (stuck ? 1u : 0u);
-        if ((bad & 1u) || stuck) atomicOr(a.status, 1u);
+        // (a stream that ends with blocks left -- cut short -- is not walked on: the call goes to the one-lane parser, whose reader
+        // gives zeros behind the end like the reference's)
+        if ((bad & 1u) || stuck || (left && Pn >= a.in_bits)) atomicOr(a.status, 1u);
         return;
     }
     if (wave <= 6) {
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const
     }
 }
 
-// ---- the same for plain 16-bit streams ---------------------------------------------------------------------------
+// ---- the same for plain 16-bit streams, and for the 8-bit streams the hand-ordered chain above does not take -------
 // Sixteen rungs, codes of up to 17 bits, units of up to 278: a row is sixteen 16-bit entries (32 bytes), a window 1536
 // positions (48 KB, two of them side by side in LDS: slot 1 is reached through the read's immediate offset, so the
 // addresses the walk carries stay window-relative).  A block has up to 16 bands here and can be longer than a window,
@@ -297,18 +299,30 @@ __global__ void __launch_bounds__(512) walk_chain_kernel(const DecArgs a0, const
 // 32 table bytes per stream bit); the rungs of the bands live in a small LDS array, and the trail holds the entries
 // read (next position | rung out), from which a writer wave derives unit lengths and segment entries.  The walk loop is
 // plain C++ here (about 1.5 x the cycles per unit of the hand-ordered 8-bit loop).
-namespace chain16 {
-constexpr uint32_t NR = 16, ROWB = 32, CW = 1536, WIN_BYTES = CW * ROWB, WIN_U4 = WIN_BYTES / 16;      // 49152 bytes, 3072 sixteen-byte pieces
-constexpr uint32_t MAXC = 17, NP = CW + 288;            // longest code; positions a table workgroup looks at
-static_assert(NP % 32 == 0 && NP >= CW + 6 + 15 * MAXC + 2 && WIN_BYTES == 0xc000 && (CW + 278) * ROWB < 65536 && WIN_U4 % 192 == 0, "16-bit window layout");
-constexpr uint32_t TR_BYTES = ((CW / 2 + 8) * 2 + 15) & ~15u;              // trail of a window: a unit is at least two bits
-constexpr uint32_t TR0 = 2 * WIN_BYTES, RS0 = TR0 + 2 * TR_BYTES, WR0 = RS0 + 64, META = WR0 + 64, LDS_BYTES = META + 128;
-constexpr uint32_t F_READY = META /* [2][4] */, F_TRAILED = META + 32, F_NUNITS = META + 40, F_O0 = META + 48,
-                   F_WALKED = META + 56, F_STOP = META + 60, F_U0 = META + 64 /* u64[2] */;
-}  // namespace chain16
+// UB = 3: 8-bit streams of 2 or more than 4 bands (and the common-factor streams of any band count but one): eight rungs, rows of
+// sixteen bytes, windows of 3072 positions -- the same kernels, half the table bytes a stream bit.
+// CF (round 4): COMMON-FACTOR streams of several bands.  A unit with the signal code -- a common-factor or index unit: its values
+// decide the rung it leaves (reference QB3decode.h:619-716) -- is marked in its table entry; the walking lane parses it outright from
+// the stream (parse_unit over global memory: the few per cent of units that have it cost microseconds each) and puts the entry the
+// table could not hold into the trail; the factor in force per band is part of the walk's state, and once a unit has brought one the
+// lane leaves the factors in force at every segment start (idx.cf, zeroed beforehand).  The writer wave makes the lane-per-unit
+// decoder's dwords (bits | entering rung) or, for 8-bit streams of 1 / 3 / 4 bands, adds the units up into the block table.
+template <uint32_t UB> struct chainN {
+    static constexpr uint32_t NR = 1u << UB, ROWB = 2 * NR, CW = 49152 / ROWB, WIN_BYTES = CW * ROWB, WIN_U4 = WIN_BYTES / 16;     // 49152 bytes, 3072 sixteen-byte pieces
+    static constexpr uint32_t MAXC = NR + 1, MAXU = UB + 2 + 16 * MAXC;         // longest code, longest plain unit (149 / 278 bits)
+    static constexpr uint32_t NP = CW + ((6 + 15 * MAXC + 2 + 31) & ~31u);       // positions a table workgroup looks at
+    static constexpr uint32_t TR_BYTES = ((CW / 2 + 8) * 2 + 15) & ~15u;         // trail of a window: a unit is at least two bits
+    static constexpr uint32_t NWS = (CW + 384 + 32 + 31) / 32, STR_BYTES = (NWS * 4 + 15) & ~15u;         // CF: the stream words of a window and of the longest unit that starts in it
+    static constexpr uint32_t TR0 = 2 * WIN_BYTES, RS0 = TR0 + 2 * TR_BYTES, WR0 = RS0 + 64, CFS0 = WR0 + 64, STR0 = CFS0 + 64, META = STR0 + 2 * STR_BYTES, LDS_BYTES = META + 128;
+    static constexpr uint32_t F_READY = META /* [2][4] */, F_TRAILED = META + 32, F_NUNITS = META + 40, F_O0 = META + 48,
+                              F_WALKED = META + 56, F_STOP = META + 60, F_U0 = META + 64 /* u64[2] */;
+    static_assert(NWS <= 128 && NP % 32 == 0 && NP >= CW + 6 + 15 * MAXC + 2 && WIN_BYTES == 0xc000 && (CW + MAXU + 64) * ROWB < 65536 && WIN_U4 % 192 == 0, "window layout");
+};
 
-__global__ void __launch_bounds__(256) walk_table16_kernel(const DecArgs a0, uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch) {
-    using namespace chain16;
+template <uint32_t UB>
+__global__ void __launch_bounds__(256) walk_tableN_kernel(const DecArgs a0, uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch) {
+    typedef chainN<UB> W;
+    constexpr uint32_t NR = W::NR, NP = W::NP, CW = W::CW, ROWB = W::ROWB, MAXC = W::MAXC;
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     const uint64_t p0 = slab0 + (uint64_t)blockIdx.x * CW;
     if (p0 >= a.in_bits + 2 * CW) return;                                   // (uniform) far beyond the stream: no walk comes here
@@ -336,12 +350,12 @@ __global__ void __launch_bounds__(256) walk_table16_kernel(const DecArgs a0, uin
         __syncthreads();
         uint8_t (*t)[NP] = src; src = dst; dst = t;
     }
-    // src = eight codes, valid for i < NP - 7 * 17; sixteen = eight + eight, formed here (up to 272: not a byte)
-    uint4 *out = tab + ((uint64_t)blockIdx.y * tab_pitch + (uint64_t)blockIdx.x * WIN_U4);
+    // src = eight codes, valid for i < NP - 7 * MAXC; sixteen = eight + eight, formed here (up to 272: not a byte)
+    uint4 *out = tab + ((uint64_t)blockIdx.y * tab_pitch + (uint64_t)blockIdx.x * W::WIN_U4);
     for (uint32_t o = tid; o < CW; o += 256) {
         const uint32_t x = bits(o);
         uint32_t delta = 0; bool sig = false;
-        const uint32_t cs = walk_switch<4>(x, delta, sig);                  // from rung 0: the step itself
+        const uint32_t cs = walk_switch<UB>(x, delta, sig);                 // from rung 0: the step itself
         const uint32_t len0 = cs + (((x >> cs) & 1) ? 17 : 1);              // rung 0: one flag, then 16 raw bits
         uint32_t e[NR];
 #pragma unroll
@@ -351,16 +365,23 @@ __global__ void __launch_bounds__(256) walk_table16_kernel(const DecArgs a0, uin
             if (r) { const uint32_t n8 = src[r - 1][o + cs]; u = cs + n8 + src[r - 1][o + cs + n8]; }
             e[rin] = ((o + u) * ROWB) | (r << 1) | (sig ? 1u : 0u);
         }
-        out[2 * o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
-        out[2 * o + 1] = make_uint4(e[8] | e[9] << 16, e[10] | e[11] << 16, e[12] | e[13] << 16, e[14] | e[15] << 16);
+        if constexpr (NR == 16) {
+            out[2 * o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+            out[2 * o + 1] = make_uint4(e[8] | e[9] << 16, e[10] | e[11] << 16, e[12] | e[13] << 16, e[14] | e[15] << 16);
+        } else out[o] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
     }
 }
 
 // A workgroup per tile, eight waves: wave 0 (one lane) walks; waves 1-6 load windows (two groups of three, as in the
 // 8-bit kernel); wave 7 writes unit lengths and segment entries from the trail.
-__global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, const uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch,
-                                                           WalkState16 *states, uint32_t first_round) {
-    using namespace chain16;
+template <uint32_t UB, bool CF>
+__global__ void __launch_bounds__(512) walk_chainN_kernel(const DecArgs a0, const uint4 *tab, uint64_t slab0, uint32_t nwin, uint64_t tab_pitch,
+                                                          WalkState16 *states, uint32_t first_round) {
+    typedef chainN<UB> W;
+    typedef typename std::conditional<UB == 3, uint8_t, uint16_t>::type T;
+    constexpr uint32_t NR = W::NR, CW = W::CW, ROWB = W::ROWB, WIN_BYTES = W::WIN_BYTES, WIN_U4 = W::WIN_U4, TR_BYTES = W::TR_BYTES, TR0 = W::TR0, RS0 = W::RS0, WR0 = W::WR0,
+                       CFS0 = W::CFS0, STR0 = W::STR0, STR_BYTES = W::STR_BYTES, NWS = W::NWS, META = W::META, F_READY = W::F_READY, F_TRAILED = W::F_TRAILED, F_NUNITS = W::F_NUNITS, F_O0 = W::F_O0, F_WALKED = W::F_WALKED,
+                       F_STOP = W::F_STOP, F_U0 = W::F_U0;
     using chain::flag_get; using chain::flag_set; using chain::SPIN_MAX;
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -373,13 +394,14 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
     if (P0 < slab0 || P0 >= slab_end || P0 >= a.in_bits || U_in >= nunits) return;         // (uniform) nothing of this tile in this slab
     const uint32_t k0 = (uint32_t)((P0 - slab0) / CW);                      // the window the walk starts in
     volatile uint32_t *rs = (volatile uint32_t *)(smem + RS0), *wr = (volatile uint32_t *)(smem + WR0);     // rung * 2 per band: the walk's, the writer's
+    volatile uint32_t *cfl = (volatile uint32_t *)(smem + CFS0);            // CF: the factor in force per band
     if (tid < 32) {     // (the first two windows find their trail slots free)
         uint32_t v = tid == (F_STOP - META) / 4 ? 0xffffffffu : 0u;
         if (tid == (k0 & 1) * 4 + 3) v = k0 + 1;
         if (tid == ((k0 + 1) & 1) * 4 + 3) v = k0 + 2;
         ((uint32_t *)(smem + META))[tid] = v;
     }
-    if (tid < 16) { const uint32_t r2 = (uint32_t)((R_in >> (4 * tid)) & 15u) << 1; rs[tid] = r2; wr[tid] = r2; }
+    if (tid < 16) { const uint32_t r2 = (uint32_t)((R_in >> (4 * tid)) & 15u) << 1; rs[tid] = r2; wr[tid] = r2; cfl[tid] = (CF && !first_round) ? S->cfs[tid] : 0u; }
     __syncthreads();
     const uint4 *wt = tab + (uint64_t)blockIdx.x * tab_pitch;
     auto ready = [&](uint32_t slot, uint32_t want) {
@@ -393,6 +415,9 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
         uint64_t U = U_in, Pn = P0;
         uint32_t c = (uint32_t)(U % B);
         bool stuck = false;
+        const uint32_t useg_n = B * NB;                                     // CF: units of a segment; units left in the one the walk is in
+        uint32_t useg = (uint32_t)(U % useg_n), cf_any = (CF && !first_round) ? S->cf_any : 0u;
+        useg = useg ? useg_n - useg : 0u;
         while (true) {
             const uint32_t s = k & 1;
             uint32_t spin = 0;
@@ -408,7 +433,51 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
             const uint32_t wbase = s * WIN_BYTES;
             LdsHalfW trw = (LdsHalfW)(uintptr_t)(TR0 + s * TR_BYTES);
             LdsWordW rsw = (LdsWordW)(uintptr_t)RS0;
-            constexpr uint32_t M = 0xffe0u, RM = (NR - 1) << 1;
+            constexpr uint32_t M = 0xffffu & ~(ROWB - 1), RM = (NR - 1) << 1;
+            if constexpr (CF) {
+                // a unit per turn; a unit with the signal code is parsed from the stream (its table entry knows neither its length nor
+                // the rung it leaves); at every segment start, once a unit has brought a factor, the factors in force go to the index
+                const uint64_t wpos = slab0 + (uint64_t)k * CW;
+                // (as below, ONE dependent LDS read a unit: the rung of the band that comes next is fetched a unit ahead -- with two bands
+                // "the band after next" is this one, whose rung the entry just read holds)
+                uint32_t cn = c + 1 == B ? 0 : c + 1;
+                uint32_t rn = rsw[cn];
+                while (A < CW * ROWB && left) {
+                    const uint32_t cn2 = cn + 1 == B ? 0 : cn + 1;
+                    uint32_t e = *(LdsHalf)(uintptr_t)(wbase + A);
+                    uint32_t r2 = rsw[cn2];
+                    if (cf_any) {           // (from the first unit that brought a factor on: the factors in force at every segment start)
+                        if (useg == 0) {
+                            const uint64_t seg = (U + n) / useg_n;
+                            for (uint32_t cc = 0; cc < B; cc++) ((T *)a.idx.cf)[seg * B + cc] = (T)cfl[cc];
+                            useg = useg_n;
+                        }
+                        useg--;
+                    }
+                    if (e & 1u) {           // parsed from the window's stream words, which the loaders put beside its table rows
+                        const uint32_t ou = A / ROWB;
+                        ReaderT<LdsWords> rd;
+                        const uint32_t at = (uint32_t)((a.in_bit0 + wpos) & 31) + ou;
+                        rd.init((LdsWords)(uintptr_t)(STR0 + s * STR_BYTES), at, 32ull * NWS);
+                        uint32_t rung = (A & RM) >> 1, fl = 0;
+                        T cf = (T)cfl[c], g[16];
+                        const bool ok = parse_unit<T, CM_BEST, ReaderT<LdsWords>>(rd, rung, cf, g, &fl);
+                        const uint64_t len = rd.position() - at;
+                        if (!ok || len > W::MAXU + 64) bad |= 1u;
+                        if (fl & 2u) {
+                            cfl[c] = (uint32_t)cf;
+                            if (!cf_any) { cf_any = 1; const uint32_t m = (uint32_t)((U + n + 1) % useg_n); useg = m ? useg_n - m : 0u; }       // (segments from the next unit on)
+                        }
+                        e = (uint32_t)((ou + (len > W::MAXU + 64 ? 1u : (uint32_t)len)) * ROWB) | (rung << 1);
+                    }
+                    trw[n++] = (uint16_t)e;
+                    rsw[c] = e & RM;
+                    if (cn2 == c) r2 = e & RM;
+                    if (cn == c) rn = e & RM;           // (one band)
+                    A = (e & M) | rn;
+                    c = cn; cn = cn2; rn = r2; left--;
+                }
+            } else
             // a unit per turn, until one starts beyond the window: ONE dependent LDS read a unit -- the rung of the band
             // that comes next is fetched a unit ahead (from registers for one or two bands, else from the LDS array)
             if (B == 1) {
@@ -461,7 +530,8 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
         uint64_t Rn = 0;
         for (uint32_t i = 0; i < B; i++) Rn |= (uint64_t)((rs[i] >> 1) & 15u) << (4 * i);
         S->P = stuck ? ~0ull : Pn; S->unit = U; S->rungs = Rn; S->bad = (bad & 1u) | (stuck ? 1u : 0u);
-        if ((bad & 1u) || stuck) atomicOr(a.status, 1u);
+        if constexpr (CF) { for (uint32_t i = 0; i < B; i++) S->cfs[i] = cfl[i]; S->cf_any = cf_any; }
+        if ((bad & 1u) || stuck || (U < nunits && Pn >= a.in_bits)) atomicOr(a.status, 1u);      // (cut short: the one-lane parser takes it)
         return;
     }
     if (wave <= 6) {
@@ -473,6 +543,12 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
 #define CH16_REP(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define CH16_LD(i) const uint4 v##i = src[lane + 64 * (part + 3 * i)];
             CH16_REP(CH16_LD)
+            uint32_t sw0 = 0, sw1 = 0;                                      // CF: the window's stream words (the first loader wave of the group)
+            if (CF && part == 0) {
+                const uint64_t w0 = (a.in_bit0 + slab0 + (uint64_t)k * CW) >> 5, endw = (a.in_bit0 + a.in_bits + 31) >> 5;
+                sw0 = (lane < NWS && w0 + lane < endw) ? a.in32[w0 + lane] : 0u;
+                sw1 = (lane + 64 < NWS && w0 + lane + 64 < endw) ? a.in32[w0 + lane + 64] : 0u;
+            }
             uint32_t spin = 0;
             bool stop = false;
             while (true) {                                                  // the slot is free when the window two back has been walked
@@ -483,6 +559,11 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
             }
             if (stop) break;
             uint4 *slot = (uint4 *)(smem + g * WIN_BYTES);
+            if (CF && part == 0) {
+                uint32_t *sws = (uint32_t *)(smem + STR0 + g * STR_BYTES);
+                if (lane < NWS) sws[lane] = sw0;
+                if (lane + 64 < NWS) sws[lane + 64] = sw1;
+            }
 #define CH16_ST(i) slot[lane + 64 * (part + 3 * i)] = v##i;
             CH16_REP(CH16_ST)
 #undef CH16_ST
@@ -493,7 +574,7 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
         }
         return;
     }
-    // writer: entry j of the trail = (16 * position the unit ENDS at | rung of its band after it): lengths by difference
+    // writer: entry j of the trail = (ROWB * position the unit ENDS at | rung of its band after it): lengths by difference
     for (uint32_t k = k0;; k++) {
         const uint32_t s = k & 1;
         uint32_t spin = 0;
@@ -509,17 +590,23 @@ __global__ void __launch_bounds__(512) walk_chain16_kernel(const DecArgs a0, con
         const uint32_t n = flag_get(F_NUNITS + 4 * s), o_first = flag_get(F_O0 + 4 * s);
         const uint16_t *tr = (const uint16_t *)(smem + TR0 + s * TR_BYTES);
         const uint64_t wpos = slab0 + (uint64_t)k * CW;
-        uint16_t *ul = (uint16_t *)a.idx.ulen + U0;
         for (uint32_t j = lane; j < n; j += 64) {
             const uint32_t o0 = j ? tr[j - 1] / ROWB : o_first, o1 = tr[j] / ROWB;
-            ul[j] = (uint16_t)(o1 - o0);
             const uint64_t Uj = U0 + j;
-            if (Uj % B == 0 && (Uj / B) % NB == 0) {        // a segment starts here: position, and every band's rung as the block finds it
+            const uint32_t cj = (uint32_t)(Uj % B);
+            if constexpr (CF) {             // the rung the unit is entered with: what its band's unit before it left
+                const int32_t jb = (int32_t)j - (int32_t)B;
+                const uint32_t rin = ((jb >= 0 ? (uint32_t)tr[jb] : wr[cj]) >> 1) & (NR - 1);
+                if (a.g.ulen_sz == ULEN_UNIT) ((uint32_t *)a.idx.ulen)[Uj] = (o1 - o0) | rin << 16;
+                else atomicAdd((uint32_t *)a.idx.ulen + Uj / B, (o1 - o0) | rin << (16 + 4 * cj));      // (8-bit, 1 / 3 / 4 bands: the block table, zeroed beforehand)
+            } else if constexpr (UB == 3) ((uint8_t *)a.idx.ulen)[Uj] = (uint8_t)(o1 - o0);
+            else ((uint16_t *)a.idx.ulen)[Uj] = (uint16_t)(o1 - o0);
+            if (cj == 0 && (Uj / B) % NB == 0) {            // a segment starts here: position, and every band's rung as the block finds it
                 const uint64_t seg = Uj / B / NB;
                 a.idx.bitpos[seg] = wpos + o0;
                 for (uint32_t cc = 0; cc < B; cc++) {       // band cc's unit before this one: B - cc units back
                     const int32_t jj = (int32_t)j - (int32_t)(B - cc);
-                    a.idx.rung[seg * B + cc] = (uint8_t)(((jj >= 0 ? (uint32_t)tr[jj] : wr[cc]) >> 1) & 15u);
+                    a.idx.rung[seg * B + cc] = (uint8_t)(((jj >= 0 ? (uint32_t)tr[jj] : wr[cc]) >> 1) & (NR - 1));
                 }
             }
         }
@@ -765,7 +852,7 @@ __global__ void __launch_bounds__(WIDE_THREADS) walk_chainW_kernel(const DecArgs
         uint64_t Rn = 0;
         for (uint32_t i = 0; i < B; i++) Rn |= (uint64_t)((rs[i] >> RSH) & 15u) << (4 * i);
         S->P = stuck ? ~0ull : Pn; S->unit = U; S->rungs = Rn; S->bad = (bad & 1u) | (stuck ? 1u : 0u);
-        if ((bad & 1u) || stuck) atomicOr(a.status, 1u);
+        if ((bad & 1u) || stuck || (U < nunits && Pn >= a.in_bits)) atomicOr(a.status, 1u);      // (cut short: the one-lane parser takes it)
         return;
     }
     if (wave <= 3 * NG) {
@@ -888,7 +975,10 @@ bool walk_chain_lds_ok() {
         ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
-        ok = ok && hipFuncSetAttribute((const void *)walk_chain16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, chain16::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainN_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, chainN<4>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainN_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, chainN<4>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainN_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, chainN<3>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chainN_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, chainN<3>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<5, 16>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainW_kernel<6, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, chainW<6, 16>::LDS_BYTES) == hipSuccess;
         return ok;
@@ -896,7 +986,7 @@ bool walk_chain_lds_ok() {
     return lds_ok;
 }
 // positions of a chain window (16-bit data: 32 table bytes a stream bit; 32/64-bit: the table of sixteen rungs, windows of 1440 / 960 positions)
-uint32_t walk_cw(uint32_t tsz) { return tsz == 2 ? chain16::CW : tsz == 4 ? chainW<5, 16>::CW : tsz == 8 ? chainW<6, 16>::CW : chain::CW; }
+uint32_t walk_cw(uint32_t tsz) { return tsz == 2 ? chainN<4>::CW : tsz == 4 ? chainW<5, 16>::CW : tsz == 8 ? chainW<6, 16>::CW : chain::CW; }
 uint32_t walk_win_bytes(uint32_t tsz) { return tsz == 1 ? chain::WIN_BYTES : walk_cw(tsz) * 32; }
 
 void walk_chain_8bit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
@@ -911,14 +1001,21 @@ void walk_chain_8bit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_byt
             else if (a.g.bands == 3) hipLaunchKernelGGL(walk_chain_kernel<3>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first);
             else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first); });
 }
-void walk_chain_16bit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+// 16-bit streams, and (UB = 3) the 8-bit streams walk_chain_8bit's hand-ordered loops do not take; common-factor streams of several bands
+template <uint32_t UB>
+static void walk_chain_n(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
+    typedef chainN<UB> W;
     const uint32_t nt = a.ntiles;
-    walk_in_slabs(a, st, tab, tab_bytes, max_bits, chain16::CW, chain16::WIN_U4, sizeof(WalkState16),
+    const bool cf = a.g.mode == CM_BEST;
+    walk_in_slabs(a, st, tab, tab_bytes, max_bits, W::CW, W::WIN_U4, sizeof(WalkState16),
         [&](hipStream_t s, uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch) {
-            hipLaunchKernelGGL(walk_table16_kernel, dim3(nwin, nt), dim3(256), 0, s, a, rows, s0, nwin, pitch); },
+            hipLaunchKernelGGL(walk_tableN_kernel<UB>, dim3(nwin, nt), dim3(256), 0, s, a, rows, s0, nwin, pitch); },
         [&](hipStream_t s, const uint4 *rows, uint64_t s0, uint32_t nwin, uint64_t pitch, uint8_t *states, uint32_t first) {
-            hipLaunchKernelGGL(walk_chain16_kernel, dim3(nt), dim3(512), chain16::LDS_BYTES, s, a, rows, s0, nwin, pitch, (WalkState16 *)states, first); });
+            if (cf) hipLaunchKernelGGL((walk_chainN_kernel<UB, true>), dim3(nt), dim3(512), W::LDS_BYTES, s, a, rows, s0, nwin, pitch, (WalkState16 *)states, first);
+            else hipLaunchKernelGGL((walk_chainN_kernel<UB, false>), dim3(nt), dim3(512), W::LDS_BYTES, s, a, rows, s0, nwin, pitch, (WalkState16 *)states, first); });
 }
+void walk_chain_16bit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) { walk_chain_n<4>(a, st, tab, tab_bytes, max_bits); }
+void walk_chain_8bit_any(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) { walk_chain_n<3>(a, st, tab, tab_bytes, max_bits); }
 // 32/64-bit FTL/BASE: the first segment parsed outright (band of rungs, entry state), then table + chain
 void walk_chain_wide(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
     const uint32_t nt = a.ntiles;

@@ -1,5 +1,6 @@
 // qb3_amd/csrc/k_host.hip -- host side of the kernels: plans, workspace layout, launch orchestration, profiling, small elementwise kernels
 #include "qb3_kernels.h"
+#include "qb3_walk.h"
 
 namespace qb3dev {
 
@@ -504,13 +505,19 @@ DecPlan plan_decode(const Geometry &g) {
     return p;
 }
 
+// plain common-factor streams of several bands that walk by the chain (k_dec_walk_chain.hip, walk_chainN_kernel<UB, true>): 8- and 16-bit
+// rasters of the lane-per-unit decoder, and 8-bit RGBA (grey and RGB go by exits)
+static bool best_chain_applies(const Geometry &g, const DecPlan &plan) {
+    return g.mode == CM_BEST && g.tsz <= 2 && g.bands >= 2 && (plan.pxu_best || (plan.px_best && g.tsz == 1 && g.bands == 4));
+}
 size_t walk_table_cap() { return tuning().walk_tab_kb ? tuning().walk_tab_kb << 10 : (size_t)1 << 30; }
 bool walk_table_applies(const Geometry &g, const DecPlan &plan) {
     // 8- and 16-bit rasters the lane-per-block decoders take; 32/64-bit rasters the unit-parallel decoder takes (a band of sixteen rungs)
     // ... and single-band common-factor streams of any width (the exits of k_dec_walk.hip)
-    if (g.mode == CM_BEST) return (g.bands == 1 || (g.bands == 3 && g.tsz == 1)) && !tuning().slow_walk && !tuning().slow_index;
-    // (16-bit rasters of the lane-per-unit decoder too: the 16-bit chain takes any band count and segment size)
-    return ((plan.px && g.tsz == 1) || ((plan.px16 || plan.pxu) && g.tsz == 2) || (g.tsz >= 4 && plan.fast)) && !tuning().slow_walk && !tuning().slow_index;
+    // ... common-factor streams of several bands of 8- and 16-bit data: the chain with the signal units parsed by the walking lane
+    if (g.mode == CM_BEST) return (g.bands == 1 || (g.bands == 3 && g.tsz == 1) || best_chain_applies(g, plan)) && !tuning().slow_walk && !tuning().slow_index;
+    // (8- and 16-bit rasters of the lane-per-unit decoder too: the 16-bit chain's kernels take any band count and segment size)
+    return (((plan.px || plan.pxu) && g.tsz == 1) || ((plan.px16 || plan.pxu) && g.tsz == 2) || (g.tsz >= 4 && plan.fast)) && !tuning().slow_walk && !tuning().slow_index;
 }
 
 // A restart table is untrusted input that the decoder takes positions, rungs and values from: before any of it is used the
@@ -585,7 +592,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     }
     // plain 32/64-bit FTL/BASE streams: unit lengths through the table of a band of rungs, when the caller brought memory for it
     const bool wide_plain = rebuild && !a.ix && unit_parallel && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk;
-    const bool pxu16_plain = rebuild && !a.ix && use_pxu && a.g.tsz == 2 && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk;
+    const bool pxu16_plain = rebuild && !a.ix && use_pxu && a.g.tsz <= 2 && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) && !tuning().slow_walk;
     if (rebuild && (use_px || use_px16 || wide_walk || wide_plain || pxu16_plain) && !tuning().slow_index) {
         // index-less stream through the lane-per-block kernels: walk the lengths, then let the parallel decoder itself
         // produce the values entering the segments (totals pass + scan)
@@ -610,7 +617,21 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         // of the segments' sums; anything else (and that walk when it has no memory): one lane parses the stream
         const bool best_plain = best && !a.ix && (a.g.bands == 1 || (a.g.bands == 3 && a.g.tsz == 1)) && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&
                                 !tuning().slow_walk && !tuning().slow_index && launch_dec_walk_best(a, st, walk_tab, walk_tab_bytes, max_bits);
+        // ... of several bands (8- and 16-bit data): the chain, the walking lane parsing the units with the signal code; values as below
+        const bool best_chain = best && !best_plain && !a.ix && best_chain_applies(a.g, plan) && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&
+                                walk_chain_lds_ok() && !tuning().slow_walk && !tuning().slow_index;
         if (best_plain) { ProfScope ps("dec_index_scan", st); launch_prev_scan(a, st); }
+        else if (best_chain) {
+            {   // the factors in force start from zero (the lane writes them from the first unit that brings one on); the block table is added up
+                const size_t cfb = (size_t)a.g.nseg * a.g.bands * a.g.tsz, ulb = a.g.ulen_sz == 4 ? (size_t)a.g.nblocks * 4 : 0;
+                if (a.ntiles > 1) { (void)hipMemset2DAsync(a.idx.cf, a.ts_idx, 0, cfb, a.ntiles, st); if (ulb) (void)hipMemset2DAsync(a.idx.ulen, a.ts_idx, 0, ulb, a.ntiles, st); }
+                else { (void)hipMemsetAsync(a.idx.cf, 0, cfb, st); if (ulb) (void)hipMemsetAsync(a.idx.ulen, 0, ulb, st); }
+            }
+            if (a.g.tsz == 2) walk_chain_16bit(a, st, walk_tab, walk_tab_bytes, max_bits); else walk_chain_8bit_any(a, st, walk_tab, walk_tab_bytes, max_bits);
+            { ProfScope ps("dec_index_prev", st); DecArgs t = a; t.totals_only = 1; if (best_pxu) launch_dec_pxu_best(t, plan, st); else launch_dec_generic(t, plan, st); }
+            ProfScope ps("dec_index_scan", st);
+            launch_prev_scan(a, st);
+        }
         else if (best && !a.ix && dec_index_walk_best_ok(a) && !tuning().slow_index) {
             // common-factor streams the exits do not take (several bands; no table memory): one wave walks lengths (units with
             // the signal code parsed outright), the generic decoder adds up every segment's values, a scan makes entering values

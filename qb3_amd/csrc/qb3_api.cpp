@@ -1209,7 +1209,8 @@ static bool decode_blocks_device(decsp p, const Geometry &g, const uint8_t *d_bu
             table = IxTable();
             dropped_table = true;
             if (!walk_table_ready(p, g, plan, 1, (uint64_t)nbytes * 8)) return false;
-        } else if (walk_tab_ok && (g.tsz >= 4 || g.mode == CM_BEST) && p->d_tab.p && walk_table_applies(g, plan)) walk_tab_ok = false;
+        } else if (walk_tab_ok && p->d_tab.p && walk_table_applies(g, plan)) walk_tab_ok = false;      // (the last rung of the ladder, for every width and mode: the one-lane
+            // parser, whose reader behaves like the reference's on a stream that ends early -- zeros behind the end, bitstream.h:36 -- where the table walks stop)
         else break;
     }
     prof_collect();
@@ -1421,11 +1422,13 @@ static size_t decode_common(decsp p, void *host_dst, const void *d_src, void *d_
         if (sz > total) { p->error = QB3E_ERR; return 0; }
         if (!p->d_in.ensure((size_t)sz + 8)) { p->error = QB3E_LIBERR; return 0; }
         if (rle0_device_write(packed, p->s_size, p->d_rle.p, true, p->d_in.p, st)) { p->error = QB3E_LIBERR; return 0; }
+        HIPOK(hipMemsetAsync((uint8_t *)p->d_in.p + sz, 0, 8, st));       // (a stream that ends early reads as zeros behind its end, not as what the buffer held before)
         nbytes = (size_t)sz;
         dev_buf = (const uint8_t *)p->d_in.p; off = 0;
     } else if (on_host) {
         if (!p->d_in.ensure(nbytes + 8)) { p->error = QB3E_LIBERR; return 0; }
         if (!upload(p->stager, p->d_in.p, p->s_in, nbytes, st)) { p->error = QB3E_LIBERR; return 0; }
+        HIPOK(hipMemsetAsync((uint8_t *)p->d_in.p + nbytes, 0, 8, st));    // (a stream that ends early reads as zeros behind its end, not as what the buffer held before)
         dev_buf = (const uint8_t *)p->d_in.p; off = 0;
     } else { dev_buf = (const uint8_t *)d_src; off = data_off; }
 

@@ -96,7 +96,7 @@ template <uint32_t UB> __device__ __forceinline__ uint32_t walk_unit(uint32_t rp
 }
 
 struct WalkState { uint64_t P; uint32_t gb, rungs, bad, pad; };           // a tile's walk between two slabs
-struct WalkState16 { uint64_t P, unit, rungs; uint32_t bad, pad; uint64_t cf; };   // a tile's walk between two slabs (rungs: 4 bits a band; cf: the exit walk of common-factor streams, the factor in force behind the first segment)
+struct WalkState16 { uint64_t P, unit, rungs; uint32_t bad, pad; uint64_t cf; uint32_t cfs[16], cf_any, pad2; };   // a tile's walk between two slabs (rungs: 4 bits a band; cf: the exit walk of common-factor streams, the factor in force behind the first segment)
 
 // The first index segment of every tile, parsed outright by one lane: unit lengths, the segment's entry, the band of rungs
 // [R0, R0 + 16) for the table (WalkState16::pad) and the walk's entry state behind the segment.
@@ -172,7 +172,8 @@ bool walk_chain_lds_ok();
 uint32_t walk_cw(uint32_t tsz);
 uint32_t walk_win_bytes(uint32_t tsz);          // ... and the table bytes of one window
 void walk_chain_8bit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);
-void walk_chain_16bit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);
+void walk_chain_16bit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);      // (also common-factor streams of several bands)
+void walk_chain_8bit_any(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);   // 8-bit streams of any band count, FTL / BASE / common factor: the 16-bit chain's kernels with eight rungs
 void walk_chain_wide(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits);      // (probes the first segment itself)
 // k_dec_walk_exit.hip: the walks by exits; false: not taken (no table memory for them)
 bool walk_exit_lds_ok();

@@ -2148,3 +2148,137 @@ def test_rle0_containers_keep_their_table(qb3, oracle):
             assert qb3.lib.qb3x_last_decode_status(d.p) == 0, "the table was dropped"
             assert "dec_index_serial" not in names or level == 1, names
     assert won >= 2
+
+
+@pytest.mark.parametrize("switch", ["", "QB3_WALK_TAB_KB=8192"], ids=["default", "chain-in-many-rounds"])
+def test_plain_streams_of_several_bands_by_the_chain(qb3, oracle, switch):
+    """plain (reference-made) streams of several bands through walk_tableN_kernel / walk_chainN_kernel (k_dec_walk_chain.hip): 8-bit
+    rasters of 2, 5 and 16 bands and 16-bit rasters of odd band counts in FTL / BASE; common-factor streams of several bands of 8- and
+    16-bit data (8-bit RGBA with the lane-per-block decoder's block table, the others with the lane-per-unit decoder's dword per unit):
+    signal units parsed by the walking lane from the window's stream words, the factors in force left at the segment starts once a
+    unit has brought one (SCALED: every unit takes a factor brought early; PALETTE, FEW: index units and factors of their own all
+    over).  With table memory for a few windows a round (the walk's state -- rungs, factors -- crosses rounds); truncated and
+    smashed streams: an error or clamped pixels, never a hang or a fault; a batch of tiles.  The walk is named in the profile."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np, torch, ctypes as C
+sys.path.insert(0, %r)
+import qb3_amd
+from qb3_amd import device as qdev
+from oracle import pyoracle as o
+L = qb3_amd.lib
+def kernels_of(fn):
+    L.qb3x_profile_enable(1); L.qb3x_profile_reset()
+    r = fn(); torch.cuda.synchronize()
+    buf = C.create_string_buffer(2048); L.qb3x_profile_names(buf, 2048); L.qb3x_profile_enable(0)
+    return r, set(buf.value.decode().split(","))
+cases = [(640, 480, 2, 0, "NOISY3", 8), (509, 259, 5, 0, "NOISY3", 4), (300, 200, 16, 0, "FEW", 8), (768, 300, 2, 1, "PALETTE", 0),
+         (512, 260, 5, 2, "LANDSAT16", 4), (260, 512, 7, 3, "DEM", 8), (128, 96, 15, 2, "RANDOM", 4),
+         (1024, 512, 4, 0, "NOISY3", 5), (509, 259, 4, 0, "PALETTE", 7), (640, 480, 4, 0, "SCALED", 5), (512, 512, 2, 0, "NOISY3", 5), (400, 300, 5, 0, "FEW", 1),
+         (512, 384, 8, 2, "LANDSAT16", 5), (256, 300, 3, 2, "TERRACE", 5), (300, 256, 4, 3, "SCALED", 5), (200, 120, 2, 2, "PALETTE", 1), (160, 100, 9, 2, "FEW", 5)]
+for (w, h, b, dt, gen, mode) in cases:
+    if gen == "SCALED":                         # every value a multiple of three: every unit takes the factor the first ones brought
+        base = o.generate(w, h, b, dt, "NOISY3", 21)
+        img = (base.astype(np.int64) // 3 * 3).astype(base.dtype)
+    else:
+        img = o.generate(w, h, b, dt, gen, 21)
+    cb = None if b in (1, 3, 4) else list(range(b))
+    ref = o.encode(img, dt, mode, cband=cb)
+    if ref[10] == 255:
+        continue
+    d = torch.from_numpy(ref).cuda()
+    dec = qdev.DeviceDecoder(d, len(ref))
+    out, names = kernels_of(lambda: dec.decode(d, index=None))
+    assert np.array_equal(out.cpu().numpy(), img.view(np.uint8).ravel()), (w, h, b, dt, gen, mode)
+    if ref[10] in (0, 1, 4, 5, 8):              # (not under RLE0: the expansion is another path to the same walk)
+        assert "dec_index_table" in names, (w, h, b, dt, gen, mode, names)
+    assert L.qb3x_last_decode_status(dec.p) == 0, (w, h, b, dt, gen, mode)
+    got, dims, _, _ = qb3_amd.decode(ref)
+    assert np.array_equal(got, img.view(np.uint8).ravel()), (w, h, b, dt, gen, mode, "host")
+import random
+rng = random.Random(7)
+for (w, h, b, dt, gen, mode) in [(768, 512, 4, 0, "NOISY3", 5), (512, 300, 5, 2, "LANDSAT16", 5), (640, 400, 2, 0, "NOISY3", 8)]:
+    img = o.generate(w, h, b, dt, gen, 22)
+    cb = None if b in (1, 3, 4) else list(range(b))
+    ref = o.encode(img, dt, mode, cband=cb)
+    damaged = [np.ascontiguousarray(ref[:cut]) for cut in (len(ref) // 2, len(ref) - 1000)]
+    for trial in range(10):
+        s = ref.copy()
+        if trial & 1:
+            for _ in range(rng.randrange(1, 6)):
+                at = rng.randrange(64, len(s)); s[at] ^= 1 << rng.randrange(8)
+        else:
+            at = rng.randrange(64, len(s)); k = min(len(s) - at, rng.randrange(1, 5000)); s[at:at + k] = rng.choice((0, 255, rng.randrange(256)))
+        damaged.append(s)
+    for s in damaged:
+        d = torch.from_numpy(s).cuda()
+        dims = (C.c_size_t * 3)()
+        q = L.qb3x_read_start_device(d.data_ptr(), len(s), dims, None)
+        if q:
+            out = torch.zeros(img.nbytes, dtype=torch.uint8, device="cuda")
+            L.qb3x_decode_device(q, d.data_ptr(), out.data_ptr(), None, None)
+            torch.cuda.synchronize()
+            L.qb3_destroy_decoder(q)
+    d = torch.from_numpy(ref).cuda()                    # the GPU is still well: the intact stream decodes
+    assert np.array_equal(qdev.DeviceDecoder(d, len(ref)).decode(d, index=None).cpu().numpy(), img.view(np.uint8).ravel())
+    cut = np.ascontiguousarray(ref[:len(ref) // 3])     # a truncated stream reads as zeros behind its end, like the reference's (bitstream.h:36)
+    want, _, _, _ = o.decode(cut, identity=True)
+    if want is not None:
+        got, _, _, _ = qb3_amd.decode(cut)
+        assert np.array_equal(got, want), (w, h, b, dt, gen, mode, "truncated")
+for (w, h, b, dt, gen, mode, n) in [(256, 192, 4, 0, "NOISY3", 5, 3), (200, 100, 5, 2, "LANDSAT16", 4, 6)]:
+    imgs = [o.generate(w, h, b, dt, gen, 60 + t) for t in range(n)]
+    cb = None if b in (1, 3, 4) else list(range(b))
+    refs = [o.encode(im, dt, mode, cband=cb) for im in imgs]
+    pitch = (max(len(r) for r in refs) + 3) // 4 * 4
+    buf = np.zeros(n * pitch, dtype=np.uint8)
+    sizes = (C.c_size_t * n)()
+    for t, r in enumerate(refs):
+        buf[t * pitch:t * pitch + len(r)] = r; sizes[t] = len(r)
+    dst = torch.from_numpy(buf).cuda()
+    dims = (C.c_size_t * 3)()
+    hdr = buf[:64].copy()
+    q = L.qb3_read_start(hdr.ctypes.data, sizes[0], dims)
+    assert L.qb3_read_info(q)
+    raw = imgs[0].nbytes
+    out = torch.zeros(n * raw, dtype=torch.uint8, device="cuda")
+    assert L.qb3x_decode_tiles(q, dst.data_ptr(), n, pitch, sizes, out.data_ptr(), raw, None, None) == n
+    got = out.cpu().numpy()
+    for t in range(n):
+        assert np.array_equal(got[t * raw:(t + 1) * raw], imgs[t].view(np.uint8).ravel()), (w, h, b, dt, t)
+    L.qb3_destroy_decoder(q)
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if switch:
+        name, _, value = switch.partition("=")
+        env[name] = value
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_streams_cut_short_decode_like_the_reference(qb3, oracle):
+    """a stream that ends early is not an error in the reference: its reader gives zeros behind the end (bitstream.h:36) and only more
+    than 7 unused bits fail (QB3decode.h:411,569,740).  Every raster family -- whichever walk its plain stream takes first (exits,
+    chains, lanes) -- ends at the one-lane parser for such a stream and returns the oracle's pixels; bytes behind the stream's end in
+    the library's buffer do not leak into them (a second decode through the same handle pool, after a longer stream)"""
+    cases = [(768, 512, 3, 0, "NOISY3", 8), (768, 512, 4, 0, "NOISY3", 8), (512, 512, 1, 0, "NOISY3", 4), (640, 400, 2, 0, "NOISY3", 8), (400, 300, 5, 0, "NOISY3", 4),
+             (512, 512, 1, 2, "DEM", 4), (512, 300, 8, 2, "LANDSAT16", 4), (512, 300, 5, 2, "LANDSAT16", 4), (256, 256, 1, 5, "DEM", 8), (256, 256, 2, 5, "DEM", 8),
+             (256, 256, 1, 7, "DEM", 8), (768, 512, 3, 0, "NOISY3", 5), (768, 512, 4, 0, "NOISY3", 5), (768, 512, 1, 0, "NOISY3", 5), (400, 300, 5, 0, "NOISY3", 5),
+             (512, 300, 5, 2, "LANDSAT16", 5), (512, 300, 8, 2, "LANDSAT16", 1), (256, 256, 1, 5, "DEM", 5), (200, 200, 3, 4, "NOISY3", 5)]
+    for (w, h, b, dt, gen, mode) in cases:
+        img = oracle.generate(w, h, b, dt, gen, 22)
+        cb = None if b in (1, 3, 4) else list(range(b))
+        ref = oracle.encode(img, dt, mode, cband=cb)
+        out, _, _, _ = qb3.decode(ref)                  # (a full-length stream first: what it leaves in the library's buffers must not show below)
+        assert np.array_equal(out, img.view(np.uint8).ravel())
+        for frac in (3, 2):
+            cut = np.ascontiguousarray(ref[:len(ref) // frac])
+            want, _, _, _ = oracle.decode(cut, identity=True)
+            if want is None:
+                with pytest.raises(RuntimeError):
+                    qb3.decode(cut)
+                continue
+            got, _, _, _ = qb3.decode(cut)
+            assert np.array_equal(got, want), (w, h, b, dt, gen, mode, frac)
