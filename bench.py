@@ -542,12 +542,16 @@ def main():
             plain[ptag] = {"workload": f"4096x4096x1 {pname}, plain container, index = NULL"}
             plain[ptag].update(plain_decode(pimg, 4096, 1, pdt_, pmode))
             del pimg
-        # several bands beyond 8-bit RGB: the chained table walks (FTL / BASE) and, for common-factor streams, one wave walking
-        # unit lengths ("what comes next" (1): these are at or below one CPU core's pace)
+        # several bands beyond 8-bit RGB: the chained table walks (k_dec_walk_chain.hip) -- common-factor streams of 8- and 16-bit data too, the
+        # walking lane parsing their signal units (round 4); 32/64-bit common-factor streams of several bands: one wave walking unit lengths
         for ptag, pw, pb, pdt_, pgen, pmode, pname in (("uint8x4_ftl", 2048, 4, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_FTL, "x4 uint8 NOISY3, QB3M_FTL"),
                                                        ("uint8x4_best", 2048, 4, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_BEST, "x4 uint8 NOISY3, QB3M_BEST"),
                                                        ("uint16x8_base", 2048, 8, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BASE, "x8 uint16 LANDSAT16, QB3M_BASE"),
                                                        ("uint16x8_best", 1024, 8, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BEST, "x8 uint16 LANDSAT16, QB3M_BEST"),
+                                                       ("uint8x2_ftl", 2048, 2, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_FTL, "x2 uint8 NOISY3, QB3M_FTL"),
+                                                       ("uint8x5_best", 2048, 5, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_CF_H, "x5 uint8 NOISY3, QB3M_CF_H"),
+                                                       ("uint16x7_base", 2048, 7, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BASE, "x7 uint16 LANDSAT16, QB3M_BASE"),
+                                                       ("uint16x3_best", 2048, 3, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_CF_H, "x3 uint16 LANDSAT16, QB3M_CF_H"),
                                                        ("int32x2_base", 2048, 2, qb3_amd.QB3_I32, "DEM", qb3_amd.QB3M_BASE, "x2 int32 DEM, QB3M_BASE")):
             pimg = synth.generate(pw, pw, pb, pdt_, pgen, 4, device=dev)
             plain[ptag] = {"workload": f"{pw}x{pw}{pname} seed 4, plain container, index = NULL"}
