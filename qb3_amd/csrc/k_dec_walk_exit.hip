@@ -337,7 +337,9 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
         for (uint32_t c = 0; c < B; c++) {
             const uint64_t u0 = rd.position();
             if (c < 4) bt |= (rung[c] & (sizeof(T) >= 4 ? 63u : 15u)) << (16 + 4 * c);
+            const uint32_t rung_in = rung[c];
             ok = parse_unit<T, MODE>(rd, rung[c], pcf[c], g) && ok;
+            if (MODE == CM_BEST && a.g.ulen_sz == ULEN_UNIT) ((uint32_t *)a.idx.ulen)[U * B + c] = (uint32_t)((rd.position() - u0) & 0xffffu) | rung_in << 16;      // (two bands: the lane-per-unit decoder's dword)
             if (MODE != CM_BEST) {
                 if (sizeof(T) == 1) ((uint8_t *)a.idx.ulen)[U * B + c] = (uint8_t)(rd.position() - u0); else ((uint16_t *)a.idx.ulen)[U * B + c] = (uint16_t)(rd.position() - u0);
             } else {                                                                        // the segment's sum of values: the scan makes entering values of them
@@ -387,7 +389,7 @@ template <uint32_t B, bool CF = false> struct exitB {
     static constexpr uint32_t T0 = 0, BM0 = T0 + ((TP * NR * 2 + 15) & ~15u), PF0 = BM0 + BMW * 4, XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
                               E1 = S0 + ((TP * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, SG0 = (WORDS + (NP1 / 32 + 3) * 4 + 15) & ~15u,
                               SL0 = SG0 + (CF ? NSIG * B * NR * 4 : 0), SP0 = SL0 + (CF ? (TP + 15) & ~15u : 0), LDS_BYTES = SP0 + (CF ? NSIG * 2 + 16 : 0);
-    static_assert(B == 3 && NKEY <= KEYM && TP + MAXU < 4095 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of RGB rasters");
+    static_assert((B == 2 || B == 3) && NKEY <= KEYM && TP + MAXU < 4095 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of two- and three-band rasters");
 };
 
 template <uint32_t B, bool CF>
@@ -697,7 +699,14 @@ static bool launch_walk_exit(const DecArgs &a, hipStream_t st, void *tab, size_t
 // Plain single-band 32/64-bit COMMON-FACTOR streams through the same exits (units with the signal code are parsed outright
 // inside the walk).  False: not taken (no memory for it) -- the caller parses the stream with one lane.
 bool launch_dec_walk_best(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
-    if (a.g.mode != CM_BEST || !walk_exit_lds_ok() || (a.g.tsz == 1 && a.g.ulen_sz != 4)) return false;    // (8-bit: the lane-per-block decoder's block table)
+    if (a.g.mode != CM_BEST || !walk_exit_lds_ok() || (a.g.tsz == 1 && a.g.ulen_sz != 4 && !(a.g.bands == 2 && a.g.ulen_sz == ULEN_UNIT))) return false;    // (8-bit: the lane-per-block decoder's block table; two bands: the lane-per-unit decoder's unit table)
+    if (a.g.bands == 2 && a.g.tsz == 1) {          // 8-bit, two bands
+        WalkState16 *states = (WalkState16 *)tab;
+        { ProfScope ps("dec_index_serial", st);
+          hipLaunchKernelGGL(walk_exit_zero_kernel<uint8_t>, dim3((uint32_t)((a.g.nseg + 255) / 256), a.ntiles), dim3(256), 0, st, a);
+          hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_BEST>), dim3(a.ntiles), dim3(64), 0, st, a, states, 8u); }
+        return launch_walk_exitB<2, CM_BEST>(a, st, tab, tab_bytes, max_bits);
+    }
     if (a.g.bands == 3 && a.g.tsz == 1) {          // 8-bit RGB
         WalkState16 *states = (WalkState16 *)tab;
         { ProfScope ps("dec_index_serial", st);
@@ -732,6 +741,8 @@ size_t walk_exit_bytes(uint32_t tsz, uint32_t bands, bool best, uint32_t nt, uin
         }
     } else if (tsz == 1 && bands == 3 && nt <= 4) {
         if (best) { sw = exitB<3, true>::SW; nx = exitB<3, true>::NKEY; } else { sw = exitB<3, false>::SW; nx = exitB<3, false>::NKEY; }
+    } else if (tsz == 1 && bands == 2 && nt <= 4) {
+        if (best) { sw = exitB<2, true>::SW; nx = exitB<2, true>::NKEY; } else { sw = exitB<2, false>::SW; nx = exitB<2, false>::NKEY; }
     } else return 0;
     const uint64_t ns = (max_bits + sw - 1) / sw;
     const size_t fixed = (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255) + (((size_t)nt * (ns + 2) * 32 + 255) & ~(size_t)255);
@@ -743,6 +754,8 @@ bool walk_exit_lds_ok() {
         bool ok = true;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<3, false>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<3, true>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<2, false>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<2, true>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<3>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<4>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
@@ -769,11 +782,12 @@ bool walk_exits_one_band(const DecArgs &a, hipStream_t st, void *tab, size_t tab
     return a.g.tsz == 1 ? launch_walk_exit<3, uint8_t, CM_FTL>(a, st, tab, tab_bytes, max_bits) : a.g.tsz == 2 ? launch_walk_exit<4, uint16_t, CM_FTL>(a, st, tab, tab_bytes, max_bits)
          : a.g.tsz == 4 ? launch_walk_exit<5, uint32_t, CM_FTL>(a, st, tab, tab_bytes, max_bits) : launch_walk_exit<6, uint64_t, CM_FTL>(a, st, tab, tab_bytes, max_bits);
 }
-// 8-bit RGB, FTL / BASE: exits with the rung of every band in the state
+// 8-bit rasters of two or three bands, FTL / BASE: exits with the rung of every band in the state
 bool walk_exits_rgb(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
     WalkState16 *states = (WalkState16 *)tab;
     { ProfScope ps("dec_index_serial", st);
       hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(a.ntiles), dim3(64), 0, st, a, states, 8u, 8u); }
+    if (a.g.bands == 2) return launch_walk_exitB<2, CM_FTL>(a, st, tab, tab_bytes, max_bits);       // (two bands: 298 positions x 64 rung pairs: a twelfth of RGB's states)
     return launch_walk_exitB<3, CM_FTL>(a, st, tab, tab_bytes, max_bits);
 }
 

@@ -615,7 +615,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     } else if (rebuild && !a.from_ix) {
         // plain single-band common-factor streams: segment entries by the walk through exits, entering values by a scan
         // of the segments' sums; anything else (and that walk when it has no memory): one lane parses the stream
-        const bool best_plain = best && !a.ix && (a.g.bands == 1 || (a.g.bands == 3 && a.g.tsz == 1)) && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&
+        const bool best_plain = best && !a.ix && (a.g.bands == 1 || ((a.g.bands == 3 || a.g.bands == 2) && a.g.tsz == 1)) && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&
                                 !tuning().slow_walk && !tuning().slow_index && launch_dec_walk_best(a, st, walk_tab, walk_tab_bytes, max_bits);
         // ... of several bands (8- and 16-bit data): the chain, the walking lane parsing the units with the signal code; values as below
         const bool best_chain = best && !best_plain && !a.ix && best_chain_applies(a.g, plan) && walk_tab && walk_tab_bytes >= walk_table_min_bytes(a.ntiles, a.g.tsz) &&

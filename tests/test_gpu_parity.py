@@ -2153,7 +2153,8 @@ def test_rle0_containers_keep_their_table(qb3, oracle):
 @pytest.mark.parametrize("switch", ["", "QB3_WALK_TAB_KB=8192"], ids=["default", "chain-in-many-rounds"])
 def test_plain_streams_of_several_bands_by_the_chain(qb3, oracle, switch):
     """plain (reference-made) streams of several bands through walk_tableN_kernel / walk_chainN_kernel (k_dec_walk_chain.hip): 8-bit
-    rasters of 2, 5 and 16 bands and 16-bit rasters of odd band counts in FTL / BASE; common-factor streams of several bands of 8- and
+    rasters of 5 and 16 bands and 16-bit rasters of odd band counts in FTL / BASE (8-bit rasters of TWO bands, plain and common factor, go
+    by exits like RGB -- walk_exitB_kernel<2>: 298 positions x 64 rung pairs -- and by the chain when a batch holds more than four tiles); common-factor streams of several bands of 8- and
     16-bit data (8-bit RGBA with the lane-per-block decoder's block table, the others with the lane-per-unit decoder's dword per unit):
     signal units parsed by the walking lane from the window's stream words, the factors in force left at the segment starts once a
     unit has brought one (SCALED: every unit takes a factor brought early; PALETTE, FEW: index units and factors of their own all
@@ -2227,7 +2228,7 @@ for (w, h, b, dt, gen, mode) in [(768, 512, 4, 0, "NOISY3", 5), (512, 300, 5, 2,
     if want is not None:
         got, _, _, _ = qb3_amd.decode(cut)
         assert np.array_equal(got, want), (w, h, b, dt, gen, mode, "truncated")
-for (w, h, b, dt, gen, mode, n) in [(256, 192, 4, 0, "NOISY3", 5, 3), (200, 100, 5, 2, "LANDSAT16", 4, 6)]:
+for (w, h, b, dt, gen, mode, n) in [(256, 192, 4, 0, "NOISY3", 5, 3), (200, 100, 5, 2, "LANDSAT16", 4, 6), (320, 200, 2, 0, "NOISY3", 8, 3), (320, 200, 2, 0, "NOISY3", 5, 6)]:
     imgs = [o.generate(w, h, b, dt, gen, 60 + t) for t in range(n)]
     cb = None if b in (1, 3, 4) else list(range(b))
     refs = [o.encode(im, dt, mode, cband=cb) for im in imgs]
