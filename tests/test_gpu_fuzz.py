@@ -2,6 +2,7 @@
 and generators (fixed seeds, so a failure names its case).  The shapes are biased towards what selects different
 kernels: widths that are / are not multiples of 4, band counts that do / do not split into groups, rungs above and
 below 8, images of one block, one chunk, several chunks."""
+import os
 import random
 
 import numpy as np
@@ -39,7 +40,7 @@ def draw(rng):
 
 @pytest.mark.parametrize("block", range(24))
 def test_random_cases_match_the_oracle(qb3, oracle, block):
-    rng = random.Random(20260 + block)
+    rng = random.Random(int(os.environ.get("QB3_FUZZ_SEED", "20260")) + block)      # (QB3_FUZZ_SEED: another draw of the same sweep)
     for k in range(60):
         w, h, b, dt, gen, mode, cb, stride = draw(rng)
         if dt >= 6 and mode in (1, 3, 5, 7) and gen in ("PALETTE", "RANDOM", "FEW"):

@@ -2283,3 +2283,21 @@ def test_streams_cut_short_decode_like_the_reference(qb3, oracle):
                 continue
             got, _, _, _ = qb3.decode(cut)
             assert np.array_equal(got, want), (w, h, b, dt, gen, mode, frac)
+
+
+def test_large_lane_per_unit_rasters_through_the_host_calls(qb3, oracle):
+    """rasters of 64 MB and more of the lane-per-unit shapes through qb3_encode / qb3_read_data (the encode side codes them strip by
+    strip): the plain container is the oracle's, the self-indexed one the oracle's plus table chunks, both decode exactly"""
+    for (w, h, b, dt, gen, mode) in [(4096, 4096, 2, 5, "DEM", 8), (4096, 2048, 5, 2, "LANDSAT16", 4), (4096, 4096, 5, 0, "NOISY3", 5)]:
+        img = oracle.generate(w, h, b, dt, gen, 5)
+        cb = list(range(b))
+        ref = oracle.encode(img, dt, mode, cband=cb)
+        for level in (0, 2):
+            got = qb3.encode(img, dt, mode, cband=cb, index_chunk=level)
+            if level == 0:
+                assert np.array_equal(got, ref), (w, h, b, dt)
+            else:
+                dt_at, extra = bytes(ref).index(b"DT", 11), len(got) - len(ref)
+                assert extra > 0 and np.array_equal(np.concatenate([got[:dt_at], got[dt_at + extra:]]), ref), (w, h, b, dt)
+            out, _, _, _ = qb3.decode(got)
+            assert np.array_equal(out, img.view(np.uint8).ravel()), (w, h, b, dt, level)
