@@ -123,7 +123,6 @@ __global__ void __launch_bounds__(256) dec_pxu_kernel(const DecArgs a0) {
     const uint32_t nb_here = (nblocks - g0 < SB) ? nblocks - g0 : SB;
     const uint32_t blk = fastdiv(lane, B, a.magic_bands), c = lane - blk * B;
     const bool act = live && blk < nb_here;
-    const uint32_t last_lane = nb_here * B - 1;             // the segment's last unit
     uint64_t P0, P1;
     uint32_t blen = 0, rg0 = 0;
     T pv0 = 0;
@@ -206,7 +205,6 @@ __global__ void __launch_bounds__(256) dec_pxu_kernel(const DecArgs a0) {
         if (used > a.in_bits) atomicOr(a.status, 4u);
         else if (a.in_bits - used > 7) atomicOr(a.status, 2u);
     }
-    (void)last_lane;
     const T pv = (T)(pv0 + sex);
     T o[16];
 #pragma unroll

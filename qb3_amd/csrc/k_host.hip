@@ -735,9 +735,11 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
         ProfScope ps("dec_units", st);
         const bool best = g.mode == CM_BEST;
         if (best && plan.pxw_best) launch_dec_pxw_best(a, plan, st);
+        else if (best && plan.pxu_best) launch_dec_pxu_best(a, plan, st);
         else if (best) launch_dec_px_best(a, plan, st);
         else if (plan.px) launch_dec_px(a, plan, st);
         else if (plan.px16) launch_dec_px16(a, plan, st);
+        else if (plan.pxu) launch_dec_pxu(a, plan, st);
         else launch_dec_pxw(a, plan, st);
         HIPCHK(hipGetLastError());
         return 0;
@@ -748,8 +750,8 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
 bool decode_strips_ok(const Geometry &g, const DecPlan &plan, const IxTable &ix) {
     if (!ix.base || !ix.block_lens || !ix.blocks || ix.blocks != g.seg_blocks || !ix.per_chunk || tuning().slow_index || tuning().no_bl) return false;
     if (ix.entry_bytes != ix_entry_bytes(g, true) || !ix_block_lens_ok(g) || ix.K != (g.nblocks + ix.blocks - 1) / ix.blocks) return false;
-    if (g.mode == CM_BEST) return (plan.px_best && g.tsz == 1) || plan.pxw_best;
-    return (plan.px && g.tsz == 1) || (plan.px16 && g.tsz == 2) || plan.pxw;
+    if (g.mode == CM_BEST) return (plan.px_best && g.tsz == 1) || plan.pxw_best || plan.pxu_best;
+    return (plan.px && g.tsz == 1) || (plan.px16 && g.tsz == 2) || plan.pxw || (plan.pxu && plan.fast);
 }
 
 }  // namespace qb3dev
