@@ -329,6 +329,12 @@ __global__ void __launch_bounds__(256) ix_bl_fill_kernel(const EncArgs a0) {
     else if (t < 6 + 2 * B) e0[t] = ((const uint8_t *)a.idx.prev)[k * B + (t - 6 - B)];
 }
 
+// four 24-bit fields as three dwords at any byte address (global memory takes unaligned dword stores)
+__device__ __forceinline__ void ix_store12(uint8_t *e, const uint32_t (&f)[4]) {
+    typedef uint32_t u32_a1 __attribute__((aligned(1)));
+    u32_a1 *d = (u32_a1 *)e;
+    d[0] = f[0] | f[1] << 24; d[1] = f[1] >> 8 | f[2] << 16; d[2] = f[2] >> 16 | f[3] << 8;
+}
 // The same for common-factor streams with a block table (8-bit grey / RGB / RGBA; 32/64-bit, one band): a three-byte field per
 // block -- its bits (12) and the rungs its units are entered with (8-bit data: 3 bits a band; wide data: the band's whole rung)
 // -- from the index's block table; a thread per four blocks writes twelve bytes and its share of the entry's fixed part
@@ -344,6 +350,7 @@ __global__ void __launch_bounds__(256) ix_bl_best_fill_kernel(const EncArgs a0) 
     uint8_t *e0 = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E) + IX_HEAD + (uint64_t)jj * a.ix_E;
     const uint32_t t = (uint32_t)(grp & 15), fixed = 6 + B * (1 + 2 * tsz);
     uint8_t *e = e0 + fixed + 4 * IX_BL_BEST_BYTES * t;
+    uint32_t fl[4];
 #pragma unroll
     for (uint32_t q = 0; q < 4; q++) {
         const uint32_t bt = blk0 + q < nblocks ? ((const uint32_t *)a.idx.ulen)[blk0 + q] : 0u;
@@ -352,8 +359,9 @@ __global__ void __launch_bounds__(256) ix_bl_best_fill_kernel(const EncArgs a0) 
 #pragma unroll
             for (uint32_t cc = 0; cc < 4; cc++) f |= ((bt >> (16 + 4 * cc)) & 7u) << (12 + 3 * cc);
         } else f |= ((bt >> 16) & 63u) << 12;
-        e[3 * q] = (uint8_t)f; e[3 * q + 1] = (uint8_t)(f >> 8); e[3 * q + 2] = (uint8_t)(f >> 16);
+        fl[q] = f;
     }
+    ix_store12(e, fl);          // (four three-byte fields: three dwords at whatever address the entry puts them)
     for (uint32_t i = t; i < fixed; i += 16) {
         uint8_t v;
         if (i < 6) v = (uint8_t)(a.idx.bitpos[k] >> (8 * i));
@@ -447,14 +455,24 @@ __global__ void __launch_bounds__(256) ix_blu_best_fill_kernel(const EncArgs a0)
     const uint32_t c = (uint32_t)(k / a.ix_per_chunk), jj = (uint32_t)(k - (uint64_t)c * a.ix_per_chunk);
     uint8_t *e0 = a.ix_dst + (uint64_t)c * (IX_HEAD + IX_PAD + (uint64_t)a.ix_per_chunk * a.ix_E) + IX_HEAD + (uint64_t)jj * a.ix_E;
     const uint32_t fixed = 6 + B * (1 + 2 * tsz);
-    for (uint32_t q = 0; q < 4; q++) {
-        const uint32_t f = 4 * t + q;
-        if (f >= upe) break;
-        const uint32_t bt = u0 + f < nunits ? ((const uint32_t *)a.idx.ulen)[u0 + f] : 0u;
-        const uint32_t fld = (bt & 0xfffu) | ((bt >> 16) & 63u) << 12;
-        uint8_t *e = e0 + fixed + IX_BL_BEST_BYTES * f;
-        e[0] = (uint8_t)fld; e[1] = (uint8_t)(fld >> 8); e[2] = (uint8_t)(fld >> 16);
-    }
+    if (4 * t + 4 <= upe) {     // four whole fields: three dwords
+        uint32_t fl[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t f = 4 * t + q;
+            const uint32_t bt = u0 + f < nunits ? ((const uint32_t *)a.idx.ulen)[u0 + f] : 0u;
+            fl[q] = (bt & 0xfffu) | ((bt >> 16) & 63u) << 12;
+        }
+        ix_store12(e0 + fixed + IX_BL_BEST_BYTES * 4 * t, fl);
+    } else
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t f = 4 * t + q;
+            if (f >= upe) break;
+            const uint32_t bt = u0 + f < nunits ? ((const uint32_t *)a.idx.ulen)[u0 + f] : 0u;
+            const uint32_t fld = (bt & 0xfffu) | ((bt >> 16) & 63u) << 12;
+            uint8_t *e = e0 + fixed + IX_BL_BEST_BYTES * f;
+            e[0] = (uint8_t)fld; e[1] = (uint8_t)(fld >> 8); e[2] = (uint8_t)(fld >> 16);
+        }
     for (uint32_t i = t; i < fixed; i += 16) {
         uint8_t v;
         if (i < 6) v = (uint8_t)(a.idx.bitpos[k] >> (8 * i));
