@@ -549,6 +549,7 @@ def main():
                                                        ("uint16x8_base", 2048, 8, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BASE, "x8 uint16 LANDSAT16, QB3M_BASE"),
                                                        ("uint16x8_best", 1024, 8, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BEST, "x8 uint16 LANDSAT16, QB3M_BEST"),
                                                        ("uint8x2_ftl", 2048, 2, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_FTL, "x2 uint8 NOISY3, QB3M_FTL"),
+                                                       ("uint16x2_base", 4096, 2, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BASE, "x2 uint16 LANDSAT16, QB3M_BASE"),
                                                        ("uint8x5_best", 2048, 5, qb3_amd.QB3_U8, "NOISY3", qb3_amd.QB3M_CF_H, "x5 uint8 NOISY3, QB3M_CF_H"),
                                                        ("uint16x7_base", 2048, 7, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_BASE, "x7 uint16 LANDSAT16, QB3M_BASE"),
                                                        ("uint16x3_best", 2048, 3, qb3_amd.QB3_U16, "LANDSAT16", qb3_amd.QB3M_CF_H, "x3 uint16 LANDSAT16, QB3M_CF_H"),

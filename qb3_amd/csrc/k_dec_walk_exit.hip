@@ -374,10 +374,10 @@ __global__ void __launch_bounds__(64) walk_exit_units_kernel(const DecArgs a0, c
 // exits are ranked through a bitmap (D, a few thousand), only those are carried through the other windows of the super-window
 // (Xd, LDS), and at the end every state composes its first-window exit with what became of it.  One hop per super-window of
 // 65 536 bits as before; 915 KB of exits per super-window, so the stream is taken in rounds of what the table memory holds.
-template <uint32_t B, bool CF = false> struct exitB {
-    static constexpr uint32_t UB = 3, NRUNG = 8, NR = 8, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;        // 149
+template <uint32_t B, bool CF = false, uint32_t UB_ = 3> struct exitB {       // UB_ = 4: 16-bit rasters of two bands (556 positions x 256 rung pairs), FTL / BASE
+    static constexpr uint32_t UB = UB_, NRUNG = 1u << UB, NR = NRUNG, MAXC = NRUNG + 1, MAXU = UB + 2 + 16 * MAXC;        // 149 / 278
     static constexpr uint32_t W = 2048, K = 64, SW = W * K, THREADS = 1024;             // (a super-window's cost is its first window's, where every state walks: long ones -- twice this: 4 % more, and the lanes that parse the units become the long pole)
-    static constexpr uint32_t PE = B * MAXU, NC = 1u << (3 * B), NKEY = PE * NC;                             // entering positions, rung combinations, states
+    static constexpr uint32_t PE = B * MAXU, NC = 1u << (UB * B), NKEY = PE * NC;                             // entering positions, rung combinations, states
     static constexpr uint32_t TP = W + (B - 1) * MAXU;                                                        // positions with a table row: the later units of a block that starts in the window
     static constexpr uint32_t NPT = (TP + UB + 2 + 15 * MAXC + 2 + 31) & ~31u, NP1 = (TP + MAXU + 2 + 63) & ~31u;
     static constexpr uint32_t KEYB = 18, KEYM = (1u << KEYB) - 1, X_STOP = KEYM, DCAP = 8192;                 // X: state | blocks << 18; stop: the state field all set
@@ -389,12 +389,12 @@ template <uint32_t B, bool CF = false> struct exitB {
     static constexpr uint32_t T0 = 0, BM0 = T0 + ((TP * NR * 2 + 15) & ~15u), PF0 = BM0 + BMW * 4, XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
                               E1 = S0 + ((TP * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT, WORDS = EB + NPT, SG0 = (WORDS + (NP1 / 32 + 3) * 4 + 15) & ~15u,
                               SL0 = SG0 + (CF ? NSIG * B * NR * 4 : 0), SP0 = SL0 + (CF ? (TP + 15) & ~15u : 0), LDS_BYTES = SP0 + (CF ? NSIG * 2 + 16 : 0);
-    static_assert((B == 2 || B == 3) && NKEY <= KEYM && TP + MAXU < 4095 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of two- and three-band rasters");
+    static_assert((B == 2 || (B == 3 && UB == 3)) && (UB == 3 || (UB == 4 && !CF)) && NKEY <= KEYM && TP + MAXU < 4095 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of two- and three-band rasters");
 };
 
-template <uint32_t B, bool CF>
+template <uint32_t B, bool CF, uint32_t UBW = 3>
 __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint32_t *xg, uint32_t s_begin, uint32_t s_count, const WalkState16 *states, uint32_t dcap) {
-    typedef exitB<B, CF> E;
+    typedef exitB<B, CF, UBW> E;
     constexpr uint32_t W = E::W, NR = E::NR, NPT = E::NPT, NP1 = E::NP1, TP = E::TP, MAXC = E::MAXC, NRUNG = E::NRUNG, NKEY = E::NKEY, NT = E::THREADS, UB = E::UB;
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     const WalkState16 &S = states[blockIdx.y];
@@ -419,9 +419,9 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
     // slower); one that takes its band's factor in force is parsed with the factor the stream had behind its first segment and
     // the exit says so (X_DEP); one that brings its own ends the walk -- the hop parses such a super-window itself.
     auto walk = [&](uint32_t key) -> uint32_t {
-        uint32_t pos = key >> (3 * B), r[B], cnt = 0, dep = 0;
+        uint32_t pos = key >> (UB * B), r[B], cnt = 0, dep = 0;
 #pragma unroll
-        for (uint32_t c = 0; c < B; c++) r[c] = (key >> (3 * c)) & 7u;
+        for (uint32_t c = 0; c < B; c++) r[c] = (key >> (UB * c)) & (NRUNG - 1);
         while (pos < W) {
 #pragma unroll
             for (uint32_t c = 0; c < B; c++) {
@@ -439,9 +439,9 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
             cnt++;
         }
         if (pos - W >= E::PE) return E::X_STOP;
-        uint32_t k2 = (pos - W) << (3 * B);
+        uint32_t k2 = (pos - W) << (UB * B);
 #pragma unroll
-        for (uint32_t c = 0; c < B; c++) k2 |= r[c] << (3 * c);
+        for (uint32_t c = 0; c < B; c++) k2 |= r[c] << (UB * c);
         return k2 | (cnt << E::KEYB) | dep;
     };
     // an exit a, then b
@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
             }
             __syncthreads();
         }
-        if (CF) {       // the units with the signal code: their places, then every (place, band, entering rung) parsed by a lane of its own
+        if constexpr (CF) {       // the units with the signal code: their places, then every (place, band, entering rung) parsed by a lane of its own
             if (tid == 0) s_nsig = 0;
             for (uint32_t o = tid; o < TP; o += NT) sig_slot[o] = 0xffu;
             __syncthreads();
@@ -574,9 +574,11 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
 }
 
 // the hop for rasters of B bands: entries {position lo, hi, block, rungs (4 bits a band)} {factors in force (a byte a band)}
-template <uint32_t B, int MODE>
+template <uint32_t B, int MODE, uint32_t UBW = 3>
 __global__ void __launch_bounds__(64) walk_exitB_chain_kernel(const DecArgs a0, const uint32_t *xg, uint32_t nsuper, uint32_t s_begin, uint32_t s_count, WalkState16 *states, uint4 *entries) {
-    typedef exitB<B, MODE == CM_BEST> E;
+    typedef exitB<B, MODE == CM_BEST, UBW> E;
+    typedef typename std::conditional<UBW == 3, uint8_t, uint16_t>::type TV;
+    constexpr uint32_t UB = E::UB, RMASK = E::NRUNG - 1;
     const DecArgs a = dec_for_tile(a0, blockIdx.x);
     if (threadIdx.x) return;
     WalkState16 *S = states + blockIdx.x;
@@ -603,16 +605,16 @@ __global__ void __launch_bounds__(64) walk_exitB_chain_kernel(const DecArgs a0, 
         if (s >= s_end) { bad = s >= nsuper; break; }
         if (P >= a.in_bits) { bad = true; break; }
         const uint64_t base = P0 + (uint64_t)s * E::SW;
-        uint32_t key = (uint32_t)(P - base) << (3 * B);
-        for (uint32_t c = 0; c < B; c++) key |= ((rr >> (4 * c)) & 7u) << (3 * c);
+        uint32_t key = (uint32_t)(P - base) << (UB * B);
+        for (uint32_t c = 0; c < B; c++) key |= ((rr >> (4 * c)) & RMASK) << (UB * c);
         const uint32_t x = x0[(uint64_t)(s - s_begin) * E::NKEY + key];
         s++;
         if ((x & E::KEYM) != E::X_STOP && !((x & E::X_DEP) && cf != spec)) {
             U += (x >> E::KEYB) & E::CNTM;
             const uint32_t k2 = x & E::KEYM;
-            P = base + E::SW + (k2 >> (3 * B));
+            P = base + E::SW + (k2 >> (UB * B));
             rr = 0;
-            for (uint32_t c = 0; c < B; c++) rr |= ((k2 >> (3 * c)) & 7u) << (4 * c);
+            for (uint32_t c = 0; c < B; c++) rr |= ((k2 >> (UB * c)) & RMASK) << (4 * c);
             continue;
         }
         // this super-window by the units themselves: whole blocks up to the first that starts behind it
@@ -620,29 +622,30 @@ __global__ void __launch_bounds__(64) walk_exitB_chain_kernel(const DecArgs a0, 
         Reader rd;
         rd.init(a.in32, a.in_bit0 + P, a.in_bit0 + a.in_bits);
         uint32_t rung[B];
-        uint8_t pc[B], g[16];
-        for (uint32_t c = 0; c < B; c++) { rung[c] = (rr >> (4 * c)) & 15u; pc[c] = (uint8_t)(cf >> (8 * c)); }
+        TV pc[B], g[16];
+        for (uint32_t c = 0; c < B; c++) { rung[c] = (rr >> (4 * c)) & 15u; pc[c] = (TV)(cf >> (8 * sizeof(TV) * c)); }
         bool ok = true;
         const uint64_t end = base + E::SW;
         while (ok && U < nblocks) {
             const uint64_t pos = rd.position() - a.in_bit0;
             if (pos >= a.in_bits || pos >= end) break;
 #pragma unroll
-            for (uint32_t c = 0; c < B; c++) ok = parse_unit<uint8_t, MODE>(rd, rung[c], pc[c], g) && ok;
+            for (uint32_t c = 0; c < B; c++) ok = parse_unit<TV, MODE>(rd, rung[c], pc[c], g) && ok;
             U++;
         }
         P = rd.position() - a.in_bit0;
         rr = 0; cf = 0;
-        for (uint32_t c = 0; c < B; c++) { rr |= rung[c] << (4 * c); cf |= (uint32_t)pc[c] << (8 * c); }
+        for (uint32_t c = 0; c < B; c++) { rr |= rung[c] << (4 * c); cf |= (uint32_t)pc[c] << (8 * sizeof(TV) * c); }
         if (!ok || (U < nblocks && (P < end || P - end >= E::PE))) { bad = true; break; }
     }
     *hd = make_uint4(s, done ? 1u : 0u, 0u, 0u);
     if (bad) { S->bad = 1u; atomicOr(a.status, 1u); }
 }
 
-template <uint32_t B, int MODE>
+template <uint32_t B, int MODE, uint32_t UBW = 3>
 static bool launch_walk_exitB(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
-    typedef exitB<B, MODE == CM_BEST> E;
+    typedef exitB<B, MODE == CM_BEST, UBW> E;
+    typedef typename std::conditional<UBW == 3, uint8_t, uint16_t>::type TV;
     const uint32_t nt = a.ntiles;
     const uint64_t ns = (max_bits + E::SW - 1) / E::SW;
     const size_t fixed = (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255) + (((size_t)nt * (ns + 2) * 32 + 255) & ~(size_t)255);
@@ -655,12 +658,12 @@ static bool launch_walk_exitB(const DecArgs &a, hipStream_t st, void *tab, size_
     for (uint32_t s0 = 0; s0 < nsuper; s0 += slab) {
         const uint32_t cnt = nsuper - s0 < slab ? nsuper - s0 : slab;
         { ProfScope ps("dec_index_table", st);
-          hipLaunchKernelGGL((walk_exitB_kernel<B, MODE == CM_BEST>), dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states, a.wide_band == 18 ? 64u : E::DCAP); }
+          hipLaunchKernelGGL((walk_exitB_kernel<B, MODE == CM_BEST, UBW>), dim3(cnt, nt), dim3(E::THREADS), E::LDS_BYTES, st, a, xg, s0, cnt, (const WalkState16 *)states, a.wide_band == 18 ? 64u : E::DCAP); }
         ProfScope ps("dec_index_serial", st);
-        hipLaunchKernelGGL((walk_exitB_chain_kernel<B, MODE>), dim3(nt), dim3(64), 0, st, a, (const uint32_t *)xg, nsuper, s0, cnt, states, entries);
+        hipLaunchKernelGGL((walk_exitB_chain_kernel<B, MODE, UBW>), dim3(nt), dim3(64), 0, st, a, (const uint32_t *)xg, nsuper, s0, cnt, states, entries);
     }
     ProfScope ps("dec_index_serial", st);
-    hipLaunchKernelGGL((walk_exit_units_kernel<uint8_t, MODE>), dim3(nsuper, nt), dim3(64), ((E::SW + E::PE) / 32 + 4) * 4, st, a, (const WalkState16 *)states, (const uint4 *)entries, nsuper, E::SW, E::PE);
+    hipLaunchKernelGGL((walk_exit_units_kernel<TV, MODE>), dim3(nsuper, nt), dim3(64), ((E::SW + E::PE) / 32 + 4) * 4, st, a, (const WalkState16 *)states, (const uint4 *)entries, nsuper, E::SW, E::PE);
     return true;
 }
 
@@ -743,6 +746,7 @@ size_t walk_exit_bytes(uint32_t tsz, uint32_t bands, bool best, uint32_t nt, uin
         if (best) { sw = exitB<3, true>::SW; nx = exitB<3, true>::NKEY; } else { sw = exitB<3, false>::SW; nx = exitB<3, false>::NKEY; }
     } else if (tsz == 1 && bands == 2 && nt <= 4) {
         if (best) { sw = exitB<2, true>::SW; nx = exitB<2, true>::NKEY; } else { sw = exitB<2, false>::SW; nx = exitB<2, false>::NKEY; }
+    } else if (tsz == 2 && bands == 2 && !best && nt <= 4) { sw = exitB<2, false, 4>::SW; nx = exitB<2, false, 4>::NKEY;
     } else return 0;
     const uint64_t ns = (max_bits + sw - 1) / sw;
     const size_t fixed = (((size_t)nt * sizeof(WalkState16) + 255) & ~(size_t)255) + (((size_t)nt * (ns + 2) * 32 + 255) & ~(size_t)255);
@@ -756,6 +760,7 @@ bool walk_exit_lds_ok() {
         ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<3, true>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<2, false>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<2, true>::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_exitB_kernel<2, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, exitB<2, false, 4>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<3>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<4>::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_exitW_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, exitW<5>::LDS_BYTES) == hipSuccess;
@@ -785,6 +790,11 @@ bool walk_exits_one_band(const DecArgs &a, hipStream_t st, void *tab, size_t tab
 // 8-bit rasters of two or three bands, FTL / BASE: exits with the rung of every band in the state
 bool walk_exits_rgb(const DecArgs &a, hipStream_t st, void *tab, size_t tab_bytes, uint64_t max_bits) {
     WalkState16 *states = (WalkState16 *)tab;
+    if (a.g.tsz == 2) {         // 16-bit rasters of two bands (dual-polarisation radar, complex samples): 556 positions x 256 rung pairs
+        { ProfScope ps("dec_index_serial", st);
+          hipLaunchKernelGGL((walk_probe_kernel<uint16_t, CM_FTL>), dim3(a.ntiles), dim3(64), 0, st, a, states, 16u, 16u); }
+        return launch_walk_exitB<2, CM_FTL, 4>(a, st, tab, tab_bytes, max_bits);
+    }
     { ProfScope ps("dec_index_serial", st);
       hipLaunchKernelGGL((walk_probe_kernel<uint8_t, CM_FTL>), dim3(a.ntiles), dim3(64), 0, st, a, states, 8u, 8u); }
     if (a.g.bands == 2) return launch_walk_exitB<2, CM_FTL>(a, st, tab, tab_bytes, max_bits);       // (two bands: 298 positions x 64 rung pairs: a twelfth of RGB's states)

@@ -2154,7 +2154,8 @@ def test_rle0_containers_keep_their_table(qb3, oracle):
 def test_plain_streams_of_several_bands_by_the_chain(qb3, oracle, switch):
     """plain (reference-made) streams of several bands through walk_tableN_kernel / walk_chainN_kernel (k_dec_walk_chain.hip): 8-bit
     rasters of 5 and 16 bands and 16-bit rasters of odd band counts in FTL / BASE (8-bit rasters of TWO bands, plain and common factor, go
-    by exits like RGB -- walk_exitB_kernel<2>: 298 positions x 64 rung pairs -- and by the chain when a batch holds more than four tiles); common-factor streams of several bands of 8- and
+    by exits like RGB -- walk_exitB_kernel<2>: 298 positions x 64 rung pairs --, 16-bit rasters of two bands in FTL / BASE too -- <2, false, 4>:
+    556 positions x 256 rung pairs -- and by the chain when a batch holds more than four tiles); common-factor streams of several bands of 8- and
     16-bit data (8-bit RGBA with the lane-per-block decoder's block table, the others with the lane-per-unit decoder's dword per unit):
     signal units parsed by the walking lane from the window's stream words, the factors in force left at the segment starts once a
     unit has brought one (SCALED: every unit takes a factor brought early; PALETTE, FEW: index units and factors of their own all
@@ -2174,7 +2175,7 @@ def kernels_of(fn):
     r = fn(); torch.cuda.synchronize()
     buf = C.create_string_buffer(2048); L.qb3x_profile_names(buf, 2048); L.qb3x_profile_enable(0)
     return r, set(buf.value.decode().split(","))
-cases = [(640, 480, 2, 0, "NOISY3", 8), (509, 259, 5, 0, "NOISY3", 4), (300, 200, 16, 0, "FEW", 8), (768, 300, 2, 1, "PALETTE", 0),
+cases = [(640, 480, 2, 0, "NOISY3", 8), (512, 300, 2, 2, "LANDSAT16", 4), (260, 200, 2, 3, "DEM", 8), (1024, 700, 2, 2, "PALETTE", 0), (509, 259, 5, 0, "NOISY3", 4), (300, 200, 16, 0, "FEW", 8), (768, 300, 2, 1, "PALETTE", 0),
          (512, 260, 5, 2, "LANDSAT16", 4), (260, 512, 7, 3, "DEM", 8), (128, 96, 15, 2, "RANDOM", 4),
          (1024, 512, 4, 0, "NOISY3", 5), (509, 259, 4, 0, "PALETTE", 7), (640, 480, 4, 0, "SCALED", 5), (512, 512, 2, 0, "NOISY3", 5), (400, 300, 5, 0, "FEW", 1),
          (512, 384, 8, 2, "LANDSAT16", 5), (256, 300, 3, 2, "TERRACE", 5), (300, 256, 4, 3, "SCALED", 5), (200, 120, 2, 2, "PALETTE", 1), (160, 100, 9, 2, "FEW", 5)]
@@ -2199,7 +2200,7 @@ for (w, h, b, dt, gen, mode) in cases:
     assert np.array_equal(got, img.view(np.uint8).ravel()), (w, h, b, dt, gen, mode, "host")
 import random
 rng = random.Random(7)
-for (w, h, b, dt, gen, mode) in [(768, 512, 4, 0, "NOISY3", 5), (512, 300, 5, 2, "LANDSAT16", 5), (640, 400, 2, 0, "NOISY3", 8)]:
+for (w, h, b, dt, gen, mode) in [(768, 512, 4, 0, "NOISY3", 5), (512, 300, 5, 2, "LANDSAT16", 5), (640, 400, 2, 0, "NOISY3", 8), (640, 400, 2, 2, "LANDSAT16", 4)]:
     img = o.generate(w, h, b, dt, gen, 22)
     cb = None if b in (1, 3, 4) else list(range(b))
     ref = o.encode(img, dt, mode, cband=cb)
@@ -2265,7 +2266,7 @@ def test_streams_cut_short_decode_like_the_reference(qb3, oracle):
     chains, lanes) -- ends at the one-lane parser for such a stream and returns the oracle's pixels; bytes behind the stream's end in
     the library's buffer do not leak into them (a second decode through the same handle pool, after a longer stream)"""
     cases = [(768, 512, 3, 0, "NOISY3", 8), (768, 512, 4, 0, "NOISY3", 8), (512, 512, 1, 0, "NOISY3", 4), (640, 400, 2, 0, "NOISY3", 8), (400, 300, 5, 0, "NOISY3", 4),
-             (512, 512, 1, 2, "DEM", 4), (512, 300, 8, 2, "LANDSAT16", 4), (512, 300, 5, 2, "LANDSAT16", 4), (256, 256, 1, 5, "DEM", 8), (256, 256, 2, 5, "DEM", 8),
+             (512, 512, 1, 2, "DEM", 4), (512, 300, 2, 2, "LANDSAT16", 4), (512, 300, 8, 2, "LANDSAT16", 4), (512, 300, 5, 2, "LANDSAT16", 4), (256, 256, 1, 5, "DEM", 8), (256, 256, 2, 5, "DEM", 8),
              (256, 256, 1, 7, "DEM", 8), (768, 512, 3, 0, "NOISY3", 5), (768, 512, 4, 0, "NOISY3", 5), (768, 512, 1, 0, "NOISY3", 5), (400, 300, 5, 0, "NOISY3", 5),
              (512, 300, 5, 2, "LANDSAT16", 5), (512, 300, 8, 2, "LANDSAT16", 1), (256, 256, 1, 5, "DEM", 5), (200, 200, 3, 4, "NOISY3", 5)]
     for (w, h, b, dt, gen, mode) in cases:
