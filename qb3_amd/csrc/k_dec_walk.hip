@@ -223,8 +223,11 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
     // one band of any width: the exits (8- and 16-bit data: the band is all the rungs; wide_band 17: the chain, a test hook)
     if (a.g.bands == 1 && a.wide_band == 16 && lds_ok && nt <= 16 && walk_exits_one_band(a, st, tab, tab_bytes, max_bits)) return;
     // 8-bit RGB, and two bands: exits with the rung of every band in the state (18: a test hook, see dcap)
+    // (a super-window costs what its first window's walks cost -- 2.2 to 3.5 ms of one CU whatever the stream's length -- so a SHORT stream, a
+    // tile of 512 x 512 and less, is walked sooner by the chain: measured crossovers, tools/small_plain.sh)
+    const uint64_t exits_from = tuning().exits_from >= 0 ? (uint64_t)tuning().exits_from : a.g.tsz == 2 ? 2500000 : a.g.bands == 2 ? 1200000 : 4500000;
     if (((a.g.tsz == 1 && (a.g.bands == 3 || a.g.bands == 2)) || (a.g.tsz == 2 && a.g.bands == 2 && a.g.mode != CM_BEST)) && (a.wide_band == 16 || a.wide_band == 18) && lds_ok && nt <= 4 &&
-        walk_exits_rgb(a, st, tab, tab_bytes, max_bits)) return;
+        (max_bits >= exits_from || a.wide_band == 18) && walk_exits_rgb(a, st, tab, tab_bytes, max_bits)) return;
     if (a.g.tsz >= 4) walk_chain_wide(a, st, tab, tab_bytes, max_bits);
     else if (a.g.tsz == 2) walk_chain_16bit(a, st, tab, tab_bytes, max_bits);
     else if (a.g.bands == 1 || a.g.bands == 3 || a.g.bands == 4) walk_chain_8bit(a, st, tab, tab_bytes, max_bits);

@@ -24,6 +24,7 @@ const Tuning &tuning() {
         { const char *e = getenv("QB3_WIDE_BAND"); v.wide_band = e && e[0] ? atoi(e) : 0; }      // plain 32/64-bit streams: rungs in the table's band (test hook)
         v.no_bl = on("QB3_NO_BLOCK_LENGTHS");        // containers whose table carries block lengths: walk them like the others
         { const char *e = getenv("QB3_BEST_SAMPLE_MIN"); v.best_sample_min = e && e[0] ? (uint32_t)strtoul(e, nullptr, 10) : BEST_SAMPLE_MIN; }   // chunks from which the common-factor encoders sample before they code (0: always -- how the tests reach the two-pass coding on small rasters)
+        { const char *e = getenv("QB3_EXITS_FROM"); v.exits_from = e && e[0] ? (int64_t)strtoll(e, nullptr, 10) : -1; }   // stream bits from which rasters of two / three bands walk by exits instead of the chain (-1: the measured crossovers; 0: always -- how the tests reach the exits on small rasters)
         return v;
     }();
     return t;

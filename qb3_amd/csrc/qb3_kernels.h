@@ -575,7 +575,7 @@ struct ProfScope {
 };
 
 // process-wide debugging switches, read once from the environment (k_host.hip)
-struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool no_bl; size_t walk_tab_kb; int wide_band; uint32_t best_sample_min; };
+struct Tuning { bool no_px; bool slow_index; bool slow_walk; bool no_bl; size_t walk_tab_kb; int wide_band; uint32_t best_sample_min; int64_t exits_from; };
 const Tuning &tuning();
 
 uint32_t magic_div(uint32_t d);

@@ -1739,13 +1739,15 @@ def test_a_damaged_restart_table_costs_time_not_pixels(qb3, oracle, case):
     assert torch.equal(dec.decode(dbad, index=None), torch.from_numpy(raw).cuda()), "device flavour"
 
 
-@pytest.mark.parametrize("switch", ["", "QB3_WALK_TAB_KB=4096", "QB3_WIDE_BAND=18", "QB3_WIDE_BAND=17"],
-                         ids=["default", "exits-in-many-rounds", "super-windows-parsed-by-the-hopping-lane", "chain-through-the-table"])
+@pytest.mark.parametrize("switch", ["QB3_EXITS_FROM=0", "QB3_WALK_TAB_KB=4096;QB3_EXITS_FROM=0", "QB3_WIDE_BAND=18", "QB3_WIDE_BAND=17", ""],
+                         ids=["exits", "exits-in-many-rounds", "super-windows-parsed-by-the-hopping-lane", "chain-through-the-table", "default-by-stream-length"])
 def test_plain_rgb_streams_by_exits(qb3, oracle, switch):
     """plain 8-bit RGB streams: the walk by exits with a rung per band in the state (walk_exitB_kernel, walk_exitB_chain_kernel,
     walk_exit_blocks_kernel) -- odd sizes, FTL and BASE, data of every kind, a truncated stream, a batch of tiles; with table
     memory for four super-windows a round; with the cap on distinct exits set so low that every super-window is parsed by
-    the hopping lane; and the chain through the table, which other band counts still take.  Pixels exact in every case."""
+    the hopping lane; and the chain through the table, which other band counts still take -- and short streams: a super-window costs
+    milliseconds whatever the stream's length, so below a measured length (QB3_EXITS_FROM overrides it: 0 = always by exits) the chain
+    is the quicker walk.  Pixels exact in every case."""
     import subprocess
     import sys
     code = """
@@ -1817,8 +1819,8 @@ for t in range(n):
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    if switch:
-        name, _, value = switch.partition("=")
+    for item in filter(None, switch.split(";")):
+        name, _, value = item.partition("=")
         env[name] = value
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
@@ -1915,8 +1917,8 @@ for t in range(n):
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    if switch:
-        name, _, value = switch.partition("=")
+    for item in filter(None, switch.split(";")):
+        name, _, value = item.partition("=")
         env[name] = value
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
@@ -2150,7 +2152,7 @@ def test_rle0_containers_keep_their_table(qb3, oracle):
     assert won >= 2
 
 
-@pytest.mark.parametrize("switch", ["", "QB3_WALK_TAB_KB=8192"], ids=["default", "chain-in-many-rounds"])
+@pytest.mark.parametrize("switch", ["", "QB3_WALK_TAB_KB=8192", "QB3_EXITS_FROM=0"], ids=["default", "chain-in-many-rounds", "two-band-rasters-by-exits-whatever-their-size"])
 def test_plain_streams_of_several_bands_by_the_chain(qb3, oracle, switch):
     """plain (reference-made) streams of several bands through walk_tableN_kernel / walk_chainN_kernel (k_dec_walk_chain.hip): 8-bit
     rasters of 5 and 16 bands and 16-bit rasters of odd band counts in FTL / BASE (8-bit rasters of TWO bands, plain and common factor, go
@@ -2253,8 +2255,8 @@ for (w, h, b, dt, gen, mode, n) in [(256, 192, 4, 0, "NOISY3", 5, 3), (200, 100,
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    if switch:
-        name, _, value = switch.partition("=")
+    for item in filter(None, switch.split(";")):
+        name, _, value = item.partition("=")
         env[name] = value
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
