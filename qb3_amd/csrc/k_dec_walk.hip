@@ -230,8 +230,8 @@ void launch_dec_walk_table(const DecArgs &a, hipStream_t st, void *tab, size_t t
         (max_bits >= exits_from || a.wide_band == 18) && walk_exits_rgb(a, st, tab, tab_bytes, max_bits)) return;
     if (a.g.tsz >= 4) walk_chain_wide(a, st, tab, tab_bytes, max_bits);
     else if (a.g.tsz == 2) walk_chain_16bit(a, st, tab, tab_bytes, max_bits);
-    else if (a.g.bands == 1 || a.g.bands == 3 || a.g.bands == 4) walk_chain_8bit(a, st, tab, tab_bytes, max_bits);
-    else walk_chain_8bit_any(a, st, tab, tab_bytes, max_bits);          // 2 or more than 4 bands: the 16-bit chain's kernels with eight rungs
+    else if (a.g.bands <= 4 && a.g.mode != CM_BEST) walk_chain_8bit(a, st, tab, tab_bytes, max_bits);        // (the hand-ordered loops: one to four bands)
+    else walk_chain_8bit_any(a, st, tab, tab_bytes, max_bits);          // more than 4 bands: the 16-bit chain's kernels with eight rungs
 }
 
 // bytes of table memory that take `max_bits` of every stream in one round (16-bit data: 32 bytes a stream bit)

@@ -119,6 +119,20 @@ __device__ __forceinline__ void walk_asm(uint32_t &A, uint32_t &T, uint32_t (&R)
               [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "+v"(e2), [t] "=&v"(t)
             : [M] "s"(M), [base] "v"(base)
             : "vcc", "scc", "memory");
+    } else if constexpr (B == 2) {
+        uint32_t e0, e1 = R[1] & 14u;
+        asm volatile(
+            CH_READ(e0)
+            "1:\n" CH_TOP CH_BOOK(e1, R1) CH_EXIT
+            CH_STEP(e0, R1, 0)
+            CH_READ(e1) CH_BOOK(e0, R0) CH_STEP(e1, R0, 2)
+            CH_READ(e0)
+            "v_add_u32 %[T], 4, %[T]\n s_sub_u32 %[left], %[left], 1\n s_branch 1b\n"
+            "2:\n s_waitcnt lgkmcnt(0)\n"
+            : [A] "+v"(A), [T] "+v"(T), [R0] "+v"(R[0]), [R1] "+v"(R[1]), [bad] "+v"(bad), [left] "+s"(left),
+              [e0] "=&v"(e0), [e1] "+v"(e1), [t] "=&v"(t)
+            : [M] "s"(M), [base] "v"(base)
+            : "vcc", "scc", "memory");
     } else if constexpr (B == 4) {
         uint32_t e0, e1, e2, e3 = R[3] & 14u;
         asm volatile(
@@ -973,6 +987,7 @@ bool walk_chain_lds_ok() {
     static const bool lds_ok = [] {
         bool ok = true;
         ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, chain::LDS_BYTES) == hipSuccess;
         ok = ok && hipFuncSetAttribute((const void *)walk_chainN_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, chainN<4>::LDS_BYTES) == hipSuccess;
@@ -998,6 +1013,7 @@ void walk_chain_8bit(const DecArgs &a, hipStream_t st, void *tab, size_t tab_byt
             using namespace chain;
             WalkState *ws = (WalkState *)states;
             if (a.g.bands == 1) hipLaunchKernelGGL(walk_chain_kernel<1>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first);
+            else if (a.g.bands == 2) hipLaunchKernelGGL(walk_chain_kernel<2>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first);
             else if (a.g.bands == 3) hipLaunchKernelGGL(walk_chain_kernel<3>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first);
             else hipLaunchKernelGGL(walk_chain_kernel<4>, dim3(nt), dim3(512), LDS_BYTES, s, a, rows, s0, nwin, pitch, ws, first); });
 }
