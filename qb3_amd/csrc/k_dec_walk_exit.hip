@@ -386,11 +386,11 @@ template <uint32_t B, bool CF = false, uint32_t UB_ = 3> struct exitB {       //
     static constexpr uint32_t X_DEP = CF ? 1u << 31 : 0u, CNTM = CF ? 0x1fffu : 0x3fffu;
     static constexpr uint32_t BMW = (NKEY + 31) / 32;                                                         // words of the bitmap of first-window exits
     static constexpr uint32_t NSIG = 128;                                                                     // (common-factor streams) positions of a window whose unit carries the signal code, at most
-    // the code lengths of 2, 4, 8 codes for ALL rungs in one pass each (seven arrays of each kind: 30 KB more) instead of a pass -- and its
-    // barrier -- per rung: 8-bit FTL / BASE streams, where the memory is there
-    static constexpr bool FUSED = !CF && UB == 3;
+    // the code lengths of 2, 4, 8 codes for FG rungs in one pass each (FG arrays of each kind) instead of a pass -- and its barrier -- per rung:
+    // all seven rungs at once for 8-bit FTL / BASE streams (30 KB more LDS), four at a time where the memory is shorter
+    static constexpr uint32_t FG = (!CF && UB == 3) ? NRUNG - 1 : 4;
     static constexpr uint32_t T0 = 0, BM0 = T0 + ((TP * NR * 2 + 15) & ~15u), PF0 = BM0 + BMW * 4, XD0 = PF0 + ((BMW * 2 + 15) & ~15u), S0 = XD0 + DCAP * 4,
-                              E1 = S0 + ((TP * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT * (FUSED ? NRUNG - 1 : 1), WORDS = EB + NPT * (FUSED ? NRUNG - 1 : 1), SG0 = (WORDS + (NP1 / 32 + 3) * 4 + 15) & ~15u,
+                              E1 = S0 + ((TP * 2 + 15) & ~15u), EA = E1 + NP1, EB = EA + NPT * FG, WORDS = EB + NPT * FG, SG0 = (WORDS + (NP1 / 32 + 3) * 4 + 15) & ~15u,
                               SL0 = SG0 + (CF ? NSIG * B * NR * 4 : 0), SP0 = SL0 + (CF ? (TP + 15) & ~15u : 0), LDS_BYTES = SP0 + (CF ? NSIG * 2 + 16 : 0);
     static_assert((B == 2 || (B == 3 && UB == 3)) && (UB == 3 || (UB == 4 && !CF)) && NKEY <= KEYM && TP + MAXU < 4095 && LDS_BYTES <= 160 * 1024, "entry layouts of the exit walk of two- and three-band rasters");
 };
@@ -468,62 +468,48 @@ __global__ void __launch_bounds__(1024) walk_exitB_kernel(const DecArgs a0, uint
             const uint32_t cs = walk_switch<UB>(bits(o), delta, sig);
             sw[o] = (uint16_t)(cs | (delta << 4) | ((sig ? 1u : 0u) << 10) | ((bits(o + cs) & 1u) << 11));
         }
-        if constexpr (!E::FUSED) for (uint32_t i = tid; i < TP * NR / 2; i += NT) ((uint32_t *)T)[i] = 0xffffffffu;      // (fused: every row is written whole below)
         __syncthreads();
-        if constexpr (E::FUSED) {
-            // every rung at once: level by level (2, 4, 8 codes), an array per rung; then every rung's row entries in one pass
+        {
+            // FG rungs at a time: level by level (2, 4, 8 codes), an array per rung of the group; then the group's row entries (the first
+            // group also rung 0 and, for positions with the signal code, the whole row of "no entry")
+            constexpr uint32_t FG = E::FG;
             uint8_t (*A)[NPT] = (uint8_t (*)[NPT])eA, (*Bq)[NPT] = (uint8_t (*)[NPT])eB;
-            for (uint32_t i = tid; i < NPT - MAXC; i += NT) {
-                const uint32_t e = t1[i];
-#pragma unroll
-                for (uint32_t r = 1; r < NRUNG; r++) A[r - 1][i] = (uint8_t)(e + t1[i + r + e]);
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < NPT - 3 * MAXC; i += NT) {
-#pragma unroll
-                for (uint32_t r = 1; r < NRUNG; r++) { const uint32_t e = A[r - 1][i]; Bq[r - 1][i] = (uint8_t)(e + A[r - 1][i + 2 * r + e]); }
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < NPT - 7 * MAXC; i += NT) {
-#pragma unroll
-                for (uint32_t r = 1; r < NRUNG; r++) { const uint32_t e = Bq[r - 1][i]; A[r - 1][i] = (uint8_t)(e + Bq[r - 1][i + 4 * r + e]); }
-            }
-            __syncthreads();
-            for (uint32_t o = tid; o < TP; o += NT) {
-                const uint32_t s = sw[o], cs = s & 15u, delta = (s >> 4) & 63u;
-                if ((s >> 10) & 1u) {       // the signal code: no entry at any rung
-                    *(uint4 *)(T + o * NR) = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-                    continue;
-                }
-#pragma unroll
-                for (uint32_t r = 0; r < NRUNG; r++) {
-                    const uint32_t bin = (r - delta) & (NRUNG - 1);
-                    uint32_t u = cs + (((s >> 11) & 1u) ? 17u : 1u);
-                    if (r) { const uint32_t n8 = 8 * r + A[r - 1][o + cs]; u = cs + n8 + 8 * r + A[r - 1][o + cs + n8]; }
-                    T[o * NR + bin] = (uint16_t)((o + u) | (r << 12));
-                }
-            }
-            __syncthreads();
-        } else
 #pragma unroll 1
-        for (uint32_t r = 0; r < NRUNG; r++) {                                              // the rung the switch leads to
-            if (r) {
-                for (uint32_t i = tid; i < NPT - MAXC; i += NT) { const uint32_t e = t1[i]; eA[i] = (uint8_t)(e + t1[i + r + e]); }
+            for (uint32_t rb = 1; rb < NRUNG; rb += FG) {
+                for (uint32_t i = tid; i < NPT - MAXC; i += NT) {
+                    const uint32_t e = t1[i];
+#pragma unroll
+                    for (uint32_t q = 0; q < FG; q++) if (rb + q < NRUNG) A[q][i] = (uint8_t)(e + t1[i + (rb + q) + e]);
+                }
                 __syncthreads();
-                for (uint32_t i = tid; i < NPT - 3 * MAXC; i += NT) { const uint32_t e = eA[i]; eB[i] = (uint8_t)(e + eA[i + 2 * r + e]); }
+                for (uint32_t i = tid; i < NPT - 3 * MAXC; i += NT) {
+#pragma unroll
+                    for (uint32_t q = 0; q < FG; q++) if (rb + q < NRUNG) { const uint32_t e = A[q][i]; Bq[q][i] = (uint8_t)(e + A[q][i + 2 * (rb + q) + e]); }
+                }
                 __syncthreads();
-                for (uint32_t i = tid; i < NPT - 7 * MAXC; i += NT) { const uint32_t e = eB[i]; eA[i] = (uint8_t)(e + eB[i + 4 * r + e]); }
+                for (uint32_t i = tid; i < NPT - 7 * MAXC; i += NT) {
+#pragma unroll
+                    for (uint32_t q = 0; q < FG; q++) if (rb + q < NRUNG) { const uint32_t e = Bq[q][i]; A[q][i] = (uint8_t)(e + Bq[q][i + 4 * (rb + q) + e]); }
+                }
+                __syncthreads();
+                for (uint32_t o = tid; o < TP; o += NT) {
+                    const uint32_t s = sw[o], cs = s & 15u, delta = (s >> 4) & 63u;
+                    if ((s >> 10) & 1u) {       // the signal code: no entry at any rung
+                        if (rb == 1) for (uint32_t r = 0; r < NR; r++) T[o * NR + r] = 0xffffu;
+                        continue;
+                    }
+                    if (rb == 1) T[o * NR + ((0u - delta) & (NRUNG - 1))] = (uint16_t)(o + cs + (((s >> 11) & 1u) ? 17u : 1u));      // rung 0
+#pragma unroll
+                    for (uint32_t q = 0; q < FG; q++) {
+                        const uint32_t r = rb + q;
+                        if (r < NRUNG) {
+                            const uint32_t n8 = 8 * r + A[q][o + cs], u = cs + n8 + 8 * r + A[q][o + cs + n8];
+                            T[o * NR + ((r - delta) & (NRUNG - 1))] = (uint16_t)((o + u) | (r << 12));
+                        }
+                    }
+                }
                 __syncthreads();
             }
-            for (uint32_t o = tid; o < TP; o += NT) {
-                const uint32_t s = sw[o], cs = s & 15u, delta = (s >> 4) & 63u;
-                if ((s >> 10) & 1u) continue;
-                const uint32_t bin = (r - delta) & (NRUNG - 1);
-                uint32_t u = cs + (((s >> 11) & 1u) ? 17u : 1u);
-                if (r) { const uint32_t n8 = 8 * r + eA[o + cs]; u = cs + n8 + 8 * r + eA[o + cs + n8]; }
-                T[o * NR + bin] = (uint16_t)((o + u) | (r << 12));
-            }
-            __syncthreads();
         }
         if constexpr (CF) {       // the units with the signal code: their places, then every (place, band, entering rung) parsed by a lane of its own
             if (tid == 0) s_nsig = 0;
