@@ -91,8 +91,10 @@ __device__ __forceinline__ void pxu_pixels(const DecArgs &a, uint8_t *tile8, uin
 // as they are (the hardware's unaligned access mode); nothing to do.
 
 // bytes of LDS a wave needs: the staged words and, in their place afterwards, the tile; then a slot per block
+// (PXU_PAD zero words behind the staged ones: what wide_values_lds reads beyond a position inside the staged bits, qb3_wide.h)
+constexpr uint32_t PXU_PAD = WIDE_PAD_DW;
 __host__ __device__ inline uint32_t pxu_wave_bytes(uint32_t in_cap_dw, uint32_t tsz) {
-    const uint32_t st = 4 * (in_cap_dw + 8), tl = 16 * 64 * tsz;
+    const uint32_t st = 4 * (in_cap_dw + PXU_PAD), tl = 16 * 64 * tsz;
     return (((st > tl ? st : tl) + 15u) & ~15u) + 8 * 32;
 }
 
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(256) dec_pxu_kernel(const DecArgs a0) {
     const bool fits = sane && ndw64 <= a.in_cap_dw;
     const uint32_t misfit = (sane && ndw64 <= a.in_cap_full) ? 16u : 8u;
     const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
-    for (uint32_t base = 0; base < ndw + 8; base += 512) {  // eight loads in flight per lane, then eight LDS stores
+    for (uint32_t base = 0; base < ndw + PXU_PAD; base += 512) {  // eight loads in flight per lane, then eight LDS stores
         uint32_t sw[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -170,14 +172,14 @@ __global__ void __launch_bounds__(256) dec_pxu_kernel(const DecArgs a0) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t i = base + lane + 64 * k;
-            if (i < ndw + 8) stage[i] = sw[k];
+            if (i < ndw + PXU_PAD) stage[i] = sw[k];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const uint32_t limit = 32 * ndw;                        // no unit starts beyond the staged bits (8 zero words follow)
+    const uint32_t limit = 32 * ndw;                        // no unit starts beyond the staged bits (PXU_PAD zero words follow)
     const uint32_t cpos = (uint32_t)(a.in_bit0 + P0 - 32 * w0);
     bool bad = !fits;
     const uint32_t binc = wave_iscan32(blen);               // inclusive: the last lane holds the bits of the segment
@@ -185,13 +187,13 @@ __global__ void __launch_bounds__(256) dec_pxu_kernel(const DecArgs a0) {
     pos = pos < limit ? pos : limit;
     bool sig = false;
     const LdsWords sw = (LdsWords)stage;
-    const uint32_t d = dec3_switch<T, LdsWords>(sw, ndw + 8, pos, &gpos, &sig);
+    const uint32_t d = dec3_switch<T, LdsWords>(sw, ndw + PXU_PAD, pos, &gpos, &sig);
     if (act && sig && STEP) bad = true;                     // common-factor / index unit in a BASE stream: not handled here
     const uint32_t dd = act ? d : 0u;
     const uint32_t rung = (rg0 + pxu_exscan_band<uint32_t>(dd, B) + dd) & UMASK;
     T run[16];
     uint32_t end = 0;
-    dec3_group<T, STEP, LdsWords>(sw, ndw + 8, gpos, rung, dtab, run, &end);
+    dec3_group<T, STEP, LdsWords, sizeof(T) >= 4>(sw, ndw + PXU_PAD, gpos, rung, dtab, run, &end);
     if (BL && act && end != pos + blen) bad = true;         // the table's lengths are not this stream's
     const T usum = act ? run[15] : (T)0;
     const T sex = pxu_exscan_band<T>(usum, B);
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(256) dec_pxu_best_kernel(const DecArgs a0) {
     const bool fits = sane && ndw64 <= a.in_cap_dw;
     const uint32_t misfit = (sane && ndw64 <= a.in_cap_full) ? 16u : 8u;      // 16: the staging was sized for the stream's average; the host calls again with the worst case
     const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
-    for (uint32_t base = 0; base < ndw + 8; base += 512) {
+    for (uint32_t base = 0; base < ndw + PXU_PAD; base += 512) {
         uint32_t sw[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(256) dec_pxu_best_kernel(const DecArgs a0) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t i = base + lane + 64 * k;
-            if (i < ndw + 8) stage[i] = sw[k];
+            if (i < ndw + PXU_PAD) stage[i] = sw[k];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -309,7 +311,7 @@ __global__ void __launch_bounds__(256) dec_pxu_best_kernel(const DecArgs a0) {
     for (int pass = 0; pass < 2; pass++) {
         if (need) {
             ReaderT<LdsWords> rd;
-            rd.init((LdsWords)stage, pos, 32ull * (ndw + 8));
+            rd.init((LdsWords)stage, pos, 32ull * (ndw + PXU_PAD));
             rung = oldrung; pcf = cf_in; flags = 0;
             ok = parse_unit<T, CM_BEST, ReaderT<LdsWords>>(rd, rung, pcf, g, &flags);
             end = (uint32_t)rd.position();

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) dec_pxw_kernel(const DecArgs a0) {
     const uint32_t NB = a.g.seg_blocks, nbx = a.g.nbx;      // NB == 64
     const uint64_t stride = a.g.stride;
     uint16_t *dtab = (uint16_t *)smem;                      // 2 KB
-    uint32_t *stage = (uint32_t *)(smem + 2048) + wave * (a.in_cap_dw + 8);
+    uint32_t *stage = (uint32_t *)(smem + 2048) + wave * (a.in_cap_dw + WIDE_PAD_DW);
 
     // loads that depend on nothing but the segment number go out first: their round trips overlap the table copy
     const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) dec_pxw_kernel(const DecArgs a0) {
     // host runs the call again with the worst case)
     const uint32_t misfit = (sane && ndw64 <= a.in_cap_full) ? 16u : 8u;
     const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
-    for (uint32_t base = 0; base < ndw + 8; base += 512) { // eight loads in flight per lane, then eight LDS stores
+    for (uint32_t base = 0; base < ndw + WIDE_PAD_DW; base += 512) { // eight loads in flight per lane, then eight LDS stores
         uint32_t sw[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) dec_pxw_kernel(const DecArgs a0) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t i = base + lane + 64 * k;
-            if (i < ndw + 8) stage[i] = sw[k];
+            if (i < ndw + WIDE_PAD_DW) stage[i] = sw[k];
         }
     }
     // the wave reads what its own lanes staged: LDS operations of a wave execute in order, the fence is for the compiler
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) dec_pxw_kernel(const DecArgs a0) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const uint32_t limit = 32 * ndw;                        // no unit starts beyond the staged bits (8 zero words follow)
+    const uint32_t limit = 32 * ndw;                        // no unit starts beyond the staged bits (WIDE_PAD_DW zero words follow)
     const uint32_t cpos = (uint32_t)(a.in_bit0 + P0 - 32 * w0);
     bool bad = !fits;
     const uint32_t binc = wave_iscan32(blen);               // inclusive: lane 63 holds the bits of the segment
@@ -126,12 +126,12 @@ __global__ void __launch_bounds__(256) dec_pxw_kernel(const DecArgs a0) {
     pos = pos < limit ? pos : limit;
     bool sig = false;
     const LdsWords sw = (LdsWords)stage;
-    const uint32_t d = dec3_switch<T, LdsWords>(sw, ndw + 8, pos, &gpos, &sig);
+    const uint32_t d = dec3_switch<T, LdsWords>(sw, ndw + WIDE_PAD_DW, pos, &gpos, &sig);
     if (act && sig && STEP) bad = true;                     // common-factor / index unit in a BASE stream: not handled here
     const uint32_t rung = (rg0 + wave_iscan32(act ? d : 0u)) & UMASK;
     T run[16];
     uint32_t end = 0;
-    dec3_group<T, STEP, LdsWords>(sw, ndw + 8, gpos, rung, dtab, run, &end);
+    dec3_group<T, STEP, LdsWords, sizeof(T) >= 4>(sw, ndw + WIDE_PAD_DW, gpos, rung, dtab, run, &end);
     if (BL && act && end != pos + blen) bad = true;         // the table's lengths are not this stream's
     const T usum = act ? run[15] : (T)0;
     const T sex = wave_exscan_t(usum);
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) dec_pxw_best_kernel(const DecArgs a0) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t NB = 64, nbx = a.g.nbx;
     const uint64_t stride = a.g.stride;
-    uint32_t *stage = (uint32_t *)smem + wave * (a.in_cap_dw + 8);         // nothing is shared between the waves: no barrier
+    uint32_t *stage = (uint32_t *)smem + wave * (a.in_cap_dw + WIDE_PAD_DW);         // nothing is shared between the waves: no barrier
     const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;
     if (seg >= a.seg_end) return;
     const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) dec_pxw_best_kernel(const DecArgs a0) {
     const bool fits = sane && ndw64 <= a.in_cap_dw;
     const uint32_t misfit = (sane && ndw64 <= a.in_cap_full) ? 16u : 8u;      // 16: the staging was sized for the stream's average; the host calls again with the worst case
     const uint32_t ndw = fits ? (uint32_t)ndw64 : 0;
-    for (uint32_t base = 0; base < ndw + 8; base += 512) {
+    for (uint32_t base = 0; base < ndw + WIDE_PAD_DW; base += 512) {
         uint32_t sw[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) dec_pxw_best_kernel(const DecArgs a0) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t i = base + lane + 64 * k;
-            if (i < ndw + 8) stage[i] = sw[k];
+            if (i < ndw + WIDE_PAD_DW) stage[i] = sw[k];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) dec_pxw_best_kernel(const DecArgs a0) {
     for (int pass = 0; pass < 2; pass++) {
         if (need) {
             ReaderT<LdsWords> rd;
-            rd.init((LdsWords)stage, pos, 32ull * (ndw + 8));
+            rd.init((LdsWords)stage, pos, 32ull * (ndw + WIDE_PAD_DW));
             rung = oldrung; pcf = cf_in; flags = 0;
             ok = parse_unit<T, CM_BEST, ReaderT<LdsWords>>(rd, rung, pcf, g, &flags);
             end = (uint32_t)rd.position();

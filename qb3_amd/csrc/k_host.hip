@@ -483,18 +483,18 @@ DecPlan plan_decode(const Geometry &g) {
         p.px_cap_dw = (p.px_cap_dw + 4 + 3) & ~3u;             // staged from a 16-byte aligned word, in 16-byte pieces
         p.lds_px = 4096 + 4 * 4 * ((size_t)p.px_cap_dw + 16);
     }
-    // 32/64-bit, one band: a wave per 64-block segment; staging for the longest valid segment + 8 zero words, behind the 2 KB table
+    // 32/64-bit, one band: a wave per 64-block segment; staging for the longest valid segment + WIDE_PAD_DW zero words, behind the 2 KB table
     p.pxw = !p.px && !p.px16 && p.fast && pxw_eligible(g) && NB == 64;
     p.lds_pxw = 0;
     if (p.pxw) {
         p.px_cap_dw = (uint32_t)(((size_t)NB * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
-        p.lds_pxw = 2048 + 4 * 4 * ((size_t)p.px_cap_dw + 8);
+        p.lds_pxw = 2048 + 4 * 4 * ((size_t)p.px_cap_dw + WIDE_PAD_DW);
     }
     // ... and the common-factor streams of such rasters (the index has a dword per block: ulen_sz == 4); no table, no barrier
     p.pxw_best = g.ulen_sz == 4 && NB == 64 && pxw_eligible(g, true);
     if (p.pxw_best) {
         p.px_cap_dw = (uint32_t)(((size_t)NB * max_unit_bits(g.tsz, g.mode) + 31) / 32 + 2);
-        p.lds_pxw = 4 * 4 * ((size_t)p.px_cap_dw + 8);
+        p.lds_pxw = 4 * 4 * ((size_t)p.px_cap_dw + WIDE_PAD_DW);
     }
     // every other raster: a wave per segment of 64 / bands blocks, a lane per unit (k_dec_pxu.hip); core bands must themselves be core
     bool core_ok = true;
@@ -673,7 +673,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
         const uint64_t bits = tb.n ? tb.max_bits : in_bits;
         uint64_t cap = bits / 32 / g.nseg;
         cap = (cap + cap / 2 + 64 + 3) & ~(uint64_t)3;
-        if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_pxw = (plan.pxw ? 2048 : 0) + 4 * 4 * ((size_t)cap + 8); }
+        if (bits && cap < plan.px_cap_dw) { plan.px_cap_dw = (uint32_t)cap; plan.lds_pxw = (plan.pxw ? 2048 : 0) + 4 * 4 * ((size_t)cap + WIDE_PAD_DW); }
     }
     if ((plan.pxu || plan.pxu_best) && !full_staging && g.nseg) {        // ... and for the lane-per-unit kernels
         const uint64_t bits = tb.n ? tb.max_bits : in_bits;

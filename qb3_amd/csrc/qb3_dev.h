@@ -53,6 +53,7 @@ IndexView index_view(const Geometry &g, void *base);
 uint32_t seg_blocks_for(const Geometry &g);      // needs w, h, bands, tsz, stride, order, mode, cband
 uint32_t ulen_size_for(uint32_t tsz, uint32_t mode, uint32_t bands);
 constexpr uint32_t ULEN_UNIT = 8;
+constexpr uint32_t WIDE_PAD_DW = 40;      // zero words behind the staged words of a 32/64-bit segment (wide_values_lds, qb3_wide.h)
 inline size_t ulen_table_bytes(const Geometry &g) { return g.ulen_sz == 4 ? (size_t)g.nblocks * 4 : g.ulen_sz == ULEN_UNIT ? (size_t)g.nblocks * g.bands * 4 : (size_t)g.nblocks * g.bands * g.ulen_sz; }
 // common-factor streams whose index holds a dword per BLOCK (its bits | the rungs its units are entered with << 16) for a
 // lane-per-block decoder: 8-bit rasters of 1/3/4 bands (four bits a band), 16/32/64-bit rasters of one band (the whole rung)

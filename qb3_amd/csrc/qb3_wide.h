@@ -78,16 +78,54 @@ __device__ __forceinline__ uint32_t dec3_switch(PTR src, uint32_t endw, uint32_t
     return delta;
 }
 
+// Sixteen values at a rung of 8 and above out of staged words in LDS, 32/64-bit data, WITHOUT A BRANCH: every code is cut out of a
+// window of 64 (96) bits read at its bit position -- three (four) LDS reads a value in place of a bit buffer with its refills, and
+// nothing a lane does depends on the form of its code (reference QB3decode.h:119-129: short r bits, middle r + 1, long r + 2).
+// The staged words must be followed by WIDE_PAD_DW zero words: sixteen codes of the longest kind (65 bits) and the last window
+// reach that far beyond a position inside the staged bits, whatever the stream holds.  (*end: the bit behind the unit)
+template <typename T, bool STEP>
+__device__ __forceinline__ void wide_values_lds(LdsWords src, uint32_t gpos, uint32_t rung, T (&g)[16], uint32_t *end) {
+    static_assert(sizeof(T) >= 4, "the 8- and 16-bit kernels read their codes through the tables");
+    uint32_t p = gpos, rb = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint32_t w = p >> 5, sh = p & 31;
+        const uint32_t w0 = src[w], w1 = src[w + 1], w2 = src[w + 2];
+        const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+        const uint32_t b0 = x0 & 1, b1 = (x0 >> 1) & b0;           // b0: middle or long form, b1: long
+        const uint32_t plen = 1 + b0, k = rung - 1 + b1;            // prefix bits, value bits
+        T v;
+        if constexpr (sizeof(T) == 8) {
+            const uint32_t x2 = __builtin_amdgcn_alignbit(src[w + 3], w2, sh);
+            const uint64_t f = (uint64_t)__builtin_amdgcn_alignbit(x1, x0, plen) | (uint64_t)__builtin_amdgcn_alignbit(x2, x1, plen) << 32;
+            v = (f & ((1ull << k) - 1)) | ((uint64_t)b0 << k);      // k <= 63
+        } else {
+            v = (__builtin_amdgcn_alignbit(x1, x0, plen) & ((1u << k) - 1)) | (b0 << k);     // k <= 31
+        }
+        g[i] = v;
+        rb |= (uint32_t)((v >> rung) & 1) << i;
+        p += plen + k;
+    }
+    if (STEP && (rb & (rb + 1)) == 0) {             // undo the step (reference QB3decode.h:285-289)
+        const uint32_t m = __popc(rb);
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) if (i == m) g[i] ^= (T)((T)1 << rung);
+    }
+    *end = p;
+}
+
 // decodes the 16 values at bit `gpos`; run[i] = sum of the first i+1 deltas in curve order.
 // Rungs 1..7 go through the LDS table (one read per value, three values per refill of the bit buffer).
 // (*end, when asked for: the bit behind the unit)
-template <typename T, bool STEP, typename PTR>
+// WINDOW (32/64-bit data staged in LDS with WIDE_PAD_DW zero words behind): rungs 8 and above by wide_values_lds
+template <typename T, bool STEP, typename PTR, bool WINDOW = false>
 __device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos, uint32_t rung, const uint16_t *dtab, T (&run)[16], uint32_t *end = nullptr) {
     ReaderT<PTR> rd;
     rd.in = src; rd.endw = endw; rd.wp = gpos >> 5;
     const uint32_t sh = gpos & 31;
-    rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
+    uint32_t endbit = 0;
     if (rung >= 1 && rung < 8) {
+        rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
         const uint16_t *tab = dtab + dec_tab_off(rung);
         const uint32_t mask = (4u << rung) - 1;
         uint32_t rb = 0;
@@ -105,9 +143,22 @@ __device__ __forceinline__ void dec3_group(PTR src, uint32_t endw, uint32_t gpos
 #pragma unroll
             for (uint32_t i = 0; i < 16; i++) if (i == m) run[i] ^= (T)((T)1 << rung);
         }
-    } else
+        endbit = (uint32_t)rd.position();
+    } else if constexpr (WINDOW) {
+        if (rung) wide_values_lds<T, STEP>(src, gpos, rung, run, &endbit);
+        else {                                      // rung 0: a flag, then sixteen bits if it is set (reference QB3decode.h:150-160)
+            rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
+            const uint32_t bits = rd.get(1) ? rd.get(16) : 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) run[i] = (T)((bits >> i) & 1);
+            endbit = (uint32_t)rd.position();
+        }
+    } else {
+        rd.buf = (uint64_t)(rd.load(rd.wp++) >> sh); rd.n = 32 - sh;
         get_group<T, STEP, ReaderT<PTR>>(rd, rung, run);
-    if (end) *end = (uint32_t)rd.position();
+        endbit = (uint32_t)rd.position();
+    }
+    if (end) *end = endbit;
     T acc = 0;
 #pragma unroll
     for (uint32_t i = 0; i < 16; i++) { acc = (T)(acc + smag_t<T>(run[i])); run[i] = acc; }

@@ -2288,6 +2288,34 @@ def test_streams_cut_short_decode_like_the_reference(qb3, oracle):
             assert np.array_equal(got, want), (w, h, b, dt, gen, mode, frac)
 
 
+@pytest.mark.parametrize("case", [(4096, 4096, 3, 7, "DEM", 8), (4096, 4096, 2, 7, "DEM", 8), (4096, 4096, 2, 7, "DEM", 0), (4096, 4096, 1, 7, "DEM", 8)],
+                         ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % c)
+def test_wide_decode_is_repeatable(qb3, case):
+    """The same container and index must decode to the same pixels every time, whatever ran on the device before.  The 64-bit
+    lane-per-unit decoder read, in a few calls out of a hundred and only right behind an encode, the last value of a block row's first
+    unit (rung 18, stream position a multiple of 32) one bit late: same inputs, status 0, the next call right again.
+    Its values now come out of a window without a branch (wide_values_lds, qb3_wide.h); this is the flow that showed the fault."""
+    import torch
+    from qb3_amd import synth, device as qdev
+    w, h, b, dt, gen, mode = case
+    img = synth.generate(w, h, b, dt, gen, 3)
+    raw = img.reshape(-1).view(torch.uint8)
+    enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, index_chunk=2)
+    out = torch.empty(raw.numel(), dtype=torch.uint8, device=img.device)
+    first = None
+    for rep in range(120):
+        dst, n, index = enc.encode(img)
+        cur = dst[:n].clone()
+        if first is None: first = cur
+        assert torch.equal(cur, first), f"run {rep}: the container differs"
+        dec = qdev.DeviceDecoder(dst, n)
+        for name, ix in (("index", index), ("table", None)):
+            out.zero_()
+            dec.decode(dst, out=out, index=ix)
+            assert torch.equal(out, raw), f"run {rep}, by the {name}: {int((out != raw).sum())} bytes differ"
+        dec.close()
+
+
 def test_large_lane_per_unit_rasters_through_the_host_calls(qb3, oracle):
     """rasters of 64 MB and more of the lane-per-unit shapes through qb3_encode / qb3_read_data (the encode side codes them strip by
     strip): the plain container is the oracle's, the self-indexed one the oracle's plus table chunks, both decode exactly"""
