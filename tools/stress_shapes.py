@@ -7,7 +7,12 @@ import qb3_amd
 from qb3_amd import synth, device as qdev
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dev = torch.device("cuda", 0)
-for (w, h, b, dt, gen, mode) in [(4096, 4096, 2, 7, "DEM", 8), (4096, 4096, 2, 5, "DEM", 8), (4096, 4096, 5, 0, "NOISY3", 8), (4096, 4096, 7, 2, "LANDSAT16", 4), (4096, 4096, 3, 5, "DEM", 7), (4096, 4096, 5, 0, "NOISY3", 5)]:
+SHAPES = [(4096, 4096, 2, 7, "DEM", 8), (4096, 4096, 3, 7, "DEM", 0), (4096, 4096, 2, 5, "DEM", 8), (4096, 4096, 5, 0, "NOISY3", 8), (4096, 4096, 7, 2, "LANDSAT16", 4),
+          (4096, 4096, 3, 5, "DEM", 7), (4096, 4096, 3, 7, "DEM", 7), (4096, 4096, 5, 0, "NOISY3", 5),
+          # the lane-per-block families
+          (8192, 8192, 3, 0, "NOISY3", 8), (8192, 8192, 3, 0, "NOISY3", 7), (4096, 4096, 8, 2, "LANDSAT16", 4), (4096, 4096, 8, 2, "LANDSAT16", 5),
+          (4096, 4096, 1, 5, "DEM", 8), (4096, 4096, 1, 7, "DEM", 7), (4096, 4096, 1, 3, "DEM", 7), (4096, 4096, 4, 0, "NOISY3", 7)]
+for (w, h, b, dt, gen, mode) in SHAPES:
     img = synth.generate(w, h, b, dt, gen, 3, device=dev)
     raw = img.reshape(-1).view(torch.uint8)
     enc = qdev.DeviceEncoder(w, h, b, dt, mode=mode, index_chunk=2)
