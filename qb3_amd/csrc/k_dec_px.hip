@@ -11,6 +11,11 @@ template <int B, bool RGB, uint64_t ORDER, bool STEP, bool BL>
 __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chk = BL ? a0.chk_wgs : 0u;
+    if (blockIdx.x < chk) {                             // the launch's first workgroups: a chunk of the container's table each (beside the decoding, not behind it)
+        ix_check_chunk(a, blockIdx.x, (uint32_t *)smem);
+        return;
+    }
     constexpr int NW = (B + 1) / 2;                     // 32-bit words of a scan packed 16 bits per band
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t NB = a.g.seg_blocks, nbx = a.g.nbx;  // NB <= 64: a WAVE owns a segment, nothing is shared but the table
@@ -23,7 +28,7 @@ __global__ void __launch_bounds__(256) dec_px_kernel(const DecArgs a0) {
     // Loads that depend on nothing but the segment number go out first -- positions, unit lengths, entering rungs and
     // values -- so that their round trips overlap the table copy and its barrier (a wave spends 45 % of its life waiting
     // for memory before it can start: the two dependent trips "position, then stream words").
-    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
+    const uint64_t seg = a.seg0 + (uint64_t)(blockIdx.x - chk) * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
     const bool live = seg < a.seg_end;
     const uint64_t segc = live ? seg : 0;
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
@@ -210,6 +215,7 @@ static void launch_dec_px_b(const DecArgs &a, const DecPlan &plan, hipStream_t s
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
     dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
     if (a.bl_mode) {
+        grid.x += a.chk_wgs;                            // (workgroups that check the container's table instead of decoding a segment)
         if (!z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, false, true>), grid, block, plan.lds_px, st, a);
         else if (!z && step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, HILBERT, true, true>), grid, block, plan.lds_px, st, a);
         else if (z && !step) hipLaunchKernelGGL((dec_px_kernel<B, RGB, ZCURVE, false, true>), grid, block, plan.lds_px, st, a);

@@ -521,41 +521,23 @@ bool walk_table_applies(const Geometry &g, const DecPlan &plan) {
     return (((plan.px || plan.pxu) && g.tsz == 1) || ((plan.px16 || plan.pxu) && g.tsz == 2) || (g.tsz >= 4 && plan.fast)) && !tuning().slow_walk && !tuning().slow_index;
 }
 
-// A restart table is untrusted input that the decoder takes positions, rungs and values from: before any of it is used the
-// chunks are checked -- their heads where the host has not read them (signature, length, version, flags, blocks per entry,
-// the pad chunk behind), and for version 3 tables the 16-bit check of every chunk's entries.  A mismatch raises status bit
-// 5; the host then decodes the call again without the table.  A workgroup per chunk.
+// A restart table is untrusted input that the decoder takes positions, rungs and values from: its chunks are checked (ix_check_chunk,
+// qb3_kernels.h) -- by this kernel in front of the decoder, or by workgroups of the decoder's own launch (dec_px_kernel, DecArgs::chk_wgs).
+// A mismatch raises status bit 5; the host then decodes the call again without the table.  A workgroup per chunk.
 __global__ void __launch_bounds__(256) ix_check_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     __shared__ uint32_t part[4];
-    const uint32_t c = blockIdx.x, nch = (a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk;
-    const uint32_t here = (c + 1 < nch) ? a.ix_per_chunk : a.ix_K - c * a.ix_per_chunk;
-    const uint8_t *chunk = a.ix + (uint64_t)c * (IX_HEAD + a.ix_pad + (uint64_t)a.ix_per_chunk * a.ix_E);
-    bool bad = false;
-    if (threadIdx.x == 0 && (a.ix_check_heads || a.ix_ver >= 3)) {
-        const uint32_t len = IX_HEAD + here * a.ix_E;
-        const uint32_t blocks = chunk[8] | (chunk[9] << 8) | (chunk[10] << 16) | ((uint32_t)chunk[11] << 24);
-        bad = chunk[0] != 'i' || chunk[1] != 'x' || (chunk[2] | (chunk[3] << 8)) != (int)len || chunk[4] != a.ix_ver ||
-              (chunk[5] & 3) != ((a.g.mode == CM_BEST ? 1u : 0u) | (a.ix_bl ? 2u : 0u)) || blocks != a.ix_blocks;
-        if (a.ix_pad) bad = bad || chunk[len] != 'z' || chunk[len + 1] != 'z' || chunk[len + 2] != 4 || chunk[len + 3] != 0;
-        if (c + 1 == nch) bad = bad || chunk[len + a.ix_pad] != 'D' || chunk[len + a.ix_pad + 1] != 'T';
-    }
-    if (a.ix_ver >= 3) {
-        uint32_t s = ix_sum_part(chunk + IX_HEAD, here * a.ix_E, threadIdx.x, 256);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) s += (uint32_t)__shfl_xor((int)s, d, 64);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) bad = bad || ix_sum_fold(part[0] + part[1] + part[2] + part[3]) != (uint32_t)(chunk[6] | (chunk[7] << 8));
-    }
-    if (bad) atomicOr(a.status, 32u);
+    ix_check_chunk(a, blockIdx.x, part);
 }
 
 static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild, hipStream_t st, void *walk_tab, size_t walk_tab_bytes, uint64_t max_bits) {
     const bool best = a.g.mode == CM_BEST;
-    if (rebuild && a.ix && a.ix_K && (a.ix_ver >= 3 || a.ix_check_heads))
-        hipLaunchKernelGGL(ix_check_kernel, dim3((a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk, a.ntiles), dim3(256), 0, st, a);
     const bool use_px = plan.px && !best && a.g.tsz == 1;
+    const bool need_check = rebuild && a.ix && a.ix_K && (a.ix_ver >= 3 || a.ix_check_heads);
+    // (the 8-bit decoder that works from the entries alone checks the table with workgroups of its own launch: one launch, not two)
+    const bool fold_check = need_check && use_px && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl;
+    if (need_check && !fold_check)
+        hipLaunchKernelGGL(ix_check_kernel, dim3((a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk, a.ntiles), dim3(256), 0, st, a);
     const bool use_px16 = plan.px16 && !best && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0;
     // 32/64-bit FTL/BASE streams that bring a restart table with an entry per index segment: the lengths-only walk too
     const bool wide_walk = rebuild && a.ix && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
@@ -586,6 +568,7 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
         // the container's table carries block (16-bit data: band pair) lengths: the lane-per-block decoder works from the entries alone
         DecArgs t = a;
         t.bl_mode = 1;
+        if (fold_check) t.chk_wgs = (a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk;
         ProfScope ps("dec_units", st);
         dec_units(t);
         HIPCHK(hipGetLastError());
@@ -683,7 +666,7 @@ int launch_decode(const Geometry &g, const DecPlan &plan_in, const uint32_t *in3
     }
     a.in_cap_full = plan_in.px_cap_dw;
     // the container's coarse restart table is usable when it matches this geometry and this library's segments
-    a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = a.ix_per_chunk = a.ix_pad = 0; a.ix_bl = 0; a.ix_ver = 0; a.ix_check_heads = 0;
+    a.ix = nullptr; a.ix_K = a.ix_blocks = a.ix_E = a.ix_per_chunk = a.ix_pad = 0; a.ix_bl = 0; a.ix_ver = 0; a.ix_check_heads = 0; a.chk_wgs = 0;
     if (ix.base && ix.blocks && ix.per_chunk && ix.blocks % g.seg_blocks == 0 && ix.entry_bytes == ix_entry_bytes(g, ix.block_lens) &&
         (!ix.block_lens || (ix_block_lens_ok(g) && ix.blocks == g.seg_blocks)) &&
         ix.K == (g.nblocks + ix.blocks - 1) / ix.blocks) {

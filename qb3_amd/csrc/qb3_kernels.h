@@ -330,6 +330,7 @@ struct DecArgs {
     uint32_t ix_K, ix_blocks, ix_E, ix_per_chunk, ix_pad;     // ix_pad: bytes of the pad chunk behind every table chunk
     uint32_t ix_bl;                 // the entries carry block lengths: the lane-per-block decoder needs no walk and no index
     uint32_t ix_ver, ix_check_heads;    // version of the table's chunks (3: with checks); the host has not seen the chunk heads behind the first
+    uint32_t chk_wgs;                   // dec_px_kernel from the entries alone: the launch's first chk_wgs workgroups check a chunk of the table each (ix_check_chunk)
     uint32_t bl_mode;               // ... and this launch decodes from them
     uint64_t seg0, seg_end;         // lane-per-block decoders: the segments this launch decodes ([0, nseg) but for the strips of a pipelined host call)
     uint32_t wide_band;             // plain 32/64-bit streams: rungs in the band the walk's table covers (16; 8: QB3_WIDE_BAND, a test hook)
@@ -364,6 +365,33 @@ __device__ __forceinline__ uint32_t ix_sum_part(const uint8_t *e, uint32_t n, ui
     return s;
 }
 __device__ __forceinline__ uint32_t ix_sum_fold(uint32_t s) { return (s ^ (s >> 16)) & 0xffffu; }
+
+// Checks chunk c of the container's restart table: its head where the host has not read it (signature, length, version, flags, blocks
+// per entry, the pad chunk behind) and, for version 3 tables, the 16-bit check of its entries.  A workgroup of 256; a mismatch raises
+// status bit 5.  part: four words of LDS (the caller's: a static array here would take LDS address 0 from dec_px_kernel's table)
+__device__ __forceinline__ void ix_check_chunk(const DecArgs &a, uint32_t c, uint32_t *part) {
+    const uint32_t nch = (a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk;
+    const uint32_t here = (c + 1 < nch) ? a.ix_per_chunk : a.ix_K - c * a.ix_per_chunk;
+    const uint8_t *chunk = a.ix + (uint64_t)c * (IX_HEAD + a.ix_pad + (uint64_t)a.ix_per_chunk * a.ix_E);
+    bool bad = false;
+    if (threadIdx.x == 0 && (a.ix_check_heads || a.ix_ver >= 3)) {
+        const uint32_t len = IX_HEAD + here * a.ix_E;
+        const uint32_t blocks = chunk[8] | (chunk[9] << 8) | (chunk[10] << 16) | ((uint32_t)chunk[11] << 24);
+        bad = chunk[0] != 'i' || chunk[1] != 'x' || (chunk[2] | (chunk[3] << 8)) != (int)len || chunk[4] != a.ix_ver ||
+              (chunk[5] & 3) != ((a.g.mode == CM_BEST ? 1u : 0u) | (a.ix_bl ? 2u : 0u)) || blocks != a.ix_blocks;
+        if (a.ix_pad) bad = bad || chunk[len] != 'z' || chunk[len + 1] != 'z' || chunk[len + 2] != 4 || chunk[len + 3] != 0;
+        if (c + 1 == nch) bad = bad || chunk[len + a.ix_pad] != 'D' || chunk[len + a.ix_pad + 1] != 'T';
+    }
+    if (a.ix_ver >= 3) {
+        uint32_t s = ix_sum_part(chunk + IX_HEAD, here * a.ix_E, threadIdx.x, 256);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) s += (uint32_t)__shfl_xor((int)s, d, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) bad = bad || ix_sum_fold(part[0] + part[1] + part[2] + part[3]) != (uint32_t)(chunk[6] | (chunk[7] << 8));
+    }
+    if (bad) atomicOr(a.status, 32u);
+}
 
 // entry k of a restart table whose first chunk starts at `base` (layout: qb3_dev.h, IxTable)
 __device__ __forceinline__ const uint8_t *ix_entry_at(const uint8_t *base, uint32_t per_chunk, uint32_t E, uint32_t pad, uint32_t k) {
