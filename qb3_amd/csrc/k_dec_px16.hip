@@ -105,6 +105,8 @@ template <int BG, bool RGB, uint64_t ORDER, bool STEP, bool BL = false>
 __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chk = BL ? a0.chk_wgs : 0u;          // the launch's first workgroups check a chunk of the container's table each (ix_check_chunk)
+    if (blockIdx.x < chk) { ix_check_chunk(a, blockIdx.x, (uint32_t *)smem); return; }
     constexpr int NW = (BG + 1) / 2;                    // 32-bit words of a scan packed 16 bits per band
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t NB = a.g.seg_blocks, nbx = a.g.nbx, B = a.g.bands, NG = a.px_ng;    // NB * NG <= 64
@@ -117,7 +119,7 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
     const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
     // loads that depend on nothing but the segment number go out first; their round trips overlap the table copy and
     // its barrier (see dec_px_kernel)
-    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
+    const uint64_t seg = a.seg0 + (uint64_t)(blockIdx.x - chk) * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
     const bool live = seg < a.seg_end;
     const uint64_t segc = live ? seg : 0;
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
@@ -416,7 +418,7 @@ __global__ void __launch_bounds__(256, 4) dec_px16_kernel(const DecArgs a0) {
 template <int BG, bool RGB>
 static void launch_dec_px16_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4) + (a.bl_mode ? a.chk_wgs : 0u), a.ntiles), block(256);
     if (a.bl_mode) {
         constexpr bool bl = true;
         if (!z && !step) hipLaunchKernelGGL((dec_px16_kernel<BG, RGB, HILBERT, false, bl>), grid, block, plan.lds_px, st, a);

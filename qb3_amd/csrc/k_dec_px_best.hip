@@ -96,6 +96,8 @@ template <int B, bool RGB, uint64_t ORDER, bool BL>
 __global__ void __launch_bounds__(256) dec_px_best_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chk = BL ? a0.chk_wgs : 0u;          // the launch's first workgroups check a chunk of the container's table each (ix_check_chunk)
+    if (blockIdx.x < chk) { ix_check_chunk(a, blockIdx.x, (uint32_t *)smem); return; }
     constexpr int NW = (B + 1) / 2;                     // 32-bit words of a scan packed 16 bits per band
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t NB = 64, nbx = a.g.nbx;              // a WAVE owns a segment of 64 blocks, nothing is shared but the table
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(256) dec_px_best_kernel(const DecArgs a0) {
     uint32_t *stage = tab + 1024 + wave * (a.in_cap_dw + 8);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)smem;
     const uint32_t stage_bit0 = 8 * (lds0 + (uint32_t)((uint8_t *)stage - smem));
-    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
+    const uint64_t seg = a.seg0 + (uint64_t)(blockIdx.x - chk) * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
     const bool live = seg < a.seg_end;
     const uint64_t segc = live ? seg : 0;
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256) dec_px_best_kernel(const DecArgs a0) {
 
 template <int B, bool RGB>
 static void launch_dec_px_best_b(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
-    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4) + (a.bl_mode ? a.chk_wgs : 0u), a.ntiles), block(256);
     if (a.bl_mode) {
         if (a.g.order == ZCURVE) hipLaunchKernelGGL((dec_px_best_kernel<B, RGB, ZCURVE, true>), grid, block, plan.lds_px, st, a);
         else hipLaunchKernelGGL((dec_px_best_kernel<B, RGB, HILBERT, true>), grid, block, plan.lds_px, st, a);

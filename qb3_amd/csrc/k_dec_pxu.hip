@@ -111,6 +111,8 @@ __global__ void __launch_bounds__(256) dec_pxu_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chk = BL ? a0.chk_wgs : 0u;          // the launch's first workgroups check a chunk of the container's table each (ix_check_chunk)
+    if (blockIdx.x < chk) { ix_check_chunk(a, blockIdx.x, (uint32_t *)smem); return; }
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t B = a.g.bands, SB = a.g.seg_blocks;
     uint16_t *dtab = (uint16_t *)smem;                      // 2 KB
@@ -118,7 +120,7 @@ __global__ void __launch_bounds__(256) dec_pxu_kernel(const DecArgs a0) {
     uint32_t *stage = (uint32_t *)wmem;
     uint64_t *origin = (uint64_t *)(wmem + pxu_wave_bytes(a.in_cap_dw, (uint32_t)sizeof(T)) - 8 * 32);
 
-    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t seg = a.seg0 + (uint64_t)(blockIdx.x - chk) * nwaves + wave;
     const bool live = seg < a.seg_end;
     const uint64_t segc = live ? seg : 0;
     const uint32_t g0 = (uint32_t)(segc * SB), nblocks = (uint32_t)a.g.nblocks;
@@ -232,12 +234,14 @@ __global__ void __launch_bounds__(256) dec_pxu_best_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chk = BL ? a0.chk_wgs : 0u;          // the launch's first workgroups check a chunk of the container's table each (ix_check_chunk)
+    if (blockIdx.x < chk) { ix_check_chunk(a, blockIdx.x, (uint32_t *)smem); return; }
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t B = a.g.bands, SB = a.g.seg_blocks;
     uint8_t *wmem = smem + (size_t)wave * pxu_wave_bytes(a.in_cap_dw, (uint32_t)sizeof(T));      // nothing is shared between the waves: no barrier
     uint32_t *stage = (uint32_t *)wmem;
     uint64_t *origin = (uint64_t *)(wmem + pxu_wave_bytes(a.in_cap_dw, (uint32_t)sizeof(T)) - 8 * 32);
-    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t seg = a.seg0 + (uint64_t)(blockIdx.x - chk) * nwaves + wave;
     if (seg >= a.seg_end) return;
     const uint32_t g0 = (uint32_t)(seg * SB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < SB) ? nblocks - g0 : SB;
@@ -364,7 +368,7 @@ size_t pxu_lds_bytes(uint32_t in_cap_dw, uint32_t tsz, bool best) { return (best
 template <typename T>
 static void launch_dec_pxu_t(const DecArgs &a, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL;
-    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4) + (a.bl_mode ? a.chk_wgs : 0u), a.ntiles), block(256);
     const size_t lds = pxu_lds_bytes(a.in_cap_dw, a.g.tsz, false);
     if (a.bl_mode) {
         if (step) hipLaunchKernelGGL((dec_pxu_kernel<T, true, true>), grid, block, lds, st, a);
@@ -385,7 +389,7 @@ void launch_dec_pxu(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
 }
 template <typename T>
 static void launch_dec_pxu_best_t(const DecArgs &a, hipStream_t st) {
-    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4) + (a.bl_mode ? a.chk_wgs : 0u), a.ntiles), block(256);
     const size_t lds = pxu_lds_bytes(a.in_cap_dw, a.g.tsz, true);
     if (a.bl_mode) hipLaunchKernelGGL((dec_pxu_best_kernel<T, true>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((dec_pxu_best_kernel<T, false>), grid, block, lds, st, a);

@@ -47,6 +47,8 @@ __global__ void __launch_bounds__(256) dec_pxw_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chk = BL ? a0.chk_wgs : 0u;          // the launch's first workgroups check a chunk of the container's table each (ix_check_chunk)
+    if (blockIdx.x < chk) { ix_check_chunk(a, blockIdx.x, (uint32_t *)smem); return; }
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t NB = a.g.seg_blocks, nbx = a.g.nbx;      // NB == 64
     const uint64_t stride = a.g.stride;
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(256) dec_pxw_kernel(const DecArgs a0) {
     uint32_t *stage = (uint32_t *)(smem + 2048) + wave * (a.in_cap_dw + WIDE_PAD_DW);
 
     // loads that depend on nothing but the segment number go out first: their round trips overlap the table copy
-    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
+    const uint64_t seg = a.seg0 + (uint64_t)(blockIdx.x - chk) * nwaves + wave;       // (seg0, seg_end: this launch's range of segments)
     const bool live = seg < a.seg_end;
     const uint64_t segc = live ? seg : 0;
     const uint32_t g0 = (uint32_t)(segc * NB), nblocks = (uint32_t)a.g.nblocks;
@@ -177,11 +179,13 @@ __global__ void __launch_bounds__(256) dec_pxw_best_kernel(const DecArgs a0) {
     const DecArgs a = dec_for_tile(a0, blockIdx.y);
     constexpr uint32_t UB = UBits<T>::v, UMASK = (1u << UB) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chk = BL ? a0.chk_wgs : 0u;          // the launch's first workgroups check a chunk of the container's table each (ix_check_chunk)
+    if (blockIdx.x < chk) { ix_check_chunk(a, blockIdx.x, (uint32_t *)smem); return; }
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t NB = 64, nbx = a.g.nbx;
     const uint64_t stride = a.g.stride;
     uint32_t *stage = (uint32_t *)smem + wave * (a.in_cap_dw + WIDE_PAD_DW);         // nothing is shared between the waves: no barrier
-    const uint64_t seg = a.seg0 + (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t seg = a.seg0 + (uint64_t)(blockIdx.x - chk) * nwaves + wave;
     if (seg >= a.seg_end) return;
     const uint32_t g0 = (uint32_t)(seg * NB), nblocks = (uint32_t)a.g.nblocks;
     const uint32_t nb_here = (nblocks - g0 < NB) ? nblocks - g0 : NB;
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(256) dec_pxw_best_kernel(const DecArgs a0) {
 
 template <typename T>
 static void launch_dec_pxw_best_t(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
-    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4) + (a.bl_mode ? a.chk_wgs : 0u), a.ntiles), block(256);
     const size_t lds = plan.lds_pxw;
     const bool z = a.g.order == ZCURVE;
     if (a.bl_mode) {
@@ -322,7 +326,7 @@ void launch_dec_pxw_best(const DecArgs &a, const DecPlan &plan, hipStream_t st) 
 template <typename T>
 static void launch_dec_pxw_t(const DecArgs &a, const DecPlan &plan, hipStream_t st) {
     const bool step = a.g.mode != CM_FTL, z = a.g.order == ZCURVE;
-    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4), a.ntiles), block(256);
+    dim3 grid((uint32_t)((a.seg_end - a.seg0 + 3) / 4) + (a.bl_mode ? a.chk_wgs : 0u), a.ntiles), block(256);
     const size_t lds = plan.lds_pxw;
     if (a.bl_mode) {
         if (!z && !step) hipLaunchKernelGGL((dec_pxw_kernel<T, HILBERT, false, true>), grid, block, lds, st, a);

@@ -534,10 +534,6 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     const bool best = a.g.mode == CM_BEST;
     const bool use_px = plan.px && !best && a.g.tsz == 1;
     const bool need_check = rebuild && a.ix && a.ix_K && (a.ix_ver >= 3 || a.ix_check_heads);
-    // (the 8-bit decoder that works from the entries alone checks the table with workgroups of its own launch: one launch, not two)
-    const bool fold_check = need_check && use_px && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl;
-    if (need_check && !fold_check)
-        hipLaunchKernelGGL(ix_check_kernel, dim3((a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk, a.ntiles), dim3(256), 0, st, a);
     const bool use_px16 = plan.px16 && !best && a.g.tsz == 2 && ((uintptr_t)a.img & 1) == 0;
     // 32/64-bit FTL/BASE streams that bring a restart table with an entry per index segment: the lengths-only walk too
     const bool wide_walk = rebuild && a.ix && !best && a.g.tsz >= 4 && plan.fast && a.ix_blocks == a.g.seg_blocks && a.g.ulen_sz == 2;
@@ -555,10 +551,17 @@ static int launch_decode_all(const DecArgs &a, const DecPlan &plan, bool rebuild
     const bool best_pxu = best && plan.pxu_best && val_aligned;
     const bool best_px = (best && plan.px_best && a.g.tsz == 1) || best_pxw || best_pxu;       // a lane-per-block (or per-unit) common-factor decoder applies
     auto dec_best_lpb = [&](const DecArgs &t) { if (best_pxw) launch_dec_pxw_best(t, plan, st); else if (best_pxu) launch_dec_pxu_best(t, plan, st); else launch_dec_px_best(t, plan, st); };
+    // the table's check: the wave-per-segment decoders that work from the entries alone make it with the first workgroups of their own
+    // launch (DecArgs::chk_wgs: one launch, not two); everything else has ix_check_kernel in front
+    const bool from_entries = rebuild && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl;
+    const bool fold_check = need_check && from_entries && (best_px || (!best && (use_px || (use_px16 && ix_block_lens_ok(a.g)) || use_pxw || use_pxu)));
+    if (need_check && !fold_check)
+        hipLaunchKernelGGL(ix_check_kernel, dim3((a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk, a.ntiles), dim3(256), 0, st, a);
     if (rebuild && best_px && a.ix && a.ix_bl && a.ix_blocks == a.g.seg_blocks && !tuning().slow_index && !tuning().no_bl) {
         // the container's table has a field per block (bits, entering rungs): the lane-per-block decoder works from the entries alone
         DecArgs t = a;
         t.bl_mode = 1;
+        if (fold_check) t.chk_wgs = (a.ix_K + a.ix_per_chunk - 1) / a.ix_per_chunk;
         ProfScope ps("dec_units", st);
         dec_best_lpb(t);
         HIPCHK(hipGetLastError());
