@@ -1704,7 +1704,8 @@ def test_large_rung_base(qb3, oracle, case, mode):
 
 
 @pytest.mark.parametrize("case", [(512, 384, 3, 0, "NOISY3", FTL, 2), (512, 384, 3, 0, "NOISY3", 5, 1), (384, 256, 8, 2, "LANDSAT16", BASE, 2),
-                                  (320, 256, 1, 5, "DEM", FTL, 2), (320, 256, 1, 7, "DEM", FTL, 2), (320, 256, 1, 5, "DEM", 5, 2), (1024, 1024, 3, 0, "NOISY3", BASE, 1)],
+                                  (320, 256, 1, 5, "DEM", FTL, 2), (320, 256, 1, 7, "DEM", FTL, 2), (320, 256, 1, 5, "DEM", 5, 2), (1024, 1024, 3, 0, "NOISY3", BASE, 1),
+                                  (320, 256, 2, 5, "DEM", FTL, 2), (320, 256, 5, 0, "NOISY3", 5, 2), (320, 256, 3, 7, "DEM", BASE, 2)],      # (the lane-per-unit decoders)
                          ids=lambda c: "%dx%dx%d-t%d-%s-m%d-l%d" % c)
 def test_a_damaged_restart_table_costs_time_not_pixels(qb3, oracle, case):
     """The table sits in an ignorable chunk the format does not protect, and the decoder takes positions, rungs, entering
