@@ -66,10 +66,12 @@ __device__ __forceinline__ uint32_t ff_pairs_in(uint32_t v) {
 // With zrun_probe (the RLE0 modes) the wave also counts, among the dwords it moves, the positions at which four zero bytes
 // in a row start and the 0xff bytes followed by another in the same dword -- RLE0 (reference QB3encode.cpp:536-565) can only
 // shorten a stream whose zero runs outweigh its pairs of 0xff (rle0_may_win, qb3_dev.h), and counting here spares the byte
-// pass over the finished stream whenever the counts decide.  A dword shared with a neighbouring chunk is tested as this
-// chunk sees it (the neighbour's bits zero) and so is the stream's last dword: zero runs can be counted too often (a run that
-// touches a shared dword has zeros in both chunks' bits of it, and each chunk tests it against its own side), pairs of 0xff
-// too rarely (never across dwords, never in bits another chunk owns) -- both on the side of running the pass.
+// pass over the finished stream whenever the counts decide.  Zero runs are counted EXACTLY: here the positions whose four bytes lie
+// in dwords this chunk owns alone (a dword shared with a neighbouring chunk counts as non-zero), in finish_seam -- on the finished
+// stream -- the positions that touch a chunk boundary.  (Round 3 tested a shared dword as each chunk sees it, the neighbour's bits
+// zero: on the side of running the pass, and config 2's QB3M_BEST stream, which has no zero run at all, came out with 5 401 -- one
+// chunk boundary in twelve -- and paid 0.2 ms for the size pass every call.)  Pairs of 0xff are counted too rarely (never across
+// dwords, never in bits another chunk owns): on the side of running the pass.
 __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
     const EncArgs a = enc_for_tile(a0, blockIdx.y);
     const uint32_t chunk = a.chunk0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -139,6 +141,7 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
                         ffp += ff_pairs_in(v[k]);
                         const bool shared = (d + k == 0 && phase) || (d + k == nd - 1 && tailbits);
                         zdw += (uint32_t)(v[k] == 0 && !shared);            // (all-zero dwords that are this chunk's alone: 4 KB of zeros hold hundreds)
+                        if (shared) v[k] = 0xffffffffu;                     // (zero runs that touch a dword two chunks share: finish_seam counts them, on the finished dword)
                     }
                 }
                 zrun += zero_runs_in(v[0], v[1]) + zero_runs_in(v[1], v[2]) + zero_runs_in(v[2], v[3]);
@@ -157,6 +160,7 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
                         if (dn < nd) {
                             const uint32_t s0 = dn < nsrc ? slot[dn] : 0u, sp = dn - 1 < nsrc ? slot[dn - 1] : 0u;
                             nxt = phase ? __builtin_amdgcn_alignbit(s0, sp, sh) : s0;
+                            if (dn == nd - 1 && tailbits) nxt = 0xffffffffu;    // (shared with the next chunk: finish_seam's)
                         }
                     }
                 }
@@ -188,12 +192,27 @@ __global__ void __launch_bounds__(256) enc_concat_kernel(const EncArgs a0) {
 // * the container header in front of the stream (device flavour).
 // the dword that holds the boundary in front of chunk k (k == nchunks: the stream's end): the OR of the edge dwords of the
 // chunks that meet in it, written by the thread of the FIRST boundary inside the dword.  cs(j): start of chunk j in the stream.
+// positions in the last three bytes of `prev` at which four zero bytes start (they reach into `cur`)
+__device__ __forceinline__ uint32_t zero_runs_into(uint32_t prev, uint32_t cur) { return zero_runs_in(prev, cur) - (uint32_t)(prev == 0); }
 template <class CS>
 __device__ __forceinline__ void finish_seam(const EncArgs &a, uint32_t k, CS cs) {
     const uint64_t Ek = (uint64_t)a.out_bit0 + cs(k);
     if (k == a.nchunks) { a.res->total_bits = Ek - a.out_bit0; }
-    if ((Ek & 31) == 0) return;
     const uint64_t d = Ek >> 5;
+    // (RLE0 modes) the zero runs enc_concat_kernel left out: the positions whose four bytes touch this boundary.  The dwords either
+    // side of it are the chunks' own and final; bytes in front of the stream and behind it count as non-zero (they are not RLE0's input).
+    const uint64_t d_last = ((uint64_t)a.out_bit0 + cs(a.nchunks) + 31) / 32;      // dwords the stream reaches into
+    // (a chunk of less than three dwords next to the boundary -- the last chunk of a raster can be one block -- has its shared dwords side
+    // by side, each assembled by another thread: no reading them here; sixteen positions are more than touch such a chunk)
+    const bool tiny = a.zrun_probe && ((k > 0 && cs(k) - cs(k - 1) < 96) || (k < a.nchunks && cs(k + 1) - cs(k) < 96));
+    if (tiny) atomicAdd((unsigned long long *)&a.res->zero_run, 16ull);
+    if ((Ek & 31) == 0) {
+        if (a.zrun_probe && !tiny && k > 0 && k < a.nchunks) {      // chunks meet on a dword boundary: runs from the last three bytes of one into the other
+            const uint32_t n = zero_runs_into(a.out32[d - 1], a.out32[d]);
+            if (n) atomicAdd((unsigned long long *)&a.res->zero_run, (unsigned long long)n);
+        }
+        return;
+    }
     if (k > 0) { const uint64_t Ep = (uint64_t)a.out_bit0 + cs(k - 1); if ((Ep >> 5) == d && (Ep & 31)) return; }
     uint32_t v = k > 0 ? a.seams[2 * (k - 1) + 1] : 0u;
     for (uint32_t j = k; j < a.nchunks; j++) {
@@ -205,6 +224,14 @@ __device__ __forceinline__ void finish_seam(const EncArgs &a, uint32_t k, CS cs)
         uint8_t *p8 = (uint8_t *)(a.out32 + d);
         for (uint32_t i = a.out_bit0 >> 3; i < 4; i++) p8[i] = (uint8_t)(v >> (8 * i));
     } else a.out32[d] = v;
+    if (a.zrun_probe && !tiny) {
+        uint32_t vz = v;
+        if (k == 0 && a.out_bit0) vz |= 0xffffffffu >> (32 - a.out_bit0);             // (header bytes)
+        if (d + 1 == d_last) { const uint32_t used = (uint32_t)(((uint64_t)a.out_bit0 + cs(a.nchunks) + 7) / 8 - 4 * d); if (used < 4) vz |= 0xffffffffu << (8 * used); }     // (bytes behind the stream)
+        uint32_t n = zero_runs_in(vz, d + 1 < d_last ? a.out32[d + 1] : 0xffffffffu);
+        if (k > 0) n += zero_runs_into(a.out32[d - 1], vz);
+        if (n) atomicAdd((unsigned long long *)&a.res->zero_run, (unsigned long long)n);
+    }
 }
 
 __global__ void __launch_bounds__(256) enc_finish_kernel(const EncArgs a0) {

@@ -504,6 +504,7 @@ static bool encode_blocks_device(encsp p, const Geometry &g, const void *d_img, 
     prof_collect();
     *bits = res.total_bits;
     // (a chunk of the stream holds plan.nbp blocks of at least two bits a unit)
+    { static const bool dbg = getenv("QB3_DEBUG_RLE") != nullptr; if (dbg && zero_run) fprintf(stderr, "encode: zero_run %llu ff_pairs %llu zero_dwords %llu (%u chunks)\n", (unsigned long long)res.zero_run, (unsigned long long)res.ff_pairs, (unsigned long long)res.zero_dwords, plan.nchunks); }
     if (zero_run) *zero_run = rle0_may_win(res) ? (rle0_no_uniform_chunk(res, (uint64_t)plan.nbp * g.bands / 4) ? 2 : 1) : 0;      // (2: and no 4 KB of the stream hold one byte value only)
     if (carry)
         for (size_t c = 0; c < p->nbands; c++) {

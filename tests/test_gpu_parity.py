@@ -2289,6 +2289,29 @@ def test_streams_cut_short_decode_like_the_reference(qb3, oracle):
             assert np.array_equal(got, want), (w, h, b, dt, gen, mode, frac)
 
 
+def test_rle0_passes_run_only_for_streams_with_zero_runs(qb3, oracle):
+    """The RLE0 modes count, while the chunks are concatenated, the positions at which four zero bytes start -- exactly, the positions at
+    chunk boundaries on the finished dwords (finish_seam) -- and a stream that has none goes without the byte passes over it; one that has
+    them gets the passes and the reference's decision.  (Counted per chunk as the chunk sees a shared dword, a noise raster of 4 113
+    chunks came out with 319 runs it does not have and paid for the size pass.)  The container is the oracle's either way."""
+    import torch
+    from qb3_amd import synth, device as qdev
+    for (w, h, b, dt, gen, expect_pass) in [(1024, 1024, 3, 0, "NOISY3", False), (1024, 1024, 1, 0, "CONST", None), (1024, 1024, 3, 0, "TERRACE", None), (1024, 1024, 8, 2, "LANDSAT16", None), (515, 389, 1, 3, "DEM", None)]:
+        img = synth.generate(w, h, b, dt, gen, 3)
+        ref = oracle.encode(img.cpu().numpy().view(oracle.NPTYPE[dt]), dt, 7, fix_b2=True)
+        enc = qdev.DeviceEncoder(w, h, b, dt, mode=7)
+        enc.encode(img)
+        qdev.profile_reset(); qdev.profile_enable(1)
+        dst, n, _ = enc.encode(img)
+        torch.cuda.synchronize()
+        qdev.profile_enable(False)
+        names = set(qdev.profile_report())
+        got = dst[:n].cpu().numpy()
+        assert n == len(ref) and np.array_equal(got, ref), (w, h, b, dt, gen, first_diff(got, ref))
+        if expect_pass is not None:
+            assert any(k.startswith("rle0") for k in names) == expect_pass, (gen, sorted(names))
+
+
 @pytest.mark.parametrize("case", [(4096, 4096, 3, 7, "DEM", 8), (4096, 4096, 2, 7, "DEM", 8), (4096, 4096, 2, 7, "DEM", 0), (4096, 4096, 1, 7, "DEM", 8)],
                          ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % c)
 def test_wide_decode_is_repeatable(qb3, case):
