@@ -2312,6 +2312,33 @@ def test_rle0_passes_run_only_for_streams_with_zero_runs(qb3, oracle):
             assert any(k.startswith("rle0") for k in names) == expect_pass, (gen, sorted(names))
 
 
+def test_rle0_decision_with_short_zero_runs_at_chunk_boundaries(qb3, oracle):
+    """Whether an RLE0 mode's byte passes run at all hangs on the count of zero runs, and a stream of noise with ONE short run of zero
+    bytes is the close call: RLE0 wins it by a byte or two, or not at all.  Flat patches of a few blocks (a handful of zero bytes in the
+    stream) are laid over the blocks around the encoder's chunk boundaries (255 blocks a chunk), where the run's bytes lie in dwords two
+    chunks share: the container must be the oracle's -- mode byte, size and bytes -- every time."""
+    import torch
+    from qb3_amd import synth, device as qdev
+    w, h, b, dt = 1024, 256, 3, 0
+    base = synth.generate(w, h, b, dt, "NOISY3", 11)
+    enc = qdev.DeviceEncoder(w, h, b, dt, mode=7)
+    rng = np.random.default_rng(5)
+    wins = 0
+    for trial in range(48):
+        k = int(rng.integers(1, (w // 4) * (h // 4) // 255))            # a chunk boundary: in front of block 255 * k
+        first = 255 * k - int(rng.integers(1, 8)); nblk = int(rng.integers(4, 12))
+        img = base.clone()
+        for g in range(first, first + nblk):
+            by, bx = divmod(g, w // 4)
+            if by < h // 4: img[4 * by:4 * by + 4, 4 * bx:4 * bx + 4, :] = 77
+        ref = oracle.encode(img.cpu().numpy().view(oracle.NPTYPE[dt]), dt, 7, fix_b2=True)
+        dst, n, _ = enc.encode(img)
+        got = dst[:n].cpu().numpy()
+        assert n == len(ref) and np.array_equal(got, ref), (trial, k, first, nblk, int(got[10]), int(ref[10]), first_diff(got, ref))
+        wins += int(ref[10]) == 7
+    assert 0 < wins, "no trial made RLE0 win: the patches are too short to test the decision"
+
+
 @pytest.mark.parametrize("case", [(4096, 4096, 3, 7, "DEM", 8), (4096, 4096, 2, 7, "DEM", 8), (4096, 4096, 2, 7, "DEM", 0), (4096, 4096, 1, 7, "DEM", 8)],
                          ids=lambda c: "%dx%dx%d-t%d-%s-m%d" % c)
 def test_wide_decode_is_repeatable(qb3, case):
