@@ -172,7 +172,7 @@ class TileBatchCoder:
 
 
 def profile_enable(on=True):
-    """True / 1: every kernel; 2: skip the microsecond kernels (less event traffic in a timed loop); False / 0: off."""
+    """True / 1: every kernel; 2: skip the microsecond kernels (less event traffic in a timed loop); 3: the coding kernels (`*_units`) alone; False / 0: off."""
     lib.qb3x_profile_enable(int(on))
 
 
